@@ -1,0 +1,35 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def parse_poly(s, N):
+    """SEAL Plaintext hex-string form ("4x^4 + 33x^3 + 42") -> coefficient list."""
+    import numpy as np
+    out = np.zeros(N, dtype=np.uint64)
+    for term in s.split("+"):
+        term = term.strip()
+        if not term:
+            continue
+        if "x^" in term:
+            c, e = term.split("x^")
+            out[int(e)] = int(c, 16)
+        else:
+            out[0] = int(term, 16)
+    return out
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    import oracle
+    oracle.load()
+    return oracle

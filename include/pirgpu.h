@@ -1,0 +1,167 @@
+/*
+ * pirgpu.h -- C ABI of the MI355X-native PIR server query path (libpirgpu.so).
+ *
+ * The reference (OpenMined/PIR) has no FFI seam: its boundary is the C++ class
+ * API of PIRServer / PIRDatabase over Microsoft SEAL objects.  Every entry
+ * point below replaces one reference interface, cited as file:line relative to
+ * /root/reference.  The host-side C++ mirror of the reference classes
+ * (pir_amd/csrc/pir_facade.h) and the ctypes binding (pir_amd/capi.py) are thin
+ * wrappers over exactly these symbols; INTEGRATION.md shows the binding a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the caller owns every host buffer, the
+ *     library owns all device memory;
+ *   - residue arrays use SEAL's in-memory layout (reference server.cpp:98,
+ *     ct_reencoder.cpp:61):
+ *        ciphertext   uint64_t[2][k][N]       (poly, residue, coefficient)
+ *        Galois key   uint64_t[k][2][k+1][N]  (digit, component, key-level residue), NTT form
+ *   - every function returns 0 on success or the numeric absl::StatusCode the
+ *     reference would have returned (3 InvalidArgument, 9 FailedPrecondition,
+ *     12 Unimplemented, 13 Internal); pirgpu_last_error() gives the message;
+ *   - one context drives one GPU; calls on one context are serialised
+ *     internally; every result is a canonical residue in [0, q_j) and is
+ *     bit-identical to the reference's SEAL CPU path on the same inputs.
+ */
+#ifndef PIRGPU_H_
+#define PIRGPU_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PIRGPU_MAX_PRIMES 8
+#define PIRGPU_MAX_DIMS 8
+
+#define PIRGPU_OK 0
+#define PIRGPU_INVALID_ARGUMENT 3
+#define PIRGPU_FAILED_PRECONDITION 9
+#define PIRGPU_UNIMPLEMENTED 12
+#define PIRGPU_INTERNAL 13
+
+typedef struct pirgpu_ctx pirgpu_ctx;
+
+/* What PIRContext + PIRParameters carry (reference context.h:36-84,
+ * pir/proto/payload.proto:45-69), flattened. */
+typedef struct pirgpu_params {
+  uint32_t poly_modulus_degree;            /* N, power of two, 1024..32768 */
+  uint32_t num_data_primes;                /* k: ciphertext level (first_context_data) */
+  uint64_t coeff_modulus[PIRGPU_MAX_PRIMES]; /* q_0..q_{k-1} */
+  uint64_t special_prime;                  /* key-switching prime p (last of SEAL's coeff_modulus) */
+  uint64_t plain_modulus;                  /* t */
+  uint32_t num_dimensions;                 /* d */
+  uint32_t dimensions[PIRGPU_MAX_DIMS];    /* PIRParameters.dimensions */
+  uint64_t num_pt;                         /* PIRParameters.num_pt */
+  uint64_t num_items;                      /* PIRParameters.num_items (0 if coefficient-loaded) */
+  uint32_t bytes_per_item;                 /* PIRParameters.bytes_per_item */
+  uint32_t items_per_plaintext;            /* PIRParameters.items_per_plaintext */
+  uint32_t bits_per_coeff;                 /* PIRParameters.bits_per_coeff (0 = floor(log2 t)) */
+  uint32_t use_ciphertext_multiplication;  /* must be 0: CT x CT mode is Unimplemented */
+  int32_t device;                          /* HIP device ordinal */
+  /* Row sharding for multi-GPU (not in the reference): this context holds the
+   * top-level indices [shard_begin, shard_end) of dimension 0 and produces the
+   * partial reply for them; 0,0 = the whole database. */
+  uint32_t shard_begin;
+  uint32_t shard_end;
+} pirgpu_params;
+
+/* PIRContext::Create + PIRDatabase::Create(params) (reference context.cpp:37-50,
+ * database.cpp:40-44): validates the parameters, builds NTT tables on the device. */
+int pirgpu_create(const pirgpu_params* params, pirgpu_ctx** out);
+void pirgpu_destroy(pirgpu_ctx* ctx);
+const char* pirgpu_last_error(const pirgpu_ctx* ctx);
+/* last error of a failed pirgpu_create (no context to ask) */
+const char* pirgpu_create_error(void);
+
+/* PIRDatabase::populate(vector<string>) (reference database.cpp:84-110,
+ * string_encoder.cpp:58-122).  items: num_items x bytes_per_item raw bytes,
+ * item-major; must equal params.num_items.  Bit packing, plain lift and forward
+ * NTT all run on the device; the encoded database stays resident in HBM. */
+int pirgpu_db_load_items(pirgpu_ctx* ctx, const uint8_t* items, uint64_t num_items, uint32_t bytes_per_item);
+/* PIRDatabase::populate from already-encoded plaintexts (the IntegerEncoder path,
+ * reference database.cpp:60-82): coeffs = n_pt x N coefficients, each < t,
+ * zero padded; plaintext indices [first_pt, first_pt + n_pt). */
+int pirgpu_db_load_coeffs(pirgpu_ctx* ctx, uint64_t first_pt, uint64_t n_pt, const uint64_t* coeffs);
+/* PIRDatabase::size() (reference database.h:97) -- plaintexts loaded so far. */
+uint64_t pirgpu_db_size(const pirgpu_ctx* ctx);
+/* Test hook: read back one encoded plaintext [k][N] (NTT form) from HBM. */
+int pirgpu_db_read_plaintext(pirgpu_ctx* ctx, uint64_t pt_index, uint64_t* out);
+
+/* What SEALDeserialize<GaloisKeys> yields per request (reference server.cpp:46-48):
+ * install the key for one Galois element.  Keys stay on the device until cleared. */
+int pirgpu_set_galois_key(pirgpu_ctx* ctx, uint32_t galois_elt, const uint64_t* key);
+int pirgpu_clear_galois_keys(pirgpu_ctx* ctx);
+
+/* PIRServer::processQuery minus (de)serialisation (reference server.cpp:173-195):
+ * query = nq ciphertexts (coefficient form), reply = reply_count ciphertexts
+ * (coefficient form).  reply_capacity is in ciphertexts. */
+int pirgpu_process_query(pirgpu_ctx* ctx, const uint64_t* query, uint32_t nq, uint64_t* reply,
+                         uint64_t reply_capacity, uint64_t* reply_count);
+/* (2 * ExpansionRatio)^(d-1) (reference client.cpp:224-226, ct_reencoder.cpp:29-38) */
+uint64_t pirgpu_reply_ct_count(const pirgpu_ctx* ctx);
+/* CiphertextReencoder::ExpansionRatio (reference ct_reencoder.cpp:29-38) */
+uint32_t pirgpu_expansion_ratio(const pirgpu_ctx* ctx);
+
+/* Device-resident split of pirgpu_process_query for pipelining and measurement:
+ * stage = H2D of the query, run = every kernel of the path (asynchronous on the
+ * context's stream), fetch = D2H of the reply, sync = wait for the stream. */
+int pirgpu_query_stage(pirgpu_ctx* ctx, const uint64_t* query, uint32_t nq);
+int pirgpu_query_run(pirgpu_ctx* ctx);
+int pirgpu_query_fetch(pirgpu_ctx* ctx, uint64_t* reply, uint64_t reply_capacity, uint64_t* reply_count);
+int pirgpu_sync(pirgpu_ctx* ctx);
+
+/* PIRServer::oblivious_expansion (reference server.cpp:105-146): one ciphertext
+ * -> num_items ciphertexts, coefficient form. */
+int pirgpu_expand(pirgpu_ctx* ctx, const uint64_t* ct, uint32_t num_items, uint64_t* out);
+/* PIRServer::oblivious_expansion, multi-ciphertext overload (reference server.cpp:148-171). */
+int pirgpu_expand_multi(pirgpu_ctx* ctx, const uint64_t* cts, uint32_t num_cts, uint64_t total_items,
+                        uint64_t* out);
+/* PIRServer::substitute_power_x_inplace (reference server.cpp:67-76). */
+int pirgpu_substitute_power_x(pirgpu_ctx* ctx, uint64_t* ct, uint32_t power);
+/* PIRServer::multiply_inverse_power_of_x (reference server.cpp:78-103). */
+int pirgpu_multiply_inverse_power_of_x(pirgpu_ctx* ctx, const uint64_t* ct, uint32_t k, uint64_t* out);
+/* PIRDatabase::multiply (reference database.cpp:290-316): selection vector of
+ * sv_count ciphertexts in coefficient form -> reply ciphertexts. */
+int pirgpu_multiply(pirgpu_ctx* ctx, const uint64_t* selection_vector, uint64_t sv_count, uint64_t* reply,
+                    uint64_t reply_capacity, uint64_t* reply_count);
+
+/* Evaluator::transform_to_ntt_inplace / transform_from_ntt_inplace on count
+ * ciphertexts (reference database.cpp:190,252) -- test hooks for the NTT kernels.
+ * key_level = 0: ciphertext layout [2][k][N] over q_0..q_{k-1};
+ * key_level = 1: polys is count x [k+1][N] over q_0..q_{k-1},p. */
+int pirgpu_ntt_forward(pirgpu_ctx* ctx, uint64_t* polys, uint64_t count, int key_level);
+int pirgpu_ntt_inverse(pirgpu_ctx* ctx, uint64_t* polys, uint64_t count, int key_level);
+
+/* Multi-GPU reduce step (not in the reference): in place, x[i] <- x[i] mod q_j
+ * over count ciphertexts whose words hold integer sums of per-shard partial
+ * replies (each partial < q_j, so an 8-way sum fits 64 bits). device_ptr is a
+ * device pointer (e.g. a torch tensor's data_ptr after the RCCL all-reduce). */
+int pirgpu_reduce_fixup_device(pirgpu_ctx* ctx, uint64_t* device_ptr, uint64_t count);
+/* Device pointer of the staged reply (valid until the next run) for collectives. */
+uint64_t* pirgpu_reply_device_ptr(pirgpu_ctx* ctx);
+
+/* Wire-level entry: PIRServer::ProcessRequest (reference server.cpp:44-65).
+ * request = serialized pir.Request (pir/proto/payload.proto:27-36); on success
+ * *response points to a malloc'd serialized pir.Response (payload.proto:39-42)
+ * that the caller releases with pirgpu_free. */
+int pirgpu_process_request(pirgpu_ctx* ctx, const uint8_t* request, size_t request_len, uint8_t** response,
+                           size_t* response_len);
+void pirgpu_free(void* p);
+
+/* Measurement: wall-clock of the phases of the last pirgpu_query_run, taken with
+ * HIP events on the context's own stream.  phase_ms[0..5] = expansion,
+ * selection-vector NTT, database scan (the streaming kernel), upper levels
+ * (re-encode + multiply-accumulate), final inverse NTT, total. */
+int pirgpu_last_timings(pirgpu_ctx* ctx, float phase_ms[6]);
+/* Enable/disable the phase events above (default off: zero overhead). */
+int pirgpu_set_profiling(pirgpu_ctx* ctx, int enabled);
+/* Algorithmic bytes the scan kernel reads per query: num_pt(shard) * k * N * 8. */
+uint64_t pirgpu_scan_bytes(const pirgpu_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIRGPU_H_ */

@@ -1,0 +1,91 @@
+"""ctypes binding of libpirgpu.so (include/pirgpu.h).  No torch types cross this boundary."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpirgpu.so")
+
+MAX_PRIMES, MAX_DIMS = 8, 8
+OK, INVALID_ARGUMENT, FAILED_PRECONDITION, UNIMPLEMENTED, INTERNAL = 0, 3, 9, 12, 13
+
+u64p = C.POINTER(C.c_uint64)
+u8p = C.POINTER(C.c_uint8)
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("poly_modulus_degree", C.c_uint32),
+        ("num_data_primes", C.c_uint32),
+        ("coeff_modulus", C.c_uint64 * MAX_PRIMES),
+        ("special_prime", C.c_uint64),
+        ("plain_modulus", C.c_uint64),
+        ("num_dimensions", C.c_uint32),
+        ("dimensions", C.c_uint32 * MAX_DIMS),
+        ("num_pt", C.c_uint64),
+        ("num_items", C.c_uint64),
+        ("bytes_per_item", C.c_uint32),
+        ("items_per_plaintext", C.c_uint32),
+        ("bits_per_coeff", C.c_uint32),
+        ("use_ciphertext_multiplication", C.c_uint32),
+        ("device", C.c_int32),
+        ("shard_begin", C.c_uint32),
+        ("shard_end", C.c_uint32),
+    ]
+
+
+# every symbol include/pirgpu.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "pirgpu_create": (C.c_int, [C.POINTER(Params), C.POINTER(C.c_void_p)]),
+    "pirgpu_destroy": (None, [C.c_void_p]),
+    "pirgpu_last_error": (C.c_char_p, [C.c_void_p]),
+    "pirgpu_create_error": (C.c_char_p, []),
+    "pirgpu_db_load_items": (C.c_int, [C.c_void_p, u8p, C.c_uint64, C.c_uint32]),
+    "pirgpu_db_load_coeffs": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, u64p]),
+    "pirgpu_db_size": (C.c_uint64, [C.c_void_p]),
+    "pirgpu_db_read_plaintext": (C.c_int, [C.c_void_p, C.c_uint64, u64p]),
+    "pirgpu_set_galois_key": (C.c_int, [C.c_void_p, C.c_uint32, u64p]),
+    "pirgpu_clear_galois_keys": (C.c_int, [C.c_void_p]),
+    "pirgpu_process_query": (C.c_int, [C.c_void_p, u64p, C.c_uint32, u64p, C.c_uint64, u64p]),
+    "pirgpu_reply_ct_count": (C.c_uint64, [C.c_void_p]),
+    "pirgpu_expansion_ratio": (C.c_uint32, [C.c_void_p]),
+    "pirgpu_query_stage": (C.c_int, [C.c_void_p, u64p, C.c_uint32]),
+    "pirgpu_query_run": (C.c_int, [C.c_void_p]),
+    "pirgpu_query_fetch": (C.c_int, [C.c_void_p, u64p, C.c_uint64, u64p]),
+    "pirgpu_sync": (C.c_int, [C.c_void_p]),
+    "pirgpu_expand": (C.c_int, [C.c_void_p, u64p, C.c_uint32, u64p]),
+    "pirgpu_expand_multi": (C.c_int, [C.c_void_p, u64p, C.c_uint32, C.c_uint64, u64p]),
+    "pirgpu_substitute_power_x": (C.c_int, [C.c_void_p, u64p, C.c_uint32]),
+    "pirgpu_multiply_inverse_power_of_x": (C.c_int, [C.c_void_p, u64p, C.c_uint32, u64p]),
+    "pirgpu_multiply": (C.c_int, [C.c_void_p, u64p, C.c_uint64, u64p, C.c_uint64, u64p]),
+    "pirgpu_ntt_forward": (C.c_int, [C.c_void_p, u64p, C.c_uint64, C.c_int]),
+    "pirgpu_ntt_inverse": (C.c_int, [C.c_void_p, u64p, C.c_uint64, C.c_int]),
+    "pirgpu_reduce_fixup_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "pirgpu_reply_device_ptr": (C.c_void_p, [C.c_void_p]),
+    "pirgpu_process_request": (C.c_int, [C.c_void_p, u8p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "pirgpu_free": (None, [C.c_void_p]),
+    "pirgpu_last_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "pirgpu_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "pirgpu_scan_bytes": (C.c_uint64, [C.c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libpirgpu.so; fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "pir_amd: %s is missing -- build the HIP extension first (python -c 'import __graft_entry__ as g; "
+            "g.build()' or python pir_amd/build.py). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

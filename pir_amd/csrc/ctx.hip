@@ -1,0 +1,822 @@
+// ctx.hip -- device context and C ABI of libpirgpu (see include/pirgpu.h).
+//
+// Host-side orchestration of the reference's PIRServer::processQuery
+// (server.cpp:173-195) and PIRDatabase (database.cpp) on one MI355X: the encoded
+// database, the Galois keys and every intermediate live in HBM; the host only
+// sequences kernel launches on the context's stream.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/pirgpu.h"
+#include "device_params.h"
+#include "host_math.h"
+#include "kernels.h"
+
+using namespace pirgpu;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Fail {
+  int code;
+  std::string msg;
+};
+
+#define HIP_TRY(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      throw Fail{PIRGPU_INTERNAL, std::string(#expr) + ": " + hipGetErrorString(e_)};     \
+  } while (0)
+
+enum Phase { PH_EXPAND = 0, PH_SVNTT, PH_SCAN, PH_UPPER, PH_FINAL, PH_COUNT };
+
+}  // namespace
+
+struct pirgpu_ctx {
+  pirgpu_params prm{};
+  uint32_t N = 0, logN = 0, k = 0, d = 0;
+  size_t ctw = 0;  // words per ciphertext
+  uint32_t dims[PIRGPU_MAX_DIMS]{};
+  uint64_t stride[PIRGPU_MAX_DIMS + 1]{};  // plaintexts under one node of level l
+  uint32_t sv_off[PIRGPU_MAX_DIMS + 1]{};  // selection-vector offset of dimension l
+  uint32_t dim_sum = 0;
+  uint32_t er = 0, E = 0;  // ExpansionRatio, 2*ER
+  uint64_t reply_cts = 1;
+  uint64_t P = 0;              // num_pt of the whole database
+  uint32_t sb = 0, se = 0;     // shard of top-level indices
+  uint64_t pt_begin = 0, pt_end = 0;  // plaintext range held by this context
+  uint32_t bits = 0;           // bits per coefficient for item packing
+
+  int device = 0;
+  hipStream_t stream = nullptr;
+  DevParams hp{};
+  DevParams* dp = nullptr;
+  std::vector<void*> allocs;
+
+  uint64_t* d_db = nullptr;
+  std::vector<uint8_t> loaded;  // per local plaintext
+  uint64_t n_loaded = 0;
+  std::map<uint32_t, uint64_t*> keys;
+
+  // workspace (allocated on first use)
+  bool ws_ready = false;
+  uint64_t *res_a = nullptr, *res_b = nullptr, *prod = nullptr, *sv_ntt = nullptr;
+  uint64_t* d_query = nullptr;
+  uint32_t staged_nq = 0;
+  std::vector<uint64_t*> lvl;      // per level results
+  std::vector<uint64_t> lvl_rows;  // nodes per level inside the shard
+  uint64_t* pt_buf = nullptr;
+  uint64_t* scan_part = nullptr;
+  uint32_t scan_nsplit = 1, scan_cps = 0, scan_rows = 0, scan_cols = 0;
+  uint64_t scan_npt = 0;
+  bool reply_valid = false;
+
+  bool prof = false;
+  hipEvent_t ev[PH_COUNT + 1]{};
+  bool ev_ready = false;
+  float timings[6]{};
+  bool timings_pending = false;
+
+  std::string err;
+  std::mutex mu;
+
+  template <typename T>
+  T* dalloc(size_t count) {
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    allocs.push_back(p);
+    return static_cast<T*>(p);
+  }
+  void use_device() { HIP_TRY(hipSetDevice(device)); }
+};
+
+namespace {
+
+int fail(pirgpu_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg;
+  return code;
+}
+
+template <typename F>
+int guarded(pirgpu_ctx* c, F&& f) {
+  if (!c) return PIRGPU_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lock(c->mu);
+  try {
+    c->use_device();
+    return f();
+  } catch (const Fail& e) {
+    return fail(c, e.code, e.msg);
+  } catch (const std::exception& e) {
+    return fail(c, PIRGPU_INTERNAL, e.what());
+  }
+}
+
+void build_tables(pirgpu_ctx* c) {
+  const uint32_t N = c->N, k = c->k;
+  DevParams& hp = c->hp;
+  hp.N = N;
+  hp.logN = c->logN;
+  hp.k = k;
+  std::vector<uint64_t> w(N), ws(N), iw(N), iws(N);
+  uint64_t qmax = 0;
+  for (uint32_t i = 0; i <= k; ++i) {
+    const uint64_t q = i < k ? c->prm.coeff_modulus[i] : c->prm.special_prime;
+    qmax = std::max(qmax, q);
+    hp.mod[i].q = q;
+    hm::u128 ratio = (~(hm::u128)0) / q;  // floor((2^128 - 1) / q) == floor(2^128 / q) for odd q > 1
+    hp.mod[i].br_lo = (uint64_t)ratio;
+    hp.mod[i].br_hi = (uint64_t)(ratio >> 64);
+    const uint64_t psi = hm::minimal_primitive_root(2ull * N, q);
+    if (!psi) throw Fail{PIRGPU_INVALID_ARGUMENT, "modulus has no primitive 2N-th root of unity"};
+    const uint64_t ipsi = hm::invmod_prime(psi, q);
+    uint64_t pw = 1, ipw = 1;
+    for (uint32_t j = 0; j < N; ++j) {
+      uint32_t r = hm::bitrev(j, c->logN);
+      w[r] = pw;
+      ws[r] = hm::shoup(pw, q);
+      iw[r] = ipw;
+      iws[r] = hm::shoup(ipw, q);
+      pw = hm::mulmod(pw, psi, q);
+      ipw = hm::mulmod(ipw, ipsi, q);
+    }
+    uint64_t* dev = c->dalloc<uint64_t>((size_t)4 * N);
+    HIP_TRY(hipMemcpy(dev, w.data(), N * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dev + N, ws.data(), N * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dev + 2 * (size_t)N, iw.data(), N * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dev + 3 * (size_t)N, iws.data(), N * 8, hipMemcpyHostToDevice));
+    hp.tab[i].w = dev;
+    hp.tab[i].ws = dev + N;
+    hp.tab[i].iw = dev + 2 * (size_t)N;
+    hp.tab[i].iws = dev + 3 * (size_t)N;
+    hp.tab[i].ninv = hm::invmod_prime(N % q, q);
+    hp.tab[i].ninvs = hm::shoup(hp.tab[i].ninv, q);
+  }
+  const uint64_t p = c->prm.special_prime, t = c->prm.plain_modulus;
+  hp.p_half = p >> 1;
+  hp.t = t;
+  hp.plain_thr = (t + 1) >> 1;
+  for (uint32_t j = 0; j < k; ++j) {
+    const uint64_t q = hp.mod[j].q;
+    hp.p_half_mod[j] = (p >> 1) % q;
+    hp.p_inv[j] = hm::invmod_prime(p % q, q);
+    hp.p_inv_s[j] = hm::shoup(hp.p_inv[j], q);
+    hp.lift_inc[j] = q - (t % q);
+  }
+  // CiphertextReencoder::Encode order (reference ct_reencoder.cpp:49-69)
+  const uint32_t b = hm::bits_per_coeff(t);
+  hp.enc_bits = b;
+  uint32_t e = 0;
+  for (uint32_t poly = 0; poly < 2; ++poly)
+    for (uint32_t j = 0; j < k; ++j) {
+      uint32_t ler = hm::local_expansion_ratio(hp.mod[j].q, b);
+      for (uint32_t i = 0; i < ler; ++i) {
+        if (e >= (uint32_t)kMaxEnc) throw Fail{PIRGPU_INVALID_ARGUMENT, "expansion ratio too large"};
+        hp.enc_poly[e] = (uint8_t)poly;
+        hp.enc_res[e] = (uint8_t)j;
+        hp.enc_shift[e] = (uint8_t)(i * b);
+        ++e;
+      }
+    }
+  hp.enc_count = e;
+  c->E = e;
+  c->er = e / 2;
+  uint32_t qbits = 64 - __builtin_clzll(qmax);
+  int room = 128 - 2 * (int)qbits;
+  hp.lazy_limit = 1u << std::min(30, std::max(0, room));
+  c->dp = c->dalloc<DevParams>(1);
+  HIP_TRY(hipMemcpy(c->dp, &hp, sizeof(DevParams), hipMemcpyHostToDevice));
+}
+
+uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+
+void ensure_workspace(pirgpu_ctx* c) {
+  if (c->ws_ready) return;
+  const uint32_t N = c->N, k = c->k, d = c->d;
+  const size_t ctw = c->ctw;
+  const uint64_t m_max = std::min<uint64_t>(N, hm::next_power_two(std::max<uint32_t>(c->dim_sum, 1)));
+  c->res_a = c->dalloc<uint64_t>(m_max * ctw);
+  c->res_b = c->dalloc<uint64_t>(m_max * ctw);
+  c->prod = c->dalloc<uint64_t>(std::max<uint64_t>(m_max / 2, 1) * 2 * (k + 1) * N);
+  c->sv_ntt = c->dalloc<uint64_t>((size_t)std::max<uint32_t>(c->dim_sum, 1) * ctw);
+  c->d_query = c->dalloc<uint64_t>((size_t)(c->dim_sum / N + 1) * ctw);
+  // per-level node counts inside this shard and result buffers
+  const uint64_t shard_pts = c->pt_end - c->pt_begin;
+  c->lvl.assign(d, nullptr);
+  c->lvl_rows.assign(d, 0);
+  uint64_t pt_words = 0;
+  for (uint32_t l = 0; l < d; ++l) {
+    uint64_t rows = l == 0 ? 1 : ceil_div(shard_pts, c->stride[l]);
+    uint64_t C = 1;
+    for (uint32_t x = l; x + 1 < d; ++x) C *= c->E;
+    c->lvl_rows[l] = rows;
+    c->lvl[l] = c->dalloc<uint64_t>(std::max<uint64_t>(rows, 1) * C * ctw);
+    if (l + 1 < d) {
+      uint64_t nch = ceil_div(shard_pts, c->stride[l + 1]);
+      uint64_t Cc = C / c->E;
+      pt_words = std::max<uint64_t>(pt_words, nch * Cc * c->E * k * N);
+    }
+  }
+  if (pt_words) c->pt_buf = c->dalloc<uint64_t>(pt_words);
+  // base-level scan geometry
+  if (d == 1) {
+    c->scan_rows = 1;
+    c->scan_cols = (uint32_t)shard_pts;
+  } else {
+    c->scan_cols = c->dims[d - 1];
+    c->scan_rows = (uint32_t)ceil_div(shard_pts, c->scan_cols);
+  }
+  c->scan_npt = shard_pts;
+  {
+    const uint32_t xblocks = (k * N / 2 + 255) / 256;
+    const uint32_t yblocks = (c->scan_rows + 3) / 4;
+    uint64_t have = (uint64_t)xblocks * std::max<uint32_t>(yblocks, 1);
+    uint32_t want = have >= 1024 ? 1 : (uint32_t)ceil_div(1024, have);
+    want = std::min<uint32_t>(want, std::max<uint32_t>(c->scan_cols, 1));
+    c->scan_cps = (uint32_t)ceil_div(std::max<uint32_t>(c->scan_cols, 1), want);
+    c->scan_nsplit = (uint32_t)ceil_div(std::max<uint32_t>(c->scan_cols, 1), c->scan_cps);
+    if (c->scan_nsplit > 1)
+      c->scan_part = c->dalloc<uint64_t>((size_t)c->scan_nsplit * std::max<uint32_t>(c->scan_rows, 1) * ctw);
+  }
+  for (int i = 0; i <= PH_COUNT; ++i) HIP_TRY(hipEventCreate(&c->ev[i]));
+  c->ev_ready = true;
+  c->ws_ready = true;
+}
+
+uint32_t galois_inverse(uint32_t g, uint32_t N) {
+  // (Z/2N)^* has exponent dividing N, so g^-1 = g^(N-1) mod 2N
+  uint64_t mod = 2ull * N, r = 1, b = g % mod;
+  uint32_t e = N - 1;
+  while (e) {
+    if (e & 1) r = (r * b) % mod;
+    b = (b * b) % mod;
+    e >>= 1;
+  }
+  return (uint32_t)r;
+}
+
+const uint64_t* find_key(pirgpu_ctx* c, uint32_t g) {
+  auto it = c->keys.find(g);
+  if (it == c->keys.end())
+    throw Fail{PIRGPU_INTERNAL, "Galois key not present"};  // SEAL throws -> InternalError (server.cpp:72-74)
+  return it->second;
+}
+
+void record(pirgpu_ctx* c, int idx) {
+  if (c->prof) HIP_TRY(hipEventRecord(c->ev[idx], c->stream));
+}
+
+// oblivious_expansion(ct, n) on the device (reference server.cpp:105-146).
+// Input ciphertext must already be in res_a[0]; returns the buffer holding the
+// next_power_two(n) results.
+uint64_t* expand_on_device(pirgpu_ctx* c, uint32_t n) {
+  const uint32_t N = c->N, k = c->k;
+  if (n > N) throw Fail{PIRGPU_INVALID_ARGUMENT, "Cannot expand more items from a CT than poly modulus degree"};
+  const uint32_t logm = hm::ceil_log2(n);
+  uint64_t *cur = c->res_a, *nxt = c->res_b;
+  for (uint32_t j = 0; j < logm; ++j) {
+    const uint32_t g = (N >> j) + 1;
+    const uint64_t* key = find_key(c, g);
+    HIP_TRY(launch_ks_level(c->stream, c->dp, N, k, cur, key, g, galois_inverse(g, N), 1u << j, 1u << j, true,
+                            c->prod, nxt));
+    std::swap(cur, nxt);
+  }
+  return cur;
+}
+
+// expansion of all staged query ciphertexts into sv_ntt (NTT form) -- reference
+// server.cpp:148-171 followed by the lazy transform_to_ntt_inplace of
+// database.cpp:190,222 applied to every selector.
+void expand_query_to_sv(pirgpu_ctx* c, const uint64_t* d_query, uint32_t nq, uint64_t* coeff_out_host) {
+  const uint32_t N = c->N, k = c->k;
+  const size_t ctw = c->ctw;
+  uint64_t remaining = c->dim_sum;
+  uint64_t produced = 0;
+  for (uint32_t q = 0; q < nq; ++q) {
+    uint32_t n = (uint32_t)std::min<uint64_t>(remaining, N);
+    if (n > 0) {
+      HIP_TRY(hipMemcpyAsync(c->res_a, d_query + (size_t)q * ctw, ctw * 8, hipMemcpyDeviceToDevice, c->stream));
+      uint64_t* res = expand_on_device(c, n);
+      if (coeff_out_host) {
+        HIP_TRY(hipMemcpyAsync(coeff_out_host + produced * ctw, res, (size_t)n * ctw * 8, hipMemcpyDeviceToHost,
+                               c->stream));
+      } else {
+        HIP_TRY(launch_ct_ntt_fwd_oop(c->stream, c->dp, N, k, res, c->sv_ntt + produced * ctw, n));
+      }
+    }
+    produced += n;
+    remaining -= n;
+    if (remaining == 0) break;
+  }
+}
+
+// PIRDatabase::multiply on the device (reference database.cpp:170-258), with the
+// selection vector already in NTT form in sv_ntt.  Leaves the reply in lvl[0].
+void multiply_on_device(pirgpu_ctx* c) {
+  const uint32_t N = c->N, k = c->k, d = c->d;
+  const size_t ctw = c->ctw;
+  if (c->n_loaded != c->pt_end - c->pt_begin)
+    throw Fail{PIRGPU_FAILED_PRECONDITION, "database not fully loaded"};
+  const uint64_t shard_pts = c->pt_end - c->pt_begin;
+  if (shard_pts == 0) {
+    HIP_TRY(hipMemsetAsync(c->lvl[0], 0, c->reply_cts * ctw * 8, c->stream));
+    return;
+  }
+  // base case: one fused multiply_plain + add_inplace pass over the database
+  const uint64_t* sv_base = c->sv_ntt + (size_t)c->sv_off[d - 1] * ctw + (d == 1 ? (size_t)c->sb * ctw : 0);
+  uint64_t* base_out = c->lvl[d - 1];
+  uint64_t* scan_out = c->scan_nsplit > 1 ? c->scan_part : base_out;
+  HIP_TRY(launch_scan(c->stream, c->dp, N, k, c->d_db, sv_base, scan_out, c->scan_rows, c->scan_cols, c->scan_npt,
+                      c->scan_nsplit, c->scan_cps));
+  if (c->scan_nsplit > 1)
+    HIP_TRY(launch_reduce_splits(c->stream, c->dp, c->scan_part, c->scan_nsplit, (uint64_t)c->scan_rows * ctw,
+                                 base_out));
+  record(c, PH_UPPER);  // end of scan phase
+  HIP_TRY(launch_ntt_batch(c->stream, c->dp, N, base_out, (uint64_t)c->scan_rows * 2 * k, k, 0, true));
+  // upper levels
+  uint64_t C = 1;  // ciphertexts per child
+  for (int l = (int)d - 2; l >= 0; --l) {
+    const uint64_t nch = ceil_div(shard_pts, c->stride[l + 1]);
+    const uint64_t rows = c->lvl_rows[l];
+    HIP_TRY(launch_reencode_lift_ntt(c->stream, c->dp, N, k, c->E, c->lvl[l + 1], nch * C, c->pt_buf));
+    const uint32_t sv_first = c->sv_off[l] + (l == 0 ? c->sb : 0);
+    HIP_TRY(launch_upper_mac(c->stream, c->dp, N, k, c->E, c->sv_ntt, c->pt_buf, (uint32_t)rows, c->dims[l],
+                             (uint32_t)nch, sv_first, (uint32_t)C, c->lvl[l]));
+    if (l == 0) record(c, PH_FINAL);
+    HIP_TRY(launch_ntt_batch(c->stream, c->dp, N, c->lvl[l], rows * C * c->E * 2 * k, k, 0, true));
+    C *= c->E;
+  }
+  if (d == 1) record(c, PH_FINAL);
+}
+
+void run_staged(pirgpu_ctx* c) {
+  ensure_workspace(c);
+  if (c->staged_nq != c->dim_sum / c->N + 1)
+    throw Fail{PIRGPU_INVALID_ARGUMENT,
+               "Number of ciphertexts doesn't match number of items for oblivious expansion."};
+  record(c, PH_EXPAND);
+  // expansion and selection-vector NTT are interleaved per query ciphertext; the
+  // PH_SVNTT mark is taken after the last expansion level of the last ciphertext.
+  expand_query_to_sv(c, c->d_query, c->staged_nq, nullptr);
+  record(c, PH_SVNTT);
+  record(c, PH_SCAN);
+  multiply_on_device(c);
+  record(c, PH_COUNT);
+  c->reply_valid = true;
+  c->timings_pending = c->prof;
+}
+
+}  // namespace
+
+// =============================================================================
+// C ABI
+// =============================================================================
+
+extern "C" {
+
+const char* pirgpu_create_error(void) { return g_create_error.c_str(); }
+
+int pirgpu_create(const pirgpu_params* p, pirgpu_ctx** out) {
+  if (!p || !out) return PIRGPU_INVALID_ARGUMENT;
+  *out = nullptr;
+  pirgpu_ctx* c = new pirgpu_ctx();
+  auto bail = [&](int code, const std::string& msg) {
+    g_create_error = msg;
+    pirgpu_destroy(c);
+    return code;
+  };
+  try {
+    c->prm = *p;
+    const uint32_t N = p->poly_modulus_degree, k = p->num_data_primes;
+    if (N < 1024 || N > 16384 || (N & (N - 1)))
+      return bail(PIRGPU_INVALID_ARGUMENT, "poly_modulus_degree must be a power of two in [1024, 16384]");
+    if (k < 1 || k > PIRGPU_MAX_PRIMES) return bail(PIRGPU_INVALID_ARGUMENT, "invalid number of data primes");
+    if (p->use_ciphertext_multiplication)
+      return bail(PIRGPU_UNIMPLEMENTED,
+                  "use_ciphertext_multiplication is not supported by the MI355X path (decomposition mode only)");
+    if (p->special_prime == 0)
+      return bail(PIRGPU_INVALID_ARGUMENT, "a key-switching special prime is required (SEAL: keyswitching unsupported)");
+    for (uint32_t i = 0; i <= k; ++i) {
+      uint64_t q = i < k ? p->coeff_modulus[i] : p->special_prime;
+      if (q >> 61 || q < 2 || !hm::is_prime(q) || (q - 1) % (2ull * N))
+        return bail(PIRGPU_INVALID_ARGUMENT, "coeff modulus must be a prime < 2^61 congruent to 1 mod 2N");
+      for (uint32_t j = 0; j < i; ++j)
+        if (p->coeff_modulus[j] == q) return bail(PIRGPU_INVALID_ARGUMENT, "coeff moduli must be distinct");
+    }
+    if (p->plain_modulus < 2 || p->plain_modulus >> 60)
+      return bail(PIRGPU_INVALID_ARGUMENT, "invalid plain modulus");
+    if (p->num_dimensions < 1 || p->num_dimensions > PIRGPU_MAX_DIMS)
+      return bail(PIRGPU_INVALID_ARGUMENT, "invalid number of dimensions");
+    c->N = N;
+    c->k = k;
+    while ((1u << c->logN) < N) ++c->logN;
+    c->ctw = (size_t)2 * k * N;
+    c->d = p->num_dimensions;
+    c->P = p->num_pt;
+    uint64_t ds = 0;
+    for (uint32_t l = 0; l < c->d; ++l) {
+      c->dims[l] = p->dimensions[l];
+      if (c->dims[l] == 0) return bail(PIRGPU_INVALID_ARGUMENT, "dimension of size 0");
+      c->sv_off[l] = (uint32_t)ds;
+      ds += c->dims[l];
+    }
+    c->sv_off[c->d] = (uint32_t)ds;
+    if (ds > (1ull << 24)) return bail(PIRGPU_INVALID_ARGUMENT, "dimension sum too large");
+    c->dim_sum = (uint32_t)ds;
+    c->stride[c->d] = 1;
+    for (int l = (int)c->d - 1; l >= 0; --l) c->stride[l] = c->stride[l + 1] * c->dims[l];
+    c->sb = p->shard_begin;
+    c->se = p->shard_end;
+    if (c->sb == 0 && c->se == 0) c->se = c->dims[0];
+    if (c->sb > c->se || c->se > c->dims[0]) return bail(PIRGPU_INVALID_ARGUMENT, "invalid shard range");
+    c->pt_begin = std::min<uint64_t>((uint64_t)c->sb * c->stride[1], c->P);
+    c->pt_end = std::min<uint64_t>((uint64_t)c->se * c->stride[1], c->P);
+    const uint32_t bdef = hm::bits_per_coeff(p->plain_modulus);
+    if (p->bits_per_coeff > bdef) return bail(PIRGPU_INVALID_ARGUMENT, "Bits per coefficient greater than max");
+    c->bits = p->bits_per_coeff ? p->bits_per_coeff : bdef;
+    c->device = p->device;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+      return bail(PIRGPU_INTERNAL, "no HIP device available (libpirgpu has no CPU fallback)");
+    if (c->device < 0 || c->device >= ndev) return bail(PIRGPU_INVALID_ARGUMENT, "invalid device ordinal");
+    c->use_device();
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(configure_kernels(N));
+    build_tables(c);
+    c->reply_cts = 1;
+    for (uint32_t l = 1; l < c->d; ++l) c->reply_cts *= c->E;
+    const uint64_t shard_pts = c->pt_end - c->pt_begin;
+    c->d_db = c->dalloc<uint64_t>(shard_pts * k * N);
+    c->loaded.assign(shard_pts, 0);
+  } catch (const Fail& e) {
+    return bail(e.code, e.msg);
+  } catch (const std::exception& e) {
+    return bail(PIRGPU_INTERNAL, e.what());
+  }
+  *out = c;
+  return PIRGPU_OK;
+}
+
+void pirgpu_destroy(pirgpu_ctx* c) {
+  if (!c) return;
+  if (c->stream) {
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+  }
+  for (auto& kv : c->keys) (void)hipFree(kv.second);
+  for (void* p : c->allocs) (void)hipFree(p);
+  if (c->ev_ready)
+    for (int i = 0; i <= PH_COUNT; ++i) (void)hipEventDestroy(c->ev[i]);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* pirgpu_last_error(const pirgpu_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+uint64_t pirgpu_db_size(const pirgpu_ctx* c) { return c ? c->n_loaded : 0; }
+uint64_t pirgpu_reply_ct_count(const pirgpu_ctx* c) { return c ? c->reply_cts : 0; }
+uint32_t pirgpu_expansion_ratio(const pirgpu_ctx* c) { return c ? c->er : 0; }
+uint64_t pirgpu_scan_bytes(const pirgpu_ctx* c) { return c ? (c->pt_end - c->pt_begin) * c->k * c->N * 8 : 0; }
+
+int pirgpu_db_load_items(pirgpu_ctx* c, const uint8_t* items, uint64_t num_items, uint32_t bytes_per_item) {
+  return guarded(c, [&]() -> int {
+    const pirgpu_params& p = c->prm;
+    if (num_items != p.num_items)  // reference database.cpp:85-90
+      return fail(c, PIRGPU_INVALID_ARGUMENT,
+                  "Database size " + std::to_string(num_items) + " does not match params value " +
+                      std::to_string(p.num_items));
+    if (bytes_per_item != p.bytes_per_item || p.items_per_plaintext == 0 || (!items && num_items))
+      return fail(c, PIRGPU_INVALID_ARGUMENT, "item size does not match parameters");
+    const uint64_t ipp = p.items_per_plaintext;
+    const uint64_t bytes_per_pt = ipp * bytes_per_item;
+    // StringEncoder::calc_num_coeff (reference string_encoder.cpp:88-95)
+    if ((uint64_t)std::ceil((double)(bytes_per_pt * 8) / c->bits) > c->N)
+      return fail(c, PIRGPU_INVALID_ARGUMENT, "Number of coefficients needed greater than poly modulus degree");
+    if (ceil_div(num_items, ipp) > c->P) return fail(c, PIRGPU_INVALID_ARGUMENT, "more items than plaintexts");
+    const uint64_t total_bytes = num_items * bytes_per_item;
+    const uint64_t chunk_pts = std::max<uint64_t>(1, (64ull << 20) / std::max<uint64_t>(bytes_per_pt, 1));
+    uint8_t* d_bytes = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_bytes, chunk_pts * bytes_per_pt));
+    try {
+      for (uint64_t pt = c->pt_begin; pt < c->pt_end; pt += chunk_pts) {
+        const uint64_t n = std::min<uint64_t>(chunk_pts, c->pt_end - pt);
+        const uint64_t b0 = std::min<uint64_t>(pt * bytes_per_pt, total_bytes);
+        const uint64_t b1 = std::min<uint64_t>((pt + n) * bytes_per_pt, total_bytes);
+        if (b1 > b0) HIP_TRY(hipMemcpyAsync(d_bytes, items + b0, b1 - b0, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(launch_db_encode(c->stream, c->dp, c->N, c->k, nullptr, d_bytes, bytes_per_pt, b1 - b0, c->bits, n,
+                                 c->d_db + (pt - c->pt_begin) * c->k * c->N));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (uint64_t i = 0; i < n; ++i)
+          if (!c->loaded[pt - c->pt_begin + i]) {
+            c->loaded[pt - c->pt_begin + i] = 1;
+            ++c->n_loaded;
+          }
+      }
+    } catch (...) {
+      (void)hipFree(d_bytes);
+      throw;
+    }
+    HIP_TRY(hipFree(d_bytes));
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_db_load_coeffs(pirgpu_ctx* c, uint64_t first_pt, uint64_t n_pt, const uint64_t* coeffs) {
+  return guarded(c, [&]() -> int {
+    if (first_pt + n_pt > c->P || (!coeffs && n_pt)) return fail(c, PIRGPU_INVALID_ARGUMENT, "plaintext range out of bounds");
+    const uint64_t lo = std::max(first_pt, c->pt_begin), hi = std::min(first_pt + n_pt, c->pt_end);
+    if (lo >= hi) return PIRGPU_OK;
+    const uint64_t chunk = std::max<uint64_t>(1, (64ull << 20) / (c->N * 8));
+    uint64_t* d_coeffs = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_coeffs, chunk * c->N * 8));
+    try {
+      for (uint64_t pt = lo; pt < hi; pt += chunk) {
+        const uint64_t n = std::min<uint64_t>(chunk, hi - pt);
+        HIP_TRY(hipMemcpyAsync(d_coeffs, coeffs + (pt - first_pt) * c->N, n * c->N * 8, hipMemcpyHostToDevice,
+                               c->stream));
+        HIP_TRY(launch_db_encode(c->stream, c->dp, c->N, c->k, d_coeffs, nullptr, 0, 0, c->bits, n,
+                                 c->d_db + (pt - c->pt_begin) * c->k * c->N));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (uint64_t i = 0; i < n; ++i)
+          if (!c->loaded[pt - c->pt_begin + i]) {
+            c->loaded[pt - c->pt_begin + i] = 1;
+            ++c->n_loaded;
+          }
+      }
+    } catch (...) {
+      (void)hipFree(d_coeffs);
+      throw;
+    }
+    HIP_TRY(hipFree(d_coeffs));
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_db_read_plaintext(pirgpu_ctx* c, uint64_t pt_index, uint64_t* out) {
+  return guarded(c, [&]() -> int {
+    if (pt_index < c->pt_begin || pt_index >= c->pt_end || !out)
+      return fail(c, PIRGPU_INVALID_ARGUMENT, "plaintext index outside this shard");
+    HIP_TRY(hipMemcpy(out, c->d_db + (pt_index - c->pt_begin) * c->k * c->N, (size_t)c->k * c->N * 8,
+                      hipMemcpyDeviceToHost));
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_set_galois_key(pirgpu_ctx* c, uint32_t g, const uint64_t* key) {
+  return guarded(c, [&]() -> int {
+    if (!key || !(g & 1) || g >= 2 * c->N) return fail(c, PIRGPU_INVALID_ARGUMENT, "invalid Galois element");
+    const size_t words = (size_t)c->k * 2 * (c->k + 1) * c->N;
+    uint64_t* dev = nullptr;
+    auto it = c->keys.find(g);
+    if (it != c->keys.end()) {
+      dev = it->second;
+    } else {
+      HIP_TRY(hipMalloc((void**)&dev, words * 8));
+      c->keys[g] = dev;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(dev, key, words * 8, hipMemcpyHostToDevice));
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_clear_galois_keys(pirgpu_ctx* c) {
+  return guarded(c, [&]() -> int {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (auto& kv : c->keys) HIP_TRY(hipFree(kv.second));
+    c->keys.clear();
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_query_stage(pirgpu_ctx* c, const uint64_t* query, uint32_t nq) {
+  return guarded(c, [&]() -> int {
+    ensure_workspace(c);
+    if (!query || nq != c->dim_sum / c->N + 1)  // reference server.cpp:154-158
+      return fail(c, PIRGPU_INVALID_ARGUMENT,
+                  "Number of ciphertexts doesn't match number of items for oblivious expansion.");
+    HIP_TRY(hipMemcpyAsync(c->d_query, query, (size_t)nq * c->ctw * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->staged_nq = nq;
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_query_run(pirgpu_ctx* c) {
+  return guarded(c, [&]() -> int {
+    run_staged(c);
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_sync(pirgpu_ctx* c) {
+  return guarded(c, [&]() -> int {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_query_fetch(pirgpu_ctx* c, uint64_t* reply, uint64_t cap, uint64_t* count) {
+  return guarded(c, [&]() -> int {
+    if (!c->reply_valid) return fail(c, PIRGPU_FAILED_PRECONDITION, "no query has been run");
+    if (!reply || cap < c->reply_cts) return fail(c, PIRGPU_INVALID_ARGUMENT, "reply buffer too small");
+    HIP_TRY(hipMemcpyAsync(reply, c->lvl[0], c->reply_cts * c->ctw * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (count) *count = c->reply_cts;
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_process_query(pirgpu_ctx* c, const uint64_t* query, uint32_t nq, uint64_t* reply, uint64_t cap,
+                         uint64_t* count) {
+  int rc = pirgpu_query_stage(c, query, nq);
+  if (rc) return rc;
+  rc = pirgpu_query_run(c);
+  if (rc) return rc;
+  return pirgpu_query_fetch(c, reply, cap, count);
+}
+
+uint64_t* pirgpu_reply_device_ptr(pirgpu_ctx* c) { return (c && c->ws_ready) ? c->lvl[0] : nullptr; }
+
+int pirgpu_expand(pirgpu_ctx* c, const uint64_t* ct, uint32_t num_items, uint64_t* out) {
+  return guarded(c, [&]() -> int {
+    ensure_workspace(c);
+    if (!ct || (!out && num_items)) return fail(c, PIRGPU_INVALID_ARGUMENT, "null buffer");
+    if (num_items > c->N)
+      return fail(c, PIRGPU_INVALID_ARGUMENT, "Cannot expand more items from a CT than poly modulus degree");
+    // the shared workspace is sized for this context's dim_sum
+    const uint64_t m_max = std::min<uint64_t>(c->N, hm::next_power_two(std::max<uint32_t>(c->dim_sum, 1)));
+    if (hm::next_power_two(num_items) > m_max)
+      return fail(c, PIRGPU_INVALID_ARGUMENT, "num_items exceeds this context's expansion workspace");
+    HIP_TRY(hipMemcpyAsync(c->res_a, ct, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
+    uint64_t* res = expand_on_device(c, num_items);
+    if (num_items)
+      HIP_TRY(hipMemcpyAsync(out, res, (size_t)num_items * c->ctw * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_expand_multi(pirgpu_ctx* c, const uint64_t* cts, uint32_t num_cts, uint64_t total_items, uint64_t* out) {
+  return guarded(c, [&]() -> int {
+    ensure_workspace(c);
+    if (!cts || !out) return fail(c, PIRGPU_INVALID_ARGUMENT, "null buffer");
+    if (num_cts != total_items / c->N + 1)  // reference server.cpp:154-158
+      return fail(c, PIRGPU_INVALID_ARGUMENT,
+                  "Number of ciphertexts doesn't match number of items for oblivious expansion.");
+    const uint64_t m_max = std::min<uint64_t>(c->N, hm::next_power_two(std::max<uint32_t>(c->dim_sum, 1)));
+    uint64_t remaining = total_items, produced = 0;
+    for (uint32_t q = 0; q < num_cts && remaining; ++q) {
+      uint32_t n = (uint32_t)std::min<uint64_t>(remaining, c->N);
+      if (hm::next_power_two(n) > m_max)
+        return fail(c, PIRGPU_INVALID_ARGUMENT, "total_items exceeds this context's expansion workspace");
+      HIP_TRY(hipMemcpyAsync(c->res_a, cts + (size_t)q * c->ctw, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
+      uint64_t* res = expand_on_device(c, n);
+      HIP_TRY(hipMemcpyAsync(out + produced * c->ctw, res, (size_t)n * c->ctw * 8, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      produced += n;
+      remaining -= n;
+    }
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_substitute_power_x(pirgpu_ctx* c, uint64_t* ct, uint32_t power) {
+  return guarded(c, [&]() -> int {
+    ensure_workspace(c);
+    if (!ct) return fail(c, PIRGPU_INVALID_ARGUMENT, "null buffer");
+    if (!(power & 1) || power >= 2 * c->N)  // SEAL: "Galois element is not valid" -> InternalError
+      return fail(c, PIRGPU_INTERNAL, "Galois element is not valid");
+    const uint64_t* key = find_key(c, power);
+    HIP_TRY(hipMemcpyAsync(c->res_a, ct, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_ks_level(c->stream, c->dp, c->N, c->k, c->res_a, key, power, galois_inverse(power, c->N), 1, 0,
+                            false, c->prod, c->res_b));
+    HIP_TRY(hipMemcpyAsync(ct, c->res_b, c->ctw * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_multiply_inverse_power_of_x(pirgpu_ctx* c, const uint64_t* ct, uint32_t kpow, uint64_t* out) {
+  return guarded(c, [&]() -> int {
+    ensure_workspace(c);
+    if (!ct || !out) return fail(c, PIRGPU_INVALID_ARGUMENT, "null buffer");
+    const uint32_t twoN = 2 * c->N;
+    const uint32_t index = (twoN - (kpow % twoN)) % twoN;  // reference server.cpp:87-88
+    HIP_TRY(hipMemcpyAsync(c->res_a, ct, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_monomial_shift(c->stream, c->dp, c->N, c->k, c->res_a, index, 1, c->res_b));
+    HIP_TRY(hipMemcpyAsync(out, c->res_b, c->ctw * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_multiply(pirgpu_ctx* c, const uint64_t* sv, uint64_t sv_count, uint64_t* reply, uint64_t cap,
+                    uint64_t* count) {
+  return guarded(c, [&]() -> int {
+    ensure_workspace(c);
+    if (sv_count != c->dim_sum)  // reference database.cpp:297-300
+      return fail(c, PIRGPU_INVALID_ARGUMENT, "Selection vector size does not match dimensions");
+    if (!sv || !reply || cap < c->reply_cts) return fail(c, PIRGPU_INVALID_ARGUMENT, "reply buffer too small");
+    // stage the coefficient-form selectors through res_a in workspace-sized pieces
+    const uint64_t m_max = std::min<uint64_t>(c->N, hm::next_power_two(std::max<uint32_t>(c->dim_sum, 1)));
+    for (uint64_t s = 0; s < sv_count; s += m_max) {
+      const uint64_t n = std::min<uint64_t>(m_max, sv_count - s);
+      HIP_TRY(hipMemcpyAsync(c->res_a, sv + s * c->ctw, n * c->ctw * 8, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(launch_ct_ntt_fwd_oop(c->stream, c->dp, c->N, c->k, c->res_a, c->sv_ntt + s * c->ctw, n));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    const bool prof = c->prof;
+    c->prof = false;
+    multiply_on_device(c);
+    c->prof = prof;
+    HIP_TRY(hipMemcpyAsync(reply, c->lvl[0], c->reply_cts * c->ctw * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (count) *count = c->reply_cts;
+    return PIRGPU_OK;
+  });
+}
+
+static int ntt_hook(pirgpu_ctx* c, uint64_t* polys, uint64_t count, int key_level, bool inverse) {
+  return guarded(c, [&]() -> int {
+    if (!polys && count) return fail(c, PIRGPU_INVALID_ARGUMENT, "null buffer");
+    const uint32_t per = key_level ? c->k + 1 : c->k;
+    const uint64_t npoly = key_level ? count * per : count * 2 * per;
+    uint64_t* dev = nullptr;
+    HIP_TRY(hipMalloc((void**)&dev, std::max<uint64_t>(npoly, 1) * c->N * 8));
+    try {
+      HIP_TRY(hipMemcpyAsync(dev, polys, npoly * c->N * 8, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(launch_ntt_batch(c->stream, c->dp, c->N, dev, npoly, per, 0, inverse));
+      HIP_TRY(hipMemcpyAsync(polys, dev, npoly * c->N * 8, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+    } catch (...) {
+      (void)hipFree(dev);
+      throw;
+    }
+    HIP_TRY(hipFree(dev));
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_ntt_forward(pirgpu_ctx* c, uint64_t* polys, uint64_t count, int key_level) {
+  return ntt_hook(c, polys, count, key_level, false);
+}
+int pirgpu_ntt_inverse(pirgpu_ctx* c, uint64_t* polys, uint64_t count, int key_level) {
+  return ntt_hook(c, polys, count, key_level, true);
+}
+
+int pirgpu_reduce_fixup_device(pirgpu_ctx* c, uint64_t* device_ptr, uint64_t count) {
+  return guarded(c, [&]() -> int {
+    if (!device_ptr) return fail(c, PIRGPU_INVALID_ARGUMENT, "null buffer");
+    HIP_TRY(launch_reduce_splits(c->stream, c->dp, device_ptr, 1, count * c->ctw, device_ptr));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_set_profiling(pirgpu_ctx* c, int enabled) {
+  return guarded(c, [&]() -> int {
+    c->prof = enabled != 0;
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_last_timings(pirgpu_ctx* c, float ms[6]) {
+  return guarded(c, [&]() -> int {
+    if (!ms) return fail(c, PIRGPU_INVALID_ARGUMENT, "null buffer");
+    if (c->timings_pending) {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      // events: [EXPAND] start, [SVNTT] end of expansion+sv ntt, [SCAN] scan start, [UPPER] scan end,
+      //         [FINAL] last upper mac end, [COUNT] end
+      float t01, t23, t34, t45, total;
+      HIP_TRY(hipEventElapsedTime(&t01, c->ev[PH_EXPAND], c->ev[PH_SVNTT]));
+      HIP_TRY(hipEventElapsedTime(&t23, c->ev[PH_SCAN], c->ev[PH_UPPER]));
+      HIP_TRY(hipEventElapsedTime(&t34, c->ev[PH_UPPER], c->ev[PH_FINAL]));
+      HIP_TRY(hipEventElapsedTime(&t45, c->ev[PH_FINAL], c->ev[PH_COUNT]));
+      HIP_TRY(hipEventElapsedTime(&total, c->ev[PH_EXPAND], c->ev[PH_COUNT]));
+      c->timings[0] = t01;
+      c->timings[1] = 0.f;  // selection-vector NTT is interleaved with expansion per query ciphertext
+      c->timings[2] = t23;
+      c->timings[3] = t34;
+      c->timings[4] = t45;
+      c->timings[5] = total;
+      c->timings_pending = false;
+    }
+    memcpy(ms, c->timings, sizeof(c->timings));
+    return PIRGPU_OK;
+  });
+}
+
+void pirgpu_free(void* p) { free(p); }
+
+}  // extern "C"

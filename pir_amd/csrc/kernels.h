@@ -1,0 +1,35 @@
+// kernels.h -- launch wrappers of the gfx950 kernels (see kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_params.h"
+
+namespace pirgpu {
+
+hipError_t configure_kernels(uint32_t N);
+
+hipError_t launch_ntt_batch(hipStream_t st, const DevParams* P, uint32_t N, uint64_t* data, uint64_t n_polys,
+                            uint32_t mod_period, uint32_t mod_base, bool inverse);
+hipError_t launch_ct_ntt_fwd_oop(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* src,
+                                 uint64_t* dst, uint64_t n_cts);
+hipError_t launch_db_encode(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* coeffs,
+                            const uint8_t* bytes, uint64_t bytes_per_pt, uint64_t total_bytes, uint32_t bits,
+                            uint64_t n_pt, uint64_t* db);
+hipError_t launch_ks_level(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* res_in,
+                           const uint64_t* key, uint32_t galois_elt, uint32_t galois_inv, uint32_t nodes,
+                           uint32_t shift_pow, bool expand_step, uint64_t* prod, uint64_t* res_out);
+hipError_t launch_monomial_shift(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* in,
+                                 uint32_t shift, uint64_t count, uint64_t* out);
+hipError_t launch_scan(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* db,
+                       const uint64_t* sv, uint64_t* out, uint32_t rows, uint32_t cols, uint64_t num_pt,
+                       uint32_t nsplit, uint32_t cols_per_split);
+hipError_t launch_reduce_splits(hipStream_t st, const DevParams* P, const uint64_t* part, uint32_t nsplit,
+                                uint64_t words, uint64_t* out);
+hipError_t launch_reencode_lift_ntt(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, uint32_t enc_count,
+                                    const uint64_t* src, uint64_t n_src, uint64_t* pt);
+hipError_t launch_upper_mac(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, uint32_t enc_count,
+                            const uint64_t* sv, const uint64_t* pt, uint32_t n_rows, uint32_t n_dim,
+                            uint32_t n_children_total, uint32_t sv_first, uint32_t C, uint64_t* out);
+
+}  // namespace pirgpu

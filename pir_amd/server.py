@@ -1,0 +1,285 @@
+"""Host-side mirror of the reference's PIRDatabase / PIRServer (pir/cpp/database.h, server.h)
+over the C ABI.  Method names, argument meaning and error codes follow the reference; SEAL
+objects are replaced by numpy residue arrays in SEAL's layout:
+
+    ciphertext  uint64[2, k, N]         Galois key  uint64[k, 2, k+1, N] (NTT form)
+
+All arithmetic runs in libpirgpu.so on the GPU; nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from typing import Dict, Iterable, List, Optional, Sequence, Union
+
+import numpy as np
+
+from . import capi
+from .parameters import PIRParameters, calculate_dimensions
+
+
+class StatusCode(enum.IntEnum):
+    """absl::StatusCode values the reference returns on this path."""
+    OK = 0
+    INVALID_ARGUMENT = 3
+    FAILED_PRECONDITION = 9
+    UNIMPLEMENTED = 12
+    INTERNAL = 13
+
+
+class PirGpuError(Exception):
+    def __init__(self, code: int, message: str):
+        super().__init__("%s: %s" % (StatusCode(code).name if code in StatusCode._value2member_map_ else code,
+                                     message))
+        self.code = code
+        self.message = message
+
+
+def _u64(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(capi.u64p)
+
+
+class PIRDatabase:
+    """reference database.h:37-133.  Owns the device context and the HBM-resident encoded database."""
+
+    def __init__(self, params: PIRParameters, device: int = 0, shard: Optional[Sequence[int]] = None):
+        self.params = params
+        enc = params.encryption_parameters
+        self.N = enc.poly_modulus_degree
+        self.k = len(enc.coeff_modulus) - 1
+        self.lib = capi.load()
+        p = capi.Params()
+        p.poly_modulus_degree = self.N
+        p.num_data_primes = self.k
+        for i, q in enumerate(enc.coeff_modulus[:-1]):
+            p.coeff_modulus[i] = q
+        p.special_prime = enc.coeff_modulus[-1] if len(enc.coeff_modulus) > 1 else 0
+        p.plain_modulus = enc.plain_modulus
+        p.num_dimensions = len(params.dimensions)
+        for i, d in enumerate(params.dimensions):
+            p.dimensions[i] = d
+        p.num_pt = params.num_pt
+        p.num_items = params.num_items
+        p.bytes_per_item = params.bytes_per_item
+        p.items_per_plaintext = params.items_per_plaintext
+        p.bits_per_coeff = params.bits_per_coeff
+        p.use_ciphertext_multiplication = 1 if params.use_ciphertext_multiplication else 0
+        p.device = device
+        if shard is not None:
+            p.shard_begin, p.shard_end = int(shard[0]), int(shard[1])
+        self._cparams = p
+        h = C.c_void_p()
+        rc = self.lib.pirgpu_create(C.byref(p), C.byref(h))
+        if rc != 0:
+            raise PirGpuError(rc, self.lib.pirgpu_create_error().decode())
+        self._h = h
+
+    # -- lifetime ---------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.pirgpu_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise PirGpuError(rc, self.lib.pirgpu_last_error(self._h).decode())
+
+    @property
+    def handle(self):
+        return self._h
+
+    # -- reference interface ------------------------------------------------------
+    @classmethod
+    def Create(cls, params: PIRParameters, rawdb=None, device: int = 0, shard=None) -> "PIRDatabase":
+        """database.cpp:40-58: Create(params) / Create(rawdb, params)."""
+        db = cls(params, device=device, shard=shard)
+        if rawdb is not None:
+            db.populate(rawdb)
+        return db
+
+    def populate(self, rawdb) -> None:
+        """database.cpp:84-110 (strings/bytes) -- encoding, plain lift and NTT run on the GPU."""
+        if isinstance(rawdb, np.ndarray) and rawdb.dtype == np.uint8 and rawdb.ndim == 2:
+            n, width = rawdb.shape
+            buf = np.ascontiguousarray(rawdb)
+        else:
+            items = list(rawdb)
+            n = len(items)
+            if n != self.params.num_items:
+                raise PirGpuError(3, "Database size %d does not match params value %d" % (n, self.params.num_items))
+            width = self.params.bytes_per_item
+            if any(len(it) != width for it in items):
+                raise PirGpuError(3, "item size does not match parameters")
+            buf = np.frombuffer(b"".join(items), dtype=np.uint8)
+        self._check(self.lib.pirgpu_db_load_items(self._h, buf.ctypes.data_as(capi.u8p), n, width))
+
+    def populate_coeffs(self, coeffs, first_pt: int = 0) -> None:
+        """Plaintexts given as coefficient rows (< t), e.g. IntegerEncoder output (database.cpp:60-82)."""
+        arr = np.zeros((len(coeffs), self.N), dtype=np.uint64)
+        for i, row in enumerate(coeffs):
+            row = np.asarray(row, dtype=np.uint64)
+            arr[i, : row.shape[0]] = row
+        self._check(self.lib.pirgpu_db_load_coeffs(self._h, first_pt, arr.shape[0], _ptr(arr)))
+
+    def size(self) -> int:
+        return int(self.lib.pirgpu_db_size(self._h))
+
+    def read_plaintext(self, index: int) -> np.ndarray:
+        out = np.empty((self.k, self.N), dtype=np.uint64)
+        self._check(self.lib.pirgpu_db_read_plaintext(self._h, index, _ptr(out)))
+        return out
+
+    def reply_ct_count(self) -> int:
+        return int(self.lib.pirgpu_reply_ct_count(self._h))
+
+    def expansion_ratio(self) -> int:
+        return int(self.lib.pirgpu_expansion_ratio(self._h))
+
+    def multiply(self, selection_vector) -> np.ndarray:
+        """database.cpp:290-316: selection vector [dim_sum, 2, k, N] (coefficient form) -> reply cts."""
+        sv = _u64(selection_vector)
+        n = self.reply_ct_count()
+        out = np.empty((n, 2, self.k, self.N), dtype=np.uint64)
+        cnt = C.c_uint64(0)
+        self._check(self.lib.pirgpu_multiply(self._h, _ptr(sv), sv.shape[0], _ptr(out), n, C.byref(cnt)))
+        return out[: cnt.value]
+
+    def calculate_indices(self, index: int) -> List[int]:
+        return self.params.calculate_indices(index)
+
+    def calculate_item_offset(self, index: int) -> int:
+        return self.params.calculate_item_offset(index)
+
+    calculate_dimensions = staticmethod(calculate_dimensions)
+
+
+class PIRServer:
+    """reference server.h:33-145."""
+
+    def __init__(self, db: PIRDatabase, params: PIRParameters):
+        self.db = db
+        self.params = params
+        self.lib = db.lib
+        self.N, self.k = db.N, db.k
+
+    @classmethod
+    def Create(cls, db: PIRDatabase, params: PIRParameters) -> "PIRServer":
+        """server.cpp:35-42"""
+        full = db._cparams.shard_begin == 0 and db._cparams.shard_end in (0, params.dimensions[0])
+        if full and params.num_pt != db.size():
+            raise PirGpuError(3, "database size mismatch")
+        return cls(db, params)
+
+    def _check(self, rc):
+        self.db._check(rc)
+
+    # -- keys -----------------------------------------------------------------------
+    def set_galois_keys(self, galois_keys: Dict[int, np.ndarray]) -> None:
+        """Install what SEALDeserialize<GaloisKeys> yields per request (server.cpp:46-48)."""
+        self._check(self.lib.pirgpu_clear_galois_keys(self.db.handle))
+        for g, key in galois_keys.items():
+            key = _u64(key)
+            assert key.shape == (self.k, 2, self.k + 1, self.N), key.shape
+            self._check(self.lib.pirgpu_set_galois_key(self.db.handle, int(g), _ptr(key)))
+
+    # -- query path -------------------------------------------------------------------
+    def process_query(self, query, galois_keys: Optional[Dict[int, np.ndarray]] = None) -> np.ndarray:
+        """processQuery (server.cpp:173-195) on residue arrays: query [nq, 2, k, N] -> reply cts."""
+        if galois_keys is not None:
+            self.set_galois_keys(galois_keys)
+        q = _u64(query)
+        n = self.db.reply_ct_count()
+        out = np.empty((n, 2, self.k, self.N), dtype=np.uint64)
+        cnt = C.c_uint64(0)
+        self._check(self.lib.pirgpu_process_query(self.db.handle, _ptr(q), q.shape[0], _ptr(out), n, C.byref(cnt)))
+        return out[: cnt.value]
+
+    def ProcessRequest(self, request: bytes) -> bytes:
+        """server.cpp:44-65: serialized pir.Request -> serialized pir.Response."""
+        buf = np.frombuffer(request, dtype=np.uint8)
+        resp = C.c_void_p()
+        rlen = C.c_size_t(0)
+        self._check(self.lib.pirgpu_process_request(self.db.handle, buf.ctypes.data_as(capi.u8p), len(request),
+                                                    C.byref(resp), C.byref(rlen)))
+        try:
+            return C.string_at(resp.value, rlen.value)
+        finally:
+            self.lib.pirgpu_free(resp)
+
+    # -- device-resident split (bench / pipelining) -----------------------------------
+    def stage_query(self, query) -> None:
+        q = _u64(query)
+        self._check(self.lib.pirgpu_query_stage(self.db.handle, _ptr(q), q.shape[0]))
+
+    def run_staged(self) -> None:
+        self._check(self.lib.pirgpu_query_run(self.db.handle))
+
+    def sync(self) -> None:
+        self._check(self.lib.pirgpu_sync(self.db.handle))
+
+    def fetch_reply(self) -> np.ndarray:
+        n = self.db.reply_ct_count()
+        out = np.empty((n, 2, self.k, self.N), dtype=np.uint64)
+        cnt = C.c_uint64(0)
+        self._check(self.lib.pirgpu_query_fetch(self.db.handle, _ptr(out), n, C.byref(cnt)))
+        return out[: cnt.value]
+
+    def set_profiling(self, on: bool) -> None:
+        self._check(self.lib.pirgpu_set_profiling(self.db.handle, 1 if on else 0))
+
+    def last_timings(self) -> Dict[str, float]:
+        ms = (C.c_float * 6)()
+        self._check(self.lib.pirgpu_last_timings(self.db.handle, ms))
+        names = ["expand_ms", "sv_ntt_ms", "scan_ms", "upper_ms", "final_ms", "total_ms"]
+        return {n: float(v) for n, v in zip(names, ms)}
+
+    def scan_bytes(self) -> int:
+        return int(self.lib.pirgpu_scan_bytes(self.db.handle))
+
+    # -- test-visible helpers (server.h:66-131) -----------------------------------------
+    def substitute_power_x_inplace(self, ct: np.ndarray, power: int) -> np.ndarray:
+        """server.cpp:67-76; returns the substituted ciphertext (ct itself is updated too)."""
+        assert ct.dtype == np.uint64 and ct.flags["C_CONTIGUOUS"]
+        self._check(self.lib.pirgpu_substitute_power_x(self.db.handle, _ptr(ct), power))
+        return ct
+
+    def multiply_inverse_power_of_x(self, ct, k: int) -> np.ndarray:
+        """server.cpp:78-103"""
+        ct = _u64(ct)
+        out = np.empty_like(ct)
+        self._check(self.lib.pirgpu_multiply_inverse_power_of_x(self.db.handle, _ptr(ct), k, _ptr(out)))
+        return out
+
+    def oblivious_expansion(self, ct, num_items: int) -> np.ndarray:
+        """server.cpp:105-146 (one ciphertext) or :148-171 (a list / 4-D array of ciphertexts)."""
+        ct = _u64(ct)
+        out = np.empty((max(num_items, 1), 2, self.k, self.N), dtype=np.uint64)
+        if ct.ndim == 3:
+            self._check(self.lib.pirgpu_expand(self.db.handle, _ptr(ct), num_items, _ptr(out)))
+        else:
+            self._check(self.lib.pirgpu_expand_multi(self.db.handle, _ptr(ct), ct.shape[0], num_items, _ptr(out)))
+        return out[:num_items]
+
+    # -- NTT test hooks -------------------------------------------------------------------
+    def ntt_forward(self, cts, key_level: bool = False) -> np.ndarray:
+        a = _u64(cts).copy()
+        count = a.shape[0]
+        self._check(self.lib.pirgpu_ntt_forward(self.db.handle, _ptr(a), count, 1 if key_level else 0))
+        return a
+
+    def ntt_inverse(self, cts, key_level: bool = False) -> np.ndarray:
+        a = _u64(cts).copy()
+        count = a.shape[0]
+        self._check(self.lib.pirgpu_ntt_inverse(self.db.handle, _ptr(a), count, 1 if key_level else 0))
+        return a

@@ -1,0 +1,28 @@
+"""Helpers shared by the GPU parity tests: oracle PirParams <-> product PIRParameters."""
+import numpy as np
+
+import oracle
+import pir_amd
+from pir_amd.parameters import EncryptionParams, PIRParameters
+
+
+def to_product_params(p: "oracle.PirParams") -> PIRParameters:
+    enc = EncryptionParams(p.N, list(p.moduli), p.t)
+    return PIRParameters(num_items=p.num_items, num_pt=p.num_pt, dimensions=list(p.dimensions),
+                         encryption_parameters=enc, bytes_per_item=p.bytes_per_item,
+                         items_per_plaintext=p.items_per_plaintext, bits_per_coeff=p.bits_per_coeff,
+                         use_ciphertext_multiplication=p.use_ciphertext_multiplication)
+
+
+def random_ct(orc, rng, n=1):
+    out = np.empty((n, 2, orc.k, orc.N), dtype=np.uint64)
+    for j in range(orc.k):
+        out[:, :, j, :] = rng.integers(0, orc.moduli[j], size=(n, 2, orc.N), dtype=np.uint64)
+    return out
+
+
+def random_key(orc, rng):
+    key = np.empty((orc.k, 2, orc.k + 1, orc.N), dtype=np.uint64)
+    for i in range(orc.k + 1):
+        key[:, :, i, :] = rng.integers(0, orc.moduli[i], size=(orc.k, 2, orc.N), dtype=np.uint64)
+    return key

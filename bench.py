@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- PIR server query path throughput on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path (PIRServer::processQuery, reference
+server.cpp:173-195: oblivious expansion -> database scan -> recursive re-encode /
+multiply-accumulate) over one query, with the encoded database, the Galois keys
+and the query ciphertext already resident in HBM.  Workload = BASELINE.json
+configs[2]: N=4096, 2 RNS primes, DB = 2^20 x 288 B, d=2 (the reference's own
+benchmark parameters, benchmark.cpp:17-23).
+
+Multi-GPU (launched by torch.distributed.run, one rank per GPU): the database is
+row-sharded across ranks, every rank expands the query, scans its rows and the
+per-shard reply ciphertexts are summed with one RCCL all-reduce + a mod-q fix-up.
+Total work is fixed as N grows -> "scaling": "strong".
+
+The GPU leg uses synthetic inputs of the right shape (uniform residues); the
+cpu_baseline leg (rank 0, N=1 only) times the CPU oracle -- the restatement of the
+reference algorithm, built natively on this host -- on the same database / keys /
+query and checks the GPU reply against it bit for bit.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def synthetic_inputs(pp, seed=42):
+    """DB bytes, Galois keys and one query: uniform random of the right shape."""
+    enc = pp.encryption_parameters
+    N, q = enc.poly_modulus_degree, enc.coeff_modulus
+    k = len(q) - 1
+    rng = np.random.default_rng(seed)
+    raw = rng.integers(0, 256, size=(pp.num_items, pp.bytes_per_item), dtype=np.uint8)
+    nq = pp.dim_sum // N + 1
+    query = np.empty((nq, 2, k, N), dtype=np.uint64)
+    for j in range(k):
+        query[:, :, j, :] = rng.integers(0, q[j], size=(nq, 2, N), dtype=np.uint64)
+    keys = {}
+    import pir_amd
+    for g in pir_amd.generate_galois_elts(N):
+        key = np.empty((k, 2, k + 1, N), dtype=np.uint64)
+        for i in range(k + 1):
+            key[:, :, i, :] = rng.integers(0, q[i], size=(k, 2, N), dtype=np.uint64)
+        keys[g] = key
+    return raw, keys, query
+
+
+def cpu_baseline(pp, raw, keys, query, gpu_reply, budget_s=25.0):
+    """Times the CPU oracle (single thread, like the reference + SEAL 3.5.6) on the same inputs."""
+    import oracle
+    try:
+        oracle.build(native=True)
+        native = True
+    except Exception:
+        native = False
+    enc = pp.encryption_parameters
+    orc = oracle.Oracle(enc.poly_modulus_degree, enc.coeff_modulus, enc.plain_modulus, native=native)
+    bits = pp.bits_per_coeff or oracle.bits_per_coeff(enc.plain_modulus)
+    t0 = time.perf_counter()
+    rc, db_ntt = orc.db_encode(raw.tobytes(), pp.num_items, pp.bytes_per_item, pp.items_per_plaintext, bits,
+                               pp.num_pt)
+    assert rc == 0
+    t_encode = time.perf_counter() - t0
+    times = []
+    reply = None
+    while True:
+        t0 = time.perf_counter()
+        rc, reply = orc.process_query(db_ntt, pp.dimensions, query, keys)
+        times.append(time.perf_counter() - t0)
+        assert rc == 0
+        if sum(times) + times[-1] > budget_s or len(times) >= 8:
+            break
+    match = bool(np.array_equal(reply, gpu_reply))
+    sec = float(np.median(times))
+    return {
+        "value": 1.0 / sec, "unit": "queries/s", "cores": 1, "kind": "port",
+        "sample": "%d full queries of the same workload (same DB, keys, query) on the CPU oracle, median; "
+                  "ms_per_query=%.1f; db_encode_s=%.1f; native_build=%s; gpu_reply_bit_exact=%s"
+                  % (len(times), sec * 1e3, t_encode, native, match),
+        "ms_per_query": sec * 1e3, "bit_exact_vs_gpu": match,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--log-items", type=int, default=20, help="database = 2^log_items x 288 B")
+    ap.add_argument("--dims", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    import torch
+    import pir_amd
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- workload: BASELINE.json configs[2] (benchmark.cpp:17-23 parameters)
+    enc = pir_amd.generate_encryption_params(4096, 24)
+    pp = pir_amd.create_pir_parameters(1 << args.log_items, 288, args.dims, enc)
+    raw, keys, query = synthetic_inputs(pp)
+
+    n0 = pp.dimensions[0]
+    shard = None
+    if world > 1:
+        lo = (n0 * rank) // world
+        hi = (n0 * (rank + 1)) // world
+        shard = (lo, hi)
+    db = pir_amd.PIRDatabase.Create(pp, device=local_rank, shard=shard)
+    t0 = time.perf_counter()
+    db.populate(raw)
+    t_populate = time.perf_counter() - t0
+    srv = pir_amd.PIRServer(db, pp) if shard else pir_amd.PIRServer.Create(db, pp)
+    srv.set_galois_keys(keys)
+    srv.stage_query(query)
+
+    reply_cts = db.reply_ct_count()
+    k, N = srv.k, srv.N
+    red = None
+    if world > 1:
+        red = torch.empty((reply_cts, 2, k, N), dtype=torch.int64, device="cuda:%d" % local_rank)
+
+    def step():
+        srv.run_staged()
+        if world > 1:
+            srv.reply_copy_to_device(red.data_ptr())          # waits for this rank's kernels
+            dist.all_reduce(red, op=dist.ReduceOp.SUM)        # RCCL over xGMI; partials < q_j so no overflow
+            torch.cuda.current_stream().synchronize()
+            srv.reduce_fixup_device(red.data_ptr())           # x mod q_j
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        srv.sync()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    srv.set_profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda:%d" % local_rank)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    timings = srv.last_timings()
+    srv.set_profiling(False)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        qps = args.steps / elapsed
+        scan_bytes = srv.scan_bytes()                   # algorithmic: num_pt(shard) * k * N * 8
+        scan_ms = timings["scan_ms"]
+        achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        out = {
+            "metric": "PIR queries/sec (ms/query in ms_per_step), N=4096 DB=2^%d x 288B d=%d" % (args.log_items,
+                                                                                                args.dims),
+            "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "N=4096, 2 RNS primes (36,36|37 bit), t=24 bit, DB=2^%d x 288B, d=%d, "
+                                   "dims=%s, num_pt=%d, 1 query/request (BASELINE.json configs[2])"
+                                   % (args.log_items, args.dims, pp.dimensions, pp.num_pt),
+                       "parallelism": "rows sharded over %d GPU(s), RCCL all-reduce of reply" % world
+                       if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "scan_kernel", "kernel_ms": scan_ms, "algorithmic_bytes": scan_bytes,
+                         "launches_averaged": timings["runs"]},
+            "phases_ms": {kk: round(v, 4) for kk, v in timings.items() if kk.endswith("_ms")},
+            "db_populate_s": round(t_populate, 2),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            gpu_reply = srv.fetch_reply()
+            out["cpu_baseline"] = cpu_baseline(pp, raw, keys, query, gpu_reply)
+            out["speedup_vs_cpu_baseline"] = qps / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

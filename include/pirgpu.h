@@ -73,6 +73,10 @@ typedef struct pirgpu_params {
 int pirgpu_create(const pirgpu_params* params, pirgpu_ctx** out);
 void pirgpu_destroy(pirgpu_ctx* ctx);
 const char* pirgpu_last_error(const pirgpu_ctx* ctx);
+/* Records an error message on the context (used by the wire-level layer). */
+void pirgpu_set_error(pirgpu_ctx* ctx, const char* message);
+/* The parameters the context was created with (shard range resolved). */
+int pirgpu_get_params(const pirgpu_ctx* ctx, pirgpu_params* out);
 /* last error of a failed pirgpu_create (no context to ask) */
 const char* pirgpu_create_error(void);
 
@@ -142,6 +146,9 @@ int pirgpu_ntt_inverse(pirgpu_ctx* ctx, uint64_t* polys, uint64_t count, int key
 int pirgpu_reduce_fixup_device(pirgpu_ctx* ctx, uint64_t* device_ptr, uint64_t count);
 /* Device pointer of the staged reply (valid until the next run) for collectives. */
 uint64_t* pirgpu_reply_device_ptr(pirgpu_ctx* ctx);
+/* Copies the reply of the last run into caller-owned DEVICE memory (e.g. a torch
+ * tensor handed to RCCL); waits for the copy. capacity is in ciphertexts. */
+int pirgpu_reply_copy_to_device(pirgpu_ctx* ctx, uint64_t* device_dst, uint64_t capacity);
 
 /* Wire-level entry: PIRServer::ProcessRequest (reference server.cpp:44-65).
  * request = serialized pir.Request (pir/proto/payload.proto:27-36); on success
@@ -151,11 +158,13 @@ int pirgpu_process_request(pirgpu_ctx* ctx, const uint8_t* request, size_t reque
                            size_t* response_len);
 void pirgpu_free(void* p);
 
-/* Measurement: wall-clock of the phases of the last pirgpu_query_run, taken with
- * HIP events on the context's own stream.  phase_ms[0..5] = expansion,
- * selection-vector NTT, database scan (the streaming kernel), upper levels
- * (re-encode + multiply-accumulate), final inverse NTT, total. */
-int pirgpu_last_timings(pirgpu_ctx* ctx, float phase_ms[6]);
+/* Measurement: mean duration of the phases of the pirgpu_query_run calls made since
+ * profiling was enabled (or since the previous call of this function), taken with
+ * HIP events on the context's own stream.  phase_ms[0..5] = expansion +
+ * selection-vector NTT, (reserved, 0), database scan (the streaming kernel alone),
+ * upper levels (inverse NTT of the scan rows, re-encode, multiply-accumulate),
+ * final inverse NTT, total.  *runs receives the number of runs averaged. */
+int pirgpu_last_timings(pirgpu_ctx* ctx, float phase_ms[6], uint32_t* runs);
 /* Enable/disable the phase events above (default off: zero overhead). */
 int pirgpu_set_profiling(pirgpu_ctx* ctx, int enabled);
 /* Algorithmic bytes the scan kernel reads per query: num_pt(shard) * k * N * 8. */

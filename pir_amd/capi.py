@@ -65,7 +65,10 @@ SIGNATURES = {
     "pirgpu_reply_device_ptr": (C.c_void_p, [C.c_void_p]),
     "pirgpu_process_request": (C.c_int, [C.c_void_p, u8p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "pirgpu_free": (None, [C.c_void_p]),
-    "pirgpu_last_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "pirgpu_last_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
+    "pirgpu_set_error": (None, [C.c_void_p, C.c_char_p]),
+    "pirgpu_get_params": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
+    "pirgpu_reply_copy_to_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "pirgpu_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "pirgpu_scan_bytes": (C.c_uint64, [C.c_void_p]),
 }

@@ -83,10 +83,11 @@ struct pirgpu_ctx {
   bool reply_valid = false;
 
   bool prof = false;
-  hipEvent_t ev[PH_COUNT + 1]{};
-  bool ev_ready = false;
+  static constexpr int kMaxProfRuns = 256;
+  std::vector<hipEvent_t> ev;  // kMaxProfRuns x (PH_COUNT + 1), created lazily
+  int prof_runs = 0;           // runs recorded since the last read-out
+  int prof_cur = -1;           // event set of the run being recorded (-1: not recording)
   float timings[6]{};
-  bool timings_pending = false;
 
   std::string err;
   std::mutex mu;
@@ -248,8 +249,6 @@ void ensure_workspace(pirgpu_ctx* c) {
     if (c->scan_nsplit > 1)
       c->scan_part = c->dalloc<uint64_t>((size_t)c->scan_nsplit * std::max<uint32_t>(c->scan_rows, 1) * ctw);
   }
-  for (int i = 0; i <= PH_COUNT; ++i) HIP_TRY(hipEventCreate(&c->ev[i]));
-  c->ev_ready = true;
   c->ws_ready = true;
 }
 
@@ -273,7 +272,17 @@ const uint64_t* find_key(pirgpu_ctx* c, uint32_t g) {
 }
 
 void record(pirgpu_ctx* c, int idx) {
-  if (c->prof) HIP_TRY(hipEventRecord(c->ev[idx], c->stream));
+  if (c->prof_cur >= 0) HIP_TRY(hipEventRecord(c->ev[(size_t)c->prof_cur * (PH_COUNT + 1) + idx], c->stream));
+}
+
+void begin_profiled_run(pirgpu_ctx* c) {
+  c->prof_cur = -1;
+  if (!c->prof || c->prof_runs >= pirgpu_ctx::kMaxProfRuns) return;
+  if (c->ev.empty()) {
+    c->ev.resize((size_t)pirgpu_ctx::kMaxProfRuns * (PH_COUNT + 1));
+    for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
+  }
+  c->prof_cur = c->prof_runs++;
 }
 
 // oblivious_expansion(ct, n) on the device (reference server.cpp:105-146).
@@ -364,6 +373,7 @@ void run_staged(pirgpu_ctx* c) {
   if (c->staged_nq != c->dim_sum / c->N + 1)
     throw Fail{PIRGPU_INVALID_ARGUMENT,
                "Number of ciphertexts doesn't match number of items for oblivious expansion."};
+  begin_profiled_run(c);
   record(c, PH_EXPAND);
   // expansion and selection-vector NTT are interleaved per query ciphertext; the
   // PH_SVNTT mark is taken after the last expansion level of the last ciphertext.
@@ -372,8 +382,8 @@ void run_staged(pirgpu_ctx* c) {
   record(c, PH_SCAN);
   multiply_on_device(c);
   record(c, PH_COUNT);
+  c->prof_cur = -1;
   c->reply_valid = true;
-  c->timings_pending = c->prof;
 }
 
 }  // namespace
@@ -475,13 +485,24 @@ void pirgpu_destroy(pirgpu_ctx* c) {
   }
   for (auto& kv : c->keys) (void)hipFree(kv.second);
   for (void* p : c->allocs) (void)hipFree(p);
-  if (c->ev_ready)
-    for (int i = 0; i <= PH_COUNT; ++i) (void)hipEventDestroy(c->ev[i]);
+  for (auto& e : c->ev) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
 
 const char* pirgpu_last_error(const pirgpu_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+void pirgpu_set_error(pirgpu_ctx* c, const char* message) {
+  if (c) c->err = message ? message : "";
+}
+
+int pirgpu_get_params(const pirgpu_ctx* c, pirgpu_params* out) {
+  if (!c || !out) return PIRGPU_INVALID_ARGUMENT;
+  *out = c->prm;
+  out->shard_begin = c->sb;
+  out->shard_end = c->se;
+  return PIRGPU_OK;
+}
 
 uint64_t pirgpu_db_size(const pirgpu_ctx* c) { return c ? c->n_loaded : 0; }
 uint64_t pirgpu_reply_ct_count(const pirgpu_ctx* c) { return c ? c->reply_cts : 0; }
@@ -648,6 +669,16 @@ int pirgpu_process_query(pirgpu_ctx* c, const uint64_t* query, uint32_t nq, uint
 
 uint64_t* pirgpu_reply_device_ptr(pirgpu_ctx* c) { return (c && c->ws_ready) ? c->lvl[0] : nullptr; }
 
+int pirgpu_reply_copy_to_device(pirgpu_ctx* c, uint64_t* dst, uint64_t cap) {
+  return guarded(c, [&]() -> int {
+    if (!c->reply_valid) return fail(c, PIRGPU_FAILED_PRECONDITION, "no query has been run");
+    if (!dst || cap < c->reply_cts) return fail(c, PIRGPU_INVALID_ARGUMENT, "reply buffer too small");
+    HIP_TRY(hipMemcpyAsync(dst, c->lvl[0], c->reply_cts * c->ctw * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PIRGPU_OK;
+  });
+}
+
 int pirgpu_expand(pirgpu_ctx* c, const uint64_t* ct, uint32_t num_items, uint64_t* out) {
   return guarded(c, [&]() -> int {
     ensure_workspace(c);
@@ -736,10 +767,8 @@ int pirgpu_multiply(pirgpu_ctx* c, const uint64_t* sv, uint64_t sv_count, uint64
       HIP_TRY(launch_ct_ntt_fwd_oop(c->stream, c->dp, c->N, c->k, c->res_a, c->sv_ntt + s * c->ctw, n));
       HIP_TRY(hipStreamSynchronize(c->stream));
     }
-    const bool prof = c->prof;
-    c->prof = false;
+    c->prof_cur = -1;
     multiply_on_device(c);
-    c->prof = prof;
     HIP_TRY(hipMemcpyAsync(reply, c->lvl[0], c->reply_cts * c->ctw * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (count) *count = c->reply_cts;
@@ -786,31 +815,40 @@ int pirgpu_reduce_fixup_device(pirgpu_ctx* c, uint64_t* device_ptr, uint64_t cou
 
 int pirgpu_set_profiling(pirgpu_ctx* c, int enabled) {
   return guarded(c, [&]() -> int {
+    HIP_TRY(hipStreamSynchronize(c->stream));
     c->prof = enabled != 0;
+    c->prof_runs = 0;
     return PIRGPU_OK;
   });
 }
 
-int pirgpu_last_timings(pirgpu_ctx* c, float ms[6]) {
+int pirgpu_last_timings(pirgpu_ctx* c, float ms[6], uint32_t* runs) {
   return guarded(c, [&]() -> int {
     if (!ms) return fail(c, PIRGPU_INVALID_ARGUMENT, "null buffer");
-    if (c->timings_pending) {
+    if (c->prof_runs > 0) {
       HIP_TRY(hipStreamSynchronize(c->stream));
-      // events: [EXPAND] start, [SVNTT] end of expansion+sv ntt, [SCAN] scan start, [UPPER] scan end,
-      //         [FINAL] last upper mac end, [COUNT] end
-      float t01, t23, t34, t45, total;
-      HIP_TRY(hipEventElapsedTime(&t01, c->ev[PH_EXPAND], c->ev[PH_SVNTT]));
-      HIP_TRY(hipEventElapsedTime(&t23, c->ev[PH_SCAN], c->ev[PH_UPPER]));
-      HIP_TRY(hipEventElapsedTime(&t34, c->ev[PH_UPPER], c->ev[PH_FINAL]));
-      HIP_TRY(hipEventElapsedTime(&t45, c->ev[PH_FINAL], c->ev[PH_COUNT]));
-      HIP_TRY(hipEventElapsedTime(&total, c->ev[PH_EXPAND], c->ev[PH_COUNT]));
-      c->timings[0] = t01;
-      c->timings[1] = 0.f;  // selection-vector NTT is interleaved with expansion per query ciphertext
-      c->timings[2] = t23;
-      c->timings[3] = t34;
-      c->timings[4] = t45;
-      c->timings[5] = total;
-      c->timings_pending = false;
+      // events per run: [EXPAND] start, [SVNTT] end of expansion + selector NTT, [SCAN] scan start,
+      //                 [UPPER] scan end, [FINAL] last multiply-accumulate end, [COUNT] end of run
+      double acc[6] = {0, 0, 0, 0, 0, 0};
+      for (int r = 0; r < c->prof_runs; ++r) {
+        hipEvent_t* e = &c->ev[(size_t)r * (PH_COUNT + 1)];
+        float t;
+        HIP_TRY(hipEventElapsedTime(&t, e[PH_EXPAND], e[PH_SVNTT]));
+        acc[0] += t;
+        HIP_TRY(hipEventElapsedTime(&t, e[PH_SCAN], e[PH_UPPER]));
+        acc[2] += t;
+        HIP_TRY(hipEventElapsedTime(&t, e[PH_UPPER], e[PH_FINAL]));
+        acc[3] += t;
+        HIP_TRY(hipEventElapsedTime(&t, e[PH_FINAL], e[PH_COUNT]));
+        acc[4] += t;
+        HIP_TRY(hipEventElapsedTime(&t, e[PH_EXPAND], e[PH_COUNT]));
+        acc[5] += t;
+      }
+      for (int i = 0; i < 6; ++i) c->timings[i] = (float)(acc[i] / c->prof_runs);
+      if (runs) *runs = (uint32_t)c->prof_runs;
+      c->prof_runs = 0;
+    } else if (runs) {
+      *runs = 0;
     }
     memcpy(ms, c->timings, sizeof(c->timings));
     return PIRGPU_OK;

@@ -240,9 +240,22 @@ class PIRServer:
 
     def last_timings(self) -> Dict[str, float]:
         ms = (C.c_float * 6)()
-        self._check(self.lib.pirgpu_last_timings(self.db.handle, ms))
-        names = ["expand_ms", "sv_ntt_ms", "scan_ms", "upper_ms", "final_ms", "total_ms"]
-        return {n: float(v) for n, v in zip(names, ms)}
+        runs = C.c_uint32(0)
+        self._check(self.lib.pirgpu_last_timings(self.db.handle, ms, C.byref(runs)))
+        names = ["expand_ms", "reserved", "scan_ms", "upper_ms", "final_ms", "total_ms"]
+        out = {n: float(v) for n, v in zip(names, ms)}
+        out["runs"] = int(runs.value)
+        return out
+
+    def reply_copy_to_device(self, device_ptr: int) -> None:
+        """D2D copy of the last reply into caller-owned device memory (for the RCCL reduce)."""
+        self._check(self.lib.pirgpu_reply_copy_to_device(self.db.handle, C.c_void_p(device_ptr),
+                                                         self.db.reply_ct_count()))
+
+    def reduce_fixup_device(self, device_ptr: int) -> None:
+        """x <- x mod q_j over the summed partial replies, in place on the device."""
+        self._check(self.lib.pirgpu_reduce_fixup_device(self.db.handle, C.c_void_p(device_ptr),
+                                                        self.db.reply_ct_count()))
 
     def scan_bytes(self) -> int:
         return int(self.lib.pirgpu_scan_bytes(self.db.handle))

@@ -1,0 +1,113 @@
+"""CPU-side checks of the product's host logic: the C-ABI library loads and exports every
+symbol include/pirgpu.h declares, fails loudly without a GPU, the parameter mirror matches
+the reference's tables, and the wire codec's hashing matches an independent implementation."""
+import ctypes as C
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle
+import pir_amd
+from pir_amd import capi, parameters as P
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "pirgpu.h")).read()
+    declared = set(re.findall(r"\b(pirgpu_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"pirgpu_ctx", "pirgpu_params"}
+    assert len(declared) >= 30
+    lib = capi.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert declared == set(capi.SIGNATURES), declared ^ set(capi.SIGNATURES)
+
+
+def test_struct_layout_matches_header():
+    # sizeof(pirgpu_params) as the C compiler lays it out (gcc, same ABI as hipcc's host side)
+    import subprocess, tempfile
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "s.c")
+        open(src, "w").write('#include <stdio.h>\n#include "pirgpu.h"\nint main(){printf("%zu %zu %zu", '
+                             'sizeof(pirgpu_params), __builtin_offsetof(pirgpu_params, num_pt), '
+                             '__builtin_offsetof(pirgpu_params, shard_begin));return 0;}')
+        exe = os.path.join(d, "s")
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe], check=True)
+        size, off_pt, off_shard = map(int, subprocess.run([exe], capture_output=True, text=True).stdout.split())
+    assert C.sizeof(capi.Params) == size
+    assert capi.Params.num_pt.offset == off_pt and capi.Params.shard_begin.offset == off_shard
+
+
+def test_create_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    pp = P.create_pir_parameters(10, 0, 1, P.generate_encryption_params(4096, 20))
+    with pytest.raises(pir_amd.PirGpuError) as e:
+        pir_amd.PIRDatabase.Create(pp)
+    assert e.value.code == pir_amd.StatusCode.INTERNAL and "no HIP device" in e.value.message
+
+
+def test_parameter_mirror_matches_reference_tables():
+    # parameters_test.cpp:47-98
+    p = P.create_pir_parameters(1026, 256)
+    assert (p.num_pt, p.items_per_plaintext, p.dimensions) == (27, 38, [27])
+    p = P.create_pir_parameters(19011, 500, 3)
+    assert (p.num_pt, p.items_per_plaintext, p.dimensions) == (1001, 19, [11, 10, 10])
+    p = P.create_pir_parameters(77412, 777, 2, P.generate_encryption_params(8192), True, 12)
+    assert (p.num_pt, p.items_per_plaintext, p.dimensions, p.bits_per_coeff) == (5161, 15, [72, 72], 12)
+    with pytest.raises(ValueError):
+        P.create_pir_parameters(10, 0, 1, P.generate_encryption_params(4096, 20), False, 25)
+    with pytest.raises(ValueError):
+        P.create_pir_parameters(10, 20000, 1)
+
+
+@pytest.mark.parametrize("dbsize,elem,d,N,bits", [(1 << 16, 288, 1, 4096, 24), (1 << 20, 288, 2, 4096, 24),
+                                                  (500, 0, 2, 4096, 24), (87, 0, 2, 4096, 16), (82, 0, 3, 4096, 16)])
+def test_parameter_mirror_matches_oracle(dbsize, elem, d, N, bits):
+    a = P.create_pir_parameters(dbsize, elem, d, P.generate_encryption_params(N, bits))
+    b = oracle.create_pir_parameters(dbsize, elem, d, N=N, plain_bits=bits)
+    assert (a.num_pt, a.items_per_plaintext, a.bytes_per_item, a.dimensions) == \
+           (b.num_pt, b.items_per_plaintext, b.bytes_per_item, b.dimensions)
+    assert a.encryption_parameters.coeff_modulus == b.moduli and a.encryption_parameters.plain_modulus == b.t
+    for idx in (0, dbsize // 3, dbsize - 1):
+        assert a.calculate_indices(idx) == oracle.calculate_indices(idx, b.items_per_plaintext, b.dimensions)
+        assert a.calculate_item_offset(idx) == oracle.calculate_item_offset(idx, b.items_per_plaintext,
+                                                                            b.bytes_per_item)
+
+
+def test_index_tables():
+    # database_test.cpp:409-464
+    for n, size, d, index, exp in [(87, 0, 2, 42, [4, 6]), (82, 0, 3, 75, [3, 3, 3]), (5000, 64, 1, 2222, [18])]:
+        p = P.create_pir_parameters(n, size, d, P.generate_encryption_params(4096, 16))
+        assert p.calculate_indices(index) == exp
+    for n, d, exp in [(82, 2, [10, 9]), (975, 2, [32, 31]), (1001, 3, [11, 10, 10]), (1000001, 3, [101, 100, 100])]:
+        assert P.calculate_dimensions(n, d) == exp
+    assert P.generate_galois_elts(4096) == oracle.generate_galois_elts(4096)
+    assert [P.next_power_two(x) for x in (0, 1, 3, 324, 4096)] == [1, 1, 4, 512, 4096]
+
+
+def test_wire_blake2b_and_parms_id_match_hashlib():
+    lib = capi.load()
+    lib.pirgpu_wire_blake2b.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    lib.pirgpu_wire_blake2b.restype = None
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 8, 64, 127, 128, 129, 300, 4096):
+        data = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        for outlen in (32, 64):
+            out = C.create_string_buffer(outlen)
+            lib.pirgpu_wire_blake2b(out, outlen, data, n)
+            assert out.raw == hashlib.blake2b(data, digest_size=outlen).digest(), (n, outlen)
+    from seal_wire import parms_id
+    lib.pirgpu_wire_parms_id.argtypes = [C.c_uint32, C.POINTER(C.c_uint64), C.c_size_t, C.c_uint64,
+                                         C.POINTER(C.c_uint64)]
+    lib.pirgpu_wire_parms_id.restype = None
+    moduli = oracle.BFV_DEFAULT[4096]
+    for mods in (moduli, moduli[:2]):
+        out = (C.c_uint64 * 4)()
+        lib.pirgpu_wire_parms_id(4096, (C.c_uint64 * len(mods))(*mods), len(mods), 0xFFC001, out)
+        assert bytes(out) == parms_id(4096, mods, 0xFFC001)

@@ -71,7 +71,7 @@ struct pirgpu_ctx {
 
   // workspace (allocated on first use)
   bool ws_ready = false;
-  uint64_t *res_a = nullptr, *res_b = nullptr, *prod = nullptr, *sv_ntt = nullptr;
+  uint64_t *res_a = nullptr, *res_b = nullptr, *prod = nullptr, *dig = nullptr, *sv_ntt = nullptr;
   uint64_t* d_query = nullptr;
   uint32_t staged_nq = 0;
   std::vector<uint64_t*> lvl;      // per level results
@@ -129,7 +129,7 @@ void build_tables(pirgpu_ctx* c) {
   hp.N = N;
   hp.logN = c->logN;
   hp.k = k;
-  std::vector<uint64_t> w(N), ws(N), iw(N), iws(N);
+  std::vector<Twiddle> tw(N), itw(N);
   uint64_t qmax = 0;
   for (uint32_t i = 0; i <= k; ++i) {
     const uint64_t q = i < k ? c->prm.coeff_modulus[i] : c->prm.special_prime;
@@ -144,24 +144,20 @@ void build_tables(pirgpu_ctx* c) {
     uint64_t pw = 1, ipw = 1;
     for (uint32_t j = 0; j < N; ++j) {
       uint32_t r = hm::bitrev(j, c->logN);
-      w[r] = pw;
-      ws[r] = hm::shoup(pw, q);
-      iw[r] = ipw;
-      iws[r] = hm::shoup(ipw, q);
+      tw[r] = Twiddle{pw, hm::shoup(pw, q)};
+      itw[r] = Twiddle{ipw, hm::shoup(ipw, q)};
       pw = hm::mulmod(pw, psi, q);
       ipw = hm::mulmod(ipw, ipsi, q);
     }
-    uint64_t* dev = c->dalloc<uint64_t>((size_t)4 * N);
-    HIP_TRY(hipMemcpy(dev, w.data(), N * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dev + N, ws.data(), N * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dev + 2 * (size_t)N, iw.data(), N * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dev + 3 * (size_t)N, iws.data(), N * 8, hipMemcpyHostToDevice));
-    hp.tab[i].w = dev;
-    hp.tab[i].ws = dev + N;
-    hp.tab[i].iw = dev + 2 * (size_t)N;
-    hp.tab[i].iws = dev + 3 * (size_t)N;
-    hp.tab[i].ninv = hm::invmod_prime(N % q, q);
-    hp.tab[i].ninvs = hm::shoup(hp.tab[i].ninv, q);
+    Twiddle* dev = c->dalloc<Twiddle>((size_t)2 * N);
+    HIP_TRY(hipMemcpy(dev, tw.data(), N * sizeof(Twiddle), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dev + N, itw.data(), N * sizeof(Twiddle), hipMemcpyHostToDevice));
+    hp.tab[i].tw = dev;
+    hp.tab[i].itw = dev + N;
+    const uint64_t ninv = hm::invmod_prime(N % q, q);
+    const uint64_t iw1n = hm::mulmod(itw[1].w, ninv, q);
+    hp.tab[i].ninv = Twiddle{ninv, hm::shoup(ninv, q)};
+    hp.tab[i].iw1n = Twiddle{iw1n, hm::shoup(iw1n, q)};
   }
   const uint64_t p = c->prm.special_prime, t = c->prm.plain_modulus;
   hp.p_half = p >> 1;
@@ -209,6 +205,7 @@ void ensure_workspace(pirgpu_ctx* c) {
   c->res_a = c->dalloc<uint64_t>(m_max * ctw);
   c->res_b = c->dalloc<uint64_t>(m_max * ctw);
   c->prod = c->dalloc<uint64_t>(std::max<uint64_t>(m_max / 2, 1) * 2 * (k + 1) * N);
+  c->dig = c->dalloc<uint64_t>(std::max<uint64_t>(m_max / 2, 1) * (k + 1) * k * N);
   c->sv_ntt = c->dalloc<uint64_t>((size_t)std::max<uint32_t>(c->dim_sum, 1) * ctw);
   c->d_query = c->dalloc<uint64_t>((size_t)(c->dim_sum / N + 1) * ctw);
   // per-level node counts inside this shard and result buffers
@@ -297,7 +294,7 @@ uint64_t* expand_on_device(pirgpu_ctx* c, uint32_t n) {
     const uint32_t g = (N >> j) + 1;
     const uint64_t* key = find_key(c, g);
     HIP_TRY(launch_ks_level(c->stream, c->dp, N, k, cur, key, g, galois_inverse(g, N), 1u << j, 1u << j, true,
-                            c->prod, nxt));
+                            c->dig, c->prod, nxt));
     std::swap(cur, nxt);
   }
   return cur;
@@ -587,8 +584,17 @@ int pirgpu_db_read_plaintext(pirgpu_ctx* c, uint64_t pt_index, uint64_t* out) {
   return guarded(c, [&]() -> int {
     if (pt_index < c->pt_begin || pt_index >= c->pt_end || !out)
       return fail(c, PIRGPU_INVALID_ARGUMENT, "plaintext index outside this shard");
-    HIP_TRY(hipMemcpy(out, c->d_db + (pt_index - c->pt_begin) * c->k * c->N, (size_t)c->k * c->N * 8,
-                      hipMemcpyDeviceToHost));
+    uint64_t* stage = nullptr;
+    HIP_TRY(hipMalloc((void**)&stage, (size_t)c->k * c->N * 8));
+    try {
+      HIP_TRY(launch_ntt_reorder(c->stream, c->N, c->d_db + (pt_index - c->pt_begin) * c->k * c->N, stage, c->k, false));
+      HIP_TRY(hipMemcpyAsync(out, stage, (size_t)c->k * c->N * 8, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+    } catch (...) {
+      (void)hipFree(stage);
+      throw;
+    }
+    HIP_TRY(hipFree(stage));
     return PIRGPU_OK;
   });
 }
@@ -605,8 +611,18 @@ int pirgpu_set_galois_key(pirgpu_ctx* c, uint32_t g, const uint64_t* key) {
       HIP_TRY(hipMalloc((void**)&dev, words * 8));
       c->keys[g] = dev;
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(dev, key, words * 8, hipMemcpyHostToDevice));
+    // keys arrive in SEAL's NTT order; HBM holds every NTT-domain array in device order
+    uint64_t* stage = nullptr;
+    HIP_TRY(hipMalloc((void**)&stage, words * 8));
+    try {
+      HIP_TRY(hipMemcpyAsync(stage, key, words * 8, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(launch_ntt_reorder(c->stream, c->N, stage, dev, (uint64_t)c->k * 2 * (c->k + 1), true));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+    } catch (...) {
+      (void)hipFree(stage);
+      throw;
+    }
+    HIP_TRY(hipFree(stage));
     return PIRGPU_OK;
   });
 }
@@ -731,7 +747,7 @@ int pirgpu_substitute_power_x(pirgpu_ctx* c, uint64_t* ct, uint32_t power) {
     const uint64_t* key = find_key(c, power);
     HIP_TRY(hipMemcpyAsync(c->res_a, ct, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(launch_ks_level(c->stream, c->dp, c->N, c->k, c->res_a, key, power, galois_inverse(power, c->N), 1, 0,
-                            false, c->prod, c->res_b));
+                            false, c->dig, c->prod, c->res_b));
     HIP_TRY(hipMemcpyAsync(ct, c->res_b, c->ctw * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PIRGPU_OK;
@@ -781,12 +797,22 @@ static int ntt_hook(pirgpu_ctx* c, uint64_t* polys, uint64_t count, int key_leve
     if (!polys && count) return fail(c, PIRGPU_INVALID_ARGUMENT, "null buffer");
     const uint32_t per = key_level ? c->k + 1 : c->k;
     const uint64_t npoly = key_level ? count * per : count * 2 * per;
+    // the hook speaks SEAL's NTT order at the boundary; the kernels use device order
     uint64_t* dev = nullptr;
-    HIP_TRY(hipMalloc((void**)&dev, std::max<uint64_t>(npoly, 1) * c->N * 8));
+    HIP_TRY(hipMalloc((void**)&dev, 2 * std::max<uint64_t>(npoly, 1) * c->N * 8));
+    uint64_t* tmp = dev + std::max<uint64_t>(npoly, 1) * c->N;
     try {
-      HIP_TRY(hipMemcpyAsync(dev, polys, npoly * c->N * 8, hipMemcpyHostToDevice, c->stream));
-      HIP_TRY(launch_ntt_batch(c->stream, c->dp, c->N, dev, npoly, per, 0, inverse));
-      HIP_TRY(hipMemcpyAsync(polys, dev, npoly * c->N * 8, hipMemcpyDeviceToHost, c->stream));
+      if (inverse) {
+        HIP_TRY(hipMemcpyAsync(tmp, polys, npoly * c->N * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(launch_ntt_reorder(c->stream, c->N, tmp, dev, npoly, true));
+        HIP_TRY(launch_ntt_batch(c->stream, c->dp, c->N, dev, npoly, per, 0, true));
+        HIP_TRY(hipMemcpyAsync(polys, dev, npoly * c->N * 8, hipMemcpyDeviceToHost, c->stream));
+      } else {
+        HIP_TRY(hipMemcpyAsync(dev, polys, npoly * c->N * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(launch_ntt_batch(c->stream, c->dp, c->N, dev, npoly, per, 0, false));
+        HIP_TRY(launch_ntt_reorder(c->stream, c->N, dev, tmp, npoly, false));
+        HIP_TRY(hipMemcpyAsync(polys, tmp, npoly * c->N * 8, hipMemcpyDeviceToHost, c->stream));
+      }
       HIP_TRY(hipStreamSynchronize(c->stream));
     } catch (...) {
       (void)hipFree(dev);

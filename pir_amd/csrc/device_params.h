@@ -4,10 +4,10 @@
 
 namespace pirgpu {
 
-constexpr int kMaxPrimes = 8;        // data primes
+constexpr int kMaxPrimes = 8;            // data primes
 constexpr int kMaxMod = kMaxPrimes + 1;  // + special prime
-constexpr int kMaxEnc = 64;          // max 2 * ExpansionRatio
-constexpr int kNttElemsPerThread = 16;   // NTT workgroup = N / 16 threads
+constexpr int kMaxEnc = 64;              // max 2 * ExpansionRatio
+constexpr int kNttElemsPerThread = 16;   // NTT workgroup = N / 16 threads, 16 residues per thread
 
 // One RNS modulus with the Barrett ratio floor(2^128 / q) (SEAL Modulus::const_ratio).
 struct ModConst {
@@ -15,15 +15,20 @@ struct ModConst {
   uint64_t br_lo, br_hi;
 };
 
-// Negacyclic NTT tables for one modulus: psi^bitrev(i), psi^-bitrev(i) with Shoup
-// quotients floor(w * 2^64 / q), and N^-1 (reference database.cpp:190,252
-// -> Evaluator::transform_to_ntt_inplace / transform_from_ntt_inplace).
+// {w, floor(w * 2^64 / q)}: one 16-byte load per twiddle.
+struct alignas(16) Twiddle {
+  uint64_t w, ws;
+};
+
+// Negacyclic NTT tables for one modulus (reference
+// database.cpp:190,252 -> Evaluator::transform_to/from_ntt_inplace):
+//   tw[i]  = psi^bitrev(i),  itw[i] = psi^-bitrev(i)   (psi = minimal primitive 2N-th root)
+// and the constants of the last inverse stage with N^-1 folded in.
 struct NttTable {
-  const uint64_t* w;
-  const uint64_t* ws;
-  const uint64_t* iw;
-  const uint64_t* iws;
-  uint64_t ninv, ninvs;
+  const Twiddle* tw;
+  const Twiddle* itw;
+  Twiddle ninv;   // N^-1
+  Twiddle iw1n;   // psi^-bitrev(1) * N^-1
 };
 
 struct DevParams {
@@ -31,16 +36,16 @@ struct DevParams {
   ModConst mod[kMaxMod];   // [0..k-1] data primes, [k] special prime
   NttTable tab[kMaxMod];
   // key-switch mod-down constants
-  uint64_t p_half;                 // floor(p / 2)
-  uint64_t p_half_mod[kMaxPrimes]; // floor(p/2) mod q_j
-  uint64_t p_inv[kMaxPrimes];      // p^-1 mod q_j
-  uint64_t p_inv_s[kMaxPrimes];    // Shoup quotient of p_inv
+  uint64_t p_half;                  // floor(p / 2)
+  uint64_t p_half_mod[kMaxPrimes];  // floor(p/2) mod q_j
+  uint64_t p_inv[kMaxPrimes];       // p^-1 mod q_j
+  uint64_t p_inv_s[kMaxPrimes];     // Shoup quotient of p_inv
   // plain lift
   uint64_t t, plain_thr;
-  uint64_t lift_inc[kMaxPrimes];   // q_j - (t mod q_j)
+  uint64_t lift_inc[kMaxPrimes];    // q_j - (t mod q_j)
   // CiphertextReencoder::Encode order (reference ct_reencoder.cpp:49-69)
-  uint32_t enc_count;              // 2 * ExpansionRatio
-  uint32_t enc_bits;               // floor(log2 t)
+  uint32_t enc_count;               // 2 * ExpansionRatio
+  uint32_t enc_bits;                // floor(log2 t)
   uint8_t enc_poly[kMaxEnc], enc_res[kMaxEnc], enc_shift[kMaxEnc];
   // how many 128-bit products of two residues may be summed before reduction
   uint32_t lazy_limit;

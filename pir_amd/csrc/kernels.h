@@ -13,12 +13,15 @@ hipError_t launch_ntt_batch(hipStream_t st, const DevParams* P, uint32_t N, uint
                             uint32_t mod_period, uint32_t mod_base, bool inverse);
 hipError_t launch_ct_ntt_fwd_oop(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* src,
                                  uint64_t* dst, uint64_t n_cts);
+hipError_t launch_ntt_reorder(hipStream_t st, uint32_t N, const uint64_t* in, uint64_t* out, uint64_t n_polys,
+                              bool to_device);
 hipError_t launch_db_encode(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* coeffs,
                             const uint8_t* bytes, uint64_t bytes_per_pt, uint64_t total_bytes, uint32_t bits,
                             uint64_t n_pt, uint64_t* db);
 hipError_t launch_ks_level(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* res_in,
                            const uint64_t* key, uint32_t galois_elt, uint32_t galois_inv, uint32_t nodes,
-                           uint32_t shift_pow, bool expand_step, uint64_t* prod, uint64_t* res_out);
+                           uint32_t shift_pow, bool expand_step, uint64_t* dig, uint64_t* prod,
+                           uint64_t* res_out);
 hipError_t launch_monomial_shift(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* in,
                                  uint32_t shift, uint64_t count, uint64_t* out);
 hipError_t launch_scan(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* db,

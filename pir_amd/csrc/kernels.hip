@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "device_params.h"
 #include "kernels.h"
 
@@ -69,58 +71,165 @@ __device__ __forceinline__ uint64_t mul_mod(uint64_t a, uint64_t b, const ModCon
   return reduce128(a * b, __umul64hi(a, b), m);
 }
 
-// ------------------------------------------------------------------ NTT in LDS
+// ------------------------------------------------------------------ NTT core
+//
+// One workgroup of N/16 threads transforms one polynomial; every thread keeps 16
+// residues in registers and runs up to four butterfly stages per pass, so a
+// 4096-point transform is 3 register passes with 2 LDS exchanges (instead of 12
+// barrier-separated LDS stages).  A pass with window LB owns, per thread, the 16
+// residues  idx = (outer << (LB+4)) | (e << LB) | inner,  tid = (outer << LB) | inner.
+//
+//  * butterflies are Harvey-lazy (forward: values < 4q, inverse: < 2q) and the
+//    results are made canonical at the end, so the bits equal SEAL's;
+//  * LDS is padded by one word per 16 (lds_idx) which makes all three access
+//    patterns (stride N/16, stride 16, contiguous 16) bank-conflict free;
+//  * NTT-domain data lives in HBM in "device order": SEAL's bit-reversed position
+//    pos = 16*tid + e is stored at e*(N/16) + tid.  Every dyadic operation is
+//    order-agnostic, both transforms read and write global memory fully
+//    coalesced, and a transform's register layout on the NTT side is exactly the
+//    layout of that order -- so key-switch products are formed between a forward
+//    and an inverse transform without leaving registers.
 
-// Forward negacyclic NTT of the N-point polynomial held in LDS (Cooley-Tukey,
-// natural order in, bit-reversed order out; twiddles psi^bitrev(m+i)).
-__device__ __forceinline__ void ntt_fwd_lds(uint64_t* s, const DevParams* __restrict__ P, int mi) {
-  const uint32_t N = P->N;
-  const uint64_t q = P->mod[mi].q;
-  const uint64_t* __restrict__ w = P->tab[mi].w;
-  const uint64_t* __restrict__ ws = P->tab[mi].ws;
-  const uint32_t half = N >> 1;
-  uint32_t logt = P->logN;
-  for (uint32_t m = 1; m < N; m <<= 1) {
-    --logt;
-    const uint32_t t = 1u << logt;
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < half; b += blockDim.x) {
-      uint32_t i = b >> logt, j = b & (t - 1);
-      uint32_t idx = (i << (logt + 1)) + j;
-      uint64_t W = w[m + i], Ws = ws[m + i];
-      uint64_t u = s[idx], v = mul_shoup(s[idx + t], W, Ws, q);
-      s[idx] = add_mod(u, v, q);
-      s[idx + t] = sub_mod(u, v, q);
-    }
-  }
-  __syncthreads();
+template <int LOGN>
+struct Plan {
+  static constexpr int N = 1 << LOGN;
+  static constexpr int NT = N / kNttElemsPerThread;
+  static constexpr int LDS_WORDS = N + N / 16;
+};
+
+__device__ __forceinline__ uint32_t lds_idx(uint32_t i) { return i + (i >> 4); }
+
+// x * w mod q up to one multiple of q: result in [0, 2q) for any 64-bit x.
+__device__ __forceinline__ uint64_t mul_shoup_lazy(uint64_t x, const Twiddle& t, uint64_t q) {
+  return x * t.w - __umul64hi(x, t.ws) * q;
 }
 
-// Inverse negacyclic NTT (Gentleman-Sande, bit-reversed in, natural out, scaled by N^-1).
-__device__ __forceinline__ void ntt_inv_lds(uint64_t* s, const DevParams* __restrict__ P, int mi) {
-  const uint32_t N = P->N;
-  const uint64_t q = P->mod[mi].q;
-  const uint64_t* __restrict__ iw = P->tab[mi].iw;
-  const uint64_t* __restrict__ iws = P->tab[mi].iws;
-  const uint32_t half = N >> 1;
-  uint32_t logt = 0;
-  for (uint32_t m = N; m > 1; m >>= 1) {
-    const uint32_t h = m >> 1, t = 1u << logt;
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < half; b += blockDim.x) {
-      uint32_t i = b >> logt, j = b & (t - 1);
-      uint32_t idx = (i << (logt + 1)) + j;
-      uint64_t W = iw[h + i], Ws = iws[h + i];
-      uint64_t u = s[idx], v = s[idx + t];
-      s[idx] = add_mod(u, v, q);
-      s[idx + t] = mul_shoup(sub_mod(u, v, q), W, Ws, q);
+template <int LB>
+__device__ __forceinline__ void lds_store16(uint64_t* s, const uint64_t (&x)[16], uint32_t tid) {
+  const uint32_t inner = tid & ((1u << LB) - 1u), outer = tid >> LB;
+  const uint32_t base = (outer << (LB + 4)) | inner;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s[lds_idx(base | ((uint32_t)e << LB))] = x[e];
+}
+
+template <int LB>
+__device__ __forceinline__ void lds_load16(const uint64_t* s, uint64_t (&x)[16], uint32_t tid) {
+  const uint32_t inner = tid & ((1u << LB) - 1u), outer = tid >> LB;
+  const uint32_t base = (outer << (LB + 4)) | inner;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) x[e] = s[lds_idx(base | ((uint32_t)e << LB))];
+}
+
+// Cooley-Tukey stages on window LB for relative bits RHI..RLO (high to low).
+template <int LOGN, int LB, int RHI, int RLO>
+__device__ __forceinline__ void fwd_stages(uint64_t (&x)[16], const Twiddle* __restrict__ tw, uint32_t outer,
+                                           uint64_t q) {
+  const uint64_t q2 = q << 1;
+#pragma unroll
+  for (int rb = RHI; rb >= RLO; --rb) {
+    const uint32_t m = 1u << (LOGN - 1 - (LB + rb));
+#pragma unroll
+    for (int g = 0; g < (8 >> rb); ++g) {
+      const Twiddle W = tw[m + (outer << (3 - rb)) + g];
+#pragma unroll
+      for (int l = 0; l < (1 << rb); ++l) {
+        const int e0 = (g << (rb + 1)) | l, e1 = e0 | (1 << rb);
+        uint64_t X = x[e0];
+        X = X >= q2 ? X - q2 : X;
+        const uint64_t T = mul_shoup_lazy(x[e1], W, q);
+        x[e0] = X + T;
+        x[e1] = X - T + q2;
+      }
     }
-    ++logt;
   }
-  __syncthreads();
-  const uint64_t ninv = P->tab[mi].ninv, ninvs = P->tab[mi].ninvs;
-  for (uint32_t i = threadIdx.x; i < N; i += blockDim.x) s[i] = mul_shoup(s[i], ninv, ninvs, q);
-  __syncthreads();
+}
+
+template <int LOGN, int LB>
+__device__ __forceinline__ void fwd_continue(uint64_t (&x)[16], uint64_t* s, const Twiddle* __restrict__ tw,
+                                             uint64_t q, uint32_t tid) {
+  if constexpr (LB > 0) {
+    constexpr int NLB = LB >= 4 ? LB - 4 : 0;
+    constexpr int RHI = LB >= 4 ? 3 : LB - 1;
+    lds_store16<LB>(s, x, tid);
+    __syncthreads();
+    lds_load16<NLB>(s, x, tid);
+    fwd_stages<LOGN, NLB, RHI, 0>(x, tw, tid >> NLB, q);
+    fwd_continue<LOGN, NLB>(x, s, tw, q, tid);
+  }
+}
+
+// Forward negacyclic NTT.  In: x[e] = coefficient e*NT + tid (canonical).
+// Out: x[e] = SEAL NTT position 16*tid + e (canonical) == device-order slot e*NT + tid.
+// The caller guarantees no thread still reads `s` (barrier) when this is entered.
+template <int LOGN>
+__device__ __forceinline__ void ntt_fwd_regs(uint64_t (&x)[16], uint64_t* s, const NttTable& tab, uint64_t q,
+                                             uint32_t tid) {
+  fwd_stages<LOGN, LOGN - 4, 3, 0>(x, tab.tw, 0u, q);
+  fwd_continue<LOGN, LOGN - 4>(x, s, tab.tw, q, tid);
+  const uint64_t q2 = q << 1;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    uint64_t v = x[e];
+    v = v >= q2 ? v - q2 : v;
+    x[e] = v >= q ? v - q : v;
+  }
+}
+
+// Gentleman-Sande stages on window LB for relative bits RLO..RHI (low to high);
+// with LAST the final stage multiplies by N^-1 (folded into both outputs).
+template <int LOGN, int LB, int RLO, int RHI, bool LAST>
+__device__ __forceinline__ void inv_stages(uint64_t (&x)[16], const NttTable& tab, uint32_t outer, uint64_t q) {
+  const uint64_t q2 = q << 1;
+  const Twiddle* __restrict__ itw = tab.itw;
+#pragma unroll
+  for (int rb = RLO; rb <= RHI; ++rb) {
+    const uint32_t h = 1u << (LOGN - 1 - (LB + rb));
+    const bool scale = LAST && (rb == RHI);
+#pragma unroll
+    for (int g = 0; g < (8 >> rb); ++g) {
+      const Twiddle W = scale ? tab.iw1n : itw[h + (outer << (3 - rb)) + g];
+#pragma unroll
+      for (int l = 0; l < (1 << rb); ++l) {
+        const int e0 = (g << (rb + 1)) | l, e1 = e0 | (1 << rb);
+        const uint64_t a = x[e0], b = x[e1];
+        uint64_t U = a + b;
+        const uint64_t T = a - b + q2;
+        if (scale) {
+          x[e0] = mul_shoup_lazy(U, tab.ninv, q);
+        } else {
+          x[e0] = U >= q2 ? U - q2 : U;
+        }
+        x[e1] = mul_shoup_lazy(T, W, q);
+      }
+    }
+  }
+}
+
+template <int LOGN, int D, int PREV>  // D = index bits already transformed; data in registers with window PREV
+__device__ __forceinline__ void inv_continue(uint64_t (&x)[16], uint64_t* s, const NttTable& tab, uint64_t q,
+                                             uint32_t tid) {
+  if constexpr (D < LOGN) {
+    constexpr int LB = (LOGN - D >= 4) ? D : LOGN - 4;
+    constexpr int RLO = D - LB;
+    constexpr bool LAST = (LB + 4 == LOGN);
+    lds_store16<PREV>(s, x, tid);
+    __syncthreads();
+    lds_load16<LB>(s, x, tid);
+    inv_stages<LOGN, LB, RLO, 3, LAST>(x, tab, tid >> LB, q);
+    inv_continue<LOGN, LB + 4, LB>(x, s, tab, q, tid);
+  }
+}
+
+// Inverse negacyclic NTT.  In: x[e] = NTT position 16*tid + e (< 2q).  Out: x[e] =
+// coefficient e*NT + tid, canonical, scaled by N^-1.
+template <int LOGN>
+__device__ __forceinline__ void ntt_inv_regs(uint64_t (&x)[16], uint64_t* s, const NttTable& tab, uint64_t q,
+                                             uint32_t tid) {
+  static_assert(LOGN >= 8, "at least two passes expected");
+  inv_stages<LOGN, 0, 0, 3, false>(x, tab, tid, q);
+  inv_continue<LOGN, 4, 0>(x, s, tab, q, tid);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) x[e] = x[e] >= q ? x[e] - q : x[e];
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -128,47 +237,81 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 // ------------------------------------------------------------------ batched NTT
 
 // One workgroup per polynomial; modulus index = mod_base + (poly % mod_period).
-__global__ void ntt_batch_kernel(const DevParams* __restrict__ P, uint64_t* __restrict__ data, uint32_t mod_period,
-                                 uint32_t mod_base, int inverse) {
+// Forward: natural coefficients -> device NTT order; inverse: the reverse.  In place.
+template <int LOGN, bool INVERSE>
+__global__ void __launch_bounds__(Plan<LOGN>::NT)
+ntt_batch_kernel(const DevParams* __restrict__ P, uint64_t* __restrict__ data, uint32_t mod_period,
+                 uint32_t mod_base) {
+  constexpr int NT = Plan<LOGN>::NT;
   uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
-  const uint32_t N = P->N;
+  const uint32_t tid = threadIdx.x;
   const int mi = mod_base + (blockIdx.x % mod_period);
-  uint64_t* poly = data + (size_t)blockIdx.x * N;
-  for (uint32_t i = threadIdx.x; i < N; i += blockDim.x) s[i] = poly[i];
-  if (inverse)
-    ntt_inv_lds(s, P, mi);
+  uint64_t* poly = data + (size_t)blockIdx.x * Plan<LOGN>::N;
+  uint64_t x[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) x[e] = poly[e * NT + tid];
+  if constexpr (INVERSE)
+    ntt_inv_regs<LOGN>(x, s, P->tab[mi], P->mod[mi].q, tid);
   else
-    ntt_fwd_lds(s, P, mi);
-  for (uint32_t i = threadIdx.x; i < N; i += blockDim.x) poly[i] = s[i];
+    ntt_fwd_regs<LOGN>(x, s, P->tab[mi], P->mod[mi].q, tid);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) poly[e * NT + tid] = x[e];
 }
 
 // Out-of-place forward NTT of ciphertexts: src[ct][2][k][N] (coefficient form)
-// -> dst[ct][2][k][N]; used to put the expanded selection vector into NTT form.
-__global__ void ct_ntt_fwd_oop_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ src,
-                                      uint64_t* __restrict__ dst) {
+// -> dst[ct][2][k][N] (device NTT order); selection vector -> NTT form.
+template <int LOGN>
+__global__ void __launch_bounds__(Plan<LOGN>::NT)
+ct_ntt_fwd_oop_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ src, uint64_t* __restrict__ dst) {
+  constexpr int NT = Plan<LOGN>::NT;
   uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
-  const uint32_t N = P->N;
+  const uint32_t tid = threadIdx.x;
   const int mi = blockIdx.x % P->k;
-  const uint64_t* in = src + (size_t)blockIdx.x * N;
-  uint64_t* out = dst + (size_t)blockIdx.x * N;
-  for (uint32_t i = threadIdx.x; i < N; i += blockDim.x) s[i] = in[i];
-  ntt_fwd_lds(s, P, mi);
-  for (uint32_t i = threadIdx.x; i < N; i += blockDim.x) out[i] = s[i];
+  const uint64_t* in = src + (size_t)blockIdx.x * Plan<LOGN>::N;
+  uint64_t* out = dst + (size_t)blockIdx.x * Plan<LOGN>::N;
+  uint64_t x[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) x[e] = in[e * NT + tid];
+  ntt_fwd_regs<LOGN>(x, s, P->tab[mi], P->mod[mi].q, tid);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) out[e * NT + tid] = x[e];
+}
+
+// SEAL NTT order <-> device NTT order for npolys polynomials (boundary only:
+// Galois-key upload and the test hooks).  to_device: out[e*NT + t] = in[16 t + e].
+__global__ void ntt_reorder_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint32_t logN,
+                                   uint64_t npolys, int to_device) {
+  const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t N = 1u << logN, NT = N >> 4;
+  if (gid >= npolys << logN) return;
+  const uint64_t poly = gid >> logN;
+  const uint32_t i = (uint32_t)(gid & (N - 1));     // device slot
+  const uint32_t e = i / NT, t = i % NT;
+  const uint32_t seal = (t << 4) | e;
+  if (to_device)
+    out[(poly << logN) + i] = in[(poly << logN) + seal];
+  else
+    out[(poly << logN) + seal] = in[(poly << logN) + i];
 }
 
 // ------------------------------------------------------------------ database encode
 
 // grid = (n_pt, k).  Source is either pre-encoded coefficients (coeffs != null)
-// or raw item bytes packed MSB-first into bits-wide coefficients.
-__global__ void db_encode_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ coeffs,
-                                 const uint8_t* __restrict__ bytes, uint64_t bytes_per_pt, uint64_t total_bytes,
-                                 uint32_t bits, uint64_t* __restrict__ db) {
+// or raw item bytes packed MSB-first into bits-wide coefficients
+// (reference string_encoder.cpp:58-122); then plain lift + forward NTT.
+template <int LOGN>
+__global__ void __launch_bounds__(Plan<LOGN>::NT)
+db_encode_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ coeffs,
+                 const uint8_t* __restrict__ bytes, uint64_t bytes_per_pt, uint64_t total_bytes, uint32_t bits,
+                 uint64_t* __restrict__ db) {
+  constexpr int NT = Plan<LOGN>::NT, N = Plan<LOGN>::N;
   uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
-  const uint32_t N = P->N, k = P->k;
+  const uint32_t tid = threadIdx.x, k = P->k;
   const uint32_t j = blockIdx.y;
   const uint64_t pt = blockIdx.x;
   const ModConst m = P->mod[j];
-  const uint64_t thr = P->plain_thr, inc = P->lift_inc[j];
+  const uint64_t thr = P->plain_thr;
+  const uint64_t inc = P->lift_inc[j] >= m.q ? P->lift_inc[j] - m.q : P->lift_inc[j];
   uint64_t L = 0;
   const uint8_t* src = nullptr;
   if (!coeffs) {
@@ -176,7 +319,10 @@ __global__ void db_encode_kernel(const DevParams* __restrict__ P, const uint64_t
     L = start >= total_bytes ? 0 : (total_bytes - start < bytes_per_pt ? total_bytes - start : bytes_per_pt);
     src = bytes + start;
   }
-  for (uint32_t c = threadIdx.x; c < N; c += blockDim.x) {
+  uint64_t x[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const uint32_t c = e * NT + tid;
     uint64_t v;
     if (coeffs) {
       v = coeffs[pt * N + c];
@@ -197,64 +343,82 @@ __global__ void db_encode_kernel(const DevParams* __restrict__ P, const uint64_t
       }
     }
     uint64_t r = reduce64(v, m);
-    if (v >= thr) r = add_mod(r, inc >= m.q ? inc - m.q : inc, m.q);
-    s[c] = r;
+    if (v >= thr) r = add_mod(r, inc, m.q);
+    x[e] = r;
   }
-  ntt_fwd_lds(s, P, j);
+  ntt_fwd_regs<LOGN>(x, s, P->tab[j], m.q, tid);
   uint64_t* out = db + (pt * k + j) * N;
-  for (uint32_t i = threadIdx.x; i < N; i += blockDim.x) out[i] = s[i];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) out[e * NT + tid] = x[e];
 }
 
 // ------------------------------------------------------------------ expansion
 
-// One level of the expansion tree, part 1: for node n and key-level modulus I,
-//   S[c][I] = sum_J NTT_I(sigma_g(c1)_J mod m_I) (.) K[J][c][I]   then INTT_I.
-// grid = (nodes, k+1); block = N/16 threads; prod layout [node][2][k+1][N].
-__global__ void ks_main_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ res_in,
-                               const uint64_t* __restrict__ key, uint32_t galois_elt, uint64_t* __restrict__ prod) {
+// One level of the expansion tree, part 1a: for node n, key-level modulus I and
+// RNS digit J:  dig[n][I][J] = NTT_I(sigma_g(c1)_J mod m_I)  (device NTT order).
+// grid = (nodes, k+1, k); block = N/16 threads.
+template <int LOGN>
+__global__ void __launch_bounds__(Plan<LOGN>::NT)
+ks_digit_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ res_in, uint32_t galois_elt,
+                uint64_t* __restrict__ dig) {
+  constexpr int NT = Plan<LOGN>::NT, N = Plan<LOGN>::N;
   uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
-  const uint32_t N = P->N, k = P->k, km = k + 1, logN = P->logN;
-  const uint32_t node = blockIdx.x, I = blockIdx.y;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t k = P->k;
+  const uint32_t node = blockIdx.x, I = blockIdx.y, J = blockIdx.z;
   const ModConst mI = P->mod[I];
-  const uint64_t* c1 = res_in + ((size_t)node * 2 + 1) * k * N;  // poly 1
-  uint64_t acc0[kNttElemsPerThread], acc1[kNttElemsPerThread];
+  const uint64_t qJ = P->mod[J].q;
+  const uint64_t* src = res_in + (((size_t)node * 2 + 1) * k + J) * N;  // poly 1, residue J
+  // sigma_g in coefficient form (SEAL GaloisTool::apply_galois), then reduce mod m_I
 #pragma unroll
-  for (int e = 0; e < kNttElemsPerThread; ++e) acc0[e] = acc1[e] = 0;
-  for (uint32_t J = 0; J < k; ++J) {
-    const uint64_t qJ = P->mod[J].q;
-    const uint64_t* src = c1 + (size_t)J * N;
-    __syncthreads();
-    // sigma_g in coefficient form (SEAL GaloisTool::apply_galois), then reduce mod m_I
-    for (uint32_t i = threadIdx.x; i < N; i += blockDim.x) {
-      uint32_t raw = i * galois_elt;
-      uint32_t idx = raw & (N - 1);
-      uint64_t v = src[i];
-      if ((raw >> logN) & 1) v = neg_mod(v, qJ);
-      s[idx] = reduce64(v, mI);
-    }
-    ntt_fwd_lds(s, P, I);
-    const uint64_t* k0 = key + (((size_t)J * 2 + 0) * km + I) * N;
-    const uint64_t* k1 = key + (((size_t)J * 2 + 1) * km + I) * N;
-#pragma unroll
-    for (int e = 0; e < kNttElemsPerThread; ++e) {
-      uint32_t pos = threadIdx.x + e * blockDim.x;
-      uint64_t x = s[pos];
-      acc0[e] = add_mod(acc0[e], mul_mod(x, k0[pos], mI), mI.q);
-      acc1[e] = add_mod(acc1[e], mul_mod(x, k1[pos], mI), mI.q);
-    }
+  for (int e = 0; e < 16; ++e) {
+    const uint32_t i = e * NT + tid;
+    const uint32_t raw = i * galois_elt;
+    uint64_t v = src[i];
+    if ((raw >> LOGN) & 1) v = neg_mod(v, qJ);
+    s[lds_idx(raw & (N - 1))] = reduce64(v, mI);
   }
-  uint64_t* out0 = prod + (((size_t)node * 2 + 0) * km + I) * N;
-  uint64_t* out1 = prod + (((size_t)node * 2 + 1) * km + I) * N;
   __syncthreads();
+  uint64_t x[16];
 #pragma unroll
-  for (int e = 0; e < kNttElemsPerThread; ++e) s[threadIdx.x + e * blockDim.x] = acc0[e];
-  ntt_inv_lds(s, P, I);
-  for (uint32_t i = threadIdx.x; i < N; i += blockDim.x) out0[i] = s[i];
-  __syncthreads();
+  for (int e = 0; e < 16; ++e) x[e] = s[lds_idx(e * NT + tid)];
+  ntt_fwd_regs<LOGN>(x, s, P->tab[I], mI.q, tid);
+  uint64_t* out = dig + (((size_t)node * (k + 1) + I) * k + J) * N;
 #pragma unroll
-  for (int e = 0; e < kNttElemsPerThread; ++e) s[threadIdx.x + e * blockDim.x] = acc1[e];
-  ntt_inv_lds(s, P, I);
-  for (uint32_t i = threadIdx.x; i < N; i += blockDim.x) out1[i] = s[i];
+  for (int e = 0; e < 16; ++e) out[e * NT + tid] = x[e];
+}
+
+// Part 1b: S[c][I] = sum_J dig[n][I][J] (.) K[J][c][I], then INTT_I -> prod[n][c][I]
+// (coefficient order).  The key is in device NTT order, so the dyadic products are
+// formed directly in the register layout the inverse transform starts from.
+// grid = (nodes, k+1, 2); block = N/16 threads.
+template <int LOGN>
+__global__ void __launch_bounds__(Plan<LOGN>::NT)
+ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ dig,
+                   const uint64_t* __restrict__ key, uint64_t* __restrict__ prod) {
+  constexpr int NT = Plan<LOGN>::NT, N = Plan<LOGN>::N;
+  uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
+  const uint32_t tid = threadIdx.x;
+  const uint32_t k = P->k, km = k + 1;
+  const uint32_t node = blockIdx.x, I = blockIdx.y, comp = blockIdx.z;
+  const ModConst mI = P->mod[I];
+  const uint64_t* d0 = dig + ((size_t)node * km + I) * k * N;
+  u128 acc[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0;
+  for (uint32_t J = 0; J < k; ++J) {  // k <= 8 products of two residues < 2^61 fit 128 bits
+    const uint64_t* dj = d0 + (size_t)J * N;
+    const uint64_t* kj = key + (((size_t)J * 2 + comp) * km + I) * N;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] += (u128)dj[e * NT + tid] * kj[e * NT + tid];
+  }
+  uint64_t x[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) x[e] = reduce128((uint64_t)acc[e], (uint64_t)(acc[e] >> 64), mI);
+  ntt_inv_regs<LOGN>(x, s, P->tab[I], mI.q, tid);
+  uint64_t* out = prod + (((size_t)node * 2 + comp) * km + I) * N;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) out[e * NT + tid] = x[e];
 }
 
 // Part 2: divide-and-round by the special prime, add sigma_g(c0), then the tree
@@ -452,27 +616,33 @@ __global__ void reduce_splits_kernel(const DevParams* __restrict__ P, const uint
 // ------------------------------------------------------------------ upper levels
 
 // CiphertextReencoder::Encode chunk e of source ciphertext c, lifted to residue
-// jt and forward-NTT'd: pt[c][e][jt][N].  grid = (n_src, enc_count, k).
-__global__ void reencode_lift_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ src,
-                                         uint64_t* __restrict__ pt) {
+// jt and forward-NTT'd: pt[c][e][jt][N] (device NTT order).  grid = (n_src, enc_count, k).
+template <int LOGN>
+__global__ void __launch_bounds__(Plan<LOGN>::NT)
+reencode_lift_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ src,
+                         uint64_t* __restrict__ pt) {
+  constexpr int NT = Plan<LOGN>::NT, N = Plan<LOGN>::N;
   uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
-  const uint32_t N = P->N, k = P->k;
-  const uint32_t c = blockIdx.x, e = blockIdx.y, jt = blockIdx.z;
+  const uint32_t tid = threadIdx.x, k = P->k;
+  const uint32_t c = blockIdx.x, e_idx = blockIdx.y, jt = blockIdx.z;
   const ModConst m = P->mod[jt];
-  const uint32_t sp = P->enc_poly[e], sj = P->enc_res[e], sh = P->enc_shift[e];
+  const uint32_t sp = P->enc_poly[e_idx], sj = P->enc_res[e_idx], sh = P->enc_shift[e_idx];
   const uint64_t mask = (1ull << P->enc_bits) - 1;
   const uint64_t thr = P->plain_thr;
   const uint64_t inc = P->lift_inc[jt] >= m.q ? P->lift_inc[jt] - m.q : P->lift_inc[jt];
   const uint64_t* in = src + (((size_t)c * 2 + sp) * k + sj) * N;
-  for (uint32_t i = threadIdx.x; i < N; i += blockDim.x) {
-    uint64_t v = (in[i] >> sh) & mask;
+  uint64_t x[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    uint64_t v = (in[e * NT + tid] >> sh) & mask;
     uint64_t r = reduce64(v, m);
     if (v >= thr) r = add_mod(r, inc, m.q);
-    s[i] = r;
+    x[e] = r;
   }
-  ntt_fwd_lds(s, P, jt);
-  uint64_t* out = pt + (((size_t)c * P->enc_count + e) * k + jt) * N;
-  for (uint32_t i = threadIdx.x; i < N; i += blockDim.x) out[i] = s[i];
+  ntt_fwd_regs<LOGN>(x, s, P->tab[jt], m.q, tid);
+  uint64_t* out = pt + (((size_t)c * P->enc_count + e_idx) * k + jt) * N;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) out[e * NT + tid] = x[e];
 }
 
 // Upper-level accumulate:  out[r][cc * E + e][p][j][i] =
@@ -517,39 +687,61 @@ __global__ void upper_mac_kernel(const DevParams* __restrict__ P, const uint64_t
 
 // ------------------------------------------------------------------ launchers
 
-static inline uint32_t ntt_threads(uint32_t N) { return N / kNttElemsPerThread; }
-static inline size_t ntt_lds(uint32_t N) { return (size_t)N * sizeof(uint64_t); }
-
 #define PIRGPU_LAUNCH_CHECK()            \
   do {                                   \
     hipError_t e_ = hipGetLastError();   \
     if (e_ != hipSuccess) return e_;     \
   } while (0)
 
-hipError_t configure_kernels(uint32_t N) {
-  // dynamic LDS beyond 64 KiB (N = 16384 -> 128 KiB of the CU's 160 KiB)
-  int bytes = (int)ntt_lds(N);
+// dispatch a LOGN-templated body over the supported ring degrees
+#define PIRGPU_DISPATCH_LOGN(logN, BODY)                  \
+  switch (logN) {                                         \
+    case 10: { constexpr int LOGN = 10; BODY; } break;    \
+    case 11: { constexpr int LOGN = 11; BODY; } break;    \
+    case 12: { constexpr int LOGN = 12; BODY; } break;    \
+    case 13: { constexpr int LOGN = 13; BODY; } break;    \
+    case 14: { constexpr int LOGN = 14; BODY; } break;    \
+    default: return hipErrorInvalidValue;                 \
+  }
+
+static inline uint32_t log2u(uint32_t N) {
+  uint32_t l = 0;
+  while ((1u << l) < N) ++l;
+  return l;
+}
+
+template <int LOGN>
+static hipError_t configure_for() {
+  // dynamic LDS beyond 64 KiB (N = 16384 -> 136 KiB of the CU's 160 KiB)
+  const int bytes = Plan<LOGN>::LDS_WORDS * 8;
   hipError_t e;
-  if ((e = hipFuncSetAttribute((const void*)ntt_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)))
-    return e;
-  if ((e = hipFuncSetAttribute((const void*)ct_ntt_fwd_oop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               bytes)))
-    return e;
-  if ((e = hipFuncSetAttribute((const void*)db_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)))
-    return e;
-  if ((e = hipFuncSetAttribute((const void*)ks_main_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)))
-    return e;
-  if ((e = hipFuncSetAttribute((const void*)reencode_lift_ntt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               bytes)))
-    return e;
+  if ((e = hipFuncSetAttribute((const void*)ntt_batch_kernel<LOGN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+  if ((e = hipFuncSetAttribute((const void*)ntt_batch_kernel<LOGN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+  if ((e = hipFuncSetAttribute((const void*)ct_ntt_fwd_oop_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+  if ((e = hipFuncSetAttribute((const void*)db_encode_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+  if ((e = hipFuncSetAttribute((const void*)ks_digit_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+  if ((e = hipFuncSetAttribute((const void*)ks_mac_intt_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+  if ((e = hipFuncSetAttribute((const void*)reencode_lift_ntt_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+  return hipSuccess;
+}
+
+hipError_t configure_kernels(uint32_t N) {
+  PIRGPU_DISPATCH_LOGN(log2u(N), return configure_for<LOGN>());
   return hipSuccess;
 }
 
 hipError_t launch_ntt_batch(hipStream_t st, const DevParams* P, uint32_t N, uint64_t* data, uint64_t n_polys,
                             uint32_t mod_period, uint32_t mod_base, bool inverse) {
   if (!n_polys) return hipSuccess;
-  hipLaunchKernelGGL(ntt_batch_kernel, dim3((uint32_t)n_polys), dim3(ntt_threads(N)), ntt_lds(N), st, P, data,
-                     mod_period, mod_base, inverse ? 1 : 0);
+  if (inverse) {
+    PIRGPU_DISPATCH_LOGN(log2u(N), hipLaunchKernelGGL((ntt_batch_kernel<LOGN, true>), dim3((uint32_t)n_polys),
+                                                      dim3(Plan<LOGN>::NT), Plan<LOGN>::LDS_WORDS * 8, st, P, data,
+                                                      mod_period, mod_base));
+  } else {
+    PIRGPU_DISPATCH_LOGN(log2u(N), hipLaunchKernelGGL((ntt_batch_kernel<LOGN, false>), dim3((uint32_t)n_polys),
+                                                      dim3(Plan<LOGN>::NT), Plan<LOGN>::LDS_WORDS * 8, st, P, data,
+                                                      mod_period, mod_base));
+  }
   PIRGPU_LAUNCH_CHECK();
   return hipSuccess;
 }
@@ -557,8 +749,18 @@ hipError_t launch_ntt_batch(hipStream_t st, const DevParams* P, uint32_t N, uint
 hipError_t launch_ct_ntt_fwd_oop(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* src,
                                  uint64_t* dst, uint64_t n_cts) {
   if (!n_cts) return hipSuccess;
-  hipLaunchKernelGGL(ct_ntt_fwd_oop_kernel, dim3((uint32_t)(n_cts * 2 * k)), dim3(ntt_threads(N)), ntt_lds(N), st,
-                     P, src, dst);
+  PIRGPU_DISPATCH_LOGN(log2u(N), hipLaunchKernelGGL(ct_ntt_fwd_oop_kernel<LOGN>, dim3((uint32_t)(n_cts * 2 * k)),
+                                                    dim3(Plan<LOGN>::NT), Plan<LOGN>::LDS_WORDS * 8, st, P, src, dst));
+  PIRGPU_LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_ntt_reorder(hipStream_t st, uint32_t N, const uint64_t* in, uint64_t* out, uint64_t n_polys,
+                              bool to_device) {
+  if (!n_polys) return hipSuccess;
+  const uint64_t total = n_polys * N;
+  hipLaunchKernelGGL(ntt_reorder_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, in, out, log2u(N),
+                     n_polys, to_device ? 1 : 0);
   PIRGPU_LAUNCH_CHECK();
   return hipSuccess;
 }
@@ -567,17 +769,24 @@ hipError_t launch_db_encode(hipStream_t st, const DevParams* P, uint32_t N, uint
                             const uint8_t* bytes, uint64_t bytes_per_pt, uint64_t total_bytes, uint32_t bits,
                             uint64_t n_pt, uint64_t* db) {
   if (!n_pt) return hipSuccess;
-  hipLaunchKernelGGL(db_encode_kernel, dim3((uint32_t)n_pt, k), dim3(ntt_threads(N)), ntt_lds(N), st, P, coeffs,
-                     bytes, bytes_per_pt, total_bytes, bits, db);
+  PIRGPU_DISPATCH_LOGN(log2u(N), hipLaunchKernelGGL(db_encode_kernel<LOGN>, dim3((uint32_t)n_pt, k),
+                                                    dim3(Plan<LOGN>::NT), Plan<LOGN>::LDS_WORDS * 8, st, P, coeffs,
+                                                    bytes, bytes_per_pt, total_bytes, bits, db));
   PIRGPU_LAUNCH_CHECK();
   return hipSuccess;
 }
 
 hipError_t launch_ks_level(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* res_in,
                            const uint64_t* key, uint32_t galois_elt, uint32_t galois_inv, uint32_t nodes,
-                           uint32_t shift_pow, bool expand_step, uint64_t* prod, uint64_t* res_out) {
-  hipLaunchKernelGGL(ks_main_kernel, dim3(nodes, k + 1), dim3(ntt_threads(N)), ntt_lds(N), st, P, res_in, key,
-                     galois_elt, prod);
+                           uint32_t shift_pow, bool expand_step, uint64_t* dig, uint64_t* prod,
+                           uint64_t* res_out) {
+  PIRGPU_DISPATCH_LOGN(log2u(N), hipLaunchKernelGGL(ks_digit_kernel<LOGN>, dim3(nodes, k + 1, k),
+                                                    dim3(Plan<LOGN>::NT), Plan<LOGN>::LDS_WORDS * 8, st, P, res_in,
+                                                    galois_elt, dig));
+  PIRGPU_LAUNCH_CHECK();
+  PIRGPU_DISPATCH_LOGN(log2u(N), hipLaunchKernelGGL(ks_mac_intt_kernel<LOGN>, dim3(nodes, k + 1, 2),
+                                                    dim3(Plan<LOGN>::NT), Plan<LOGN>::LDS_WORDS * 8, st, P, dig, key,
+                                                    prod));
   PIRGPU_LAUNCH_CHECK();
   uint64_t total = (uint64_t)nodes * k * N;
   hipLaunchKernelGGL(ks_combine_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, P, res_in, prod,
@@ -620,8 +829,9 @@ hipError_t launch_reduce_splits(hipStream_t st, const DevParams* P, const uint64
 hipError_t launch_reencode_lift_ntt(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, uint32_t enc_count,
                                     const uint64_t* src, uint64_t n_src, uint64_t* pt) {
   if (!n_src) return hipSuccess;
-  hipLaunchKernelGGL(reencode_lift_ntt_kernel, dim3((uint32_t)n_src, enc_count, k), dim3(ntt_threads(N)),
-                     ntt_lds(N), st, P, src, pt);
+  PIRGPU_DISPATCH_LOGN(log2u(N), hipLaunchKernelGGL(reencode_lift_ntt_kernel<LOGN>,
+                                                    dim3((uint32_t)n_src, enc_count, k), dim3(Plan<LOGN>::NT),
+                                                    Plan<LOGN>::LDS_WORDS * 8, st, P, src, pt));
   PIRGPU_LAUNCH_CHECK();
   return hipSuccess;
 }

@@ -79,6 +79,7 @@ struct pirgpu_ctx {
   uint64_t* pt_buf = nullptr;
   uint64_t* scan_part = nullptr;
   uint32_t scan_nsplit = 1, scan_cps = 0, scan_rows = 0, scan_cols = 0;
+  uint32_t scan_rpt = 4, scan_block = 256;  // rows per thread / workgroup size of the scan kernel
   uint64_t scan_npt = 0;
   bool reply_valid = false;
 
@@ -236,11 +237,23 @@ void ensure_workspace(pirgpu_ctx* c) {
   }
   c->scan_npt = shard_pts;
   {
-    const uint32_t xblocks = (k * N / 2 + 255) / 256;
-    const uint32_t yblocks = (c->scan_rows + 3) / 4;
-    uint64_t have = (uint64_t)xblocks * std::max<uint32_t>(yblocks, 1);
-    uint32_t want = have >= 1024 ? 1 : (uint32_t)ceil_div(1024, have);
-    want = std::min<uint32_t>(want, std::max<uint32_t>(c->scan_cols, 1));
+    // Scan launch geometry.  Tuning knobs (environment, read once per context):
+    //   PIRGPU_SCAN_ROWS   rows accumulated per thread (1,2,3,4,6,8)
+    //   PIRGPU_SCAN_BLOCK  workgroup size (64..256)
+    //   PIRGPU_SCAN_NSPLIT column splits (partial sums reduced by reduce_splits_kernel)
+    auto env_u32 = [](const char* name, uint32_t dflt) {
+      const char* v = getenv(name);
+      return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
+    };
+    c->scan_rpt = env_u32("PIRGPU_SCAN_ROWS", 4);
+    c->scan_block = env_u32("PIRGPU_SCAN_BLOCK", 256);
+    const uint32_t xblocks = (k * N / 2 + c->scan_block - 1) / c->scan_block;
+    const uint32_t yblocks = (c->scan_rows + c->scan_rpt - 1) / c->scan_rpt;
+    uint64_t have = (uint64_t)xblocks * std::max<uint32_t>(yblocks, 1) * c->scan_block / 256;
+    // split the columns only when whole rows cannot fill the chip (d = 1 / few rows)
+    uint32_t want = have >= 512 ? 1 : (uint32_t)ceil_div(1024, std::max<uint64_t>(have, 1));
+    want = env_u32("PIRGPU_SCAN_NSPLIT", want);
+    want = std::max<uint32_t>(1, std::min<uint32_t>(want, std::max<uint32_t>(c->scan_cols, 1)));
     c->scan_cps = (uint32_t)ceil_div(std::max<uint32_t>(c->scan_cols, 1), want);
     c->scan_nsplit = (uint32_t)ceil_div(std::max<uint32_t>(c->scan_cols, 1), c->scan_cps);
     if (c->scan_nsplit > 1)
@@ -343,7 +356,7 @@ void multiply_on_device(pirgpu_ctx* c) {
   uint64_t* base_out = c->lvl[d - 1];
   uint64_t* scan_out = c->scan_nsplit > 1 ? c->scan_part : base_out;
   HIP_TRY(launch_scan(c->stream, c->dp, N, k, c->d_db, sv_base, scan_out, c->scan_rows, c->scan_cols, c->scan_npt,
-                      c->scan_nsplit, c->scan_cps));
+                      c->scan_nsplit, c->scan_cps, c->scan_rpt, c->scan_block));
   if (c->scan_nsplit > 1)
     HIP_TRY(launch_reduce_splits(c->stream, c->dp, c->scan_part, c->scan_nsplit, (uint64_t)c->scan_rows * ctw,
                                  base_out));

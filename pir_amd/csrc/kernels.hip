@@ -516,12 +516,52 @@ __device__ __forceinline__ void load_vec(const uint64_t* __restrict__ p, uint64_
   }
 }
 
-// Base case of DatabaseMultiplier::multiply fused over a whole row:
+// Base case of DatabaseMultiplier::multiply fused over whole rows (the streaming kernel):
 //   out[split][row][p][j][c] = sum_{col in split} sv[col][p][j][c] * db[row*cols + col][j][c]  mod q_j
-// Each thread owns VEC adjacent coefficients of one residue for ROWS rows and
-// streams the database exactly once (16-byte loads, fully coalesced); products
-// accumulate lazily in 128 bits and are reduced once (or every lazy_limit terms).
+// Each thread owns VEC adjacent residues for ROWS rows and streams the database
+// exactly once with 16-byte non-temporal loads (fully coalesced, 1 KiB per wave
+// instruction); the selectors are re-read from L2 (one load per ROWS database
+// loads).  Loads of column c+1 are issued before the products of column c are
+// formed (two register buffers), so every wave always has (ROWS+2) x 1 KiB in
+// flight.  Products accumulate lazily in 128 bits and are reduced once (or every
+// lazy_limit columns for wide moduli).
 // grid = (k*N / (VEC*block), ceil(rows / ROWS), nsplit).
+template <int ROWS, int VEC>
+struct ScanBuf {
+  uint64_t d[ROWS][VEC];
+  uint64_t s[2][VEC];
+};
+
+template <int ROWS, int VEC>
+__device__ __forceinline__ void scan_load(ScanBuf<ROWS, VEC>& b, const uint64_t* const (&rp)[ROWS],
+                                          const uint64_t* __restrict__ svp, uint32_t col, uint32_t kN) {
+  const size_t off = (size_t)col * kN;
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    if constexpr (VEC == 2) {
+      u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(rp[r] + off));
+      b.d[r][0] = v.x;
+      b.d[r][1] = v.y;
+    } else {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) b.d[r][v] = __builtin_nontemporal_load(rp[r] + off + v);
+    }
+  }
+  load_vec<VEC>(svp + 2 * off, b.s[0]);
+  load_vec<VEC>(svp + 2 * off + kN, b.s[1]);
+}
+
+template <int ROWS, int VEC>
+__device__ __forceinline__ void scan_mac(u128 (&acc)[ROWS][2][VEC], const ScanBuf<ROWS, VEC>& b) {
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      acc[r][0][v] += (u128)b.s[0][v] * b.d[r][v];
+      acc[r][1][v] += (u128)b.s[1][v] * b.d[r][v];
+    }
+}
+
 template <int ROWS, int VEC>
 __global__ void __launch_bounds__(256)
 scan_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ db, const uint64_t* __restrict__ sv,
@@ -546,28 +586,65 @@ scan_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ db, co
 #pragma unroll
       for (int v = 0; v < VEC; ++v) acc[r][p][v] = 0;
 
-  // number of valid columns per row (database may end inside the last row)
+  // Rows past the end of this launch are redirected to the last real row (their
+  // sums are discarded); only the database's final row can be shorter than cols.
+  const uint64_t* rp[ROWS];
   uint32_t ncol[ROWS];
+  uint32_t nfull = col_end;
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
-    uint32_t row = row0 + r;
+    uint32_t row = row0 + r < rows ? row0 + r : rows - 1;
     uint64_t first = (uint64_t)row * cols;
-    uint64_t avail = (row < rows && first < num_pt) ? num_pt - first : 0;
+    uint64_t avail = first < num_pt ? num_pt - first : 0;
     ncol[r] = avail > cols ? cols : (uint32_t)avail;
+    if (ncol[r] < nfull) nfull = ncol[r];
+    rp[r] = db + first * kN + c0;
   }
+  if (nfull < col_begin) nfull = col_begin;
+  const uint64_t* svp = sv + c0;
 
+  // ---- main loop: columns [col_begin, nfull) exist in every row of the group
+  for (uint32_t chunk = col_begin; chunk < nfull;) {
+    const uint32_t chunk_end = nfull - chunk > lazy ? chunk + lazy : nfull;
+    // Two register buffers; the prefetches are unconditional (the column index is
+    // clamped) so the s_waitcnt counters stay exact and a full buffer is always in flight.
+    ScanBuf<ROWS, VEC> A, B;
+    const uint32_t last = chunk_end - 1;
+    scan_load<ROWS, VEC>(A, rp, svp, chunk, kN);
+    uint32_t col = chunk;
+    for (; col + 2 <= chunk_end; col += 2) {
+      scan_load<ROWS, VEC>(B, rp, svp, col + 1, kN);
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the products (hipcc sinks loads otherwise)
+      scan_mac<ROWS, VEC>(acc, A);
+      __builtin_amdgcn_sched_barrier(0);
+      scan_load<ROWS, VEC>(A, rp, svp, col + 2 < last ? col + 2 : last, kN);
+      __builtin_amdgcn_sched_barrier(0);
+      scan_mac<ROWS, VEC>(acc, B);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (col < chunk_end) scan_mac<ROWS, VEC>(acc, A);  // odd count: A holds column `last`
+    chunk = chunk_end;
+    if (chunk < col_end) {  // more columns follow: fold the lazy sums
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v)
+            acc[r][p][v] = reduce128((uint64_t)acc[r][p][v], (uint64_t)(acc[r][p][v] >> 64), m);
+    }
+  }
+  // ---- ragged tail (only the group holding the database's last, shorter row)
   uint32_t since = 0;
-  for (uint32_t col = col_begin; col < col_end; ++col) {
-    const uint64_t* svp = sv + (size_t)col * 2 * kN + c0;
+  for (uint32_t col = nfull; col < col_end; ++col) {
     uint64_t s0[VEC], s1[VEC];
-    load_vec<VEC>(svp, s0);
-    load_vec<VEC>(svp + kN, s1);
+    load_vec<VEC>(svp + (size_t)col * 2 * kN, s0);
+    load_vec<VEC>(svp + (size_t)col * 2 * kN + kN, s1);
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
       if (col < ncol[r]) {
-        const uint64_t* dp = db + ((size_t)(row0 + r) * cols + col) * kN + c0;
         uint64_t d[VEC];
-        load_vec<VEC>(dp, d);
+        load_vec<VEC>(rp[r] + (size_t)col * kN, d);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
           acc[r][0][v] += (u128)s0[v] * d[v];
@@ -804,17 +881,32 @@ hipError_t launch_monomial_shift(hipStream_t st, const DevParams* P, uint32_t N,
   return hipSuccess;
 }
 
-hipError_t launch_scan(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* db,
-                       const uint64_t* sv, uint64_t* out, uint32_t rows, uint32_t cols, uint64_t num_pt,
-                       uint32_t nsplit, uint32_t cols_per_split) {
-  constexpr int ROWS = 4, VEC = 2;
-  const uint32_t kN = k * N;
-  const uint32_t block = 256;
+template <int ROWS, int VEC>
+static hipError_t launch_scan_variant(hipStream_t st, const DevParams* P, uint32_t kN, uint32_t block,
+                                      const uint64_t* db, const uint64_t* sv, uint64_t* out, uint32_t rows,
+                                      uint32_t cols, uint64_t num_pt, uint32_t nsplit, uint32_t cols_per_split) {
   dim3 grid((kN / VEC + block - 1) / block, (rows + ROWS - 1) / ROWS, nsplit);
   hipLaunchKernelGGL((scan_kernel<ROWS, VEC>), grid, dim3(block), 0, st, P, db, sv, out, rows, cols, num_pt,
                      cols_per_split);
-  PIRGPU_LAUNCH_CHECK();
-  return hipSuccess;
+  return hipGetLastError();
+}
+
+hipError_t launch_scan(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* db,
+                       const uint64_t* sv, uint64_t* out, uint32_t rows, uint32_t cols, uint64_t num_pt,
+                       uint32_t nsplit, uint32_t cols_per_split, uint32_t rows_per_thread, uint32_t block) {
+  const uint32_t kN = k * N;
+#define PIRGPU_SCAN_CASE(R) \
+  case R: return launch_scan_variant<R, 2>(st, P, kN, block, db, sv, out, rows, cols, num_pt, nsplit, cols_per_split)
+  switch (rows_per_thread) {
+    PIRGPU_SCAN_CASE(1);
+    PIRGPU_SCAN_CASE(2);
+    PIRGPU_SCAN_CASE(3);
+    PIRGPU_SCAN_CASE(4);
+    PIRGPU_SCAN_CASE(6);
+    PIRGPU_SCAN_CASE(8);
+    default: return hipErrorInvalidValue;
+  }
+#undef PIRGPU_SCAN_CASE
 }
 
 hipError_t launch_reduce_splits(hipStream_t st, const DevParams* P, const uint64_t* part, uint32_t nsplit,

@@ -80,6 +80,7 @@ struct pirgpu_ctx {
   uint64_t* scan_part = nullptr;
   uint32_t scan_nsplit = 1, scan_cps = 0, scan_rows = 0, scan_cols = 0;
   uint32_t scan_rpt = 4, scan_block = 256;  // rows per thread / workgroup size of the scan kernel
+  bool scan_limb = false;                   // 28-bit limb accumulators (all data moduli < 2^50)
   uint64_t scan_npt = 0;
   bool reply_valid = false;
 
@@ -245,6 +246,10 @@ void ensure_workspace(pirgpu_ctx* c) {
       const char* v = getenv(name);
       return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
     };
+    //   PIRGPU_SCAN_LIMB   0 forces the generic 128-bit accumulators
+    c->scan_limb = true;
+    for (uint32_t j = 0; j < k; ++j) c->scan_limb = c->scan_limb && (c->hp.mod[j].q >> 50) == 0;
+    if (!env_u32("PIRGPU_SCAN_LIMB", 1)) c->scan_limb = false;
     c->scan_rpt = env_u32("PIRGPU_SCAN_ROWS", 4);
     c->scan_block = env_u32("PIRGPU_SCAN_BLOCK", 256);
     const uint32_t xblocks = (k * N / 2 + c->scan_block - 1) / c->scan_block;
@@ -356,7 +361,7 @@ void multiply_on_device(pirgpu_ctx* c) {
   uint64_t* base_out = c->lvl[d - 1];
   uint64_t* scan_out = c->scan_nsplit > 1 ? c->scan_part : base_out;
   HIP_TRY(launch_scan(c->stream, c->dp, N, k, c->d_db, sv_base, scan_out, c->scan_rows, c->scan_cols, c->scan_npt,
-                      c->scan_nsplit, c->scan_cps, c->scan_rpt, c->scan_block));
+                      c->scan_nsplit, c->scan_cps, c->scan_rpt, c->scan_block, c->scan_limb));
   if (c->scan_nsplit > 1)
     HIP_TRY(launch_reduce_splits(c->stream, c->dp, c->scan_part, c->scan_nsplit, (uint64_t)c->scan_rows * ctw,
                                  base_out));

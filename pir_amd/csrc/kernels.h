@@ -26,7 +26,8 @@ hipError_t launch_monomial_shift(hipStream_t st, const DevParams* P, uint32_t N,
                                  uint32_t shift, uint64_t count, uint64_t* out);
 hipError_t launch_scan(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* db,
                        const uint64_t* sv, uint64_t* out, uint32_t rows, uint32_t cols, uint64_t num_pt,
-                       uint32_t nsplit, uint32_t cols_per_split, uint32_t rows_per_thread, uint32_t block);
+                       uint32_t nsplit, uint32_t cols_per_split, uint32_t rows_per_thread, uint32_t block,
+                       bool limb);
 hipError_t launch_reduce_splits(hipStream_t st, const DevParams* P, const uint64_t* part, uint32_t nsplit,
                                 uint64_t words, uint64_t* out);
 hipError_t launch_reencode_lift_ntt(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, uint32_t enc_count,

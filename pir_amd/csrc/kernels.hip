@@ -551,18 +551,74 @@ __device__ __forceinline__ void scan_load(ScanBuf<ROWS, VEC>& b, const uint64_t*
   load_vec<VEC>(svp + 2 * off + kN, b.s[1]);
 }
 
+// Lazy accumulators of residue products.
+//  AccWide: exact 128-bit sum, any modulus < 2^61, up to lazy_limit terms.
+//  AccLimb: for moduli < 2^50 the residues are split at bit 28 and the four
+//    partial products accumulate in three 64-bit sums with no carry handling at
+//    all (4 v_mad_u64_u32 per product, ~3x fewer VALU ops than the 128-bit path);
+//    exact for up to kLimbLazy terms: s00 < 128 * 2^56, s01 < 128 * 2^51, s11 < 128 * 2^44.
+constexpr uint32_t kLimbLazy = 128;
+
+struct AccWide {
+  u128 v;
+  __device__ __forceinline__ void clear() { v = 0; }
+  __device__ __forceinline__ uint64_t fold(const ModConst& m) const {
+    return reduce128((uint64_t)v, (uint64_t)(v >> 64), m);
+  }
+  __device__ __forceinline__ void set(uint64_t r) { v = r; }
+};
+
+struct AccLimb {
+  uint64_t s00, s01, s11;
+  __device__ __forceinline__ void clear() { s00 = s01 = s11 = 0; }
+  __device__ __forceinline__ uint64_t fold(const ModConst& m) const {
+    u128 t = (u128)s00 + ((u128)s01 << 28) + ((u128)s11 << 56);
+    return reduce128((uint64_t)t, (uint64_t)(t >> 64), m);
+  }
+  __device__ __forceinline__ void set(uint64_t r) {
+    s00 = r;
+    s01 = s11 = 0;
+  }
+};
+
 template <int ROWS, int VEC>
-__device__ __forceinline__ void scan_mac(u128 (&acc)[ROWS][2][VEC], const ScanBuf<ROWS, VEC>& b) {
+__device__ __forceinline__ void scan_mac(AccWide (&acc)[ROWS][2][VEC], const ScanBuf<ROWS, VEC>& b) {
 #pragma unroll
   for (int r = 0; r < ROWS; ++r)
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
-      acc[r][0][v] += (u128)b.s[0][v] * b.d[r][v];
-      acc[r][1][v] += (u128)b.s[1][v] * b.d[r][v];
+      acc[r][0][v].v += (u128)b.s[0][v] * b.d[r][v];
+      acc[r][1][v].v += (u128)b.s[1][v] * b.d[r][v];
     }
 }
 
 template <int ROWS, int VEC>
+__device__ __forceinline__ void scan_mac(AccLimb (&acc)[ROWS][2][VEC], const ScanBuf<ROWS, VEC>& b) {
+  uint32_t a0[2][VEC], a1[2][VEC];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      a0[p][v] = (uint32_t)b.s[p][v] & 0x0FFFFFFFu;
+      a1[p][v] = (uint32_t)(b.s[p][v] >> 28);
+    }
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const uint32_t b0 = (uint32_t)b.d[r][v] & 0x0FFFFFFFu;
+      const uint32_t b1 = (uint32_t)(b.d[r][v] >> 28);
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        acc[r][p][v].s00 += (uint64_t)a0[p][v] * b0;
+        acc[r][p][v].s01 += (uint64_t)a0[p][v] * b1;
+        acc[r][p][v].s01 += (uint64_t)a1[p][v] * b0;
+        acc[r][p][v].s11 += (uint64_t)a1[p][v] * b1;
+      }
+    }
+}
+
+template <int ROWS, int VEC, typename ACC>
 __global__ void __launch_bounds__(256)
 scan_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ db, const uint64_t* __restrict__ sv,
             uint64_t* __restrict__ out, uint32_t rows, uint32_t cols, uint64_t num_pt, uint32_t cols_per_split) {
@@ -576,15 +632,15 @@ scan_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ db, co
   const uint32_t col_begin = blockIdx.z * cols_per_split;
   uint32_t col_end = col_begin + cols_per_split;
   if (col_end > cols) col_end = cols;
-  const uint32_t lazy = P->lazy_limit;
+  const uint32_t lazy = std::is_same<ACC, AccLimb>::value ? kLimbLazy : P->lazy_limit;
 
-  u128 acc[ROWS][2][VEC];
+  ACC acc[ROWS][2][VEC];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r)
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) acc[r][p][v] = 0;
+      for (int v = 0; v < VEC; ++v) acc[r][p][v].clear();
 
   // Rows past the end of this launch are redirected to the last real row (their
   // sums are discarded); only the database's final row can be shorter than cols.
@@ -630,26 +686,20 @@ scan_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ db, co
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
-          for (int v = 0; v < VEC; ++v)
-            acc[r][p][v] = reduce128((uint64_t)acc[r][p][v], (uint64_t)(acc[r][p][v] >> 64), m);
+          for (int v = 0; v < VEC; ++v) acc[r][p][v].set(acc[r][p][v].fold(m));
     }
   }
   // ---- ragged tail (only the group holding the database's last, shorter row)
   uint32_t since = 0;
   for (uint32_t col = nfull; col < col_end; ++col) {
-    uint64_t s0[VEC], s1[VEC];
-    load_vec<VEC>(svp + (size_t)col * 2 * kN, s0);
-    load_vec<VEC>(svp + (size_t)col * 2 * kN + kN, s1);
+    ScanBuf<1, VEC> tb;
+    load_vec<VEC>(svp + (size_t)col * 2 * kN, tb.s[0]);
+    load_vec<VEC>(svp + (size_t)col * 2 * kN + kN, tb.s[1]);
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
       if (col < ncol[r]) {
-        uint64_t d[VEC];
-        load_vec<VEC>(rp[r] + (size_t)col * kN, d);
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          acc[r][0][v] += (u128)s0[v] * d[v];
-          acc[r][1][v] += (u128)s1[v] * d[v];
-        }
+        load_vec<VEC>(rp[r] + (size_t)col * kN, tb.d[0]);
+        scan_mac<1, VEC>(reinterpret_cast<ACC(&)[1][2][VEC]>(acc[r]), tb);
       }
     }
     if (++since == lazy) {
@@ -659,8 +709,7 @@ scan_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ db, co
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
-          for (int v = 0; v < VEC; ++v)
-            acc[r][p][v] = reduce128((uint64_t)acc[r][p][v], (uint64_t)(acc[r][p][v] >> 64), m);
+          for (int v = 0; v < VEC; ++v) acc[r][p][v].set(acc[r][p][v].fold(m));
     }
   }
 #pragma unroll
@@ -671,8 +720,7 @@ scan_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ db, co
 #pragma unroll
       for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int v = 0; v < VEC; ++v)
-          o[(size_t)p * kN + v] = reduce128((uint64_t)acc[r][p][v], (uint64_t)(acc[r][p][v] >> 64), m);
+        for (int v = 0; v < VEC; ++v) o[(size_t)p * kN + v] = acc[r][p][v].fold(m);
     }
   }
 }
@@ -881,22 +929,27 @@ hipError_t launch_monomial_shift(hipStream_t st, const DevParams* P, uint32_t N,
   return hipSuccess;
 }
 
-template <int ROWS, int VEC>
+template <int ROWS, int VEC, typename ACC>
 static hipError_t launch_scan_variant(hipStream_t st, const DevParams* P, uint32_t kN, uint32_t block,
                                       const uint64_t* db, const uint64_t* sv, uint64_t* out, uint32_t rows,
                                       uint32_t cols, uint64_t num_pt, uint32_t nsplit, uint32_t cols_per_split) {
   dim3 grid((kN / VEC + block - 1) / block, (rows + ROWS - 1) / ROWS, nsplit);
-  hipLaunchKernelGGL((scan_kernel<ROWS, VEC>), grid, dim3(block), 0, st, P, db, sv, out, rows, cols, num_pt,
+  hipLaunchKernelGGL((scan_kernel<ROWS, VEC, ACC>), grid, dim3(block), 0, st, P, db, sv, out, rows, cols, num_pt,
                      cols_per_split);
   return hipGetLastError();
 }
 
 hipError_t launch_scan(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* db,
                        const uint64_t* sv, uint64_t* out, uint32_t rows, uint32_t cols, uint64_t num_pt,
-                       uint32_t nsplit, uint32_t cols_per_split, uint32_t rows_per_thread, uint32_t block) {
+                       uint32_t nsplit, uint32_t cols_per_split, uint32_t rows_per_thread, uint32_t block,
+                       bool limb) {
   const uint32_t kN = k * N;
-#define PIRGPU_SCAN_CASE(R) \
-  case R: return launch_scan_variant<R, 2>(st, P, kN, block, db, sv, out, rows, cols, num_pt, nsplit, cols_per_split)
+#define PIRGPU_SCAN_CASE(R)                                                                                        \
+  case R:                                                                                                          \
+    return limb ? launch_scan_variant<R, 2, AccLimb>(st, P, kN, block, db, sv, out, rows, cols, num_pt, nsplit,     \
+                                                     cols_per_split)                                               \
+                : launch_scan_variant<R, 2, AccWide>(st, P, kN, block, db, sv, out, rows, cols, num_pt, nsplit,     \
+                                                     cols_per_split)
   switch (rows_per_thread) {
     PIRGPU_SCAN_CASE(1);
     PIRGPU_SCAN_CASE(2);

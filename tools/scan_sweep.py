@@ -8,18 +8,19 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 configs = []
-for rows in (2, 3, 4, 6, 8):
-    for block in (64, 128, 256):
-        for nsplit in (1, 2):
-            configs.append((rows, block, nsplit))
-print("rows block nsplit scan_ms GB/s total_ms")
-for rows, block, nsplit in configs:
-    env = dict(os.environ, PIRGPU_SCAN_ROWS=str(rows), PIRGPU_SCAN_BLOCK=str(block), PIRGPU_SCAN_NSPLIT=str(nsplit))
+for limb in (1, 0):
+    for rows in (2, 3, 4, 6):
+        for block in (64, 128, 256):
+            configs.append((limb, rows, block, 1))
+print("limb rows block nsplit scan_ms GB/s total_ms")
+for limb, rows, block, nsplit in configs:
+    env = dict(os.environ, PIRGPU_SCAN_ROWS=str(rows), PIRGPU_SCAN_BLOCK=str(block), PIRGPU_SCAN_NSPLIT=str(nsplit),
+               PIRGPU_SCAN_LIMB=str(limb))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3",
                         "--no-cpu-baseline"], env=env, capture_output=True, text=True)
     try:
         j = json.loads(r.stdout.strip().splitlines()[-1])
-        print(rows, block, nsplit, "%.4f" % j["roofline"]["kernel_ms"], "%.0f" % j["roofline"]["achieved"],
+        print(limb, rows, block, nsplit, "%.4f" % j["roofline"]["kernel_ms"], "%.0f" % j["roofline"]["achieved"],
               "%.3f" % j["ms_per_step"], flush=True)
     except Exception as e:
-        print(rows, block, nsplit, "FAILED", r.stderr[-300:], flush=True)
+        print(limb, rows, block, nsplit, "FAILED", r.stderr[-300:], flush=True)

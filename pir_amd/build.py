@@ -9,7 +9,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpirgpu.so")
 SOURCES = ["kernels.hip", "ctx.hip", "wire.cpp"]
-HEADERS = ["device_params.h", "kernels.h", "host_math.h", "wire.h", os.path.join("..", "..", "include", "pirgpu.h")]
+NTT_SOURCE = "ntt_kernels.hip"      # compiled once per ring degree (-DPIRGPU_LOGN)
+NTT_LOGNS = [11, 12, 13, 14]
+HEADERS = ["device_params.h", "kernels.h", "host_math.h", "wire.h", "arith.h", "ntt_core.h", NTT_SOURCE, os.path.join("..", "..", "include", "pirgpu.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -28,14 +30,25 @@ def _stale() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
-    objs = []
+    jobs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.rsplit(".", 1)[0] + ".o")
-        cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        jobs.append(([HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) +
+                     ["-c", os.path.join(CSRC, src), "-o", obj], obj))
+    for logn in NTT_LOGNS:
+        obj = os.path.join(CSRC, "ntt_kernels_%d.o" % logn)
+        jobs.append(([HIPCC] + FLAGS + ["-x", "hip", "-DPIRGPU_LOGN=%d" % logn, "-c", os.path.join(CSRC, NTT_SOURCE),
+                      "-o", obj], obj))
+
+    def run(job):
         if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.run(cmd, check=True)
-        objs.append(obj)
+            print(" ".join(job[0]), file=sys.stderr)
+        subprocess.run(job[0], check=True)
+        return job[1]
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(run, jobs))
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

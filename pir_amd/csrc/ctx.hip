@@ -60,6 +60,8 @@ struct pirgpu_ctx {
 
   int device = 0;
   hipStream_t stream = nullptr;
+  const NttOps* ops = nullptr;  // NTT kernels for this ring degree
+  int mode = kNttInt;           // arithmetic flavour of the NTT kernels (NttMode)
   DevParams hp{};
   DevParams* dp = nullptr;
   std::vector<void*> allocs;
@@ -160,7 +162,30 @@ void build_tables(pirgpu_ctx* c) {
     const uint64_t iw1n = hm::mulmod(itw[1].w, ninv, q);
     hp.tab[i].ninv = Twiddle{ninv, hm::shoup(ninv, q)};
     hp.tab[i].iw1n = Twiddle{iw1n, hm::shoup(iw1n, q)};
+    // exact-fp64 flavour: the same constants as signed doubles in (-q/2, q/2]
+    auto centered = [q](uint64_t v) { return v > q / 2 ? -(double)(q - v) : (double)v; };
+    std::vector<double> twf(N), itwf(N);
+    for (uint32_t j = 0; j < N; ++j) {
+      twf[j] = centered(tw[j].w);
+      itwf[j] = centered(itw[j].w);
+    }
+    double* devf = c->dalloc<double>((size_t)2 * N);
+    HIP_TRY(hipMemcpy(devf, twf.data(), N * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(devf + N, itwf.data(), N * sizeof(double), hipMemcpyHostToDevice));
+    hp.tab[i].twf = devf;
+    hp.tab[i].itwf = devf + N;
+    hp.tab[i].ninv_f = centered(ninv);
+    hp.tab[i].iw1n_f = centered(iw1n);
+    hp.tab[i].qd = (double)q;
+    hp.tab[i].qinvd = 1.0 / (double)q;
   }
+  // NTT arithmetic flavour (ntt_core.h).  PIRGPU_NTT_MODE=0 forces the integer path.
+  c->mode = qmax < (1ull << 46) ? kNttF64 : (qmax < (1ull << 49) ? kNttF64Wide : kNttInt);
+  if (const char* v = getenv("PIRGPU_NTT_MODE")) {
+    int want = atoi(v);
+    if (want == kNttInt || (want == kNttF64Wide && c->mode != kNttInt) || want == c->mode) c->mode = want;
+  }
+  hp.ntt_mode = c->mode;
   const uint64_t p = c->prm.special_prime, t = c->prm.plain_modulus;
   hp.p_half = p >> 1;
   hp.t = t;
@@ -311,8 +336,10 @@ uint64_t* expand_on_device(pirgpu_ctx* c, uint32_t n) {
   for (uint32_t j = 0; j < logm; ++j) {
     const uint32_t g = (N >> j) + 1;
     const uint64_t* key = find_key(c, g);
-    HIP_TRY(launch_ks_level(c->stream, c->dp, N, k, cur, key, g, galois_inverse(g, N), 1u << j, 1u << j, true,
-                            c->dig, c->prod, nxt));
+    HIP_TRY(c->ops->ks_digit(c->stream, c->mode, c->dp, k, cur, g, 1u << j, c->dig));
+    HIP_TRY(c->ops->ks_mac_intt(c->stream, c->mode, c->dp, k, c->dig, key, 1u << j, c->prod));
+    HIP_TRY(launch_ks_combine(c->stream, c->dp, N, k, cur, c->prod, galois_inverse(g, N), 1u << j, 1u << j, true,
+                              nxt));
     std::swap(cur, nxt);
   }
   return cur;
@@ -335,7 +362,7 @@ void expand_query_to_sv(pirgpu_ctx* c, const uint64_t* d_query, uint32_t nq, uin
         HIP_TRY(hipMemcpyAsync(coeff_out_host + produced * ctw, res, (size_t)n * ctw * 8, hipMemcpyDeviceToHost,
                                c->stream));
       } else {
-        HIP_TRY(launch_ct_ntt_fwd_oop(c->stream, c->dp, N, k, res, c->sv_ntt + produced * ctw, n));
+        HIP_TRY(c->ops->ct_ntt_fwd_oop(c->stream, c->mode, c->dp, k, res, c->sv_ntt + produced * ctw, n));
       }
     }
     produced += n;
@@ -366,18 +393,18 @@ void multiply_on_device(pirgpu_ctx* c) {
     HIP_TRY(launch_reduce_splits(c->stream, c->dp, c->scan_part, c->scan_nsplit, (uint64_t)c->scan_rows * ctw,
                                  base_out));
   record(c, PH_UPPER);  // end of scan phase
-  HIP_TRY(launch_ntt_batch(c->stream, c->dp, N, base_out, (uint64_t)c->scan_rows * 2 * k, k, 0, true));
+  HIP_TRY(c->ops->ntt_batch(c->stream, c->mode, c->dp, base_out, (uint64_t)c->scan_rows * 2 * k, k, 0, true));
   // upper levels
   uint64_t C = 1;  // ciphertexts per child
   for (int l = (int)d - 2; l >= 0; --l) {
     const uint64_t nch = ceil_div(shard_pts, c->stride[l + 1]);
     const uint64_t rows = c->lvl_rows[l];
-    HIP_TRY(launch_reencode_lift_ntt(c->stream, c->dp, N, k, c->E, c->lvl[l + 1], nch * C, c->pt_buf));
+    if (nch * C) HIP_TRY(c->ops->reencode_lift_ntt(c->stream, c->mode, c->dp, k, c->E, c->lvl[l + 1], nch * C, c->pt_buf));
     const uint32_t sv_first = c->sv_off[l] + (l == 0 ? c->sb : 0);
     HIP_TRY(launch_upper_mac(c->stream, c->dp, N, k, c->E, c->sv_ntt, c->pt_buf, (uint32_t)rows, c->dims[l],
                              (uint32_t)nch, sv_first, (uint32_t)C, c->lvl[l]));
     if (l == 0) record(c, PH_FINAL);
-    HIP_TRY(launch_ntt_batch(c->stream, c->dp, N, c->lvl[l], rows * C * c->E * 2 * k, k, 0, true));
+    HIP_TRY(c->ops->ntt_batch(c->stream, c->mode, c->dp, c->lvl[l], rows * C * c->E * 2 * k, k, 0, true));
     C *= c->E;
   }
   if (d == 1) record(c, PH_FINAL);
@@ -423,8 +450,8 @@ int pirgpu_create(const pirgpu_params* p, pirgpu_ctx** out) {
   try {
     c->prm = *p;
     const uint32_t N = p->poly_modulus_degree, k = p->num_data_primes;
-    if (N < 1024 || N > 16384 || (N & (N - 1)))
-      return bail(PIRGPU_INVALID_ARGUMENT, "poly_modulus_degree must be a power of two in [1024, 16384]");
+    if (N < 2048 || N > 16384 || (N & (N - 1)))
+      return bail(PIRGPU_INVALID_ARGUMENT, "poly_modulus_degree must be 2048, 4096, 8192 or 16384");
     if (k < 1 || k > PIRGPU_MAX_PRIMES) return bail(PIRGPU_INVALID_ARGUMENT, "invalid number of data primes");
     if (p->use_ciphertext_multiplication)
       return bail(PIRGPU_UNIMPLEMENTED,
@@ -476,8 +503,10 @@ int pirgpu_create(const pirgpu_params* p, pirgpu_ctx** out) {
     if (c->device < 0 || c->device >= ndev) return bail(PIRGPU_INVALID_ARGUMENT, "invalid device ordinal");
     c->use_device();
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_TRY(configure_kernels(N));
+    c->ops = ntt_ops_for(N);
+    if (!c->ops) return bail(PIRGPU_INVALID_ARGUMENT, "poly_modulus_degree must be 2048, 4096, 8192 or 16384");
     build_tables(c);
+    HIP_TRY(c->ops->configure(c->mode));
     c->reply_cts = 1;
     for (uint32_t l = 1; l < c->d; ++l) c->reply_cts *= c->E;
     const uint64_t shard_pts = c->pt_end - c->pt_begin;
@@ -549,8 +578,8 @@ int pirgpu_db_load_items(pirgpu_ctx* c, const uint8_t* items, uint64_t num_items
         const uint64_t b0 = std::min<uint64_t>(pt * bytes_per_pt, total_bytes);
         const uint64_t b1 = std::min<uint64_t>((pt + n) * bytes_per_pt, total_bytes);
         if (b1 > b0) HIP_TRY(hipMemcpyAsync(d_bytes, items + b0, b1 - b0, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(launch_db_encode(c->stream, c->dp, c->N, c->k, nullptr, d_bytes, bytes_per_pt, b1 - b0, c->bits, n,
-                                 c->d_db + (pt - c->pt_begin) * c->k * c->N));
+        HIP_TRY(c->ops->db_encode(c->stream, c->mode, c->dp, c->k, nullptr, d_bytes, bytes_per_pt, b1 - b0, c->bits,
+                                  n, c->d_db + (pt - c->pt_begin) * c->k * c->N));
         HIP_TRY(hipStreamSynchronize(c->stream));
         for (uint64_t i = 0; i < n; ++i)
           if (!c->loaded[pt - c->pt_begin + i]) {
@@ -580,8 +609,8 @@ int pirgpu_db_load_coeffs(pirgpu_ctx* c, uint64_t first_pt, uint64_t n_pt, const
         const uint64_t n = std::min<uint64_t>(chunk, hi - pt);
         HIP_TRY(hipMemcpyAsync(d_coeffs, coeffs + (pt - first_pt) * c->N, n * c->N * 8, hipMemcpyHostToDevice,
                                c->stream));
-        HIP_TRY(launch_db_encode(c->stream, c->dp, c->N, c->k, d_coeffs, nullptr, 0, 0, c->bits, n,
-                                 c->d_db + (pt - c->pt_begin) * c->k * c->N));
+        HIP_TRY(c->ops->db_encode(c->stream, c->mode, c->dp, c->k, d_coeffs, nullptr, 0, 0, c->bits, n,
+                                  c->d_db + (pt - c->pt_begin) * c->k * c->N));
         HIP_TRY(hipStreamSynchronize(c->stream));
         for (uint64_t i = 0; i < n; ++i)
           if (!c->loaded[pt - c->pt_begin + i]) {
@@ -605,7 +634,8 @@ int pirgpu_db_read_plaintext(pirgpu_ctx* c, uint64_t pt_index, uint64_t* out) {
     uint64_t* stage = nullptr;
     HIP_TRY(hipMalloc((void**)&stage, (size_t)c->k * c->N * 8));
     try {
-      HIP_TRY(launch_ntt_reorder(c->stream, c->N, c->d_db + (pt_index - c->pt_begin) * c->k * c->N, stage, c->k, false));
+      HIP_TRY(launch_ntt_reorder(c->stream, c->N, c->d_db + (pt_index - c->pt_begin) * c->k * c->N, stage, c->k, false,
+                                 false));
       HIP_TRY(hipMemcpyAsync(out, stage, (size_t)c->k * c->N * 8, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(hipStreamSynchronize(c->stream));
     } catch (...) {
@@ -634,7 +664,8 @@ int pirgpu_set_galois_key(pirgpu_ctx* c, uint32_t g, const uint64_t* key) {
     HIP_TRY(hipMalloc((void**)&stage, words * 8));
     try {
       HIP_TRY(hipMemcpyAsync(stage, key, words * 8, hipMemcpyHostToDevice, c->stream));
-      HIP_TRY(launch_ntt_reorder(c->stream, c->N, stage, dev, (uint64_t)c->k * 2 * (c->k + 1), true));
+      HIP_TRY(launch_ntt_reorder(c->stream, c->N, stage, dev, (uint64_t)c->k * 2 * (c->k + 1), true,
+                                 c->mode != kNttInt));
       HIP_TRY(hipStreamSynchronize(c->stream));
     } catch (...) {
       (void)hipFree(stage);
@@ -764,8 +795,10 @@ int pirgpu_substitute_power_x(pirgpu_ctx* c, uint64_t* ct, uint32_t power) {
       return fail(c, PIRGPU_INTERNAL, "Galois element is not valid");
     const uint64_t* key = find_key(c, power);
     HIP_TRY(hipMemcpyAsync(c->res_a, ct, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(launch_ks_level(c->stream, c->dp, c->N, c->k, c->res_a, key, power, galois_inverse(power, c->N), 1, 0,
-                            false, c->dig, c->prod, c->res_b));
+    HIP_TRY(c->ops->ks_digit(c->stream, c->mode, c->dp, c->k, c->res_a, power, 1, c->dig));
+    HIP_TRY(c->ops->ks_mac_intt(c->stream, c->mode, c->dp, c->k, c->dig, key, 1, c->prod));
+    HIP_TRY(launch_ks_combine(c->stream, c->dp, c->N, c->k, c->res_a, c->prod, galois_inverse(power, c->N), 1, 0,
+                              false, c->res_b));
     HIP_TRY(hipMemcpyAsync(ct, c->res_b, c->ctw * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PIRGPU_OK;
@@ -798,7 +831,7 @@ int pirgpu_multiply(pirgpu_ctx* c, const uint64_t* sv, uint64_t sv_count, uint64
     for (uint64_t s = 0; s < sv_count; s += m_max) {
       const uint64_t n = std::min<uint64_t>(m_max, sv_count - s);
       HIP_TRY(hipMemcpyAsync(c->res_a, sv + s * c->ctw, n * c->ctw * 8, hipMemcpyHostToDevice, c->stream));
-      HIP_TRY(launch_ct_ntt_fwd_oop(c->stream, c->dp, c->N, c->k, c->res_a, c->sv_ntt + s * c->ctw, n));
+      HIP_TRY(c->ops->ct_ntt_fwd_oop(c->stream, c->mode, c->dp, c->k, c->res_a, c->sv_ntt + s * c->ctw, n));
       HIP_TRY(hipStreamSynchronize(c->stream));
     }
     c->prof_cur = -1;
@@ -822,13 +855,13 @@ static int ntt_hook(pirgpu_ctx* c, uint64_t* polys, uint64_t count, int key_leve
     try {
       if (inverse) {
         HIP_TRY(hipMemcpyAsync(tmp, polys, npoly * c->N * 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(launch_ntt_reorder(c->stream, c->N, tmp, dev, npoly, true));
-        HIP_TRY(launch_ntt_batch(c->stream, c->dp, c->N, dev, npoly, per, 0, true));
+        HIP_TRY(launch_ntt_reorder(c->stream, c->N, tmp, dev, npoly, true, false));
+        HIP_TRY(c->ops->ntt_batch(c->stream, c->mode, c->dp, dev, npoly, per, 0, true));
         HIP_TRY(hipMemcpyAsync(polys, dev, npoly * c->N * 8, hipMemcpyDeviceToHost, c->stream));
       } else {
         HIP_TRY(hipMemcpyAsync(dev, polys, npoly * c->N * 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(launch_ntt_batch(c->stream, c->dp, c->N, dev, npoly, per, 0, false));
-        HIP_TRY(launch_ntt_reorder(c->stream, c->N, dev, tmp, npoly, false));
+        HIP_TRY(c->ops->ntt_batch(c->stream, c->mode, c->dp, dev, npoly, per, 0, false));
+        HIP_TRY(launch_ntt_reorder(c->stream, c->N, dev, tmp, npoly, false, false));
         HIP_TRY(hipMemcpyAsync(polys, tmp, npoly * c->N * 8, hipMemcpyDeviceToHost, c->stream));
       }
       HIP_TRY(hipStreamSynchronize(c->stream));

@@ -29,7 +29,18 @@ struct NttTable {
   const Twiddle* itw;
   Twiddle ninv;   // N^-1
   Twiddle iw1n;   // psi^-bitrev(1) * N^-1
+  // exact-fp64 flavour (moduli < 2^49): the same tables as signed doubles in (-q/2, q/2]
+  const double* twf;
+  const double* itwf;
+  double ninv_f, iw1n_f;
+  double qd, qinvd;
 };
+
+// Arithmetic flavour of the NTT kernels, chosen per context from the largest modulus:
+//   kNttInt      64-bit integer Shoup/Harvey butterflies, any modulus < 2^61
+//   kNttF64      exact fp64 butterflies, all moduli < 2^46
+//   kNttF64Wide  exact fp64 with an extra normalisation per forward butterfly, all moduli < 2^49
+enum NttMode : int { kNttInt = 0, kNttF64 = 1, kNttF64Wide = 2 };
 
 struct DevParams {
   uint32_t N, logN, k, pad0;
@@ -49,6 +60,7 @@ struct DevParams {
   uint8_t enc_poly[kMaxEnc], enc_res[kMaxEnc], enc_shift[kMaxEnc];
   // how many 128-bit products of two residues may be summed before reduction
   uint32_t lazy_limit;
+  int32_t ntt_mode;  // NttMode
 };
 
 }  // namespace pirgpu

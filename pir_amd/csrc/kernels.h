@@ -1,4 +1,4 @@
-// kernels.h -- launch wrappers of the gfx950 kernels (see kernels.hip).
+// kernels.h -- launch wrappers of the gfx950 kernels (kernels.hip, ntt_kernels.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -7,21 +7,32 @@
 
 namespace pirgpu {
 
-hipError_t configure_kernels(uint32_t N);
+// Kernels that contain an NTT, for one ring degree (ntt_kernels.hip is compiled once
+// per degree).  `mode` is an NttMode.
+struct NttOps {
+  hipError_t (*configure)(int mode);
+  hipError_t (*ntt_batch)(hipStream_t st, int mode, const DevParams* P, uint64_t* data, uint64_t n_polys,
+                          uint32_t mod_period, uint32_t mod_base, bool inverse);
+  hipError_t (*ct_ntt_fwd_oop)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* src,
+                               uint64_t* dst, uint64_t n_cts);
+  hipError_t (*db_encode)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* coeffs,
+                          const uint8_t* bytes, uint64_t bytes_per_pt, uint64_t total_bytes, uint32_t bits,
+                          uint64_t n_pt, uint64_t* db);
+  hipError_t (*ks_digit)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* res_in,
+                         uint32_t galois_elt, uint32_t nodes, uint64_t* dig);
+  hipError_t (*ks_mac_intt)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* dig,
+                            const uint64_t* key, uint32_t nodes, uint64_t* prod);
+  hipError_t (*reencode_lift_ntt)(hipStream_t st, int mode, const DevParams* P, uint32_t k, uint32_t enc_count,
+                                  const uint64_t* src, uint64_t n_src, uint64_t* pt);
+};
 
-hipError_t launch_ntt_batch(hipStream_t st, const DevParams* P, uint32_t N, uint64_t* data, uint64_t n_polys,
-                            uint32_t mod_period, uint32_t mod_base, bool inverse);
-hipError_t launch_ct_ntt_fwd_oop(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* src,
-                                 uint64_t* dst, uint64_t n_cts);
+const NttOps* ntt_ops_for(uint32_t N);  // nullptr for unsupported degrees
+
 hipError_t launch_ntt_reorder(hipStream_t st, uint32_t N, const uint64_t* in, uint64_t* out, uint64_t n_polys,
-                              bool to_device);
-hipError_t launch_db_encode(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* coeffs,
-                            const uint8_t* bytes, uint64_t bytes_per_pt, uint64_t total_bytes, uint32_t bits,
-                            uint64_t n_pt, uint64_t* db);
-hipError_t launch_ks_level(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* res_in,
-                           const uint64_t* key, uint32_t galois_elt, uint32_t galois_inv, uint32_t nodes,
-                           uint32_t shift_pow, bool expand_step, uint64_t* dig, uint64_t* prod,
-                           uint64_t* res_out);
+                              bool to_device, bool as_f64);
+hipError_t launch_ks_combine(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* res_in,
+                             const uint64_t* prod, uint32_t galois_inv, uint32_t nodes, uint32_t shift_pow,
+                             bool expand_step, uint64_t* res_out);
 hipError_t launch_monomial_shift(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* in,
                                  uint32_t shift, uint64_t count, uint64_t* out);
 hipError_t launch_scan(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* db,
@@ -30,8 +41,6 @@ hipError_t launch_scan(hipStream_t st, const DevParams* P, uint32_t N, uint32_t 
                        bool limb);
 hipError_t launch_reduce_splits(hipStream_t st, const DevParams* P, const uint64_t* part, uint32_t nsplit,
                                 uint64_t words, uint64_t* out);
-hipError_t launch_reencode_lift_ntt(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, uint32_t enc_count,
-                                    const uint64_t* src, uint64_t n_src, uint64_t* pt);
 hipError_t launch_upper_mac(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, uint32_t enc_count,
                             const uint64_t* sv, const uint64_t* pt, uint32_t n_rows, uint32_t n_dim,
                             uint32_t n_children_total, uint32_t sv_first, uint32_t C, uint64_t* out);

@@ -19,407 +19,36 @@
 
 #include <type_traits>
 
+#include "arith.h"
 #include "device_params.h"
 #include "kernels.h"
 
 namespace pirgpu {
 
-typedef unsigned __int128 u128;
-
-// ------------------------------------------------------------------ arithmetic
-
-__device__ __forceinline__ uint64_t mul_shoup(uint64_t x, uint64_t w, uint64_t ws, uint64_t q) {
-  uint64_t h = __umul64hi(x, ws);
-  uint64_t r = x * w - h * q;
-  return r >= q ? r - q : r;
-}
-
-__device__ __forceinline__ uint64_t add_mod(uint64_t a, uint64_t b, uint64_t q) {
-  uint64_t s = a + b;
-  return s >= q ? s - q : s;
-}
-
-__device__ __forceinline__ uint64_t sub_mod(uint64_t a, uint64_t b, uint64_t q) {
-  return a >= b ? a - b : a + q - b;
-}
-
-__device__ __forceinline__ uint64_t neg_mod(uint64_t a, uint64_t q) { return a ? q - a : 0; }
-
-// x mod q for any 64-bit x (Barrett with floor(2^64 / q) = br_hi).
-__device__ __forceinline__ uint64_t reduce64(uint64_t x, const ModConst& m) {
-  uint64_t h = __umul64hi(x, m.br_hi);
-  uint64_t r = x - h * m.q;
-  return r >= m.q ? r - m.q : r;
-}
-
-// (hi:lo) mod q for any 128-bit input (SEAL barrett_reduce_128).
-__device__ __forceinline__ uint64_t reduce128(uint64_t lo, uint64_t hi, const ModConst& m) {
-  uint64_t carry = __umul64hi(lo, m.br_lo);
-  uint64_t t2lo = lo * m.br_hi, t2hi = __umul64hi(lo, m.br_hi);
-  uint64_t t1 = t2lo + carry;
-  uint64_t t3 = t2hi + (t1 < t2lo);
-  t2lo = hi * m.br_lo;
-  t2hi = __umul64hi(hi, m.br_lo);
-  uint64_t t1b = t1 + t2lo;
-  carry = t2hi + (t1b < t1);
-  uint64_t qhat = hi * m.br_hi + t3 + carry;
-  uint64_t r = lo - qhat * m.q;
-  return r >= m.q ? r - m.q : r;
-}
-
-__device__ __forceinline__ uint64_t mul_mod(uint64_t a, uint64_t b, const ModConst& m) {
-  return reduce128(a * b, __umul64hi(a, b), m);
-}
-
-// ------------------------------------------------------------------ NTT core
-//
-// One workgroup of N/16 threads transforms one polynomial; every thread keeps 16
-// residues in registers and runs up to four butterfly stages per pass, so a
-// 4096-point transform is 3 register passes with 2 LDS exchanges (instead of 12
-// barrier-separated LDS stages).  A pass with window LB owns, per thread, the 16
-// residues  idx = (outer << (LB+4)) | (e << LB) | inner,  tid = (outer << LB) | inner.
-//
-//  * butterflies are Harvey-lazy (forward: values < 4q, inverse: < 2q) and the
-//    results are made canonical at the end, so the bits equal SEAL's;
-//  * LDS is padded by one word per 16 (lds_idx) which makes all three access
-//    patterns (stride N/16, stride 16, contiguous 16) bank-conflict free;
-//  * NTT-domain data lives in HBM in "device order": SEAL's bit-reversed position
-//    pos = 16*tid + e is stored at e*(N/16) + tid.  Every dyadic operation is
-//    order-agnostic, both transforms read and write global memory fully
-//    coalesced, and a transform's register layout on the NTT side is exactly the
-//    layout of that order -- so key-switch products are formed between a forward
-//    and an inverse transform without leaving registers.
-
-template <int LOGN>
-struct Plan {
-  static constexpr int N = 1 << LOGN;
-  static constexpr int NT = N / kNttElemsPerThread;
-  static constexpr int LDS_WORDS = N + N / 16;
-};
-
-__device__ __forceinline__ uint32_t lds_idx(uint32_t i) { return i + (i >> 4); }
-
-// x * w mod q up to one multiple of q: result in [0, 2q) for any 64-bit x.
-__device__ __forceinline__ uint64_t mul_shoup_lazy(uint64_t x, const Twiddle& t, uint64_t q) {
-  return x * t.w - __umul64hi(x, t.ws) * q;
-}
-
-template <int LB>
-__device__ __forceinline__ void lds_store16(uint64_t* s, const uint64_t (&x)[16], uint32_t tid) {
-  const uint32_t inner = tid & ((1u << LB) - 1u), outer = tid >> LB;
-  const uint32_t base = (outer << (LB + 4)) | inner;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) s[lds_idx(base | ((uint32_t)e << LB))] = x[e];
-}
-
-template <int LB>
-__device__ __forceinline__ void lds_load16(const uint64_t* s, uint64_t (&x)[16], uint32_t tid) {
-  const uint32_t inner = tid & ((1u << LB) - 1u), outer = tid >> LB;
-  const uint32_t base = (outer << (LB + 4)) | inner;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) x[e] = s[lds_idx(base | ((uint32_t)e << LB))];
-}
-
-// Cooley-Tukey stages on window LB for relative bits RHI..RLO (high to low).
-template <int LOGN, int LB, int RHI, int RLO>
-__device__ __forceinline__ void fwd_stages(uint64_t (&x)[16], const Twiddle* __restrict__ tw, uint32_t outer,
-                                           uint64_t q) {
-  const uint64_t q2 = q << 1;
-#pragma unroll
-  for (int rb = RHI; rb >= RLO; --rb) {
-    const uint32_t m = 1u << (LOGN - 1 - (LB + rb));
-#pragma unroll
-    for (int g = 0; g < (8 >> rb); ++g) {
-      const Twiddle W = tw[m + (outer << (3 - rb)) + g];
-#pragma unroll
-      for (int l = 0; l < (1 << rb); ++l) {
-        const int e0 = (g << (rb + 1)) | l, e1 = e0 | (1 << rb);
-        uint64_t X = x[e0];
-        X = X >= q2 ? X - q2 : X;
-        const uint64_t T = mul_shoup_lazy(x[e1], W, q);
-        x[e0] = X + T;
-        x[e1] = X - T + q2;
-      }
-    }
-  }
-}
-
-template <int LOGN, int LB>
-__device__ __forceinline__ void fwd_continue(uint64_t (&x)[16], uint64_t* s, const Twiddle* __restrict__ tw,
-                                             uint64_t q, uint32_t tid) {
-  if constexpr (LB > 0) {
-    constexpr int NLB = LB >= 4 ? LB - 4 : 0;
-    constexpr int RHI = LB >= 4 ? 3 : LB - 1;
-    lds_store16<LB>(s, x, tid);
-    __syncthreads();
-    lds_load16<NLB>(s, x, tid);
-    fwd_stages<LOGN, NLB, RHI, 0>(x, tw, tid >> NLB, q);
-    fwd_continue<LOGN, NLB>(x, s, tw, q, tid);
-  }
-}
-
-// Forward negacyclic NTT.  In: x[e] = coefficient e*NT + tid (canonical).
-// Out: x[e] = SEAL NTT position 16*tid + e (canonical) == device-order slot e*NT + tid.
-// The caller guarantees no thread still reads `s` (barrier) when this is entered.
-template <int LOGN>
-__device__ __forceinline__ void ntt_fwd_regs(uint64_t (&x)[16], uint64_t* s, const NttTable& tab, uint64_t q,
-                                             uint32_t tid) {
-  fwd_stages<LOGN, LOGN - 4, 3, 0>(x, tab.tw, 0u, q);
-  fwd_continue<LOGN, LOGN - 4>(x, s, tab.tw, q, tid);
-  const uint64_t q2 = q << 1;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    uint64_t v = x[e];
-    v = v >= q2 ? v - q2 : v;
-    x[e] = v >= q ? v - q : v;
-  }
-}
-
-// Gentleman-Sande stages on window LB for relative bits RLO..RHI (low to high);
-// with LAST the final stage multiplies by N^-1 (folded into both outputs).
-template <int LOGN, int LB, int RLO, int RHI, bool LAST>
-__device__ __forceinline__ void inv_stages(uint64_t (&x)[16], const NttTable& tab, uint32_t outer, uint64_t q) {
-  const uint64_t q2 = q << 1;
-  const Twiddle* __restrict__ itw = tab.itw;
-#pragma unroll
-  for (int rb = RLO; rb <= RHI; ++rb) {
-    const uint32_t h = 1u << (LOGN - 1 - (LB + rb));
-    const bool scale = LAST && (rb == RHI);
-#pragma unroll
-    for (int g = 0; g < (8 >> rb); ++g) {
-      const Twiddle W = scale ? tab.iw1n : itw[h + (outer << (3 - rb)) + g];
-#pragma unroll
-      for (int l = 0; l < (1 << rb); ++l) {
-        const int e0 = (g << (rb + 1)) | l, e1 = e0 | (1 << rb);
-        const uint64_t a = x[e0], b = x[e1];
-        uint64_t U = a + b;
-        const uint64_t T = a - b + q2;
-        if (scale) {
-          x[e0] = mul_shoup_lazy(U, tab.ninv, q);
-        } else {
-          x[e0] = U >= q2 ? U - q2 : U;
-        }
-        x[e1] = mul_shoup_lazy(T, W, q);
-      }
-    }
-  }
-}
-
-template <int LOGN, int D, int PREV>  // D = index bits already transformed; data in registers with window PREV
-__device__ __forceinline__ void inv_continue(uint64_t (&x)[16], uint64_t* s, const NttTable& tab, uint64_t q,
-                                             uint32_t tid) {
-  if constexpr (D < LOGN) {
-    constexpr int LB = (LOGN - D >= 4) ? D : LOGN - 4;
-    constexpr int RLO = D - LB;
-    constexpr bool LAST = (LB + 4 == LOGN);
-    lds_store16<PREV>(s, x, tid);
-    __syncthreads();
-    lds_load16<LB>(s, x, tid);
-    inv_stages<LOGN, LB, RLO, 3, LAST>(x, tab, tid >> LB, q);
-    inv_continue<LOGN, LB + 4, LB>(x, s, tab, q, tid);
-  }
-}
-
-// Inverse negacyclic NTT.  In: x[e] = NTT position 16*tid + e (< 2q).  Out: x[e] =
-// coefficient e*NT + tid, canonical, scaled by N^-1.
-template <int LOGN>
-__device__ __forceinline__ void ntt_inv_regs(uint64_t (&x)[16], uint64_t* s, const NttTable& tab, uint64_t q,
-                                             uint32_t tid) {
-  static_assert(LOGN >= 8, "at least two passes expected");
-  inv_stages<LOGN, 0, 0, 3, false>(x, tab, tid, q);
-  inv_continue<LOGN, 4, 0>(x, s, tab, q, tid);
-#pragma unroll
-  for (int e = 0; e < 16; ++e) x[e] = x[e] >= q ? x[e] - q : x[e];
-}
-
-extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-
-// ------------------------------------------------------------------ batched NTT
-
-// One workgroup per polynomial; modulus index = mod_base + (poly % mod_period).
-// Forward: natural coefficients -> device NTT order; inverse: the reverse.  In place.
-template <int LOGN, bool INVERSE>
-__global__ void __launch_bounds__(Plan<LOGN>::NT)
-ntt_batch_kernel(const DevParams* __restrict__ P, uint64_t* __restrict__ data, uint32_t mod_period,
-                 uint32_t mod_base) {
-  constexpr int NT = Plan<LOGN>::NT;
-  uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
-  const uint32_t tid = threadIdx.x;
-  const int mi = mod_base + (blockIdx.x % mod_period);
-  uint64_t* poly = data + (size_t)blockIdx.x * Plan<LOGN>::N;
-  uint64_t x[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) x[e] = poly[e * NT + tid];
-  if constexpr (INVERSE)
-    ntt_inv_regs<LOGN>(x, s, P->tab[mi], P->mod[mi].q, tid);
-  else
-    ntt_fwd_regs<LOGN>(x, s, P->tab[mi], P->mod[mi].q, tid);
-#pragma unroll
-  for (int e = 0; e < 16; ++e) poly[e * NT + tid] = x[e];
-}
-
-// Out-of-place forward NTT of ciphertexts: src[ct][2][k][N] (coefficient form)
-// -> dst[ct][2][k][N] (device NTT order); selection vector -> NTT form.
-template <int LOGN>
-__global__ void __launch_bounds__(Plan<LOGN>::NT)
-ct_ntt_fwd_oop_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ src, uint64_t* __restrict__ dst) {
-  constexpr int NT = Plan<LOGN>::NT;
-  uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
-  const uint32_t tid = threadIdx.x;
-  const int mi = blockIdx.x % P->k;
-  const uint64_t* in = src + (size_t)blockIdx.x * Plan<LOGN>::N;
-  uint64_t* out = dst + (size_t)blockIdx.x * Plan<LOGN>::N;
-  uint64_t x[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) x[e] = in[e * NT + tid];
-  ntt_fwd_regs<LOGN>(x, s, P->tab[mi], P->mod[mi].q, tid);
-#pragma unroll
-  for (int e = 0; e < 16; ++e) out[e * NT + tid] = x[e];
-}
-
 // SEAL NTT order <-> device NTT order for npolys polynomials (boundary only:
 // Galois-key upload and the test hooks).  to_device: out[e*NT + t] = in[16 t + e].
+// as_f64: the device-order side holds the residues as exact doubles (fp64 NTT flavours).
 __global__ void ntt_reorder_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint32_t logN,
-                                   uint64_t npolys, int to_device) {
+                                   uint64_t npolys, int to_device, int as_f64) {
   const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t N = 1u << logN, NT = N >> 4;
   if (gid >= npolys << logN) return;
   const uint64_t poly = gid >> logN;
-  const uint32_t i = (uint32_t)(gid & (N - 1));     // device slot
+  const uint32_t i = (uint32_t)(gid & (N - 1));  // device slot
   const uint32_t e = i / NT, t = i % NT;
   const uint32_t seal = (t << 4) | e;
-  if (to_device)
-    out[(poly << logN) + i] = in[(poly << logN) + seal];
-  else
-    out[(poly << logN) + seal] = in[(poly << logN) + i];
-}
-
-// ------------------------------------------------------------------ database encode
-
-// grid = (n_pt, k).  Source is either pre-encoded coefficients (coeffs != null)
-// or raw item bytes packed MSB-first into bits-wide coefficients
-// (reference string_encoder.cpp:58-122); then plain lift + forward NTT.
-template <int LOGN>
-__global__ void __launch_bounds__(Plan<LOGN>::NT)
-db_encode_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ coeffs,
-                 const uint8_t* __restrict__ bytes, uint64_t bytes_per_pt, uint64_t total_bytes, uint32_t bits,
-                 uint64_t* __restrict__ db) {
-  constexpr int NT = Plan<LOGN>::NT, N = Plan<LOGN>::N;
-  uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
-  const uint32_t tid = threadIdx.x, k = P->k;
-  const uint32_t j = blockIdx.y;
-  const uint64_t pt = blockIdx.x;
-  const ModConst m = P->mod[j];
-  const uint64_t thr = P->plain_thr;
-  const uint64_t inc = P->lift_inc[j] >= m.q ? P->lift_inc[j] - m.q : P->lift_inc[j];
-  uint64_t L = 0;
-  const uint8_t* src = nullptr;
-  if (!coeffs) {
-    uint64_t start = pt * bytes_per_pt;
-    L = start >= total_bytes ? 0 : (total_bytes - start < bytes_per_pt ? total_bytes - start : bytes_per_pt);
-    src = bytes + start;
+  if (to_device) {
+    uint64_t v = in[(poly << logN) + seal];
+    if (as_f64) v = (uint64_t)__double_as_longlong(f64_from_u64(v));
+    out[(poly << logN) + i] = v;
+  } else {
+    uint64_t v = in[(poly << logN) + i];
+    if (as_f64) v = f64_to_u64(__longlong_as_double((long long)v));
+    out[(poly << logN) + seal] = v;
   }
-  uint64_t x[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const uint32_t c = e * NT + tid;
-    uint64_t v;
-    if (coeffs) {
-      v = coeffs[pt * N + c];
-    } else {
-      v = 0;
-      uint64_t bitpos = (uint64_t)c * bits;
-      uint64_t byte = bitpos >> 3;
-      uint32_t off = (uint32_t)(bitpos & 7);
-      int need = (int)bits;
-      while (need > 0) {
-        uint32_t B = byte < L ? src[byte] : 0u;
-        int avail = 8 - (int)off;
-        int take = avail < need ? avail : need;
-        v = (v << take) | ((B >> (avail - take)) & ((1u << take) - 1u));
-        need -= take;
-        off = 0;
-        ++byte;
-      }
-    }
-    uint64_t r = reduce64(v, m);
-    if (v >= thr) r = add_mod(r, inc, m.q);
-    x[e] = r;
-  }
-  ntt_fwd_regs<LOGN>(x, s, P->tab[j], m.q, tid);
-  uint64_t* out = db + (pt * k + j) * N;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) out[e * NT + tid] = x[e];
 }
 
 // ------------------------------------------------------------------ expansion
-
-// One level of the expansion tree, part 1a: for node n, key-level modulus I and
-// RNS digit J:  dig[n][I][J] = NTT_I(sigma_g(c1)_J mod m_I)  (device NTT order).
-// grid = (nodes, k+1, k); block = N/16 threads.
-template <int LOGN>
-__global__ void __launch_bounds__(Plan<LOGN>::NT)
-ks_digit_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ res_in, uint32_t galois_elt,
-                uint64_t* __restrict__ dig) {
-  constexpr int NT = Plan<LOGN>::NT, N = Plan<LOGN>::N;
-  uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
-  const uint32_t tid = threadIdx.x;
-  const uint32_t k = P->k;
-  const uint32_t node = blockIdx.x, I = blockIdx.y, J = blockIdx.z;
-  const ModConst mI = P->mod[I];
-  const uint64_t qJ = P->mod[J].q;
-  const uint64_t* src = res_in + (((size_t)node * 2 + 1) * k + J) * N;  // poly 1, residue J
-  // sigma_g in coefficient form (SEAL GaloisTool::apply_galois), then reduce mod m_I
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const uint32_t i = e * NT + tid;
-    const uint32_t raw = i * galois_elt;
-    uint64_t v = src[i];
-    if ((raw >> LOGN) & 1) v = neg_mod(v, qJ);
-    s[lds_idx(raw & (N - 1))] = reduce64(v, mI);
-  }
-  __syncthreads();
-  uint64_t x[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) x[e] = s[lds_idx(e * NT + tid)];
-  ntt_fwd_regs<LOGN>(x, s, P->tab[I], mI.q, tid);
-  uint64_t* out = dig + (((size_t)node * (k + 1) + I) * k + J) * N;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) out[e * NT + tid] = x[e];
-}
-
-// Part 1b: S[c][I] = sum_J dig[n][I][J] (.) K[J][c][I], then INTT_I -> prod[n][c][I]
-// (coefficient order).  The key is in device NTT order, so the dyadic products are
-// formed directly in the register layout the inverse transform starts from.
-// grid = (nodes, k+1, 2); block = N/16 threads.
-template <int LOGN>
-__global__ void __launch_bounds__(Plan<LOGN>::NT)
-ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ dig,
-                   const uint64_t* __restrict__ key, uint64_t* __restrict__ prod) {
-  constexpr int NT = Plan<LOGN>::NT, N = Plan<LOGN>::N;
-  uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
-  const uint32_t tid = threadIdx.x;
-  const uint32_t k = P->k, km = k + 1;
-  const uint32_t node = blockIdx.x, I = blockIdx.y, comp = blockIdx.z;
-  const ModConst mI = P->mod[I];
-  const uint64_t* d0 = dig + ((size_t)node * km + I) * k * N;
-  u128 acc[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0;
-  for (uint32_t J = 0; J < k; ++J) {  // k <= 8 products of two residues < 2^61 fit 128 bits
-    const uint64_t* dj = d0 + (size_t)J * N;
-    const uint64_t* kj = key + (((size_t)J * 2 + comp) * km + I) * N;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] += (u128)dj[e * NT + tid] * kj[e * NT + tid];
-  }
-  uint64_t x[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) x[e] = reduce128((uint64_t)acc[e], (uint64_t)(acc[e] >> 64), mI);
-  ntt_inv_regs<LOGN>(x, s, P->tab[I], mI.q, tid);
-  uint64_t* out = prod + (((size_t)node * 2 + comp) * km + I) * N;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) out[e * NT + tid] = x[e];
-}
 
 // Part 2: divide-and-round by the special prime, add sigma_g(c0), then the tree
 // butterfly   res_out[n] = a + g,   res_out[n + nodes] = x^(-2^j) * (a - g)
@@ -500,8 +129,6 @@ __global__ void monomial_shift_kernel(const DevParams* __restrict__ P, const uin
 }
 
 // ------------------------------------------------------------------ database scan
-
-typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
 
 // VEC adjacent residues with one (16-byte when VEC == 2) global load.
 template <int VEC>
@@ -740,36 +367,6 @@ __global__ void reduce_splits_kernel(const DevParams* __restrict__ P, const uint
 
 // ------------------------------------------------------------------ upper levels
 
-// CiphertextReencoder::Encode chunk e of source ciphertext c, lifted to residue
-// jt and forward-NTT'd: pt[c][e][jt][N] (device NTT order).  grid = (n_src, enc_count, k).
-template <int LOGN>
-__global__ void __launch_bounds__(Plan<LOGN>::NT)
-reencode_lift_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ src,
-                         uint64_t* __restrict__ pt) {
-  constexpr int NT = Plan<LOGN>::NT, N = Plan<LOGN>::N;
-  uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
-  const uint32_t tid = threadIdx.x, k = P->k;
-  const uint32_t c = blockIdx.x, e_idx = blockIdx.y, jt = blockIdx.z;
-  const ModConst m = P->mod[jt];
-  const uint32_t sp = P->enc_poly[e_idx], sj = P->enc_res[e_idx], sh = P->enc_shift[e_idx];
-  const uint64_t mask = (1ull << P->enc_bits) - 1;
-  const uint64_t thr = P->plain_thr;
-  const uint64_t inc = P->lift_inc[jt] >= m.q ? P->lift_inc[jt] - m.q : P->lift_inc[jt];
-  const uint64_t* in = src + (((size_t)c * 2 + sp) * k + sj) * N;
-  uint64_t x[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    uint64_t v = (in[e * NT + tid] >> sh) & mask;
-    uint64_t r = reduce64(v, m);
-    if (v >= thr) r = add_mod(r, inc, m.q);
-    x[e] = r;
-  }
-  ntt_fwd_regs<LOGN>(x, s, P->tab[jt], m.q, tid);
-  uint64_t* out = pt + (((size_t)c * P->enc_count + e_idx) * k + jt) * N;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) out[e * NT + tid] = x[e];
-}
-
 // Upper-level accumulate:  out[r][cc * E + e][p][j][i] =
 //    sum_{ii < nchild(r)} sv[ii][p][j][i] * pt[(child0(r) + ii) * C + cc][e][j][i]   mod q_j
 // where C = ciphertexts per child and E = enc_count.  One thread per output word.
@@ -818,101 +415,41 @@ __global__ void upper_mac_kernel(const DevParams* __restrict__ P, const uint64_t
     if (e_ != hipSuccess) return e_;     \
   } while (0)
 
-// dispatch a LOGN-templated body over the supported ring degrees
-#define PIRGPU_DISPATCH_LOGN(logN, BODY)                  \
-  switch (logN) {                                         \
-    case 10: { constexpr int LOGN = 10; BODY; } break;    \
-    case 11: { constexpr int LOGN = 11; BODY; } break;    \
-    case 12: { constexpr int LOGN = 12; BODY; } break;    \
-    case 13: { constexpr int LOGN = 13; BODY; } break;    \
-    case 14: { constexpr int LOGN = 14; BODY; } break;    \
-    default: return hipErrorInvalidValue;                 \
-  }
-
 static inline uint32_t log2u(uint32_t N) {
   uint32_t l = 0;
   while ((1u << l) < N) ++l;
   return l;
 }
 
-template <int LOGN>
-static hipError_t configure_for() {
-  // dynamic LDS beyond 64 KiB (N = 16384 -> 136 KiB of the CU's 160 KiB)
-  const int bytes = Plan<LOGN>::LDS_WORDS * 8;
-  hipError_t e;
-  if ((e = hipFuncSetAttribute((const void*)ntt_batch_kernel<LOGN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-  if ((e = hipFuncSetAttribute((const void*)ntt_batch_kernel<LOGN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-  if ((e = hipFuncSetAttribute((const void*)ct_ntt_fwd_oop_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-  if ((e = hipFuncSetAttribute((const void*)db_encode_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-  if ((e = hipFuncSetAttribute((const void*)ks_digit_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-  if ((e = hipFuncSetAttribute((const void*)ks_mac_intt_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-  if ((e = hipFuncSetAttribute((const void*)reencode_lift_ntt_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-  return hipSuccess;
-}
+// kernels with an NTT inside are compiled per ring degree (ntt_kernels.hip)
+const NttOps* ntt_ops_11();
+const NttOps* ntt_ops_12();
+const NttOps* ntt_ops_13();
+const NttOps* ntt_ops_14();
 
-hipError_t configure_kernels(uint32_t N) {
-  PIRGPU_DISPATCH_LOGN(log2u(N), return configure_for<LOGN>());
-  return hipSuccess;
-}
-
-hipError_t launch_ntt_batch(hipStream_t st, const DevParams* P, uint32_t N, uint64_t* data, uint64_t n_polys,
-                            uint32_t mod_period, uint32_t mod_base, bool inverse) {
-  if (!n_polys) return hipSuccess;
-  if (inverse) {
-    PIRGPU_DISPATCH_LOGN(log2u(N), hipLaunchKernelGGL((ntt_batch_kernel<LOGN, true>), dim3((uint32_t)n_polys),
-                                                      dim3(Plan<LOGN>::NT), Plan<LOGN>::LDS_WORDS * 8, st, P, data,
-                                                      mod_period, mod_base));
-  } else {
-    PIRGPU_DISPATCH_LOGN(log2u(N), hipLaunchKernelGGL((ntt_batch_kernel<LOGN, false>), dim3((uint32_t)n_polys),
-                                                      dim3(Plan<LOGN>::NT), Plan<LOGN>::LDS_WORDS * 8, st, P, data,
-                                                      mod_period, mod_base));
+const NttOps* ntt_ops_for(uint32_t N) {
+  switch (log2u(N)) {
+    case 11: return ntt_ops_11();
+    case 12: return ntt_ops_12();
+    case 13: return ntt_ops_13();
+    case 14: return ntt_ops_14();
+    default: return nullptr;
   }
-  PIRGPU_LAUNCH_CHECK();
-  return hipSuccess;
-}
-
-hipError_t launch_ct_ntt_fwd_oop(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* src,
-                                 uint64_t* dst, uint64_t n_cts) {
-  if (!n_cts) return hipSuccess;
-  PIRGPU_DISPATCH_LOGN(log2u(N), hipLaunchKernelGGL(ct_ntt_fwd_oop_kernel<LOGN>, dim3((uint32_t)(n_cts * 2 * k)),
-                                                    dim3(Plan<LOGN>::NT), Plan<LOGN>::LDS_WORDS * 8, st, P, src, dst));
-  PIRGPU_LAUNCH_CHECK();
-  return hipSuccess;
 }
 
 hipError_t launch_ntt_reorder(hipStream_t st, uint32_t N, const uint64_t* in, uint64_t* out, uint64_t n_polys,
-                              bool to_device) {
+                              bool to_device, bool as_f64) {
   if (!n_polys) return hipSuccess;
   const uint64_t total = n_polys * N;
   hipLaunchKernelGGL(ntt_reorder_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, in, out, log2u(N),
-                     n_polys, to_device ? 1 : 0);
+                     n_polys, to_device ? 1 : 0, as_f64 ? 1 : 0);
   PIRGPU_LAUNCH_CHECK();
   return hipSuccess;
 }
 
-hipError_t launch_db_encode(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* coeffs,
-                            const uint8_t* bytes, uint64_t bytes_per_pt, uint64_t total_bytes, uint32_t bits,
-                            uint64_t n_pt, uint64_t* db) {
-  if (!n_pt) return hipSuccess;
-  PIRGPU_DISPATCH_LOGN(log2u(N), hipLaunchKernelGGL(db_encode_kernel<LOGN>, dim3((uint32_t)n_pt, k),
-                                                    dim3(Plan<LOGN>::NT), Plan<LOGN>::LDS_WORDS * 8, st, P, coeffs,
-                                                    bytes, bytes_per_pt, total_bytes, bits, db));
-  PIRGPU_LAUNCH_CHECK();
-  return hipSuccess;
-}
-
-hipError_t launch_ks_level(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* res_in,
-                           const uint64_t* key, uint32_t galois_elt, uint32_t galois_inv, uint32_t nodes,
-                           uint32_t shift_pow, bool expand_step, uint64_t* dig, uint64_t* prod,
-                           uint64_t* res_out) {
-  PIRGPU_DISPATCH_LOGN(log2u(N), hipLaunchKernelGGL(ks_digit_kernel<LOGN>, dim3(nodes, k + 1, k),
-                                                    dim3(Plan<LOGN>::NT), Plan<LOGN>::LDS_WORDS * 8, st, P, res_in,
-                                                    galois_elt, dig));
-  PIRGPU_LAUNCH_CHECK();
-  PIRGPU_DISPATCH_LOGN(log2u(N), hipLaunchKernelGGL(ks_mac_intt_kernel<LOGN>, dim3(nodes, k + 1, 2),
-                                                    dim3(Plan<LOGN>::NT), Plan<LOGN>::LDS_WORDS * 8, st, P, dig, key,
-                                                    prod));
-  PIRGPU_LAUNCH_CHECK();
+hipError_t launch_ks_combine(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* res_in,
+                             const uint64_t* prod, uint32_t galois_inv, uint32_t nodes, uint32_t shift_pow,
+                             bool expand_step, uint64_t* res_out) {
   uint64_t total = (uint64_t)nodes * k * N;
   hipLaunchKernelGGL(ks_combine_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, P, res_in, prod,
                      galois_inv, nodes, shift_pow, expand_step ? 1 : 0, res_out);
@@ -967,16 +504,6 @@ hipError_t launch_reduce_splits(hipStream_t st, const DevParams* P, const uint64
   if (!words) return hipSuccess;
   hipLaunchKernelGGL(reduce_splits_kernel, dim3((uint32_t)((words + 255) / 256)), dim3(256), 0, st, P, part, nsplit,
                      words, out);
-  PIRGPU_LAUNCH_CHECK();
-  return hipSuccess;
-}
-
-hipError_t launch_reencode_lift_ntt(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, uint32_t enc_count,
-                                    const uint64_t* src, uint64_t n_src, uint64_t* pt) {
-  if (!n_src) return hipSuccess;
-  PIRGPU_DISPATCH_LOGN(log2u(N), hipLaunchKernelGGL(reencode_lift_ntt_kernel<LOGN>,
-                                                    dim3((uint32_t)n_src, enc_count, k), dim3(Plan<LOGN>::NT),
-                                                    Plan<LOGN>::LDS_WORDS * 8, st, P, src, pt));
   PIRGPU_LAUNCH_CHECK();
   return hipSuccess;
 }

@@ -1,0 +1,253 @@
+// ntt_core.h -- register-resident negacyclic NTT for one workgroup per polynomial.
+//
+// One workgroup of N/16 threads transforms one polynomial; every thread keeps 16
+// residues in registers and runs up to four butterfly stages per pass, so a
+// 4096-point transform is 3 register passes with 2 LDS exchanges.  A pass with
+// window LB owns, per thread, the 16 residues
+//     idx = (outer << (LB+4)) | (e << LB) | inner,      tid = (outer << LB) | inner.
+//
+//  * LDS is padded by one word per 16 (lds_idx), which makes all three access
+//    patterns (stride N/16, stride 16, contiguous 16) bank-conflict free;
+//  * NTT-domain data lives in HBM in "device order": SEAL's bit-reversed position
+//    pos = 16*tid + e is stored at slot e*(N/16) + tid.  Every dyadic operation is
+//    order-agnostic, both transforms read and write global memory fully
+//    coalesced, and the register layout on the NTT side is exactly that order --
+//    key-switch products are formed between a forward and an inverse transform
+//    without leaving registers;
+//  * the butterflies come in two exact flavours (Arith<MODE>): 64-bit integer
+//    Harvey/Shoup for any modulus < 2^61, and error-free fp64 for moduli < 2^49
+//    (arith.h).  Outputs are canonical residues either way, so the bits are the
+//    ones SEAL's ntt_negacyclic_harvey / inverse_ntt_negacyclic_harvey produce
+//    (reference database.cpp:190,222,252).
+#pragma once
+#include "arith.h"
+
+namespace pirgpu {
+
+template <int LOGN>
+struct Plan {
+  static constexpr int N = 1 << LOGN;
+  static constexpr int NT = N / kNttElemsPerThread;
+  static constexpr int LDS_WORDS = N + N / 16;
+};
+
+__device__ __forceinline__ uint32_t lds_idx(uint32_t i) { return i + (i >> 4); }
+
+// ------------------------------------------------------------------ arithmetic policies
+
+template <int MODE>
+struct Arith;
+
+template <>
+struct Arith<kNttInt> {
+  using T = uint64_t;
+  using TW = Twiddle;
+  struct Mod {
+    uint64_t q, q2;
+  };
+  static __device__ __forceinline__ Mod mod(const DevParams* P, int mi) {
+    const uint64_t q = P->mod[mi].q;
+    return Mod{q, q << 1};
+  }
+  static __device__ __forceinline__ const TW* tw(const DevParams* P, int mi) { return P->tab[mi].tw; }
+  static __device__ __forceinline__ const TW* itw(const DevParams* P, int mi) { return P->tab[mi].itw; }
+  static __device__ __forceinline__ TW ninv(const DevParams* P, int mi) { return P->tab[mi].ninv; }
+  static __device__ __forceinline__ TW iw1n(const DevParams* P, int mi) { return P->tab[mi].iw1n; }
+  // canonical residue < q  <->  register element
+  static __device__ __forceinline__ T in(uint64_t v, const Mod&) { return v; }
+  static __device__ __forceinline__ uint64_t out(T v, const Mod&) { return v; }
+  // Harvey lazy butterflies: forward keeps values < 4q, inverse < 2q
+  static __device__ __forceinline__ void fwd(T& a, T& b, const TW& w, const Mod& m) {
+    T X = a >= m.q2 ? a - m.q2 : a;
+    const T t = mul_shoup_lazy(b, w, m.q);
+    a = X + t;
+    b = X - t + m.q2;
+  }
+  static __device__ __forceinline__ void inv(T& a, T& b, const TW& w, const Mod& m) {
+    const T u = a + b, d = a - b + m.q2;
+    a = u >= m.q2 ? u - m.q2 : u;
+    b = mul_shoup_lazy(d, w, m.q);
+  }
+  static __device__ __forceinline__ void inv_last(T& a, T& b, const TW& ninv, const TW& iw1n, const Mod& m) {
+    const T u = a + b, d = a - b + m.q2;
+    a = mul_shoup_lazy(u, ninv, m.q);
+    b = mul_shoup_lazy(d, iw1n, m.q);
+  }
+  static __device__ __forceinline__ T canon_fwd(T v, const Mod& m) {
+    v = v >= m.q2 ? v - m.q2 : v;
+    return v >= m.q ? v - m.q : v;
+  }
+  static __device__ __forceinline__ T canon_inv(T v, const Mod& m) { return v >= m.q ? v - m.q : v; }
+};
+
+template <int MODE>
+struct ArithF64 {
+  using T = double;
+  using TW = double;
+  using Mod = F64Mod;
+  static __device__ __forceinline__ Mod mod(const DevParams* P, int mi) {
+    return Mod{P->tab[mi].qd, P->tab[mi].qinvd};
+  }
+  static __device__ __forceinline__ const TW* tw(const DevParams* P, int mi) { return P->tab[mi].twf; }
+  static __device__ __forceinline__ const TW* itw(const DevParams* P, int mi) { return P->tab[mi].itwf; }
+  static __device__ __forceinline__ TW ninv(const DevParams* P, int mi) { return P->tab[mi].ninv_f; }
+  static __device__ __forceinline__ TW iw1n(const DevParams* P, int mi) { return P->tab[mi].iw1n_f; }
+  static __device__ __forceinline__ T in(uint64_t v, const Mod&) { return f64_from_u64(v); }
+  static __device__ __forceinline__ uint64_t out(T v, const Mod&) { return f64_to_u64(v); }
+  // forward: |a| grows by at most 0.6 q per stage from < q (<= 9.4 q < 2^53 after 14 stages)
+  static __device__ __forceinline__ void fwd(T& a, T& b, const TW& w, const Mod& m) {
+    const T y = MODE == kNttF64Wide ? f64_norm(b, m) : b;
+    const T t = f64_mulmod(y, w, m);
+    b = a - t;
+    a = a + t;
+  }
+  // inverse: the sum is renormalised every stage, so |values| <= 0.7 q throughout
+  static __device__ __forceinline__ void inv(T& a, T& b, const TW& w, const Mod& m) {
+    const T u = a + b, d = a - b;
+    a = f64_norm(u, m);
+    b = f64_mulmod(d, w, m);
+  }
+  static __device__ __forceinline__ void inv_last(T& a, T& b, const TW& ninv, const TW& iw1n, const Mod& m) {
+    const T u = a + b, d = a - b;
+    a = f64_mulmod(u, ninv, m);
+    b = f64_mulmod(d, iw1n, m);
+  }
+  static __device__ __forceinline__ T canon_fwd(T v, const Mod& m) { return f64_canon(f64_norm(v, m), m); }
+  static __device__ __forceinline__ T canon_inv(T v, const Mod& m) { return f64_canon(v, m); }
+};
+
+template <>
+struct Arith<kNttF64> : ArithF64<kNttF64> {};
+template <>
+struct Arith<kNttF64Wide> : ArithF64<kNttF64Wide> {};
+
+// ------------------------------------------------------------------ passes
+
+template <int LB, typename T>
+__device__ __forceinline__ void lds_store16(T* s, const T (&x)[16], uint32_t tid) {
+  const uint32_t inner = tid & ((1u << LB) - 1u), outer = tid >> LB;
+  const uint32_t base = (outer << (LB + 4)) | inner;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s[lds_idx(base | ((uint32_t)e << LB))] = x[e];
+}
+
+template <int LB, typename T>
+__device__ __forceinline__ void lds_load16(const T* s, T (&x)[16], uint32_t tid) {
+  const uint32_t inner = tid & ((1u << LB) - 1u), outer = tid >> LB;
+  const uint32_t base = (outer << (LB + 4)) | inner;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) x[e] = s[lds_idx(base | ((uint32_t)e << LB))];
+}
+
+// Cooley-Tukey stages on window LB for relative bits RHI..RLO (high to low).
+template <typename A, int LOGN, int LB, int RHI, int RLO>
+__device__ __forceinline__ void fwd_stages(typename A::T (&x)[16], const typename A::TW* __restrict__ tw,
+                                           uint32_t outer, const typename A::Mod& m) {
+#pragma unroll
+  for (int rb = RHI; rb >= RLO; --rb) {
+    const uint32_t mm = 1u << (LOGN - 1 - (LB + rb));
+#pragma unroll
+    for (int g = 0; g < (8 >> rb); ++g) {
+      const typename A::TW W = tw[mm + (outer << (3 - rb)) + g];
+#pragma unroll
+      for (int l = 0; l < (1 << rb); ++l) {
+        const int e0 = (g << (rb + 1)) | l, e1 = e0 | (1 << rb);
+        A::fwd(x[e0], x[e1], W, m);
+      }
+    }
+  }
+}
+
+template <typename A, int LOGN, int LB>
+__device__ __forceinline__ void fwd_continue(typename A::T (&x)[16], typename A::T* s,
+                                             const typename A::TW* __restrict__ tw, const typename A::Mod& m,
+                                             uint32_t tid) {
+  if constexpr (LB > 0) {
+    constexpr int NLB = LB >= 4 ? LB - 4 : 0;
+    constexpr int RHI = LB >= 4 ? 3 : LB - 1;
+    lds_store16<LB>(s, x, tid);
+    __syncthreads();
+    lds_load16<NLB>(s, x, tid);
+    fwd_stages<A, LOGN, NLB, RHI, 0>(x, tw, tid >> NLB, m);
+    fwd_continue<A, LOGN, NLB>(x, s, tw, m, tid);
+  }
+}
+
+// Forward NTT.  In: x[e] = coefficient e*NT + tid (A::in of a canonical residue).
+// Out: x[e] = SEAL NTT position 16*tid + e == device-order slot e*NT + tid, canonical
+// representative (A::out gives the residue).  The caller guarantees nobody still reads
+// `s` (barrier) when this is entered.
+template <int MODE, int LOGN>
+__device__ __forceinline__ void ntt_forward(typename Arith<MODE>::T (&x)[16], void* lds, const DevParams* P, int mi,
+                                            uint32_t tid) {
+  using A = Arith<MODE>;
+  typename A::T* s = reinterpret_cast<typename A::T*>(lds);
+  const typename A::Mod m = A::mod(P, mi);
+  const typename A::TW* tw = A::tw(P, mi);
+  fwd_stages<A, LOGN, LOGN - 4, 3, 0>(x, tw, 0u, m);
+  fwd_continue<A, LOGN, LOGN - 4>(x, s, tw, m, tid);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) x[e] = A::canon_fwd(x[e], m);
+}
+
+// Gentleman-Sande stages on window LB for relative bits RLO..RHI (low to high); with
+// LAST the final stage multiplies by N^-1 (folded into both outputs).
+template <typename A, int LOGN, int LB, int RLO, int RHI, bool LAST>
+__device__ __forceinline__ void inv_stages(typename A::T (&x)[16], const typename A::TW* __restrict__ itw,
+                                           const typename A::TW& ninv, const typename A::TW& iw1n, uint32_t outer,
+                                           const typename A::Mod& m) {
+#pragma unroll
+  for (int rb = RLO; rb <= RHI; ++rb) {
+    const uint32_t h = 1u << (LOGN - 1 - (LB + rb));
+    if (LAST && rb == RHI) {
+#pragma unroll
+      for (int l = 0; l < 8; ++l) A::inv_last(x[l], x[l | 8], ninv, iw1n, m);
+    } else {
+#pragma unroll
+      for (int g = 0; g < (8 >> rb); ++g) {
+        const typename A::TW W = itw[h + (outer << (3 - rb)) + g];
+#pragma unroll
+        for (int l = 0; l < (1 << rb); ++l) {
+          const int e0 = (g << (rb + 1)) | l, e1 = e0 | (1 << rb);
+          A::inv(x[e0], x[e1], W, m);
+        }
+      }
+    }
+  }
+}
+
+template <typename A, int LOGN, int D, int PREV>  // D = index bits done; registers hold window PREV
+__device__ __forceinline__ void inv_continue(typename A::T (&x)[16], typename A::T* s,
+                                             const typename A::TW* __restrict__ itw, const typename A::TW& ninv,
+                                             const typename A::TW& iw1n, const typename A::Mod& m, uint32_t tid) {
+  if constexpr (D < LOGN) {
+    constexpr int LB = (LOGN - D >= 4) ? D : LOGN - 4;
+    constexpr int RLO = D - LB;
+    constexpr bool LAST = (LB + 4 == LOGN);
+    lds_store16<PREV>(s, x, tid);
+    __syncthreads();
+    lds_load16<LB>(s, x, tid);
+    inv_stages<A, LOGN, LB, RLO, 3, LAST>(x, itw, ninv, iw1n, tid >> LB, m);
+    inv_continue<A, LOGN, LB + 4, LB>(x, s, itw, ninv, iw1n, m, tid);
+  }
+}
+
+// Inverse NTT.  In: x[e] = NTT position 16*tid + e (any representative the flavour
+// accepts: < 2q for integers, |v| <= 4q for fp64).  Out: x[e] = coefficient e*NT + tid,
+// canonical, scaled by N^-1.
+template <int MODE, int LOGN>
+__device__ __forceinline__ void ntt_inverse(typename Arith<MODE>::T (&x)[16], void* lds, const DevParams* P, int mi,
+                                            uint32_t tid) {
+  static_assert(LOGN >= 8, "at least two passes expected");
+  using A = Arith<MODE>;
+  typename A::T* s = reinterpret_cast<typename A::T*>(lds);
+  const typename A::Mod m = A::mod(P, mi);
+  const typename A::TW* itw = A::itw(P, mi);
+  const typename A::TW ninv = A::ninv(P, mi), iw1n = A::iw1n(P, mi);
+  inv_stages<A, LOGN, 0, 0, 3, false>(x, itw, ninv, iw1n, tid, m);
+  inv_continue<A, LOGN, 4, 0>(x, s, itw, ninv, iw1n, m, tid);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) x[e] = A::canon_inv(x[e], m);
+}
+
+}  // namespace pirgpu

@@ -1,0 +1,343 @@
+// ntt_kernels.hip -- every kernel that contains a negacyclic NTT, for ONE ring degree.
+//
+// Compiled once per supported degree with -DPIRGPU_LOGN=<11..14> (build.py), which keeps
+// each translation unit small and lets the degrees build in parallel.  Each kernel
+// exists in the three arithmetic flavours of ntt_core.h (integer / fp64 / wide fp64).
+//
+// Reference call sites replaced (paths relative to /root/reference):
+//   ntt_batch_kernel          Evaluator::transform_to/from_ntt_inplace   database.cpp:190,222,252
+//   ct_ntt_fwd_oop_kernel     transform_to_ntt_inplace(selection vector) database.cpp:188-191,221-224
+//   db_encode_kernel          StringEncoder::encode + transform_to_ntt   database.cpp:100-106, string_encoder.cpp:58-122
+//   ks_digit_kernel,
+//   ks_mac_intt_kernel        Evaluator::apply_galois_inplace key switch server.cpp:71
+//   reencode_lift_ntt_kernel  CiphertextReencoder::Encode + plain NTT    database.cpp:218,225-228, ct_reencoder.cpp:40-71
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_params.h"
+#include "kernels.h"
+#include "ntt_core.h"
+
+#ifndef PIRGPU_LOGN
+#error "compile with -DPIRGPU_LOGN=<11..14>"
+#endif
+
+#define PIRGPU_CAT2(a, b) a##b
+#define PIRGPU_CAT(a, b) PIRGPU_CAT2(a, b)
+#define PIRGPU_OPS_NAME PIRGPU_CAT(ntt_ops_, PIRGPU_LOGN)
+#define PIRGPU_DEG_NS PIRGPU_CAT(deg, PIRGPU_LOGN)
+
+namespace pirgpu {
+// every degree gets its own namespace: the kernels of the four translation units must
+// not share mangled names (they differ only in the compile-time degree)
+namespace PIRGPU_DEG_NS {
+
+constexpr int LOGN = PIRGPU_LOGN;
+constexpr int NT = Plan<LOGN>::NT;
+constexpr int N = Plan<LOGN>::N;
+constexpr size_t kLdsBytes = (size_t)Plan<LOGN>::LDS_WORDS * 8;
+
+extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+// One workgroup per polynomial; modulus index = mod_base + (poly % mod_period).
+// Forward: natural coefficients -> device NTT order; inverse: the reverse.  In place.
+template <int MODE, bool INVERSE>
+__global__ void __launch_bounds__(NT)
+ntt_batch_kernel(const DevParams* __restrict__ P, uint64_t* __restrict__ data, uint32_t mod_period,
+                 uint32_t mod_base) {
+  using A = Arith<MODE>;
+  const uint32_t tid = threadIdx.x;
+  const int mi = mod_base + (blockIdx.x % mod_period);
+  const typename A::Mod m = A::mod(P, mi);
+  uint64_t* poly = data + (size_t)blockIdx.x * N;
+  typename A::T x[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) x[e] = A::in(poly[e * NT + tid], m);
+  if constexpr (INVERSE)
+    ntt_inverse<MODE, LOGN>(x, smem_raw, P, mi, tid);
+  else
+    ntt_forward<MODE, LOGN>(x, smem_raw, P, mi, tid);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) poly[e * NT + tid] = A::out(x[e], m);
+}
+
+// Out-of-place forward NTT of ciphertexts: src[ct][2][k][N] (coefficient form)
+// -> dst[ct][2][k][N] (device NTT order); selection vector -> NTT form.
+template <int MODE>
+__global__ void __launch_bounds__(NT)
+ct_ntt_fwd_oop_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ src, uint64_t* __restrict__ dst) {
+  using A = Arith<MODE>;
+  const uint32_t tid = threadIdx.x;
+  const int mi = blockIdx.x % P->k;
+  const typename A::Mod m = A::mod(P, mi);
+  const uint64_t* in = src + (size_t)blockIdx.x * N;
+  uint64_t* out = dst + (size_t)blockIdx.x * N;
+  typename A::T x[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) x[e] = A::in(in[e * NT + tid], m);
+  ntt_forward<MODE, LOGN>(x, smem_raw, P, mi, tid);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
+}
+
+// grid = (n_pt, k).  Source is either pre-encoded coefficients (coeffs != null)
+// or raw item bytes packed MSB-first into bits-wide coefficients
+// (reference string_encoder.cpp:58-122); then plain lift + forward NTT.
+template <int MODE>
+__global__ void __launch_bounds__(NT)
+db_encode_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ coeffs,
+                 const uint8_t* __restrict__ bytes, uint64_t bytes_per_pt, uint64_t total_bytes, uint32_t bits,
+                 uint64_t* __restrict__ db) {
+  using A = Arith<MODE>;
+  const uint32_t tid = threadIdx.x, k = P->k;
+  const uint32_t j = blockIdx.y;
+  const uint64_t pt = blockIdx.x;
+  const ModConst mc = P->mod[j];
+  const typename A::Mod m = A::mod(P, j);
+  const uint64_t thr = P->plain_thr;
+  const uint64_t inc = P->lift_inc[j] >= mc.q ? P->lift_inc[j] - mc.q : P->lift_inc[j];
+  uint64_t L = 0;
+  const uint8_t* src = nullptr;
+  if (!coeffs) {
+    uint64_t start = pt * bytes_per_pt;
+    L = start >= total_bytes ? 0 : (total_bytes - start < bytes_per_pt ? total_bytes - start : bytes_per_pt);
+    src = bytes + start;
+  }
+  typename A::T x[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const uint32_t c = e * NT + tid;
+    uint64_t v;
+    if (coeffs) {
+      v = coeffs[pt * N + c];
+    } else {
+      v = 0;
+      uint64_t bitpos = (uint64_t)c * bits;
+      uint64_t byte = bitpos >> 3;
+      uint32_t off = (uint32_t)(bitpos & 7);
+      int need = (int)bits;
+      while (need > 0) {
+        uint32_t B = byte < L ? src[byte] : 0u;
+        int avail = 8 - (int)off;
+        int take = avail < need ? avail : need;
+        v = (v << take) | ((B >> (avail - take)) & ((1u << take) - 1u));
+        need -= take;
+        off = 0;
+        ++byte;
+      }
+    }
+    // Evaluator::transform_to_ntt_inplace(Plaintext): m >= (t+1)/2 ? m + (q_j - t) : m  
+    uint64_t r = reduce64(v, mc);
+    if (v >= thr) r = add_mod(r, inc, mc.q);
+    x[e] = A::in(r, m);
+  }
+  ntt_forward<MODE, LOGN>(x, smem_raw, P, j, tid);
+  uint64_t* out = db + (pt * k + j) * N;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
+}
+
+// One level of the expansion tree, part 1a: for node n, key-level modulus I and
+// RNS digit J:  dig[n][I][J] = NTT_I(sigma_g(c1)_J mod m_I)  (device NTT order, stored in
+// the flavour's register type).  grid = (nodes, k+1, k).
+template <int MODE>
+__global__ void __launch_bounds__(NT)
+ks_digit_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ res_in, uint32_t galois_elt,
+                uint64_t* __restrict__ dig) {
+  using A = Arith<MODE>;
+  uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
+  const uint32_t tid = threadIdx.x;
+  const uint32_t k = P->k;
+  const uint32_t node = blockIdx.x, I = blockIdx.y, J = blockIdx.z;
+  const ModConst mI = P->mod[I];
+  const typename A::Mod m = A::mod(P, I);
+  const uint64_t qJ = P->mod[J].q;
+  const uint64_t* src = res_in + (((size_t)node * 2 + 1) * k + J) * N;  // poly 1, residue J
+  // sigma_g in coefficient form (SEAL GaloisTool::apply_galois), then reduce mod m_I
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const uint32_t i = e * NT + tid;
+    const uint32_t raw = i * galois_elt;
+    uint64_t v = src[i];
+    if ((raw >> LOGN) & 1) v = neg_mod(v, qJ);
+    s[lds_idx(raw & (N - 1))] = reduce64(v, mI);
+  }
+  __syncthreads();
+  typename A::T x[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) x[e] = A::in(s[lds_idx(e * NT + tid)], m);
+  __syncthreads();  // the transform reuses the same LDS words with its own element type
+  ntt_forward<MODE, LOGN>(x, smem_raw, P, I, tid);
+  typename A::T* out = reinterpret_cast<typename A::T*>(dig) + (((size_t)node * (k + 1) + I) * k + J) * N;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) out[e * NT + tid] = x[e];
+}
+
+// Part 1b: S[c][I] = sum_J dig[n][I][J] (.) K[J][c][I], then INTT_I -> prod[n][c][I]
+// (coefficient order, canonical u64).  The key is in device NTT order (and in the
+// flavour's register type), so the dyadic products are formed directly in the register
+// layout the inverse transform starts from.  grid = (nodes, k+1, 2).
+template <int MODE>
+__global__ void __launch_bounds__(NT)
+ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ dig_raw,
+                   const uint64_t* __restrict__ key_raw, uint64_t* __restrict__ prod) {
+  using A = Arith<MODE>;
+  using T = typename A::T;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t k = P->k, km = k + 1;
+  const uint32_t node = blockIdx.x, I = blockIdx.y, comp = blockIdx.z;
+  const ModConst mI = P->mod[I];
+  const typename A::Mod m = A::mod(P, I);
+  const T* d0 = reinterpret_cast<const T*>(dig_raw) + ((size_t)node * km + I) * k * N;
+  const T* key = reinterpret_cast<const T*>(key_raw);
+  T x[16];
+  if constexpr (MODE == kNttInt) {
+    u128 acc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0;
+    for (uint32_t J = 0; J < k; ++J) {  // k <= 8 products of two residues < 2^61 fit 128 bits
+      const T* dj = d0 + (size_t)J * N;
+      const T* kj = key + (((size_t)J * 2 + comp) * km + I) * N;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] += (u128)dj[e * NT + tid] * kj[e * NT + tid];
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x[e] = reduce128((uint64_t)acc[e], (uint64_t)(acc[e] >> 64), mI);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x[e] = 0.0;
+    for (uint32_t J = 0; J < k; ++J) {
+      const T* dj = d0 + (size_t)J * N;
+      const T* kj = key + (((size_t)J * 2 + comp) * km + I) * N;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) x[e] += f64_mulmod(dj[e * NT + tid], kj[e * NT + tid], m);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x[e] = f64_norm(x[e], m);
+  }
+  ntt_inverse<MODE, LOGN>(x, smem_raw, P, I, tid);
+  uint64_t* out = prod + (((size_t)node * 2 + comp) * km + I) * N;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
+}
+
+// CiphertextReencoder::Encode chunk e of source ciphertext c, lifted to residue
+// jt and forward-NTT'd: pt[c][e][jt][N] (device NTT order).  grid = (n_src, enc_count, k).
+template <int MODE>
+__global__ void __launch_bounds__(NT)
+reencode_lift_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ src,
+                         uint64_t* __restrict__ pt) {
+  using A = Arith<MODE>;
+  const uint32_t tid = threadIdx.x, k = P->k;
+  const uint32_t c = blockIdx.x, e_idx = blockIdx.y, jt = blockIdx.z;
+  const ModConst mc = P->mod[jt];
+  const typename A::Mod m = A::mod(P, jt);
+  const uint32_t sp = P->enc_poly[e_idx], sj = P->enc_res[e_idx], sh = P->enc_shift[e_idx];
+  const uint64_t mask = (1ull << P->enc_bits) - 1;
+  const uint64_t thr = P->plain_thr;
+  const uint64_t inc = P->lift_inc[jt] >= mc.q ? P->lift_inc[jt] - mc.q : P->lift_inc[jt];
+  const uint64_t* in = src + (((size_t)c * 2 + sp) * k + sj) * N;
+  typename A::T x[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    uint64_t v = (in[e * NT + tid] >> sh) & mask;
+    uint64_t r = reduce64(v, mc);
+    if (v >= thr) r = add_mod(r, inc, mc.q);
+    x[e] = A::in(r, m);
+  }
+  ntt_forward<MODE, LOGN>(x, smem_raw, P, jt, tid);
+  uint64_t* out = pt + (((size_t)c * P->enc_count + e_idx) * k + jt) * N;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
+}
+
+// ------------------------------------------------------------------ host side
+
+#define PIRGPU_BY_MODE(mode, EXPR)                                \
+  switch (mode) {                                                 \
+    case kNttInt: { constexpr int MODE = kNttInt; EXPR; } break;  \
+    case kNttF64: { constexpr int MODE = kNttF64; EXPR; } break;  \
+    default: { constexpr int MODE = kNttF64Wide; EXPR; } break;   \
+  }
+
+template <int MODE>
+static hipError_t configure_mode() {
+  const int bytes = (int)kLdsBytes;  // beyond 64 KiB for N = 16384 (136 KiB of the CU's 160 KiB)
+  hipError_t e;
+#define PIRGPU_SET(K) \
+  if ((e = hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e
+  PIRGPU_SET((ntt_batch_kernel<MODE, false>));
+  PIRGPU_SET((ntt_batch_kernel<MODE, true>));
+  PIRGPU_SET(ct_ntt_fwd_oop_kernel<MODE>);
+  PIRGPU_SET(db_encode_kernel<MODE>);
+  PIRGPU_SET(ks_digit_kernel<MODE>);
+  PIRGPU_SET(ks_mac_intt_kernel<MODE>);
+  PIRGPU_SET(reencode_lift_ntt_kernel<MODE>);
+#undef PIRGPU_SET
+  return hipSuccess;
+}
+
+static hipError_t op_configure(int mode) {
+  PIRGPU_BY_MODE(mode, return configure_mode<MODE>());
+  return hipSuccess;
+}
+
+static hipError_t op_ntt_batch(hipStream_t st, int mode, const DevParams* P, uint64_t* data, uint64_t n_polys,
+                               uint32_t mod_period, uint32_t mod_base, bool inverse) {
+  if (inverse) {
+    PIRGPU_BY_MODE(mode, hipLaunchKernelGGL((ntt_batch_kernel<MODE, true>), dim3((uint32_t)n_polys), dim3(NT),
+                                            kLdsBytes, st, P, data, mod_period, mod_base));
+  } else {
+    PIRGPU_BY_MODE(mode, hipLaunchKernelGGL((ntt_batch_kernel<MODE, false>), dim3((uint32_t)n_polys), dim3(NT),
+                                            kLdsBytes, st, P, data, mod_period, mod_base));
+  }
+  return hipGetLastError();
+}
+
+static hipError_t op_ct_ntt_fwd_oop(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* src,
+                                    uint64_t* dst, uint64_t n_cts) {
+  PIRGPU_BY_MODE(mode, hipLaunchKernelGGL(ct_ntt_fwd_oop_kernel<MODE>, dim3((uint32_t)(n_cts * 2 * k)), dim3(NT),
+                                          kLdsBytes, st, P, src, dst));
+  return hipGetLastError();
+}
+
+static hipError_t op_db_encode(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* coeffs,
+                               const uint8_t* bytes, uint64_t bytes_per_pt, uint64_t total_bytes, uint32_t bits,
+                               uint64_t n_pt, uint64_t* db) {
+  PIRGPU_BY_MODE(mode, hipLaunchKernelGGL(db_encode_kernel<MODE>, dim3((uint32_t)n_pt, k), dim3(NT), kLdsBytes, st,
+                                          P, coeffs, bytes, bytes_per_pt, total_bytes, bits, db));
+  return hipGetLastError();
+}
+
+static hipError_t op_ks_digit(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* res_in,
+                              uint32_t galois_elt, uint32_t nodes, uint64_t* dig) {
+  PIRGPU_BY_MODE(mode, hipLaunchKernelGGL(ks_digit_kernel<MODE>, dim3(nodes, k + 1, k), dim3(NT), kLdsBytes, st, P,
+                                          res_in, galois_elt, dig));
+  return hipGetLastError();
+}
+
+static hipError_t op_ks_mac_intt(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* dig,
+                                 const uint64_t* key, uint32_t nodes, uint64_t* prod) {
+  PIRGPU_BY_MODE(mode, hipLaunchKernelGGL(ks_mac_intt_kernel<MODE>, dim3(nodes, k + 1, 2), dim3(NT), kLdsBytes, st,
+                                          P, dig, key, prod));
+  return hipGetLastError();
+}
+
+static hipError_t op_reencode(hipStream_t st, int mode, const DevParams* P, uint32_t k, uint32_t enc_count,
+                              const uint64_t* src, uint64_t n_src, uint64_t* pt) {
+  PIRGPU_BY_MODE(mode, hipLaunchKernelGGL(reencode_lift_ntt_kernel<MODE>, dim3((uint32_t)n_src, enc_count, k),
+                                          dim3(NT), kLdsBytes, st, P, src, pt));
+  return hipGetLastError();
+}
+
+}  // namespace PIRGPU_DEG_NS
+
+// host-only accessor (a namespace-scope const object would also be emitted for the device)
+const NttOps* PIRGPU_OPS_NAME() {
+  using namespace PIRGPU_DEG_NS;
+  static const NttOps ops = {op_configure, op_ntt_batch,   op_ct_ntt_fwd_oop, op_db_encode,
+                             op_ks_digit,  op_ks_mac_intt, op_reencode};
+  return &ops;
+}
+
+}  // namespace pirgpu

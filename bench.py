@@ -123,12 +123,8 @@ def main():
     pp = pir_amd.create_pir_parameters(1 << args.log_items, 288, args.dims, enc)
     raw, keys, query = synthetic_inputs(pp)
 
-    n0 = pp.dimensions[0]
-    shard = None
-    if world > 1:
-        lo = (n0 * rank) // world
-        hi = (n0 * (rank + 1)) // world
-        shard = (lo, hi)
+    from pir_amd.distributed import all_reduce_reply, shard_range
+    shard = shard_range(pp.dimensions[0], rank, world) if world > 1 else None
     db = pir_amd.PIRDatabase.Create(pp, device=local_rank, shard=shard)
     t0 = time.perf_counter()
     db.populate(raw)
@@ -146,10 +142,7 @@ def main():
     def step():
         srv.run_staged()
         if world > 1:
-            srv.reply_copy_to_device(red.data_ptr())          # waits for this rank's kernels
-            dist.all_reduce(red, op=dist.ReduceOp.SUM)        # RCCL over xGMI; partials < q_j so no overflow
-            torch.cuda.current_stream().synchronize()
-            srv.reduce_fixup_device(red.data_ptr())           # x mod q_j
+            all_reduce_reply(srv, red, dist)
 
     def barrier():
         if world > 1:

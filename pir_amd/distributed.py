@@ -1,0 +1,28 @@
+"""Multi-GPU glue (one process per GPU, torch.distributed over RCCL): row sharding of the
+database and the sum of per-shard partial replies.  Not in the reference (single-threaded,
+single-process); see DESIGN.md section 7."""
+from __future__ import annotations
+
+from typing import Tuple
+
+
+def shard_range(n_top: int, rank: int, world: int) -> Tuple[int, int]:
+    """Top-level index range [begin, end) of dimension 0 held by `rank` (contiguous, balanced)."""
+    if not 0 <= rank < world:
+        raise ValueError("rank out of range")
+    return (n_top * rank) // world, (n_top * (rank + 1)) // world
+
+
+def all_reduce_reply(server, reply_tensor, dist) -> None:
+    """Sum the ranks' partial replies in place and reduce mod q_j.
+
+    reply_tensor: int64 CUDA tensor [reply_cts, 2, k, N] owned by the caller.  Partial replies
+    are canonical residues (< q_j < 2^61), so the integer sum over <= 8 ranks cannot overflow.
+    """
+    import torch
+    if not reply_tensor.is_cuda:
+        raise RuntimeError("all_reduce_reply needs a CUDA tensor (RCCL); there is no CPU path")
+    server.reply_copy_to_device(reply_tensor.data_ptr())     # waits for this rank's kernels
+    dist.all_reduce(reply_tensor, op=dist.ReduceOp.SUM)      # RCCL over xGMI
+    torch.cuda.current_stream().synchronize()
+    server.reduce_fixup_device(reply_tensor.data_ptr())      # x mod q_j on the GPU

@@ -288,3 +288,55 @@ def test_sharded_partial_replies_sum_to_full_reply(dbsize, elem, d):
     for j, qj in enumerate(s.orc.moduli[: s.orc.k]):
         acc[:, :, j, :] %= np.uint64(qj)
     assert np.array_equal(acc, exp)
+
+
+# ---------------------------------------------------------------- wire level (ProcessRequest)
+
+def test_process_request_wire_roundtrip():
+    """server_test.cpp:98-186 shape: serialized pir.Request (payload.proto) -> pir.Response, single,
+    batch and 2-dim, against the residue-level path."""
+    import seal_wire as W
+    s = PirSetup(82, 0, 2, N=N, plain_bits=24)
+    db, srv = make_server(s)
+    o = s.orc
+    data_pid = W.parms_id(N, o.moduli[: o.k], o.t)
+    key_pid = W.parms_id(N, o.moduli, o.t)
+    gk = W.save_galois_keys(s.galois_keys, N, key_pid)
+    indexes = [3, 42, 81]
+    queries = [s.client.create_query_for(s.params, i) for i in indexes]
+    resp = srv.ProcessRequest(W.save_request(queries, gk, data_pid))
+    replies = W.load_response(resp)
+    assert len(replies) == len(indexes)                       # reply[i] answers query[i] (server.cpp:60-63)
+    srv.set_galois_keys(s.galois_keys)
+    for idx, q, r in zip(indexes, queries, replies):
+        assert np.array_equal(r, srv.process_query(q))
+        assert s.client.process_response(s.params, idx, r) == s.item(idx)
+    # zero queries -> empty response
+    assert srv.ProcessRequest(W.save_request([], gk, data_pid)) == b""
+    db.close()
+
+
+def test_process_request_wire_errors():
+    import seal_wire as W
+    s = PirSetup(10, 0, 1, N=N, plain_bits=20)
+    db, srv = make_server(s)
+    o = s.orc
+    data_pid = W.parms_id(N, o.moduli[: o.k], o.t)
+    key_pid = W.parms_id(N, o.moduli, o.t)
+    gk = W.save_galois_keys(s.galois_keys, N, key_pid)
+    q = s.client.create_query_for(s.params, 3)
+    for bad in (W.save_request([q], b"", data_pid),                      # empty galois_keys: load throws
+                W.save_request([q], gk[:100], data_pid),                 # truncated keys
+                W.save_request([q], gk, key_pid),                        # query at the wrong level
+                W.save_request([np.concatenate([q, q])], gk, data_pid),  # wrong ciphertext count
+                b"\x0a\xff\xff"):                                        # malformed proto
+        with pytest.raises(pir_amd.PirGpuError) as e:
+            srv.ProcessRequest(bad)
+        assert e.value.code == pir_amd.StatusCode.INVALID_ARGUMENT       # serialization.h:113-115
+    # a coefficient >= q_j is rejected like SEAL's is_data_valid_for
+    q_bad = q.copy()
+    q_bad[0, 0, 0, 0] = o.moduli[0]
+    with pytest.raises(pir_amd.PirGpuError) as e:
+        srv.ProcessRequest(W.save_request([q_bad], gk, data_pid))
+    assert e.value.code == pir_amd.StatusCode.INVALID_ARGUMENT
+    db.close()

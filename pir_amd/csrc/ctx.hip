@@ -79,6 +79,8 @@ struct pirgpu_ctx {
   std::vector<uint64_t*> lvl;      // per level results
   std::vector<uint64_t> lvl_rows;  // nodes per level inside the shard
   uint64_t* pt_buf = nullptr;
+  uint64_t pt_words = 0;
+  uint32_t upper_blocks = 512;   // target workgroup count of upper_fused_kernel (PIRGPU_UPPER_BLOCKS)
   uint64_t* scan_part = nullptr;
   uint32_t scan_nsplit = 1, scan_cps = 0, scan_rows = 0, scan_cols = 0;
   uint32_t scan_rpt = 4, scan_block = 256;  // rows per thread / workgroup size of the scan kernel
@@ -237,6 +239,7 @@ void ensure_workspace(pirgpu_ctx* c) {
   c->d_query = c->dalloc<uint64_t>((size_t)(c->dim_sum / N + 1) * ctw);
   // per-level node counts inside this shard and result buffers
   const uint64_t shard_pts = c->pt_end - c->pt_begin;
+  if (const char* v = getenv("PIRGPU_UPPER_BLOCKS")) c->upper_blocks = std::max(1, atoi(v));
   c->lvl.assign(d, nullptr);
   c->lvl_rows.assign(d, 0);
   uint64_t pt_words = 0;
@@ -247,11 +250,13 @@ void ensure_workspace(pirgpu_ctx* c) {
     c->lvl_rows[l] = rows;
     c->lvl[l] = c->dalloc<uint64_t>(std::max<uint64_t>(rows, 1) * C * ctw);
     if (l + 1 < d) {
-      uint64_t nch = ceil_div(shard_pts, c->stride[l + 1]);
-      uint64_t Cc = C / c->E;
-      pt_words = std::max<uint64_t>(pt_words, nch * Cc * c->E * k * N);
+      // chunk partial sums of upper_fused_kernel: n_chunks x (rows * C * E * 2 * k) polynomials
+      const uint64_t per_chunk = std::max<uint64_t>(rows, 1) * (C / c->E) * c->E * k;
+      const uint64_t n_chunks = std::min<uint64_t>(c->dims[l], std::max<uint64_t>(1, ceil_div(c->upper_blocks, per_chunk)));
+      pt_words = std::max<uint64_t>(pt_words, (n_chunks + 1) * std::max<uint64_t>(rows, 1) * C * 2 * k * N);
     }
   }
+  c->pt_words = pt_words;
   if (pt_words) c->pt_buf = c->dalloc<uint64_t>(pt_words);
   // base-level scan geometry
   if (d == 1) {
@@ -394,17 +399,28 @@ void multiply_on_device(pirgpu_ctx* c) {
                                  base_out));
   record(c, PH_UPPER);  // end of scan phase
   HIP_TRY(c->ops->ntt_batch(c->stream, c->mode, c->dp, base_out, (uint64_t)c->scan_rows * 2 * k, k, 0, true));
-  // upper levels
+  // upper levels: fused re-encode + lift + NTT + multiply-accumulate over chunks of children,
+  // then one kernel folds the chunk sums and applies the inverse NTT
   uint64_t C = 1;  // ciphertexts per child
   for (int l = (int)d - 2; l >= 0; --l) {
     const uint64_t nch = ceil_div(shard_pts, c->stride[l + 1]);
     const uint64_t rows = c->lvl_rows[l];
-    if (nch * C) HIP_TRY(c->ops->reencode_lift_ntt(c->stream, c->mode, c->dp, k, c->E, c->lvl[l + 1], nch * C, c->pt_buf));
     const uint32_t sv_first = c->sv_off[l] + (l == 0 ? c->sb : 0);
-    HIP_TRY(launch_upper_mac(c->stream, c->dp, N, k, c->E, c->sv_ntt, c->pt_buf, (uint32_t)rows, c->dims[l],
-                             (uint32_t)nch, sv_first, (uint32_t)C, c->lvl[l]));
+    // enough workgroups to fill the chip: ~1024 over (rows * C * chunks * E * k)
+    const uint64_t per_chunk = rows * C * c->E * k;
+    uint32_t n_chunks = (uint32_t)std::min<uint64_t>(c->dims[l], std::max<uint64_t>(1, ceil_div(c->upper_blocks, per_chunk)));
+    const uint32_t chunk_len = (uint32_t)ceil_div(c->dims[l], n_chunks);
+    n_chunks = (uint32_t)ceil_div(c->dims[l], chunk_len);
+    const uint64_t out_polys = rows * C * c->E * 2 * k;
+    if (out_polys * n_chunks * N > c->pt_words)
+      throw Fail{PIRGPU_INTERNAL, "upper-level scratch undersized"};
+    HIP_TRY(c->ops->upper_fused(c->stream, c->mode, c->dp, k, c->E, c->lvl[l + 1], c->sv_ntt, c->pt_buf,
+                                (uint32_t)rows, c->dims[l], (uint32_t)nch, sv_first, (uint32_t)C, chunk_len,
+                                n_chunks));
     if (l == 0) record(c, PH_FINAL);
-    HIP_TRY(c->ops->ntt_batch(c->stream, c->mode, c->dp, c->lvl[l], rows * C * c->E * 2 * k, k, 0, true));
+    // fold the chunk sums (wide, elementwise) and return to coefficient form (database.cpp:250-254)
+    HIP_TRY(launch_reduce_splits(c->stream, c->dp, c->pt_buf, n_chunks, out_polys * N, c->lvl[l]));
+    HIP_TRY(c->ops->ntt_batch(c->stream, c->mode, c->dp, c->lvl[l], out_polys, k, 0, true));
     C *= c->E;
   }
   if (d == 1) record(c, PH_FINAL);

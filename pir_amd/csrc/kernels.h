@@ -24,6 +24,12 @@ struct NttOps {
                             const uint64_t* key, uint32_t nodes, uint64_t* prod);
   hipError_t (*reencode_lift_ntt)(hipStream_t st, int mode, const DevParams* P, uint32_t k, uint32_t enc_count,
                                   const uint64_t* src, uint64_t n_src, uint64_t* pt);
+  hipError_t (*upper_fused)(hipStream_t st, int mode, const DevParams* P, uint32_t k, uint32_t enc_count,
+                            const uint64_t* src, const uint64_t* sv, uint64_t* part, uint32_t n_rows,
+                            uint32_t n_dim, uint32_t n_children_total, uint32_t sv_first, uint32_t C,
+                            uint32_t chunk_len, uint32_t n_chunks);
+  hipError_t (*sum_intt)(hipStream_t st, int mode, const DevParams* P, const uint64_t* part, uint32_t n_parts,
+                         uint64_t part_stride, uint64_t n_polys, uint64_t* out);
 };
 
 const NttOps* ntt_ops_for(uint32_t N);  // nullptr for unsupported degrees

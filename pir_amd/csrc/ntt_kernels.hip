@@ -251,6 +251,138 @@ reencode_lift_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __rest
   for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
 }
 
+// Upper recursion level, fused: for output slot (row r, source ciphertext cc, Encode chunk
+// e_idx, target residue jt) and a chunk of the row's children,
+//   part[chunk][r][cc*E+e_idx][p][jt] = sum_{ii in chunk} sv[sv_first+ii][p][jt] (.)
+//                                        NTT_jt(lift(Encode_e_idx(child[(r*n_dim+ii)*C+cc])))
+// i.e. CiphertextReencoder::Encode + transform_to_ntt_inplace(Plaintext) + multiply_plain +
+// add_inplace of database.cpp:218-247 without materialising the re-encoded plaintexts: the
+// transformed plaintext stays in registers and is multiplied into both polynomials of the
+// selector.  grid = (n_rows*C*n_chunks, E, k); partial sums are folded by sum_intt_kernel.
+template <int MODE>
+__global__ void __launch_bounds__(NT)
+upper_fused_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ src,
+                   const uint64_t* __restrict__ sv, uint64_t* __restrict__ part, uint32_t n_rows, uint32_t n_dim,
+                   uint32_t n_children_total, uint32_t sv_first, uint32_t C, uint32_t chunk_len,
+                   uint32_t n_chunks) {
+  using A = Arith<MODE>;
+  using T = typename A::T;
+  const uint32_t tid = threadIdx.x, k = P->k, E = P->enc_count;
+  const uint32_t chunk = blockIdx.x % n_chunks;
+  const uint32_t cc = (blockIdx.x / n_chunks) % C;
+  const uint32_t r = blockIdx.x / (n_chunks * C);
+  const uint32_t e_idx = blockIdx.y, jt = blockIdx.z;
+  const ModConst mc = P->mod[jt];
+  const typename A::Mod m = A::mod(P, jt);
+  const uint32_t sp = P->enc_poly[e_idx], sj = P->enc_res[e_idx], sh = P->enc_shift[e_idx];
+  const uint64_t mask = (1ull << P->enc_bits) - 1;
+  const uint64_t thr = P->plain_thr;
+  const uint64_t inc = P->lift_inc[jt] >= mc.q ? P->lift_inc[jt] - mc.q : P->lift_inc[jt];
+  const uint32_t child0 = r * n_dim;
+  uint32_t nchild = n_children_total > child0 ? n_children_total - child0 : 0;
+  if (nchild > n_dim) nchild = n_dim;
+  const uint32_t ii0 = chunk * chunk_len;
+  const uint32_t ii1 = ii0 + chunk_len < nchild ? ii0 + chunk_len : nchild;
+
+  // lazy accumulators: fp64 sums of signed representatives (|term| <= 0.7 q, renormalised
+  // every 8 terms) or exact 128-bit integer sums (folded every lazy_limit terms)
+  T acc0[16], acc1[16];
+  u128 wide0[MODE == kNttInt ? 16 : 1], wide1[MODE == kNttInt ? 16 : 1];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    acc0[e] = 0;
+    acc1[e] = 0;
+    if constexpr (MODE == kNttInt) wide0[e] = wide1[e] = 0;
+  }
+  uint32_t since = 0;
+  for (uint32_t ii = ii0; ii < ii1; ++ii) {
+    const uint64_t* in = src + ((((size_t)(child0 + ii) * C + cc) * 2 + sp) * k + sj) * N;
+    T x[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      uint64_t v = (in[e * NT + tid] >> sh) & mask;
+      uint64_t rr = reduce64(v, mc);
+      if (v >= thr) rr = add_mod(rr, inc, mc.q);
+      x[e] = A::in(rr, m);
+    }
+    __syncthreads();  // previous iteration's transform may still be reading LDS
+    ntt_forward<MODE, LOGN>(x, smem_raw, P, jt, tid);
+    const uint64_t* s0 = sv + (((size_t)(sv_first + ii) * 2 + 0) * k + jt) * N;
+    const uint64_t* s1 = sv + (((size_t)(sv_first + ii) * 2 + 1) * k + jt) * N;
+    if constexpr (MODE == kNttInt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        wide0[e] += (u128)x[e] * s0[e * NT + tid];
+        wide1[e] += (u128)x[e] * s1[e * NT + tid];
+      }
+      if (++since == P->lazy_limit) {
+        since = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          wide0[e] = reduce128((uint64_t)wide0[e], (uint64_t)(wide0[e] >> 64), mc);
+          wide1[e] = reduce128((uint64_t)wide1[e], (uint64_t)(wide1[e] >> 64), mc);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        acc0[e] += f64_mulmod(x[e], f64_from_u64(s0[e * NT + tid]), m);
+        acc1[e] += f64_mulmod(x[e], f64_from_u64(s1[e * NT + tid]), m);
+      }
+      if (++since == 8) {
+        since = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          acc0[e] = f64_norm(acc0[e], m);
+          acc1[e] = f64_norm(acc1[e], m);
+        }
+      }
+    }
+  }
+  const size_t slot = (((size_t)chunk * n_rows + r) * C + cc) * E + e_idx;
+  uint64_t* o0 = part + ((slot * 2 + 0) * k + jt) * N;
+  uint64_t* o1 = part + ((slot * 2 + 1) * k + jt) * N;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    if constexpr (MODE == kNttInt) {
+      o0[e * NT + tid] = reduce128((uint64_t)wide0[e], (uint64_t)(wide0[e] >> 64), mc);
+      o1[e * NT + tid] = reduce128((uint64_t)wide1[e], (uint64_t)(wide1[e] >> 64), mc);
+    } else {
+      o0[e * NT + tid] = f64_to_u64(f64_canon(f64_norm(acc0[e], m), m));
+      o1[e * NT + tid] = f64_to_u64(f64_canon(f64_norm(acc1[e], m), m));
+    }
+  }
+}
+
+// out[poly] = INTT(sum_s part[s][poly] mod q): folds the chunk partial sums of
+// upper_fused_kernel (device NTT order) and leaves coefficient form (database.cpp:250-254).
+// grid = n_polys (ciphertext layout: modulus = poly % k).
+template <int MODE>
+__global__ void __launch_bounds__(NT)
+sum_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ part, uint32_t n_parts,
+                uint64_t part_stride, uint64_t* __restrict__ out) {
+  using A = Arith<MODE>;
+  const uint32_t tid = threadIdx.x;
+  const int mi = blockIdx.x % P->k;
+  const uint64_t q = P->mod[mi].q;
+  const typename A::Mod m = A::mod(P, mi);
+  const uint64_t* in = part + (size_t)blockIdx.x * N;
+  uint64_t sum[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) sum[e] = 0;
+  for (uint32_t s = 0; s < n_parts; ++s) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sum[e] = add_mod(sum[e], in[(size_t)s * part_stride + e * NT + tid], q);
+  }
+  typename A::T x[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) x[e] = A::in(sum[e], m);
+  ntt_inverse<MODE, LOGN>(x, smem_raw, P, mi, tid);
+  uint64_t* o = out + (size_t)blockIdx.x * N;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) o[e * NT + tid] = A::out(x[e], m);
+}
+
 // ------------------------------------------------------------------ host side
 
 #define PIRGPU_BY_MODE(mode, EXPR)                                \
@@ -273,6 +405,8 @@ static hipError_t configure_mode() {
   PIRGPU_SET(ks_digit_kernel<MODE>);
   PIRGPU_SET(ks_mac_intt_kernel<MODE>);
   PIRGPU_SET(reencode_lift_ntt_kernel<MODE>);
+  PIRGPU_SET(upper_fused_kernel<MODE>);
+  PIRGPU_SET(sum_intt_kernel<MODE>);
 #undef PIRGPU_SET
   return hipSuccess;
 }
@@ -330,13 +464,30 @@ static hipError_t op_reencode(hipStream_t st, int mode, const DevParams* P, uint
   return hipGetLastError();
 }
 
+static hipError_t op_upper_fused(hipStream_t st, int mode, const DevParams* P, uint32_t k, uint32_t enc_count,
+                                 const uint64_t* src, const uint64_t* sv, uint64_t* part, uint32_t n_rows,
+                                 uint32_t n_dim, uint32_t n_children_total, uint32_t sv_first, uint32_t C,
+                                 uint32_t chunk_len, uint32_t n_chunks) {
+  PIRGPU_BY_MODE(mode, hipLaunchKernelGGL(upper_fused_kernel<MODE>, dim3(n_rows * C * n_chunks, enc_count, k),
+                                          dim3(NT), kLdsBytes, st, P, src, sv, part, n_rows, n_dim,
+                                          n_children_total, sv_first, C, chunk_len, n_chunks));
+  return hipGetLastError();
+}
+
+static hipError_t op_sum_intt(hipStream_t st, int mode, const DevParams* P, const uint64_t* part, uint32_t n_parts,
+                              uint64_t part_stride, uint64_t n_polys, uint64_t* out) {
+  PIRGPU_BY_MODE(mode, hipLaunchKernelGGL(sum_intt_kernel<MODE>, dim3((uint32_t)n_polys), dim3(NT), kLdsBytes, st,
+                                          P, part, n_parts, part_stride, out));
+  return hipGetLastError();
+}
+
 }  // namespace PIRGPU_DEG_NS
 
 // host-only accessor (a namespace-scope const object would also be emitted for the device)
 const NttOps* PIRGPU_OPS_NAME() {
   using namespace PIRGPU_DEG_NS;
-  static const NttOps ops = {op_configure, op_ntt_batch,   op_ct_ntt_fwd_oop, op_db_encode,
-                             op_ks_digit,  op_ks_mac_intt, op_reencode};
+  static const NttOps ops = {op_configure, op_ntt_batch,   op_ct_ntt_fwd_oop, op_db_encode,   op_ks_digit,
+                             op_ks_mac_intt, op_reencode,  op_upper_fused,    op_sum_intt};
   return &ops;
 }
 

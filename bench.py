@@ -1,12 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- PIR server query path throughput on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the hot path (PIRServer::processQuery, reference
-server.cpp:173-195: oblivious expansion -> database scan -> recursive re-encode /
-multiply-accumulate) over one query, with the encoded database, the Galois keys
-and the query ciphertext already resident in HBM.  Workload = BASELINE.json
-configs[2]: N=4096, 2 RNS primes, DB = 2^20 x 288 B, d=2 (the reference's own
-benchmark parameters, benchmark.cpp:17-23).
+One "step" = one pass of the hot path (PIRServer::ProcessRequest's query loop, reference
+server.cpp:60-63 -> processQuery :173-195: oblivious expansion -> database scan ->
+recursive re-encode / multiply-accumulate) over one batch of `--batch` independent
+queries (default 8, different synthetic query ciphertexts), with the encoded database,
+the Galois keys and the query ciphertexts already resident in HBM.  The queries of a
+batch run concurrently on `--workers` working sets (HIP streams), so the latency-bound
+expansion of one query overlaps the bandwidth-bound scan of another; every query does
+the full work.  `value` = queries/s over the timed steps; the single-query latency
+(`--batch 1` behaviour, what benchmark.cpp:71-79 times per request) is measured as well
+and reported as `latency_ms_single_query`, and the scan kernel's roofline comes from
+those single-query runs (one scan launch per query, HIP events on the library's stream).
+Workload = BASELINE.json configs[2]: N=4096, 2 RNS primes, DB = 2^20 x 288 B, d=2 (the
+reference's own benchmark parameters, benchmark.cpp:17-23).
 
 Multi-GPU (launched by torch.distributed.run, one rank per GPU): the database is
 row-sharded across ranks, every rank expands the query, scans its rows and the
@@ -35,17 +42,17 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def synthetic_inputs(pp, seed=42):
-    """DB bytes, Galois keys and one query: uniform random of the right shape."""
+def synthetic_inputs(pp, seed=42, n_queries=1):
+    """DB bytes, Galois keys and n_queries queries: uniform random of the right shape."""
     enc = pp.encryption_parameters
     N, q = enc.poly_modulus_degree, enc.coeff_modulus
     k = len(q) - 1
     rng = np.random.default_rng(seed)
     raw = rng.integers(0, 256, size=(pp.num_items, pp.bytes_per_item), dtype=np.uint8)
     nq = pp.dim_sum // N + 1
-    query = np.empty((nq, 2, k, N), dtype=np.uint64)
+    query = np.empty((n_queries, nq, 2, k, N), dtype=np.uint64)
     for j in range(k):
-        query[:, :, j, :] = rng.integers(0, q[j], size=(nq, 2, N), dtype=np.uint64)
+        query[:, :, :, j, :] = rng.integers(0, q[j], size=(n_queries, nq, 2, N), dtype=np.uint64)
     keys = {}
     import pir_amd
     for g in pir_amd.generate_galois_elts(N):
@@ -95,8 +102,11 @@ def cpu_baseline(pp, raw, keys, query, gpu_reply, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="queries per step (per request)")
+    ap.add_argument("--workers", type=int, default=0, help="queries in flight on the GPU (0 = min(batch, 8))")
+    ap.add_argument("--latency-runs", type=int, default=30, help="single-query runs for latency + roofline")
     ap.add_argument("--log-items", type=int, default=20, help="database = 2^log_items x 288 B")
     ap.add_argument("--dims", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -121,9 +131,12 @@ def main():
     # ---- workload: BASELINE.json configs[2] (benchmark.cpp:17-23 parameters)
     enc = pir_amd.generate_encryption_params(4096, 24)
     pp = pir_amd.create_pir_parameters(1 << args.log_items, 288, args.dims, enc)
-    raw, keys, query = synthetic_inputs(pp)
+    batch = max(1, args.batch)
+    workers = args.workers if args.workers > 0 else min(batch, 8)
+    raw, keys, queries = synthetic_inputs(pp, n_queries=batch)
+    query = queries[0]
 
-    from pir_amd.distributed import all_reduce_reply, shard_range
+    from pir_amd.distributed import all_reduce_batch_replies, all_reduce_reply, shard_range
     shard = shard_range(pp.dimensions[0], rank, world) if world > 1 else None
     db = pir_amd.PIRDatabase.Create(pp, device=local_rank, shard=shard)
     t0 = time.perf_counter()
@@ -131,18 +144,14 @@ def main():
     t_populate = time.perf_counter() - t0
     srv = pir_amd.PIRServer(db, pp) if shard else pir_amd.PIRServer.Create(db, pp)
     srv.set_galois_keys(keys)
-    srv.stage_query(query)
 
     reply_cts = db.reply_ct_count()
     k, N = srv.k, srv.N
-    red = None
+    dev = "cuda:%d" % local_rank
+    red1 = redb = None
     if world > 1:
-        red = torch.empty((reply_cts, 2, k, N), dtype=torch.int64, device="cuda:%d" % local_rank)
-
-    def step():
-        srv.run_staged()
-        if world > 1:
-            all_reduce_reply(srv, red, dist)
+        red1 = torch.empty((reply_cts, 2, k, N), dtype=torch.int64, device=dev)
+        redb = torch.empty((batch, reply_cts, 2, k, N), dtype=torch.int64, device=dev)
 
     def barrier():
         if world > 1:
@@ -150,9 +159,36 @@ def main():
         srv.sync()
         torch.cuda.synchronize()
 
+    # ---- (1) single-query latency + scan-kernel roofline (one scan launch per query)
+    srv.stage_query(query)
+    for _ in range(3):
+        srv.run_staged()
+        if world > 1:
+            all_reduce_reply(srv, red1, dist)
+    srv.set_profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.latency_runs):
+        srv.run_staged()
+        if world > 1:
+            all_reduce_reply(srv, red1, dist)
+    barrier()
+    latency_ms = (time.perf_counter() - t0) / args.latency_runs * 1e3
+    timings = srv.last_timings()
+    srv.set_profiling(False)
+    single_reply = srv.fetch_reply() if world == 1 else None
+
+    # ---- (2) throughput: `batch` queries per step, `workers` in flight
+    srv.set_concurrency(workers)
+    srv.stage_batch(queries)
+
+    def step():
+        srv.run_batch()
+        if world > 1:
+            all_reduce_batch_replies(srv, redb, dist)
+
     for _ in range(args.warmup):
         step()
-    srv.set_profiling(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -160,15 +196,13 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda:%d" % local_rank)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    timings = srv.last_timings()
-    srv.set_profiling(False)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        qps = args.steps / elapsed
+        qps = args.steps * batch / elapsed
         scan_bytes = srv.scan_bytes()                   # algorithmic: num_pt(shard) * k * N * 8
         scan_ms = timings["scan_ms"]
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
@@ -179,20 +213,24 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": "N=4096, 2 RNS primes (36,36|37 bit), t=24 bit, DB=2^%d x 288B, d=%d, "
-                                   "dims=%s, num_pt=%d, 1 query/request (BASELINE.json configs[2])"
-                                   % (args.log_items, args.dims, pp.dimensions, pp.num_pt),
+                                   "dims=%s, num_pt=%d, %d queries/step, %d in flight (BASELINE.json configs[2])"
+                                   % (args.log_items, args.dims, pp.dimensions, pp.num_pt, batch, workers),
+                       "queries_per_step": batch, "workers": workers,
                        "parallelism": "rows sharded over %d GPU(s), RCCL all-reduce of reply" % world
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "scan_kernel", "kernel_ms": scan_ms, "algorithmic_bytes": scan_bytes,
                          "launches_averaged": timings["runs"]},
-            "phases_ms": {kk: round(v, 4) for kk, v in timings.items() if kk.endswith("_ms")},
+            "latency_ms_single_query": round(latency_ms, 4),
+            "single_query_qps": round(1e3 / latency_ms, 1),
+            "phases_ms_single_query": {kk: round(v, 4) for kk, v in timings.items() if kk.endswith("_ms")},
             "db_populate_s": round(t_populate, 2),
         }
         if world == 1 and not args.no_cpu_baseline:
-            gpu_reply = srv.fetch_reply()
-            out["cpu_baseline"] = cpu_baseline(pp, raw, keys, query, gpu_reply)
+            batch_replies = srv.fetch_batch()
+            out["batch_reply0_equals_single_query_reply"] = bool(np.array_equal(batch_replies[0], single_reply))
+            out["cpu_baseline"] = cpu_baseline(pp, raw, keys, query, single_reply)
             out["speedup_vs_cpu_baseline"] = qps / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:

@@ -117,6 +117,20 @@ int pirgpu_query_run(pirgpu_ctx* ctx);
 int pirgpu_query_fetch(pirgpu_ctx* ctx, uint64_t* reply, uint64_t reply_capacity, uint64_t* reply_count);
 int pirgpu_sync(pirgpu_ctx* ctx);
 
+/* Batch mode -- the `for (const auto& query : request.query())` loop of
+ * PIRServer::ProcessRequest (reference server.cpp:60-63) with several queries in flight:
+ * set_concurrency gives the context n_workers independent working sets (stream +
+ * intermediates, ~0.4 GB each at N=4096 / dim_sum=324); batch_stage uploads `count`
+ * queries of nq ciphertexts each; batch_run enqueues all of them round-robin over the
+ * workers (asynchronous); batch_fetch waits and downloads count x reply_ct_count
+ * ciphertexts, reply i answering query i. */
+int pirgpu_set_concurrency(pirgpu_ctx* ctx, uint32_t n_workers);
+int pirgpu_batch_stage(pirgpu_ctx* ctx, const uint64_t* queries, uint32_t nq, uint32_t count);
+int pirgpu_batch_run(pirgpu_ctx* ctx);
+int pirgpu_batch_fetch(pirgpu_ctx* ctx, uint64_t* replies, uint64_t reply_capacity, uint64_t* reply_count);
+/* Waits for the batch and copies its replies into caller-owned DEVICE memory (multi-GPU reduce). */
+int pirgpu_batch_reply_copy_to_device(pirgpu_ctx* ctx, uint64_t* device_dst, uint64_t capacity);
+
 /* PIRServer::oblivious_expansion (reference server.cpp:105-146): one ciphertext
  * -> num_items ciphertexts, coefficient form. */
 int pirgpu_expand(pirgpu_ctx* ctx, const uint64_t* ct, uint32_t num_items, uint64_t* out);

@@ -54,6 +54,11 @@ SIGNATURES = {
     "pirgpu_query_run": (C.c_int, [C.c_void_p]),
     "pirgpu_query_fetch": (C.c_int, [C.c_void_p, u64p, C.c_uint64, u64p]),
     "pirgpu_sync": (C.c_int, [C.c_void_p]),
+    "pirgpu_set_concurrency": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "pirgpu_batch_stage": (C.c_int, [C.c_void_p, u64p, C.c_uint32, C.c_uint32]),
+    "pirgpu_batch_run": (C.c_int, [C.c_void_p]),
+    "pirgpu_batch_fetch": (C.c_int, [C.c_void_p, u64p, C.c_uint64, u64p]),
+    "pirgpu_batch_reply_copy_to_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "pirgpu_expand": (C.c_int, [C.c_void_p, u64p, C.c_uint32, u64p]),
     "pirgpu_expand_multi": (C.c_int, [C.c_void_p, u64p, C.c_uint32, C.c_uint64, u64p]),
     "pirgpu_substitute_power_x": (C.c_int, [C.c_void_p, u64p, C.c_uint32]),

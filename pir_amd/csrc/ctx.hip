@@ -43,6 +43,21 @@ enum Phase { PH_EXPAND = 0, PH_SVNTT, PH_SCAN, PH_UPPER, PH_FINAL, PH_COUNT };
 
 }  // namespace
 
+// Per-query working set: one HIP stream plus every intermediate of one query in flight.
+// A context owns one worker by default; pirgpu_set_concurrency adds more so that several
+// queries overlap on the GPU (the latency-bound expansion of one hides under the
+// bandwidth-bound scan of another).  Database, keys and tables are shared, read-only.
+struct Worker {
+  hipStream_t stream = nullptr;
+  uint64_t *res_a = nullptr, *res_b = nullptr, *prod = nullptr, *dig = nullptr, *sv_ntt = nullptr;
+  uint64_t* d_query = nullptr;
+  uint32_t staged_nq = 0;
+  std::vector<uint64_t*> lvl;  // per level results; lvl[0] = reply
+  uint64_t* pt_buf = nullptr;
+  uint64_t* scan_part = nullptr;
+  bool reply_valid = false;
+};
+
 struct pirgpu_ctx {
   pirgpu_params prm{};
   uint32_t N = 0, logN = 0, k = 0, d = 0;
@@ -71,22 +86,22 @@ struct pirgpu_ctx {
   uint64_t n_loaded = 0;
   std::map<uint32_t, uint64_t*> keys;
 
-  // workspace (allocated on first use)
+  // workspace geometry (computed on first use) and the workers holding the buffers
   bool ws_ready = false;
-  uint64_t *res_a = nullptr, *res_b = nullptr, *prod = nullptr, *dig = nullptr, *sv_ntt = nullptr;
-  uint64_t* d_query = nullptr;
-  uint32_t staged_nq = 0;
-  std::vector<uint64_t*> lvl;      // per level results
+  std::vector<Worker> workers;     // workers[0] uses `stream`
   std::vector<uint64_t> lvl_rows;  // nodes per level inside the shard
-  uint64_t* pt_buf = nullptr;
+  std::vector<uint64_t> lvl_cts;   // ciphertexts per level result buffer
+  uint64_t m_max = 1;              // expansion tree width (ciphertexts)
   uint64_t pt_words = 0;
+  // batch mode (pirgpu_batch_*): queries and replies of one batch, device resident
+  uint64_t *d_bquery = nullptr, *d_breply = nullptr;
+  uint32_t batch_cap = 0, batch_count = 0, n_active = 1;
+  bool batch_valid = false;
   uint32_t upper_blocks = 512;   // target workgroup count of upper_fused_kernel (PIRGPU_UPPER_BLOCKS)
-  uint64_t* scan_part = nullptr;
   uint32_t scan_nsplit = 1, scan_cps = 0, scan_rows = 0, scan_cols = 0;
   uint32_t scan_rpt = 4, scan_block = 256;  // rows per thread / workgroup size of the scan kernel
   bool scan_limb = false;                   // 28-bit limb accumulators (all data moduli < 2^50)
   uint64_t scan_npt = 0;
-  bool reply_valid = false;
 
   bool prof = false;
   static constexpr int kMaxProfRuns = 256;
@@ -226,29 +241,26 @@ void build_tables(pirgpu_ctx* c) {
 
 uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
+void alloc_worker(pirgpu_ctx* c, Worker& w);
+
 void ensure_workspace(pirgpu_ctx* c) {
   if (c->ws_ready) return;
   const uint32_t N = c->N, k = c->k, d = c->d;
-  const size_t ctw = c->ctw;
+
   const uint64_t m_max = std::min<uint64_t>(N, hm::next_power_two(std::max<uint32_t>(c->dim_sum, 1)));
-  c->res_a = c->dalloc<uint64_t>(m_max * ctw);
-  c->res_b = c->dalloc<uint64_t>(m_max * ctw);
-  c->prod = c->dalloc<uint64_t>(std::max<uint64_t>(m_max / 2, 1) * 2 * (k + 1) * N);
-  c->dig = c->dalloc<uint64_t>(std::max<uint64_t>(m_max / 2, 1) * (k + 1) * k * N);
-  c->sv_ntt = c->dalloc<uint64_t>((size_t)std::max<uint32_t>(c->dim_sum, 1) * ctw);
-  c->d_query = c->dalloc<uint64_t>((size_t)(c->dim_sum / N + 1) * ctw);
+  c->m_max = m_max;
   // per-level node counts inside this shard and result buffers
   const uint64_t shard_pts = c->pt_end - c->pt_begin;
   if (const char* v = getenv("PIRGPU_UPPER_BLOCKS")) c->upper_blocks = std::max(1, atoi(v));
-  c->lvl.assign(d, nullptr);
   c->lvl_rows.assign(d, 0);
+  c->lvl_cts.assign(d, 0);
   uint64_t pt_words = 0;
   for (uint32_t l = 0; l < d; ++l) {
     uint64_t rows = l == 0 ? 1 : ceil_div(shard_pts, c->stride[l]);
     uint64_t C = 1;
     for (uint32_t x = l; x + 1 < d; ++x) C *= c->E;
     c->lvl_rows[l] = rows;
-    c->lvl[l] = c->dalloc<uint64_t>(std::max<uint64_t>(rows, 1) * C * ctw);
+    c->lvl_cts[l] = std::max<uint64_t>(rows, 1) * C;
     if (l + 1 < d) {
       // chunk partial sums of upper_fused_kernel: n_chunks x (rows * C * E * 2 * k) polynomials
       const uint64_t per_chunk = std::max<uint64_t>(rows, 1) * (C / c->E) * c->E * k;
@@ -257,7 +269,6 @@ void ensure_workspace(pirgpu_ctx* c) {
     }
   }
   c->pt_words = pt_words;
-  if (pt_words) c->pt_buf = c->dalloc<uint64_t>(pt_words);
   // base-level scan geometry
   if (d == 1) {
     c->scan_rows = 1;
@@ -291,10 +302,30 @@ void ensure_workspace(pirgpu_ctx* c) {
     want = std::max<uint32_t>(1, std::min<uint32_t>(want, std::max<uint32_t>(c->scan_cols, 1)));
     c->scan_cps = (uint32_t)ceil_div(std::max<uint32_t>(c->scan_cols, 1), want);
     c->scan_nsplit = (uint32_t)ceil_div(std::max<uint32_t>(c->scan_cols, 1), c->scan_cps);
-    if (c->scan_nsplit > 1)
-      c->scan_part = c->dalloc<uint64_t>((size_t)c->scan_nsplit * std::max<uint32_t>(c->scan_rows, 1) * ctw);
   }
   c->ws_ready = true;
+  if (c->workers.empty()) c->workers.emplace_back();
+  c->workers[0].stream = c->stream;
+  for (Worker& w : c->workers) alloc_worker(c, w);
+}
+
+// Allocates one worker's buffers (and its stream unless it is the context's main stream).
+void alloc_worker(pirgpu_ctx* c, Worker& w) {
+  if (w.res_a) return;
+  const uint32_t N = c->N, k = c->k;
+  const size_t ctw = c->ctw;
+  if (!w.stream) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+  w.res_a = c->dalloc<uint64_t>(c->m_max * ctw);
+  w.res_b = c->dalloc<uint64_t>(c->m_max * ctw);
+  w.prod = c->dalloc<uint64_t>(std::max<uint64_t>(c->m_max / 2, 1) * 2 * (k + 1) * N);
+  w.dig = c->dalloc<uint64_t>(std::max<uint64_t>(c->m_max / 2, 1) * (k + 1) * k * N);
+  w.sv_ntt = c->dalloc<uint64_t>((size_t)std::max<uint32_t>(c->dim_sum, 1) * ctw);
+  w.d_query = c->dalloc<uint64_t>((size_t)(c->dim_sum / N + 1) * ctw);
+  w.lvl.assign(c->d, nullptr);
+  for (uint32_t l = 0; l < c->d; ++l) w.lvl[l] = c->dalloc<uint64_t>(c->lvl_cts[l] * ctw);
+  if (c->pt_words) w.pt_buf = c->dalloc<uint64_t>(c->pt_words);
+  if (c->scan_nsplit > 1)
+    w.scan_part = c->dalloc<uint64_t>((size_t)c->scan_nsplit * std::max<uint32_t>(c->scan_rows, 1) * ctw);
 }
 
 uint32_t galois_inverse(uint32_t g, uint32_t N) {
@@ -316,8 +347,8 @@ const uint64_t* find_key(pirgpu_ctx* c, uint32_t g) {
   return it->second;
 }
 
-void record(pirgpu_ctx* c, int idx) {
-  if (c->prof_cur >= 0) HIP_TRY(hipEventRecord(c->ev[(size_t)c->prof_cur * (PH_COUNT + 1) + idx], c->stream));
+void record(pirgpu_ctx* c, Worker& w, int idx) {
+  if (c->prof_cur >= 0) HIP_TRY(hipEventRecord(c->ev[(size_t)c->prof_cur * (PH_COUNT + 1) + idx], w.stream));
 }
 
 void begin_profiled_run(pirgpu_ctx* c) {
@@ -333,17 +364,17 @@ void begin_profiled_run(pirgpu_ctx* c) {
 // oblivious_expansion(ct, n) on the device (reference server.cpp:105-146).
 // Input ciphertext must already be in res_a[0]; returns the buffer holding the
 // next_power_two(n) results.
-uint64_t* expand_on_device(pirgpu_ctx* c, uint32_t n) {
+uint64_t* expand_on_device(pirgpu_ctx* c, Worker& w, uint32_t n) {
   const uint32_t N = c->N, k = c->k;
   if (n > N) throw Fail{PIRGPU_INVALID_ARGUMENT, "Cannot expand more items from a CT than poly modulus degree"};
   const uint32_t logm = hm::ceil_log2(n);
-  uint64_t *cur = c->res_a, *nxt = c->res_b;
+  uint64_t *cur = w.res_a, *nxt = w.res_b;
   for (uint32_t j = 0; j < logm; ++j) {
     const uint32_t g = (N >> j) + 1;
     const uint64_t* key = find_key(c, g);
-    HIP_TRY(c->ops->ks_digit(c->stream, c->mode, c->dp, k, cur, g, 1u << j, c->dig));
-    HIP_TRY(c->ops->ks_mac_intt(c->stream, c->mode, c->dp, k, c->dig, key, 1u << j, c->prod));
-    HIP_TRY(launch_ks_combine(c->stream, c->dp, N, k, cur, c->prod, galois_inverse(g, N), 1u << j, 1u << j, true,
+    HIP_TRY(c->ops->ks_digit(w.stream, c->mode, c->dp, k, cur, g, 1u << j, w.dig));
+    HIP_TRY(c->ops->ks_mac_intt(w.stream, c->mode, c->dp, k, w.dig, key, 1u << j, w.prod));
+    HIP_TRY(launch_ks_combine(w.stream, c->dp, N, k, cur, w.prod, galois_inverse(g, N), 1u << j, 1u << j, true,
                               nxt));
     std::swap(cur, nxt);
   }
@@ -353,7 +384,7 @@ uint64_t* expand_on_device(pirgpu_ctx* c, uint32_t n) {
 // expansion of all staged query ciphertexts into sv_ntt (NTT form) -- reference
 // server.cpp:148-171 followed by the lazy transform_to_ntt_inplace of
 // database.cpp:190,222 applied to every selector.
-void expand_query_to_sv(pirgpu_ctx* c, const uint64_t* d_query, uint32_t nq, uint64_t* coeff_out_host) {
+void expand_query_to_sv(pirgpu_ctx* c, Worker& w, const uint64_t* d_query, uint32_t nq, uint64_t* coeff_out_host) {
   const uint32_t N = c->N, k = c->k;
   const size_t ctw = c->ctw;
   uint64_t remaining = c->dim_sum;
@@ -361,13 +392,13 @@ void expand_query_to_sv(pirgpu_ctx* c, const uint64_t* d_query, uint32_t nq, uin
   for (uint32_t q = 0; q < nq; ++q) {
     uint32_t n = (uint32_t)std::min<uint64_t>(remaining, N);
     if (n > 0) {
-      HIP_TRY(hipMemcpyAsync(c->res_a, d_query + (size_t)q * ctw, ctw * 8, hipMemcpyDeviceToDevice, c->stream));
-      uint64_t* res = expand_on_device(c, n);
+      HIP_TRY(hipMemcpyAsync(w.res_a, d_query + (size_t)q * ctw, ctw * 8, hipMemcpyDeviceToDevice, w.stream));
+      uint64_t* res = expand_on_device(c, w, n);
       if (coeff_out_host) {
         HIP_TRY(hipMemcpyAsync(coeff_out_host + produced * ctw, res, (size_t)n * ctw * 8, hipMemcpyDeviceToHost,
-                               c->stream));
+                               w.stream));
       } else {
-        HIP_TRY(c->ops->ct_ntt_fwd_oop(c->stream, c->mode, c->dp, k, res, c->sv_ntt + produced * ctw, n));
+        HIP_TRY(c->ops->ct_ntt_fwd_oop(w.stream, c->mode, c->dp, k, res, w.sv_ntt + produced * ctw, n));
       }
     }
     produced += n;
@@ -378,27 +409,27 @@ void expand_query_to_sv(pirgpu_ctx* c, const uint64_t* d_query, uint32_t nq, uin
 
 // PIRDatabase::multiply on the device (reference database.cpp:170-258), with the
 // selection vector already in NTT form in sv_ntt.  Leaves the reply in lvl[0].
-void multiply_on_device(pirgpu_ctx* c) {
+void multiply_on_device(pirgpu_ctx* c, Worker& w) {
   const uint32_t N = c->N, k = c->k, d = c->d;
   const size_t ctw = c->ctw;
   if (c->n_loaded != c->pt_end - c->pt_begin)
     throw Fail{PIRGPU_FAILED_PRECONDITION, "database not fully loaded"};
   const uint64_t shard_pts = c->pt_end - c->pt_begin;
   if (shard_pts == 0) {
-    HIP_TRY(hipMemsetAsync(c->lvl[0], 0, c->reply_cts * ctw * 8, c->stream));
+    HIP_TRY(hipMemsetAsync(w.lvl[0], 0, c->reply_cts * ctw * 8, w.stream));
     return;
   }
   // base case: one fused multiply_plain + add_inplace pass over the database
-  const uint64_t* sv_base = c->sv_ntt + (size_t)c->sv_off[d - 1] * ctw + (d == 1 ? (size_t)c->sb * ctw : 0);
-  uint64_t* base_out = c->lvl[d - 1];
-  uint64_t* scan_out = c->scan_nsplit > 1 ? c->scan_part : base_out;
-  HIP_TRY(launch_scan(c->stream, c->dp, N, k, c->d_db, sv_base, scan_out, c->scan_rows, c->scan_cols, c->scan_npt,
+  const uint64_t* sv_base = w.sv_ntt + (size_t)c->sv_off[d - 1] * ctw + (d == 1 ? (size_t)c->sb * ctw : 0);
+  uint64_t* base_out = w.lvl[d - 1];
+  uint64_t* scan_out = c->scan_nsplit > 1 ? w.scan_part : base_out;
+  HIP_TRY(launch_scan(w.stream, c->dp, N, k, c->d_db, sv_base, scan_out, c->scan_rows, c->scan_cols, c->scan_npt,
                       c->scan_nsplit, c->scan_cps, c->scan_rpt, c->scan_block, c->scan_limb));
   if (c->scan_nsplit > 1)
-    HIP_TRY(launch_reduce_splits(c->stream, c->dp, c->scan_part, c->scan_nsplit, (uint64_t)c->scan_rows * ctw,
+    HIP_TRY(launch_reduce_splits(w.stream, c->dp, w.scan_part, c->scan_nsplit, (uint64_t)c->scan_rows * ctw,
                                  base_out));
-  record(c, PH_UPPER);  // end of scan phase
-  HIP_TRY(c->ops->ntt_batch(c->stream, c->mode, c->dp, base_out, (uint64_t)c->scan_rows * 2 * k, k, 0, true));
+  record(c, w, PH_UPPER);  // end of scan phase
+  HIP_TRY(c->ops->ntt_batch(w.stream, c->mode, c->dp, base_out, (uint64_t)c->scan_rows * 2 * k, k, 0, true));
   // upper levels: fused re-encode + lift + NTT + multiply-accumulate over chunks of children,
   // then one kernel folds the chunk sums and applies the inverse NTT
   uint64_t C = 1;  // ciphertexts per child
@@ -414,34 +445,35 @@ void multiply_on_device(pirgpu_ctx* c) {
     const uint64_t out_polys = rows * C * c->E * 2 * k;
     if (out_polys * n_chunks * N > c->pt_words)
       throw Fail{PIRGPU_INTERNAL, "upper-level scratch undersized"};
-    HIP_TRY(c->ops->upper_fused(c->stream, c->mode, c->dp, k, c->E, c->lvl[l + 1], c->sv_ntt, c->pt_buf,
+    HIP_TRY(c->ops->upper_fused(w.stream, c->mode, c->dp, k, c->E, w.lvl[l + 1], w.sv_ntt, w.pt_buf,
                                 (uint32_t)rows, c->dims[l], (uint32_t)nch, sv_first, (uint32_t)C, chunk_len,
                                 n_chunks));
-    if (l == 0) record(c, PH_FINAL);
+    if (l == 0) record(c, w, PH_FINAL);
     // fold the chunk sums (wide, elementwise) and return to coefficient form (database.cpp:250-254)
-    HIP_TRY(launch_reduce_splits(c->stream, c->dp, c->pt_buf, n_chunks, out_polys * N, c->lvl[l]));
-    HIP_TRY(c->ops->ntt_batch(c->stream, c->mode, c->dp, c->lvl[l], out_polys, k, 0, true));
+    HIP_TRY(launch_reduce_splits(w.stream, c->dp, w.pt_buf, n_chunks, out_polys * N, w.lvl[l]));
+    HIP_TRY(c->ops->ntt_batch(w.stream, c->mode, c->dp, w.lvl[l], out_polys, k, 0, true));
     C *= c->E;
   }
-  if (d == 1) record(c, PH_FINAL);
+  if (d == 1) record(c, w, PH_FINAL);
 }
 
-void run_staged(pirgpu_ctx* c) {
+void run_staged(pirgpu_ctx* c, Worker& w, bool profile) {
   ensure_workspace(c);
-  if (c->staged_nq != c->dim_sum / c->N + 1)
+  if (w.staged_nq != c->dim_sum / c->N + 1)
     throw Fail{PIRGPU_INVALID_ARGUMENT,
                "Number of ciphertexts doesn't match number of items for oblivious expansion."};
-  begin_profiled_run(c);
-  record(c, PH_EXPAND);
+  c->prof_cur = -1;
+  if (profile) begin_profiled_run(c);
+  record(c, w, PH_EXPAND);
   // expansion and selection-vector NTT are interleaved per query ciphertext; the
   // PH_SVNTT mark is taken after the last expansion level of the last ciphertext.
-  expand_query_to_sv(c, c->d_query, c->staged_nq, nullptr);
-  record(c, PH_SVNTT);
-  record(c, PH_SCAN);
-  multiply_on_device(c);
-  record(c, PH_COUNT);
+  expand_query_to_sv(c, w, w.d_query, w.staged_nq, nullptr);
+  record(c, w, PH_SVNTT);
+  record(c, w, PH_SCAN);
+  multiply_on_device(c, w);
+  record(c, w, PH_COUNT);
   c->prof_cur = -1;
-  c->reply_valid = true;
+  w.reply_valid = true;
 }
 
 }  // namespace
@@ -542,10 +574,14 @@ void pirgpu_destroy(pirgpu_ctx* c) {
   if (c->stream) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    for (size_t i = 1; i < c->workers.size(); ++i)
+      if (c->workers[i].stream) (void)hipStreamSynchronize(c->workers[i].stream);
   }
   for (auto& kv : c->keys) (void)hipFree(kv.second);
   for (void* p : c->allocs) (void)hipFree(p);
   for (auto& e : c->ev) (void)hipEventDestroy(e);
+  for (size_t i = 1; i < c->workers.size(); ++i)
+    if (c->workers[i].stream) (void)hipStreamDestroy(c->workers[i].stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -695,6 +731,8 @@ int pirgpu_set_galois_key(pirgpu_ctx* c, uint32_t g, const uint64_t* key) {
 int pirgpu_clear_galois_keys(pirgpu_ctx* c) {
   return guarded(c, [&]() -> int {
     HIP_TRY(hipStreamSynchronize(c->stream));
+    for (Worker& w : c->workers)
+      if (w.stream) HIP_TRY(hipStreamSynchronize(w.stream));
     for (auto& kv : c->keys) HIP_TRY(hipFree(kv.second));
     c->keys.clear();
     return PIRGPU_OK;
@@ -704,19 +742,21 @@ int pirgpu_clear_galois_keys(pirgpu_ctx* c) {
 int pirgpu_query_stage(pirgpu_ctx* c, const uint64_t* query, uint32_t nq) {
   return guarded(c, [&]() -> int {
     ensure_workspace(c);
+    Worker& w = c->workers[0];
     if (!query || nq != c->dim_sum / c->N + 1)  // reference server.cpp:154-158
       return fail(c, PIRGPU_INVALID_ARGUMENT,
                   "Number of ciphertexts doesn't match number of items for oblivious expansion.");
-    HIP_TRY(hipMemcpyAsync(c->d_query, query, (size_t)nq * c->ctw * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(w.d_query, query, (size_t)nq * c->ctw * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->staged_nq = nq;
+    w.staged_nq = nq;
     return PIRGPU_OK;
   });
 }
 
 int pirgpu_query_run(pirgpu_ctx* c) {
   return guarded(c, [&]() -> int {
-    run_staged(c);
+    ensure_workspace(c);
+    run_staged(c, c->workers[0], true);
     return PIRGPU_OK;
   });
 }
@@ -724,15 +764,19 @@ int pirgpu_query_run(pirgpu_ctx* c) {
 int pirgpu_sync(pirgpu_ctx* c) {
   return guarded(c, [&]() -> int {
     HIP_TRY(hipStreamSynchronize(c->stream));
+    for (Worker& w : c->workers)
+      if (w.stream) HIP_TRY(hipStreamSynchronize(w.stream));
     return PIRGPU_OK;
   });
 }
 
 int pirgpu_query_fetch(pirgpu_ctx* c, uint64_t* reply, uint64_t cap, uint64_t* count) {
   return guarded(c, [&]() -> int {
-    if (!c->reply_valid) return fail(c, PIRGPU_FAILED_PRECONDITION, "no query has been run");
+    if (c->workers.empty()) return fail(c, PIRGPU_FAILED_PRECONDITION, "no query has been run");
+    Worker& w = c->workers[0];
+    if (!w.reply_valid) return fail(c, PIRGPU_FAILED_PRECONDITION, "no query has been run");
     if (!reply || cap < c->reply_cts) return fail(c, PIRGPU_INVALID_ARGUMENT, "reply buffer too small");
-    HIP_TRY(hipMemcpyAsync(reply, c->lvl[0], c->reply_cts * c->ctw * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(reply, w.lvl[0], c->reply_cts * c->ctw * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (count) *count = c->reply_cts;
     return PIRGPU_OK;
@@ -748,13 +792,15 @@ int pirgpu_process_query(pirgpu_ctx* c, const uint64_t* query, uint32_t nq, uint
   return pirgpu_query_fetch(c, reply, cap, count);
 }
 
-uint64_t* pirgpu_reply_device_ptr(pirgpu_ctx* c) { return (c && c->ws_ready) ? c->lvl[0] : nullptr; }
+uint64_t* pirgpu_reply_device_ptr(pirgpu_ctx* c) { return (c && c->ws_ready) ? c->workers[0].lvl[0] : nullptr; }
 
 int pirgpu_reply_copy_to_device(pirgpu_ctx* c, uint64_t* dst, uint64_t cap) {
   return guarded(c, [&]() -> int {
-    if (!c->reply_valid) return fail(c, PIRGPU_FAILED_PRECONDITION, "no query has been run");
+    if (c->workers.empty()) return fail(c, PIRGPU_FAILED_PRECONDITION, "no query has been run");
+    Worker& w = c->workers[0];
+    if (!w.reply_valid) return fail(c, PIRGPU_FAILED_PRECONDITION, "no query has been run");
     if (!dst || cap < c->reply_cts) return fail(c, PIRGPU_INVALID_ARGUMENT, "reply buffer too small");
-    HIP_TRY(hipMemcpyAsync(dst, c->lvl[0], c->reply_cts * c->ctw * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dst, w.lvl[0], c->reply_cts * c->ctw * 8, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PIRGPU_OK;
   });
@@ -763,6 +809,7 @@ int pirgpu_reply_copy_to_device(pirgpu_ctx* c, uint64_t* dst, uint64_t cap) {
 int pirgpu_expand(pirgpu_ctx* c, const uint64_t* ct, uint32_t num_items, uint64_t* out) {
   return guarded(c, [&]() -> int {
     ensure_workspace(c);
+    Worker& w = c->workers[0];
     if (!ct || (!out && num_items)) return fail(c, PIRGPU_INVALID_ARGUMENT, "null buffer");
     if (num_items > c->N)
       return fail(c, PIRGPU_INVALID_ARGUMENT, "Cannot expand more items from a CT than poly modulus degree");
@@ -770,8 +817,8 @@ int pirgpu_expand(pirgpu_ctx* c, const uint64_t* ct, uint32_t num_items, uint64_
     const uint64_t m_max = std::min<uint64_t>(c->N, hm::next_power_two(std::max<uint32_t>(c->dim_sum, 1)));
     if (hm::next_power_two(num_items) > m_max)
       return fail(c, PIRGPU_INVALID_ARGUMENT, "num_items exceeds this context's expansion workspace");
-    HIP_TRY(hipMemcpyAsync(c->res_a, ct, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
-    uint64_t* res = expand_on_device(c, num_items);
+    HIP_TRY(hipMemcpyAsync(w.res_a, ct, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
+    uint64_t* res = expand_on_device(c, w, num_items);
     if (num_items)
       HIP_TRY(hipMemcpyAsync(out, res, (size_t)num_items * c->ctw * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -782,6 +829,7 @@ int pirgpu_expand(pirgpu_ctx* c, const uint64_t* ct, uint32_t num_items, uint64_
 int pirgpu_expand_multi(pirgpu_ctx* c, const uint64_t* cts, uint32_t num_cts, uint64_t total_items, uint64_t* out) {
   return guarded(c, [&]() -> int {
     ensure_workspace(c);
+    Worker& w = c->workers[0];
     if (!cts || !out) return fail(c, PIRGPU_INVALID_ARGUMENT, "null buffer");
     if (num_cts != total_items / c->N + 1)  // reference server.cpp:154-158
       return fail(c, PIRGPU_INVALID_ARGUMENT,
@@ -792,8 +840,8 @@ int pirgpu_expand_multi(pirgpu_ctx* c, const uint64_t* cts, uint32_t num_cts, ui
       uint32_t n = (uint32_t)std::min<uint64_t>(remaining, c->N);
       if (hm::next_power_two(n) > m_max)
         return fail(c, PIRGPU_INVALID_ARGUMENT, "total_items exceeds this context's expansion workspace");
-      HIP_TRY(hipMemcpyAsync(c->res_a, cts + (size_t)q * c->ctw, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
-      uint64_t* res = expand_on_device(c, n);
+      HIP_TRY(hipMemcpyAsync(w.res_a, cts + (size_t)q * c->ctw, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
+      uint64_t* res = expand_on_device(c, w, n);
       HIP_TRY(hipMemcpyAsync(out + produced * c->ctw, res, (size_t)n * c->ctw * 8, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(hipStreamSynchronize(c->stream));
       produced += n;
@@ -806,16 +854,17 @@ int pirgpu_expand_multi(pirgpu_ctx* c, const uint64_t* cts, uint32_t num_cts, ui
 int pirgpu_substitute_power_x(pirgpu_ctx* c, uint64_t* ct, uint32_t power) {
   return guarded(c, [&]() -> int {
     ensure_workspace(c);
+    Worker& w = c->workers[0];
     if (!ct) return fail(c, PIRGPU_INVALID_ARGUMENT, "null buffer");
     if (!(power & 1) || power >= 2 * c->N)  // SEAL: "Galois element is not valid" -> InternalError
       return fail(c, PIRGPU_INTERNAL, "Galois element is not valid");
     const uint64_t* key = find_key(c, power);
-    HIP_TRY(hipMemcpyAsync(c->res_a, ct, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c->ops->ks_digit(c->stream, c->mode, c->dp, c->k, c->res_a, power, 1, c->dig));
-    HIP_TRY(c->ops->ks_mac_intt(c->stream, c->mode, c->dp, c->k, c->dig, key, 1, c->prod));
-    HIP_TRY(launch_ks_combine(c->stream, c->dp, c->N, c->k, c->res_a, c->prod, galois_inverse(power, c->N), 1, 0,
-                              false, c->res_b));
-    HIP_TRY(hipMemcpyAsync(ct, c->res_b, c->ctw * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(w.res_a, ct, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c->ops->ks_digit(c->stream, c->mode, c->dp, c->k, w.res_a, power, 1, w.dig));
+    HIP_TRY(c->ops->ks_mac_intt(c->stream, c->mode, c->dp, c->k, w.dig, key, 1, w.prod));
+    HIP_TRY(launch_ks_combine(c->stream, c->dp, c->N, c->k, w.res_a, w.prod, galois_inverse(power, c->N), 1, 0,
+                              false, w.res_b));
+    HIP_TRY(hipMemcpyAsync(ct, w.res_b, c->ctw * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PIRGPU_OK;
   });
@@ -824,12 +873,13 @@ int pirgpu_substitute_power_x(pirgpu_ctx* c, uint64_t* ct, uint32_t power) {
 int pirgpu_multiply_inverse_power_of_x(pirgpu_ctx* c, const uint64_t* ct, uint32_t kpow, uint64_t* out) {
   return guarded(c, [&]() -> int {
     ensure_workspace(c);
+    Worker& w = c->workers[0];
     if (!ct || !out) return fail(c, PIRGPU_INVALID_ARGUMENT, "null buffer");
     const uint32_t twoN = 2 * c->N;
     const uint32_t index = (twoN - (kpow % twoN)) % twoN;  // reference server.cpp:87-88
-    HIP_TRY(hipMemcpyAsync(c->res_a, ct, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(launch_monomial_shift(c->stream, c->dp, c->N, c->k, c->res_a, index, 1, c->res_b));
-    HIP_TRY(hipMemcpyAsync(out, c->res_b, c->ctw * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(w.res_a, ct, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_monomial_shift(c->stream, c->dp, c->N, c->k, w.res_a, index, 1, w.res_b));
+    HIP_TRY(hipMemcpyAsync(out, w.res_b, c->ctw * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PIRGPU_OK;
   });
@@ -839,6 +889,7 @@ int pirgpu_multiply(pirgpu_ctx* c, const uint64_t* sv, uint64_t sv_count, uint64
                     uint64_t* count) {
   return guarded(c, [&]() -> int {
     ensure_workspace(c);
+    Worker& w = c->workers[0];
     if (sv_count != c->dim_sum)  // reference database.cpp:297-300
       return fail(c, PIRGPU_INVALID_ARGUMENT, "Selection vector size does not match dimensions");
     if (!sv || !reply || cap < c->reply_cts) return fail(c, PIRGPU_INVALID_ARGUMENT, "reply buffer too small");
@@ -846,15 +897,91 @@ int pirgpu_multiply(pirgpu_ctx* c, const uint64_t* sv, uint64_t sv_count, uint64
     const uint64_t m_max = std::min<uint64_t>(c->N, hm::next_power_two(std::max<uint32_t>(c->dim_sum, 1)));
     for (uint64_t s = 0; s < sv_count; s += m_max) {
       const uint64_t n = std::min<uint64_t>(m_max, sv_count - s);
-      HIP_TRY(hipMemcpyAsync(c->res_a, sv + s * c->ctw, n * c->ctw * 8, hipMemcpyHostToDevice, c->stream));
-      HIP_TRY(c->ops->ct_ntt_fwd_oop(c->stream, c->mode, c->dp, c->k, c->res_a, c->sv_ntt + s * c->ctw, n));
+      HIP_TRY(hipMemcpyAsync(w.res_a, sv + s * c->ctw, n * c->ctw * 8, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(c->ops->ct_ntt_fwd_oop(c->stream, c->mode, c->dp, c->k, w.res_a, w.sv_ntt + s * c->ctw, n));
       HIP_TRY(hipStreamSynchronize(c->stream));
     }
     c->prof_cur = -1;
-    multiply_on_device(c);
-    HIP_TRY(hipMemcpyAsync(reply, c->lvl[0], c->reply_cts * c->ctw * 8, hipMemcpyDeviceToHost, c->stream));
+    multiply_on_device(c, w);
+    HIP_TRY(hipMemcpyAsync(reply, w.lvl[0], c->reply_cts * c->ctw * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (count) *count = c->reply_cts;
+    return PIRGPU_OK;
+  });
+}
+
+// ---- batch mode: `count` independent queries, spread round-robin over the workers ----
+
+int pirgpu_set_concurrency(pirgpu_ctx* c, uint32_t n_workers) {
+  return guarded(c, [&]() -> int {
+    if (n_workers < 1 || n_workers > 32) return fail(c, PIRGPU_INVALID_ARGUMENT, "workers must be in [1, 32]");
+    ensure_workspace(c);
+    while (c->workers.size() < n_workers) {
+      c->workers.emplace_back();
+      alloc_worker(c, c->workers.back());
+    }
+    c->n_active = n_workers;
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_batch_stage(pirgpu_ctx* c, const uint64_t* queries, uint32_t nq, uint32_t count) {
+  return guarded(c, [&]() -> int {
+    ensure_workspace(c);
+    if (!queries || nq != c->dim_sum / c->N + 1)  // reference server.cpp:154-158
+      return fail(c, PIRGPU_INVALID_ARGUMENT,
+                  "Number of ciphertexts doesn't match number of items for oblivious expansion.");
+    if (count == 0 || count > 4096) return fail(c, PIRGPU_INVALID_ARGUMENT, "batch size must be in [1, 4096]");
+    if (count > c->batch_cap) {
+      c->d_bquery = c->dalloc<uint64_t>((size_t)count * nq * c->ctw);
+      c->d_breply = c->dalloc<uint64_t>((size_t)count * c->reply_cts * c->ctw);
+      c->batch_cap = count;
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_bquery, queries, (size_t)count * nq * c->ctw * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->batch_count = count;
+    c->batch_valid = false;
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_batch_run(pirgpu_ctx* c) {
+  return guarded(c, [&]() -> int {
+    if (!c->batch_count) return fail(c, PIRGPU_FAILED_PRECONDITION, "no batch has been staged");
+    const uint32_t nq = c->dim_sum / c->N + 1;
+    const size_t qwords = (size_t)nq * c->ctw, rwords = (size_t)c->reply_cts * c->ctw;
+    const uint32_t W = std::max<uint32_t>(1, std::min<uint32_t>(c->n_active, (uint32_t)c->workers.size()));
+    for (uint32_t i = 0; i < c->batch_count; ++i) {
+      Worker& w = c->workers[i % W];
+      HIP_TRY(hipMemcpyAsync(w.d_query, c->d_bquery + i * qwords, qwords * 8, hipMemcpyDeviceToDevice, w.stream));
+      w.staged_nq = nq;
+      run_staged(c, w, false);
+      HIP_TRY(hipMemcpyAsync(c->d_breply + i * rwords, w.lvl[0], rwords * 8, hipMemcpyDeviceToDevice, w.stream));
+    }
+    c->batch_valid = true;
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_batch_reply_copy_to_device(pirgpu_ctx* c, uint64_t* dst, uint64_t cap) {
+  return guarded(c, [&]() -> int {
+    if (!c->batch_valid) return fail(c, PIRGPU_FAILED_PRECONDITION, "no batch has been run");
+    const uint64_t total = (uint64_t)c->batch_count * c->reply_cts;
+    if (!dst || cap < total) return fail(c, PIRGPU_INVALID_ARGUMENT, "reply buffer too small");
+    for (Worker& w : c->workers) HIP_TRY(hipStreamSynchronize(w.stream));
+    HIP_TRY(hipMemcpy(dst, c->d_breply, total * c->ctw * 8, hipMemcpyDeviceToDevice));
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_batch_fetch(pirgpu_ctx* c, uint64_t* replies, uint64_t cap, uint64_t* count) {
+  return guarded(c, [&]() -> int {
+    if (!c->batch_valid) return fail(c, PIRGPU_FAILED_PRECONDITION, "no batch has been run");
+    const uint64_t total = (uint64_t)c->batch_count * c->reply_cts;
+    if (!replies || cap < total) return fail(c, PIRGPU_INVALID_ARGUMENT, "reply buffer too small");
+    for (Worker& w : c->workers) HIP_TRY(hipStreamSynchronize(w.stream));
+    HIP_TRY(hipMemcpy(replies, c->d_breply, total * c->ctw * 8, hipMemcpyDeviceToHost));
+    if (count) *count = total;
     return PIRGPU_OK;
   });
 }

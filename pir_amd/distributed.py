@@ -26,3 +26,14 @@ def all_reduce_reply(server, reply_tensor, dist) -> None:
     dist.all_reduce(reply_tensor, op=dist.ReduceOp.SUM)      # RCCL over xGMI
     torch.cuda.current_stream().synchronize()
     server.reduce_fixup_device(reply_tensor.data_ptr())      # x mod q_j on the GPU
+
+
+def all_reduce_batch_replies(server, reply_tensor, dist) -> None:
+    """Batch-mode counterpart of all_reduce_reply: reply_tensor int64 CUDA [count, reply_cts, 2, k, N]."""
+    import torch
+    if not reply_tensor.is_cuda:
+        raise RuntimeError("all_reduce_batch_replies needs a CUDA tensor (RCCL); there is no CPU path")
+    server.batch_reply_copy_to_device(reply_tensor.data_ptr())   # waits for every worker stream
+    dist.all_reduce(reply_tensor, op=dist.ReduceOp.SUM)
+    torch.cuda.current_stream().synchronize()
+    server.reduce_fixup_device_n(reply_tensor.data_ptr(), reply_tensor.shape[0] * reply_tensor.shape[1])

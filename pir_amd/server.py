@@ -235,6 +235,41 @@ class PIRServer:
         self._check(self.lib.pirgpu_query_fetch(self.db.handle, _ptr(out), n, C.byref(cnt)))
         return out[: cnt.value]
 
+    # -- batch mode: several queries in flight (server.cpp:60-63 loop, overlapped on the GPU) ----
+    def set_concurrency(self, n_workers: int) -> None:
+        self._check(self.lib.pirgpu_set_concurrency(self.db.handle, n_workers))
+
+    def stage_batch(self, queries) -> None:
+        """queries: [count, nq, 2, k, N]"""
+        q = _u64(queries)
+        self._batch_count = q.shape[0]
+        self._check(self.lib.pirgpu_batch_stage(self.db.handle, _ptr(q), q.shape[1], q.shape[0]))
+
+    def run_batch(self) -> None:
+        self._check(self.lib.pirgpu_batch_run(self.db.handle))
+
+    def fetch_batch(self) -> np.ndarray:
+        n = self.db.reply_ct_count()
+        out = np.empty((self._batch_count, n, 2, self.k, self.N), dtype=np.uint64)
+        cnt = C.c_uint64(0)
+        self._check(self.lib.pirgpu_batch_fetch(self.db.handle, _ptr(out), self._batch_count * n, C.byref(cnt)))
+        return out
+
+    def batch_reply_copy_to_device(self, device_ptr: int) -> None:
+        self._check(self.lib.pirgpu_batch_reply_copy_to_device(self.db.handle, C.c_void_p(device_ptr),
+                                                               self._batch_count * self.db.reply_ct_count()))
+
+    def reduce_fixup_device_n(self, device_ptr: int, n_cts: int) -> None:
+        self._check(self.lib.pirgpu_reduce_fixup_device(self.db.handle, C.c_void_p(device_ptr), n_cts))
+
+    def process_batch(self, queries, n_workers: Optional[int] = None) -> np.ndarray:
+        """All queries of one request: [count, nq, 2, k, N] -> [count, reply_cts, 2, k, N]."""
+        if n_workers is not None:
+            self.set_concurrency(n_workers)
+        self.stage_batch(queries)
+        self.run_batch()
+        return self.fetch_batch()
+
     def set_profiling(self, on: bool) -> None:
         self._check(self.lib.pirgpu_set_profiling(self.db.handle, 1 if on else 0))
 

@@ -290,6 +290,28 @@ def test_sharded_partial_replies_sum_to_full_reply(dbsize, elem, d):
     assert np.array_equal(acc, exp)
 
 
+@pytest.mark.parametrize("n_workers,count", [(1, 3), (3, 5), (4, 4)])
+def test_batch_mode_matches_single_queries(n_workers, count):
+    """Several queries in flight on separate workers give exactly the single-query replies, in order."""
+    s = PirSetup(300, 288, 2, N=N, plain_bits=24)
+    db, srv = make_server(s)
+    srv.set_galois_keys(s.galois_keys)
+    indexes = [(37 * i + 5) % 300 for i in range(count)]
+    queries = np.stack([s.client.create_query_for(s.params, i) for i in indexes])
+    got = srv.process_batch(queries, n_workers=n_workers)
+    assert got.shape[0] == count
+    for i, idx in enumerate(indexes):
+        rc, exp = s.orc.process_query(s.db_ntt, s.params.dimensions, queries[i], s.galois_keys)
+        assert np.array_equal(got[i], exp)
+        assert s.client.process_response(s.params, idx, got[i]) == s.item(idx)
+    # the single-query path still works afterwards on worker 0
+    assert np.array_equal(srv.process_query(queries[0]), got[0])
+    with pytest.raises(pir_amd.PirGpuError) as e:
+        srv.stage_batch(np.concatenate([queries, queries], axis=1))     # wrong ciphertext count per query
+    assert e.value.code == pir_amd.StatusCode.INVALID_ARGUMENT
+    db.close()
+
+
 # ---------------------------------------------------------------- wire level (ProcessRequest)
 
 def test_process_request_wire_roundtrip():

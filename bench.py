@@ -206,6 +206,13 @@ def main():
         scan_bytes = srv.scan_bytes()                   # algorithmic: num_pt(shard) * k * N * 8
         scan_ms = timings["scan_ms"]
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        traffic = None
+        try:   # HBM bytes per scan launch from the committed PMC passes (profiles/), same workload only
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_scan_traffic.json")))
+            if args.log_items == 20 and args.dims == 2 and world == 1:
+                traffic = pm["traffic_bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "PIR queries/sec (ms/query in ms_per_step), N=4096 DB=2^%d x 288B d=%d" % (args.log_items,
                                                                                                 args.dims),
@@ -219,7 +226,8 @@ def main():
                        "parallelism": "rows sharded over %d GPU(s), RCCL all-reduce of reply" % world
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, profiles/r01_pmc_scan_traffic.json",
                          "kernel": "scan_kernel", "kernel_ms": scan_ms, "algorithmic_bytes": scan_bytes,
                          "launches_averaged": timings["runs"]},
             "latency_ms_single_query": round(latency_ms, 4),

@@ -122,9 +122,14 @@ def main():
     import pir_amd
 
     dist = None
-    if world > 1:
+    # PIRGPU_FORCE_DIST=1 exercises the RCCL reduce path with a single rank (1-GPU boxes)
+    use_dist = world > 1 or os.environ.get("PIRGPU_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
@@ -149,12 +154,12 @@ def main():
     k, N = srv.k, srv.N
     dev = "cuda:%d" % local_rank
     red1 = redb = None
-    if world > 1:
+    if use_dist:
         red1 = torch.empty((reply_cts, 2, k, N), dtype=torch.int64, device=dev)
         redb = torch.empty((batch, reply_cts, 2, k, N), dtype=torch.int64, device=dev)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         srv.sync()
         torch.cuda.synchronize()
@@ -163,14 +168,14 @@ def main():
     srv.stage_query(query)
     for _ in range(3):
         srv.run_staged()
-        if world > 1:
+        if use_dist:
             all_reduce_reply(srv, red1, dist)
     srv.set_profiling(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.latency_runs):
         srv.run_staged()
-        if world > 1:
+        if use_dist:
             all_reduce_reply(srv, red1, dist)
     barrier()
     latency_ms = (time.perf_counter() - t0) / args.latency_runs * 1e3
@@ -184,7 +189,7 @@ def main():
 
     def step():
         srv.run_batch()
-        if world > 1:
+        if use_dist:
             all_reduce_batch_replies(srv, redb, dist)
 
     for _ in range(args.warmup):
@@ -195,7 +200,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -241,7 +246,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(pp, raw, keys, query, single_reply)
             out["speedup_vs_cpu_baseline"] = qps / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
+        if world == 1 and rank == 0:   # forced single-rank run: the reduced replies must equal the plain ones
+            ok = bool(np.array_equal(redb.cpu().numpy().view(np.uint64), srv.fetch_batch()))
+            print("forced-dist check: all-reduced batch replies equal plain replies: %s" % ok, file=sys.stderr)
         dist.barrier()
         dist.destroy_process_group()
 

@@ -233,7 +233,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, profiles/r01_pmc_scan_traffic.json",
-                         "kernel": "scan_kernel", "kernel_ms": scan_ms, "algorithmic_bytes": scan_bytes,
+                         "kernel": "scan_mq_kernel<4 rows/wave, 1 query> (one launch = one query's pass over the database)",
+                         "kernel_ms": scan_ms, "algorithmic_bytes": scan_bytes,
                          "launches_averaged": timings["runs"]},
             "latency_ms_single_query": round(latency_ms, 4),
             "single_query_qps": round(1e3 / latency_ms, 1),

@@ -56,6 +56,7 @@ struct Worker {
   uint64_t* pt_buf = nullptr;
   uint64_t* scan_part = nullptr;
   bool reply_valid = false;
+  hipEvent_t ev_expanded = nullptr, ev_scanned = nullptr;  // batch mode: cross-stream hand-offs
 };
 
 struct pirgpu_ctx {
@@ -101,6 +102,9 @@ struct pirgpu_ctx {
   uint32_t scan_nsplit = 1, scan_cps = 0, scan_rows = 0, scan_cols = 0;
   uint32_t scan_rpt = 4, scan_block = 256;  // rows per thread / workgroup size of the scan kernel
   bool scan_limb = false;                   // 28-bit limb accumulators (all data moduli < 2^50)
+  uint32_t mq_nq = 4, mq_rows = 1;          // batch mode: queries per database pass / rows per wave
+  bool mq_single = true;                    // use the LDS-shared scan kernel for single queries too
+  uint32_t mq_single_rows = 4;              // rows per wave of that kernel for a single query (2 or 4)
   uint64_t scan_npt = 0;
 
   bool prof = false;
@@ -291,6 +295,14 @@ void ensure_workspace(pirgpu_ctx* c) {
     c->scan_limb = true;
     for (uint32_t j = 0; j < k; ++j) c->scan_limb = c->scan_limb && (c->hp.mod[j].q >> 50) == 0;
     if (!env_u32("PIRGPU_SCAN_LIMB", 1)) c->scan_limb = false;
+    //   PIRGPU_SCAN_NQ     queries sharing one database pass in batch mode (1, 2, 4)
+    //   PIRGPU_SCAN_MQ_ROWS rows per wave of the multi-query kernel (1, 2, 4)
+    //   PIRGPU_SCAN_MQ_SINGLE=0 routes single queries through scan_kernel instead of the LDS-shared
+    //                      scan_mq_kernel (PIRGPU_SCAN_MQ_SINGLE_ROWS = 2 or 4 rows per wave)
+    c->mq_nq = env_u32("PIRGPU_SCAN_NQ", 4);
+    c->mq_rows = env_u32("PIRGPU_SCAN_MQ_ROWS", c->mq_nq == 4 ? 1 : 2);
+    c->mq_single = env_u32("PIRGPU_SCAN_MQ_SINGLE", 1) != 0;
+    c->mq_single_rows = env_u32("PIRGPU_SCAN_MQ_SINGLE_ROWS", 4) == 2 ? 2 : 4;
     c->scan_rpt = env_u32("PIRGPU_SCAN_ROWS", 4);
     c->scan_block = env_u32("PIRGPU_SCAN_BLOCK", 256);
     const uint32_t xblocks = (k * N / 2 + c->scan_block - 1) / c->scan_block;
@@ -326,6 +338,8 @@ void alloc_worker(pirgpu_ctx* c, Worker& w) {
   if (c->pt_words) w.pt_buf = c->dalloc<uint64_t>(c->pt_words);
   if (c->scan_nsplit > 1)
     w.scan_part = c->dalloc<uint64_t>((size_t)c->scan_nsplit * std::max<uint32_t>(c->scan_rows, 1) * ctw);
+  HIP_TRY(hipEventCreateWithFlags(&w.ev_expanded, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&w.ev_scanned, hipEventDisableTiming));
 }
 
 uint32_t galois_inverse(uint32_t g, uint32_t N) {
@@ -409,25 +423,47 @@ void expand_query_to_sv(pirgpu_ctx* c, Worker& w, const uint64_t* d_query, uint3
 
 // PIRDatabase::multiply on the device (reference database.cpp:170-258), with the
 // selection vector already in NTT form in sv_ntt.  Leaves the reply in lvl[0].
-void multiply_on_device(pirgpu_ctx* c, Worker& w) {
+// selectors of the scanned (last) dimension for this worker's query
+const uint64_t* scan_selectors(pirgpu_ctx* c, Worker& w) {
+  return w.sv_ntt + (size_t)c->sv_off[c->d - 1] * c->ctw + (c->d == 1 ? (size_t)c->sb * c->ctw : 0);
+}
+
+bool mq_usable(pirgpu_ctx* c) { return c->scan_nsplit == 1 && c->scan_rows >= 1 && c->scan_cols >= 1; }
+
+// Base case of PIRDatabase::multiply (reference database.cpp:185-194,238-247): one fused
+// multiply_plain + add_inplace pass over the database.  Leaves NTT-form row sums in lvl[d-1].
+void scan_on_device(pirgpu_ctx* c, Worker& w) {
   const uint32_t N = c->N, k = c->k, d = c->d;
   const size_t ctw = c->ctw;
   if (c->n_loaded != c->pt_end - c->pt_begin)
     throw Fail{PIRGPU_FAILED_PRECONDITION, "database not fully loaded"};
-  const uint64_t shard_pts = c->pt_end - c->pt_begin;
-  if (shard_pts == 0) {
-    HIP_TRY(hipMemsetAsync(w.lvl[0], 0, c->reply_cts * ctw * 8, w.stream));
+  if (c->pt_end == c->pt_begin) return;
+  const uint64_t* sv_base = scan_selectors(c, w);
+  uint64_t* base_out = w.lvl[d - 1];
+  if (c->mq_single && mq_usable(c)) {
+    HIP_TRY(launch_scan_mq(w.stream, c->dp, N, k, c->d_db, &sv_base, &base_out, 1, c->scan_rows, c->scan_cols,
+                           c->mq_single_rows, c->scan_limb));
     return;
   }
-  // base case: one fused multiply_plain + add_inplace pass over the database
-  const uint64_t* sv_base = w.sv_ntt + (size_t)c->sv_off[d - 1] * ctw + (d == 1 ? (size_t)c->sb * ctw : 0);
-  uint64_t* base_out = w.lvl[d - 1];
   uint64_t* scan_out = c->scan_nsplit > 1 ? w.scan_part : base_out;
   HIP_TRY(launch_scan(w.stream, c->dp, N, k, c->d_db, sv_base, scan_out, c->scan_rows, c->scan_cols, c->scan_npt,
                       c->scan_nsplit, c->scan_cps, c->scan_rpt, c->scan_block, c->scan_limb));
   if (c->scan_nsplit > 1)
     HIP_TRY(launch_reduce_splits(w.stream, c->dp, w.scan_part, c->scan_nsplit, (uint64_t)c->scan_rows * ctw,
                                  base_out));
+}
+
+// Everything after the scan: inverse NTT of the row sums and the upper recursion levels
+// (reference database.cpp:196-254).  Leaves the reply in lvl[0].
+void post_scan_on_device(pirgpu_ctx* c, Worker& w) {
+  const uint32_t N = c->N, k = c->k, d = c->d;
+  const size_t ctw = c->ctw;
+  const uint64_t shard_pts = c->pt_end - c->pt_begin;
+  if (shard_pts == 0) {
+    HIP_TRY(hipMemsetAsync(w.lvl[0], 0, c->reply_cts * ctw * 8, w.stream));
+    return;
+  }
+  uint64_t* base_out = w.lvl[d - 1];
   record(c, w, PH_UPPER);  // end of scan phase
   HIP_TRY(c->ops->ntt_batch(w.stream, c->mode, c->dp, base_out, (uint64_t)c->scan_rows * 2 * k, k, 0, true));
   // upper levels: fused re-encode + lift + NTT + multiply-accumulate over chunks of children,
@@ -455,6 +491,11 @@ void multiply_on_device(pirgpu_ctx* c, Worker& w) {
     C *= c->E;
   }
   if (d == 1) record(c, w, PH_FINAL);
+}
+
+void multiply_on_device(pirgpu_ctx* c, Worker& w) {
+  scan_on_device(c, w);
+  post_scan_on_device(c, w);
 }
 
 void run_staged(pirgpu_ctx* c, Worker& w, bool profile) {
@@ -558,7 +599,12 @@ int pirgpu_create(const pirgpu_params* p, pirgpu_ctx** out) {
     c->reply_cts = 1;
     for (uint32_t l = 1; l < c->d; ++l) c->reply_cts *= c->E;
     const uint64_t shard_pts = c->pt_end - c->pt_begin;
-    c->d_db = c->dalloc<uint64_t>(shard_pts * k * N);
+    // rows are padded with zero plaintexts to full length so the scan kernels are branch-free
+    const uint64_t cols_last = c->dims[c->d - 1];
+    const uint64_t padded = c->d == 1 ? shard_pts : ceil_div(shard_pts, cols_last) * cols_last;
+    c->d_db = c->dalloc<uint64_t>(padded * k * N);
+    if (padded > shard_pts)
+      HIP_TRY(hipMemset(c->d_db + shard_pts * k * N, 0, (padded - shard_pts) * k * N * 8));
     c->loaded.assign(shard_pts, 0);
   } catch (const Fail& e) {
     return bail(e.code, e.msg);
@@ -580,6 +626,10 @@ void pirgpu_destroy(pirgpu_ctx* c) {
   for (auto& kv : c->keys) (void)hipFree(kv.second);
   for (void* p : c->allocs) (void)hipFree(p);
   for (auto& e : c->ev) (void)hipEventDestroy(e);
+  for (Worker& w : c->workers) {
+    if (w.ev_expanded) (void)hipEventDestroy(w.ev_expanded);
+    if (w.ev_scanned) (void)hipEventDestroy(w.ev_scanned);
+  }
   for (size_t i = 1; i < c->workers.size(); ++i)
     if (c->workers[i].stream) (void)hipStreamDestroy(c->workers[i].stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -951,12 +1001,58 @@ int pirgpu_batch_run(pirgpu_ctx* c) {
     const uint32_t nq = c->dim_sum / c->N + 1;
     const size_t qwords = (size_t)nq * c->ctw, rwords = (size_t)c->reply_cts * c->ctw;
     const uint32_t W = std::max<uint32_t>(1, std::min<uint32_t>(c->n_active, (uint32_t)c->workers.size()));
-    for (uint32_t i = 0; i < c->batch_count; ++i) {
-      Worker& w = c->workers[i % W];
-      HIP_TRY(hipMemcpyAsync(w.d_query, c->d_bquery + i * qwords, qwords * 8, hipMemcpyDeviceToDevice, w.stream));
-      w.staged_nq = nq;
-      run_staged(c, w, false);
-      HIP_TRY(hipMemcpyAsync(c->d_breply + i * rwords, w.lvl[0], rwords * 8, hipMemcpyDeviceToDevice, w.stream));
+    const uint32_t G = mq_usable(c) && c->pt_end > c->pt_begin ? std::min<uint32_t>(c->mq_nq, kMaxScanQueries) : 1;
+    c->prof_cur = -1;
+    // rounds of W queries (one per worker); inside a round, groups of G workers share one
+    // pass over the database (scan_mq_kernel), hand-offs between streams through events
+    for (uint32_t base = 0; base < c->batch_count; base += W) {
+      const uint32_t n = std::min<uint32_t>(W, c->batch_count - base);
+      for (uint32_t j = 0; j < n; ++j) {
+        Worker& w = c->workers[j];
+        HIP_TRY(hipMemcpyAsync(w.d_query, c->d_bquery + (base + j) * qwords, qwords * 8, hipMemcpyDeviceToDevice,
+                               w.stream));
+        w.staged_nq = nq;
+        expand_query_to_sv(c, w, w.d_query, nq, nullptr);
+        if (G > 1) HIP_TRY(hipEventRecord(w.ev_expanded, w.stream));
+      }
+      for (uint32_t j0 = 0; j0 < n; j0 += G) {
+        const uint32_t g = std::min<uint32_t>(G, n - j0);
+        // group sizes the kernel is instantiated for: 4, 2, 1
+        uint32_t done = 0;
+        while (done < g) {
+          const uint32_t take = g - done >= 4 && G >= 4 ? 4 : (g - done >= 2 && G >= 2 ? 2 : 1);
+          Worker& lead = c->workers[j0 + done];
+          if (take == 1) {
+            scan_on_device(c, lead);
+            if (G > 1) HIP_TRY(hipEventRecord(lead.ev_scanned, lead.stream));
+          } else {
+            const uint64_t* svp[kMaxScanQueries];
+            uint64_t* outp[kMaxScanQueries];
+            for (uint32_t q = 0; q < take; ++q) {
+              Worker& m = c->workers[j0 + done + q];
+              if (q) HIP_TRY(hipStreamWaitEvent(lead.stream, m.ev_expanded, 0));
+              svp[q] = scan_selectors(c, m);
+              outp[q] = m.lvl[c->d - 1];
+            }
+            if (c->n_loaded != c->pt_end - c->pt_begin)
+              throw Fail{PIRGPU_FAILED_PRECONDITION, "database not fully loaded"};
+            const uint32_t rpw = take == 4 ? (c->mq_rows > 2 ? 1 : c->mq_rows) : (c->mq_rows > 2 ? 2 : c->mq_rows);
+            HIP_TRY(launch_scan_mq(lead.stream, c->dp, c->N, c->k, c->d_db, svp, outp, take, c->scan_rows,
+                                   c->scan_cols, rpw, c->scan_limb));
+            HIP_TRY(hipEventRecord(lead.ev_scanned, lead.stream));
+            for (uint32_t q = 1; q < take; ++q)
+              HIP_TRY(hipStreamWaitEvent(c->workers[j0 + done + q].stream, lead.ev_scanned, 0));
+          }
+          done += take;
+        }
+      }
+      for (uint32_t j = 0; j < n; ++j) {
+        Worker& w = c->workers[j];
+        post_scan_on_device(c, w);
+        HIP_TRY(hipMemcpyAsync(c->d_breply + (base + j) * rwords, w.lvl[0], rwords * 8, hipMemcpyDeviceToDevice,
+                               w.stream));
+        w.reply_valid = true;
+      }
     }
     c->batch_valid = true;
     return PIRGPU_OK;

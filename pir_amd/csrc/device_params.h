@@ -7,6 +7,7 @@ namespace pirgpu {
 constexpr int kMaxPrimes = 8;            // data primes
 constexpr int kMaxMod = kMaxPrimes + 1;  // + special prime
 constexpr int kMaxEnc = 64;              // max 2 * ExpansionRatio
+constexpr int kMaxScanQueries = 4;       // queries sharing one database pass in batch mode
 constexpr int kNttElemsPerThread = 16;   // NTT workgroup = N / 16 threads, 16 residues per thread
 
 // One RNS modulus with the Barrett ratio floor(2^128 / q) (SEAL Modulus::const_ratio).

@@ -45,6 +45,9 @@ hipError_t launch_scan(hipStream_t st, const DevParams* P, uint32_t N, uint32_t 
                        const uint64_t* sv, uint64_t* out, uint32_t rows, uint32_t cols, uint64_t num_pt,
                        uint32_t nsplit, uint32_t cols_per_split, uint32_t rows_per_thread, uint32_t block,
                        bool limb);
+hipError_t launch_scan_mq(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* db,
+                          const uint64_t* const* sv, uint64_t* const* out, uint32_t nq, uint32_t rows,
+                          uint32_t cols, uint32_t rows_per_wave, bool limb);
 hipError_t launch_reduce_splits(hipStream_t st, const DevParams* P, const uint64_t* part, uint32_t nsplit,
                                 uint64_t words, uint64_t* out);
 hipError_t launch_upper_mac(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, uint32_t enc_count,

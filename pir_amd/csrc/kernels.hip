@@ -352,6 +352,162 @@ scan_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ db, co
   }
 }
 
+// ------------------------------------------------------------------ multi-query scan
+//
+// Batch mode: NQ queries share one pass over the database, so each query pays 1/NQ of the
+// HBM traffic.  A workgroup = 4 waves that own the SAME 128 residues (64 lanes x 2) of
+// 4*ROWS_W consecutive rows; the NQ x 2 selector rows of those residues are staged once per
+// workgroup in LDS (tiles of TCOLS columns, double buffered, loads for tile t+1 in flight
+// while tile t is consumed) instead of being re-read from L2 by every wave.  Database rows
+// are zero padded to full length in HBM (ctx.hip), so the loop is branch-free.
+struct MqArgs {
+  const uint64_t* sv[kMaxScanQueries];  // per query: first selector of the scanned dimension (NTT form)
+  uint64_t* out[kMaxScanQueries];       // per query: [rows][2][k][N]
+};
+
+template <int ROWS_W, int NQ, int TCOLS, typename ACC>
+__global__ void __launch_bounds__(256)
+scan_mq_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ db, MqArgs a, uint32_t rows,
+               uint32_t cols) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char mq_smem[];
+  u64x2(*tile)[TCOLS * NQ * 2][64] = reinterpret_cast<u64x2(*)[TCOLS * NQ * 2][64]>(mq_smem);
+  constexpr int PIECES = TCOLS * NQ * 2 * 64 / 256;
+  const uint32_t N = P->N, k = P->k;
+  const uint32_t kN = k * N;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t chunk_base = blockIdx.x * 128;
+  const uint32_t c0 = chunk_base + lane * 2;
+  const uint32_t j = c0 >> P->logN;
+  const ModConst m = P->mod[j];
+  const uint32_t row0 = blockIdx.y * (4 * ROWS_W) + wave * ROWS_W;
+  const uint32_t lazy = std::is_same<ACC, AccLimb>::value ? kLimbLazy : P->lazy_limit;
+
+  const uint64_t* rp[ROWS_W];
+#pragma unroll
+  for (int r = 0; r < ROWS_W; ++r) {
+    const uint32_t row = row0 + r < rows ? row0 + r : rows - 1;
+    rp[r] = db + (size_t)row * cols * kN + c0;
+  }
+  ACC acc[NQ][ROWS_W][2][2];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int r = 0; r < ROWS_W; ++r)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        acc[q][r][p][0].clear();
+        acc[q][r][p][1].clear();
+      }
+
+  const uint32_t ntiles = (cols + TCOLS - 1) / TCOLS;
+  const uint32_t last_col = cols - 1;
+  u64x2 st[PIECES];
+  static_assert(TCOLS == 4, "the database ring below assumes 4-column tiles");
+  u64x2 dbuf[4][ROWS_W];  // ring of 4 columns, prefetch distance 2 (static indices: t is unrolled)
+
+  auto stage_load = [&](uint32_t t0) {
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const uint32_t piece = tid + 256u * i;
+      const uint32_t ridx = piece >> 6, l = piece & 63;
+      const uint32_t t = ridx / (NQ * 2), q = (ridx >> 1) % NQ, p = ridx & 1;
+      const uint32_t col = t0 + t < last_col ? t0 + t : last_col;
+      st[i] = *reinterpret_cast<const u64x2*>(a.sv[q] + (size_t)col * 2 * kN + (size_t)p * kN + chunk_base + 2 * l);
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const uint32_t piece = tid + 256u * i;
+      tile[buf][piece >> 6][piece & 63] = st[i];
+    }
+  };
+  uint32_t since = 0;
+  // one tile step with compile-time buffer indices (runtime-indexed register arrays would
+  // be demoted to scratch): consumes buffers BUF, prefetches the next tile into BUF^1
+  auto step = [&](auto bufc, uint32_t tl) {
+    constexpr int BUF = decltype(bufc)::value;
+    const uint32_t t0 = tl * TCOLS;
+    // prefetch the next selector tile (clamped, hence unconditional: exact s_waitcnt counters)
+    stage_load(t0 + TCOLS);
+#pragma unroll
+    for (int t = 0; t < TCOLS; ++t) {
+      {  // database column t+2 -> ring slot (t+2)&3, two columns ahead of its use
+        const uint32_t col = t0 + t + 2 < last_col ? t0 + t + 2 : last_col;
+#pragma unroll
+        for (int r = 0; r < ROWS_W; ++r)
+          dbuf[(t + 2) & 3][r] =
+              __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(rp[r] + (size_t)col * kN));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (t0 + t < cols) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          ScanBuf<ROWS_W, 2> sb;
+          const u64x2 s0 = tile[BUF][(t * NQ + q) * 2 + 0][lane];
+          const u64x2 s1 = tile[BUF][(t * NQ + q) * 2 + 1][lane];
+          sb.s[0][0] = s0.x;
+          sb.s[0][1] = s0.y;
+          sb.s[1][0] = s1.x;
+          sb.s[1][1] = s1.y;
+#pragma unroll
+          for (int r = 0; r < ROWS_W; ++r) {
+            sb.d[r][0] = dbuf[t & 3][r].x;
+            sb.d[r][1] = dbuf[t & 3][r].y;
+          }
+          scan_mac<ROWS_W, 2>(acc[q], sb);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    since += TCOLS;
+    if (since + TCOLS > lazy) {  // fold before the lazy sums could overflow
+      since = 0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int r = 0; r < ROWS_W; ++r)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            acc[q][r][p][0].set(acc[q][r][p][0].fold(m));
+            acc[q][r][p][1].set(acc[q][r][p][1].fold(m));
+          }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    stage_store(BUF ^ 1);
+    __syncthreads();
+  };
+
+  stage_load(0);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const uint32_t col = (uint32_t)t < last_col ? (uint32_t)t : last_col;
+#pragma unroll
+    for (int r = 0; r < ROWS_W; ++r)
+      dbuf[t][r] = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(rp[r] + (size_t)col * kN));
+  }
+  stage_store(0);
+  __syncthreads();
+  for (uint32_t tl = 0; tl < ntiles; tl += 2) {
+    step(std::integral_constant<int, 0>{}, tl);
+    if (tl + 1 < ntiles) step(std::integral_constant<int, 1>{}, tl + 1);
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int r = 0; r < ROWS_W; ++r) {
+      const uint32_t row = row0 + r;
+      if (row < rows) {
+        uint64_t* o = a.out[q] + (size_t)row * 2 * kN + c0;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          o[(size_t)p * kN + 0] = acc[q][r][p][0].fold(m);
+          o[(size_t)p * kN + 1] = acc[q][r][p][1].fold(m);
+        }
+      }
+    }
+}
+
 // out[x] = sum_s part[s][x] mod q_j over ciphertext words (split reduce and
 // multi-GPU fix-up share this kernel: nsplit == 1 is a pure x mod q_j).
 __global__ void reduce_splits_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ part,
@@ -497,6 +653,45 @@ hipError_t launch_scan(hipStream_t st, const DevParams* P, uint32_t N, uint32_t 
     default: return hipErrorInvalidValue;
   }
 #undef PIRGPU_SCAN_CASE
+}
+
+template <int ROWS_W, int NQ, int TCOLS, typename ACC>
+static hipError_t launch_scan_mq_variant(hipStream_t st, const DevParams* P, uint32_t kN, const uint64_t* db,
+                                         const MqArgs& a, uint32_t rows, uint32_t cols) {
+  const size_t lds = (size_t)2 * TCOLS * NQ * 2 * 1024;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute((const void*)scan_mq_kernel<ROWS_W, NQ, TCOLS, ACC>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    configured = true;
+  }
+  dim3 grid(kN / 128, (rows + 4 * ROWS_W - 1) / (4 * ROWS_W));
+  hipLaunchKernelGGL((scan_mq_kernel<ROWS_W, NQ, TCOLS, ACC>), grid, dim3(256), lds, st, P, db, a, rows, cols);
+  return hipGetLastError();
+}
+
+// Multi-query scan: nq in {1,2,4} queries per pass (batch mode).  sv[q] / out[q] as in MqArgs.
+hipError_t launch_scan_mq(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* db,
+                          const uint64_t* const* sv, uint64_t* const* out, uint32_t nq, uint32_t rows,
+                          uint32_t cols, uint32_t rows_per_wave, bool limb) {
+  MqArgs a{};
+  for (uint32_t q = 0; q < nq; ++q) {
+    a.sv[q] = sv[q];
+    a.out[q] = out[q];
+  }
+  const uint32_t kN = k * N;
+#define PIRGPU_MQ(RW, NQ_, T)                                                                   \
+  return limb ? launch_scan_mq_variant<RW, NQ_, T, AccLimb>(st, P, kN, db, a, rows, cols)        \
+              : launch_scan_mq_variant<RW, NQ_, T, AccWide>(st, P, kN, db, a, rows, cols)
+  if (nq == 1 && rows_per_wave == 4) { PIRGPU_MQ(4, 1, 4); }
+  if (nq == 1 && rows_per_wave == 2) { PIRGPU_MQ(2, 1, 4); }
+  if (nq == 2 && rows_per_wave == 2) { PIRGPU_MQ(2, 2, 4); }
+  if (nq == 2 && rows_per_wave == 1) { PIRGPU_MQ(1, 2, 4); }
+  if (nq == 4 && rows_per_wave == 1) { PIRGPU_MQ(1, 4, 4); }
+  if (nq == 4 && rows_per_wave == 2) { PIRGPU_MQ(2, 4, 4); }
+#undef PIRGPU_MQ
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch_reduce_splits(hipStream_t st, const DevParams* P, const uint64_t* part, uint32_t nsplit,

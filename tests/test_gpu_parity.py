@@ -362,3 +362,44 @@ def test_process_request_wire_errors():
         srv.ProcessRequest(W.save_request([q_bad], gk, data_pid))
     assert e.value.code == pir_amd.StatusCode.INVALID_ARGUMENT
     db.close()
+
+
+# ---------------------------------------------------------------- BASELINE.json parameter sets
+
+def _baseline_moduli(cfg):
+    """Moduli choices for the BASELINE.json configs."""
+    if cfg == 1:   # N=2048, 1 data prime + special, total <= 54 bits: CoeffModulus::Create(2048, {27, 27})
+        return 2048, oracle.coeff_modulus_create(2048, [27, 27]), oracle.plain_modulus_batching(2048, 14)
+    if cfg == 4:   # N=8192, 3 data primes: first 3 of BFVDefault(8192) + its last prime as the special prime
+        m = oracle.BFV_DEFAULT[8192]
+        return 8192, m[:3] + [m[4]], oracle.plain_modulus_batching(8192, 24)
+    if cfg == 5:   # N=16384, 4 data primes: first 4 of BFVDefault(16384) + its last prime as the special prime
+        m = oracle.BFV_DEFAULT[16384]
+        return 16384, m[:4] + [m[8]], oracle.plain_modulus_batching(16384, 24)
+    raise ValueError(cfg)
+
+
+@pytest.mark.parametrize("cfg,dbsize,elem,d", [(1, 1 << 10, 32, 1), (4, 600, 1024, 2), (5, 2000, 288, 2)])
+def test_baseline_parameter_sets(cfg, dbsize, elem, d):
+    """configs[0] exactly, configs[3]/[4] with their ring / modulus chain at a reduced item count:
+    GPU reply bit-exact vs the oracle and the item decodes."""
+    Nn, moduli, t = _baseline_moduli(cfg)
+    s = PirSetup(dbsize, elem, d, N=Nn, moduli=moduli, t=t)
+    if cfg == 1:
+        assert s.params.items_per_plaintext == 104 and s.params.num_pt == 10 and s.orc.expansion_ratio() == 3
+    if cfg == 4:
+        assert s.params.items_per_plaintext == 23 and s.orc.expansion_ratio() == 6
+    if cfg == 5:
+        assert s.params.items_per_plaintext == 163 and s.orc.expansion_ratio() == 12
+    db, srv = make_server(s)
+    srv.set_galois_keys(s.galois_keys)
+    assert db.reply_ct_count() == s.orc.reply_ct_count(d)
+    idx = dbsize - 7
+    q = s.client.create_query_for(s.params, idx)
+    rc, exp = s.orc.process_query(s.db_ntt, s.params.dimensions, q, s.galois_keys)
+    assert rc == 0
+    got = srv.process_query(q)
+    assert np.array_equal(got, exp)
+    if cfg != 1:   # configs[0] has a thin noise margin by construction (SURVEY 8d); parity is what is pinned
+        assert s.client.process_response(s.params, idx, got) == s.item(idx)
+    db.close()

@@ -403,3 +403,35 @@ def test_baseline_parameter_sets(cfg, dbsize, elem, d):
     if cfg != 1:   # configs[0] has a thin noise margin by construction; parity is what is pinned
         assert s.client.process_response(s.params, idx, got) == s.item(idx)
     db.close()
+
+
+def test_multi_ciphertext_query_end_to_end():
+    """dim_sum > N: the query is two ciphertexts (server_test.cpp:124-151, client.cpp:109-134)."""
+    s = PirSetup(4200, 0, 1, N=N, plain_bits=20)
+    assert s.params.dim_sum == 4200 and s.params.num_pt == 4200
+    db, srv = make_server(s)
+    srv.set_galois_keys(s.galois_keys)
+    idx = 4150
+    q = s.client.create_query_for(s.params, idx)
+    assert q.shape[0] == 2
+    rc, exp = s.orc.process_query(s.db_ntt, s.params.dimensions, q, s.galois_keys)
+    assert rc == 0
+    got = srv.process_query(q)
+    assert np.array_equal(got, exp)
+    assert s.client.process_response(s.params, idx, got) == s.item(idx)
+    db.close()
+
+
+def test_batch_mode_one_dimension():
+    """d=1 (column-split scan, no shared pass) through the batch API."""
+    s = PirSetup(1500, 288, 1, N=N, plain_bits=24)
+    db, srv = make_server(s)
+    srv.set_galois_keys(s.galois_keys)
+    indexes = [0, 749, 1499]
+    queries = np.stack([s.client.create_query_for(s.params, i) for i in indexes])
+    got = srv.process_batch(queries, n_workers=2)
+    for i, idx in enumerate(indexes):
+        rc, exp = s.orc.process_query(s.db_ntt, s.params.dimensions, queries[i], s.galois_keys)
+        assert np.array_equal(got[i], exp)
+        assert s.client.process_response(s.params, idx, got[i]) == s.item(idx)
+    db.close()

@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--log-items", type=int, default=20, help="database = 2^log_items x 288 B")
     ap.add_argument("--dims", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5],
+                    help="BASELINE.json config (1-based as in SURVEY.md section 8): 3 = the headline workload; "
+                         "2/4/5 are reference points (other ring degrees / database shapes)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -134,8 +137,21 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     # ---- workload: BASELINE.json configs[2] (benchmark.cpp:17-23 parameters)
-    enc = pir_amd.generate_encryption_params(4096, 24)
-    pp = pir_amd.create_pir_parameters(1 << args.log_items, 288, args.dims, enc)
+    item_bytes = 288
+    if args.config == 2:      # N=4096, 2 primes, DB = 2^16 x 288 B, d=1
+        enc = pir_amd.generate_encryption_params(4096, 24)
+        args.log_items, args.dims = 16, 1
+    elif args.config == 4:    # N=8192, 3 data primes (first 3 of BFVDefault + its last as special), 2^22 x 1 KB, d=2
+        m = pir_amd.BFV_DEFAULT[8192]
+        enc = pir_amd.generate_encryption_params(8192, 24, coeff_modulus=m[:3] + [m[4]])
+        args.log_items, args.dims, item_bytes = 22, 2, 1024
+    elif args.config == 5:    # N=16384, 4 data primes (first 4 of BFVDefault + its last as special), 2^24 x 288 B, d=2
+        m = pir_amd.BFV_DEFAULT[16384]
+        enc = pir_amd.generate_encryption_params(16384, 24, coeff_modulus=m[:4] + [m[8]])
+        args.log_items, args.dims = 24, 2
+    else:
+        enc = pir_amd.generate_encryption_params(4096, 24)
+    pp = pir_amd.create_pir_parameters(1 << args.log_items, item_bytes, args.dims, enc)
     batch = max(1, args.batch)
     workers = args.workers if args.workers > 0 else min(batch, 8)
     raw, keys, queries = synthetic_inputs(pp, n_queries=batch)
@@ -214,26 +230,29 @@ def main():
         traffic = None
         try:   # HBM bytes per scan launch from the committed PMC passes (profiles/), same workload only
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_scan_traffic.json")))
-            if args.log_items == 20 and args.dims == 2 and world == 1:
+            if args.config == 3 and args.log_items == 20 and args.dims == 2 and world == 1:
                 traffic = pm["traffic_bytes_per_launch"]
         except Exception:
             pass
         out = {
-            "metric": "PIR queries/sec (ms/query in ms_per_step), N=4096 DB=2^%d x 288B d=%d" % (args.log_items,
-                                                                                                args.dims),
+            "metric": "PIR queries/sec (ms/query in ms_per_step), N=%d DB=2^%d x %dB d=%d"
+                      % (enc.poly_modulus_degree, args.log_items, item_bytes, args.dims),
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "N=4096, 2 RNS primes (36,36|37 bit), t=24 bit, DB=2^%d x 288B, d=%d, "
-                                   "dims=%s, num_pt=%d, %d queries/step, %d in flight (BASELINE.json configs[2])"
-                                   % (args.log_items, args.dims, pp.dimensions, pp.num_pt, batch, workers),
+            "config": {"workload": "N=%d, %d RNS data primes (%s bit | special %d bit), t=24 bit, DB=2^%d x %dB, "
+                                   "d=%d, dims=%s, num_pt=%d, %d queries/step, %d in flight (BASELINE.json configs[%d])"
+                                   % (enc.poly_modulus_degree, len(enc.coeff_modulus) - 1,
+                                      ",".join(str(q.bit_length()) for q in enc.coeff_modulus[:-1]),
+                                      enc.coeff_modulus[-1].bit_length(), args.log_items, item_bytes, args.dims,
+                                      pp.dimensions, pp.num_pt, batch, workers, args.config - 1),
                        "queries_per_step": batch, "workers": workers,
                        "parallelism": "rows sharded over %d GPU(s), RCCL all-reduce of reply" % world
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, profiles/r01_pmc_scan_traffic.json",
-                         "kernel": "scan_mq_kernel<4 rows/wave, 1 query> (one launch = one query's pass over the database)",
+                         "kernel": "scan_mq_kernel<4 rows/wave, 1 query>" if args.dims > 1 else "scan_kernel + reduce_splits (column split)",
                          "kernel_ms": scan_ms, "algorithmic_bytes": scan_bytes,
                          "launches_averaged": timings["runs"]},
             "latency_ms_single_query": round(latency_ms, 4),

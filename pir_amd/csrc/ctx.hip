@@ -105,6 +105,7 @@ struct pirgpu_ctx {
   uint32_t mq_nq = 4, mq_rows = 1;          // batch mode: queries per database pass / rows per wave
   bool mq_single = true;                    // use the LDS-shared scan kernel for single queries too
   uint32_t mq_single_rows = 4;              // rows per wave of that kernel for a single query (2 or 4)
+  bool mq_single_limb = false;              // single query: 128-bit accumulators need fewer registers (3 WG/CU)
   uint64_t scan_npt = 0;
 
   bool prof = false;
@@ -303,6 +304,7 @@ void ensure_workspace(pirgpu_ctx* c) {
     c->mq_rows = env_u32("PIRGPU_SCAN_MQ_ROWS", c->mq_nq == 4 ? 1 : 2);
     c->mq_single = env_u32("PIRGPU_SCAN_MQ_SINGLE", 1) != 0;
     c->mq_single_rows = env_u32("PIRGPU_SCAN_MQ_SINGLE_ROWS", 4) == 2 ? 2 : 4;
+    c->mq_single_limb = env_u32("PIRGPU_SCAN_MQ_SINGLE_LIMB", 0) != 0;
     c->scan_rpt = env_u32("PIRGPU_SCAN_ROWS", 4);
     c->scan_block = env_u32("PIRGPU_SCAN_BLOCK", 256);
     const uint32_t xblocks = (k * N / 2 + c->scan_block - 1) / c->scan_block;
@@ -442,7 +444,7 @@ void scan_on_device(pirgpu_ctx* c, Worker& w) {
   uint64_t* base_out = w.lvl[d - 1];
   if (c->mq_single && mq_usable(c)) {
     HIP_TRY(launch_scan_mq(w.stream, c->dp, N, k, c->d_db, &sv_base, &base_out, 1, c->scan_rows, c->scan_cols,
-                           c->mq_single_rows, c->scan_limb));
+                           c->mq_single_rows, c->mq_single_limb && c->scan_limb));
     return;
   }
   uint64_t* scan_out = c->scan_nsplit > 1 ? w.scan_part : base_out;

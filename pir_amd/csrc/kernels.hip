@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "arith.h"
@@ -365,8 +367,8 @@ struct MqArgs {
   uint64_t* out[kMaxScanQueries];       // per query: [rows][2][k][N]
 };
 
-template <int ROWS_W, int NQ, int TCOLS, typename ACC>
-__global__ void __launch_bounds__(256)
+template <int ROWS_W, int NQ, int TCOLS, typename ACC, int MINWAVES = 1>
+__global__ void __launch_bounds__(256, MINWAVES)
 scan_mq_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ db, MqArgs a, uint32_t rows,
                uint32_t cols) {
   extern __shared__ __attribute__((aligned(16))) unsigned char mq_smem[];
@@ -655,19 +657,20 @@ hipError_t launch_scan(hipStream_t st, const DevParams* P, uint32_t N, uint32_t 
 #undef PIRGPU_SCAN_CASE
 }
 
-template <int ROWS_W, int NQ, int TCOLS, typename ACC>
+template <int ROWS_W, int NQ, int TCOLS, typename ACC, int MINWAVES = 1>
 static hipError_t launch_scan_mq_variant(hipStream_t st, const DevParams* P, uint32_t kN, const uint64_t* db,
                                          const MqArgs& a, uint32_t rows, uint32_t cols) {
   const size_t lds = (size_t)2 * TCOLS * NQ * 2 * 1024;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute((const void*)scan_mq_kernel<ROWS_W, NQ, TCOLS, ACC>,
+    hipError_t e = hipFuncSetAttribute((const void*)scan_mq_kernel<ROWS_W, NQ, TCOLS, ACC, MINWAVES>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     configured = true;
   }
   dim3 grid(kN / 128, (rows + 4 * ROWS_W - 1) / (4 * ROWS_W));
-  hipLaunchKernelGGL((scan_mq_kernel<ROWS_W, NQ, TCOLS, ACC>), grid, dim3(256), lds, st, P, db, a, rows, cols);
+  hipLaunchKernelGGL((scan_mq_kernel<ROWS_W, NQ, TCOLS, ACC, MINWAVES>), grid, dim3(256), lds, st, P, db, a, rows,
+                     cols);
   return hipGetLastError();
 }
 
@@ -684,6 +687,8 @@ hipError_t launch_scan_mq(hipStream_t st, const DevParams* P, uint32_t N, uint32
 #define PIRGPU_MQ(RW, NQ_, T)                                                                   \
   return limb ? launch_scan_mq_variant<RW, NQ_, T, AccLimb>(st, P, kN, db, a, rows, cols)        \
               : launch_scan_mq_variant<RW, NQ_, T, AccWide>(st, P, kN, db, a, rows, cols)
+  if (nq == 1 && rows_per_wave == 4 && !limb && getenv("PIRGPU_SCAN_OCC3"))  // experiment: 3 workgroups per CU
+    return launch_scan_mq_variant<4, 1, 4, AccWide, 3>(st, P, kN, db, a, rows, cols);
   if (nq == 1 && rows_per_wave == 4) { PIRGPU_MQ(4, 1, 4); }
   if (nq == 1 && rows_per_wave == 2) { PIRGPU_MQ(2, 1, 4); }
   if (nq == 2 && rows_per_wave == 2) { PIRGPU_MQ(2, 2, 4); }

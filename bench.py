@@ -157,7 +157,8 @@ def main():
     raw, keys, queries = synthetic_inputs(pp, n_queries=batch)
     query = queries[0]
 
-    from pir_amd.distributed import all_reduce_batch_replies, all_reduce_reply, shard_range
+    from pir_amd.distributed import (all_reduce_batch_replies, all_reduce_reply, run_batch_query_parallel,
+                                     shard_range)
     shard = shard_range(pp.dimensions[0], rank, world) if world > 1 else None
     db = pir_amd.PIRDatabase.Create(pp, device=local_rank, shard=shard)
     t0 = time.perf_counter()
@@ -169,10 +170,15 @@ def main():
     reply_cts = db.reply_ct_count()
     k, N = srv.k, srv.N
     dev = "cuda:%d" % local_rank
-    red1 = redb = None
+    red1 = redb = sv_all = None
+    # multi-GPU: query-parallel expansion + all-gather of the selection vectors when the batch
+    # divides evenly over the ranks; otherwise every rank expands every query (replicated)
+    query_parallel = use_dist and batch % world == 0 and os.environ.get("PIRGPU_REPLICATED_EXPANSION") != "1"
     if use_dist:
         red1 = torch.empty((reply_cts, 2, k, N), dtype=torch.int64, device=dev)
         redb = torch.empty((batch, reply_cts, 2, k, N), dtype=torch.int64, device=dev)
+        if query_parallel:
+            sv_all = torch.empty((batch, pp.dim_sum, 2, k, N), dtype=torch.int64, device=dev)
 
     def barrier():
         if use_dist:
@@ -204,9 +210,12 @@ def main():
     srv.stage_batch(queries)
 
     def step():
-        srv.run_batch()
-        if use_dist:
-            all_reduce_batch_replies(srv, redb, dist)
+        if query_parallel:
+            run_batch_query_parallel(srv, sv_all, redb, dist, rank, world)
+        else:
+            srv.run_batch()
+            if use_dist:
+                all_reduce_batch_replies(srv, redb, dist)
 
     for _ in range(args.warmup):
         step()
@@ -247,7 +256,9 @@ def main():
                                       enc.coeff_modulus[-1].bit_length(), args.log_items, item_bytes, args.dims,
                                       pp.dimensions, pp.num_pt, batch, workers, args.config - 1),
                        "queries_per_step": batch, "workers": workers,
-                       "parallelism": "rows sharded over %d GPU(s), RCCL all-reduce of reply" % world
+                       "parallelism": ("rows sharded over %d GPU(s), %s, RCCL all-reduce of replies"
+                                       % (world, "query-parallel expansion + RCCL all-gather of selection vectors"
+                                          if query_parallel else "replicated expansion"))
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

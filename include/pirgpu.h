@@ -63,7 +63,8 @@ typedef struct pirgpu_params {
   int32_t device;                          /* HIP device ordinal */
   /* Row sharding for multi-GPU (not in the reference): this context holds the
    * top-level indices [shard_begin, shard_end) of dimension 0 and produces the
-   * partial reply for them; 0,0 = the whole database. */
+   * partial reply for them; 0,0 = the whole database (an empty shard is any begin == end != 0,
+   * e.g. dimensions[0],dimensions[0]; its partial reply is all zero). */
   uint32_t shard_begin;
   uint32_t shard_end;
 } pirgpu_params;
@@ -128,6 +129,15 @@ int pirgpu_set_concurrency(pirgpu_ctx* ctx, uint32_t n_workers);
 int pirgpu_batch_stage(pirgpu_ctx* ctx, const uint64_t* queries, uint32_t nq, uint32_t count);
 int pirgpu_batch_run(pirgpu_ctx* ctx);
 int pirgpu_batch_fetch(pirgpu_ctx* ctx, uint64_t* replies, uint64_t reply_capacity, uint64_t* reply_count);
+/* Multi-GPU, query-parallel expansion (not in the reference).  batch_expand runs
+ * only oblivious_expansion + the selector NTT for the staged queries [first, first+count) and writes
+ * their selection vectors (count x dim_sum ciphertexts, NTT form, device order) to caller-owned DEVICE
+ * memory, e.g. this rank's slice of an RCCL all-gather buffer.  batch_run_selectors then runs
+ * PIRDatabase::multiply for `count` queries whose selection vectors are already in DEVICE memory
+ * (query i at device_sv + i * dim_sum ciphertexts) on this context's database shard; replies go to
+ * the batch reply buffer like pirgpu_batch_run's. */
+int pirgpu_batch_expand(pirgpu_ctx* ctx, uint32_t first, uint32_t count, uint64_t* device_dst);
+int pirgpu_batch_run_selectors(pirgpu_ctx* ctx, const uint64_t* device_sv, uint32_t count);
 /* Waits for the batch and copies its replies into caller-owned DEVICE memory (multi-GPU reduce). */
 int pirgpu_batch_reply_copy_to_device(pirgpu_ctx* ctx, uint64_t* device_dst, uint64_t capacity);
 

@@ -59,6 +59,8 @@ SIGNATURES = {
     "pirgpu_batch_run": (C.c_int, [C.c_void_p]),
     "pirgpu_batch_fetch": (C.c_int, [C.c_void_p, u64p, C.c_uint64, u64p]),
     "pirgpu_batch_reply_copy_to_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "pirgpu_batch_expand": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "pirgpu_batch_run_selectors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "pirgpu_expand": (C.c_int, [C.c_void_p, u64p, C.c_uint32, u64p]),
     "pirgpu_expand_multi": (C.c_int, [C.c_void_p, u64p, C.c_uint32, C.c_uint64, u64p]),
     "pirgpu_substitute_power_x": (C.c_int, [C.c_void_p, u64p, C.c_uint32]),

@@ -52,6 +52,7 @@ struct Worker {
   uint64_t *res_a = nullptr, *res_b = nullptr, *prod = nullptr, *dig = nullptr, *sv_ntt = nullptr;
   uint64_t* d_query = nullptr;
   uint32_t staged_nq = 0;
+  const uint64_t* sv_cur = nullptr;  // selection vector the multiply reads: sv_ntt, or caller-owned memory
   std::vector<uint64_t*> lvl;  // per level results; lvl[0] = reply
   uint64_t* pt_buf = nullptr;
   uint64_t* scan_part = nullptr;
@@ -401,6 +402,7 @@ uint64_t* expand_on_device(pirgpu_ctx* c, Worker& w, uint32_t n) {
 // server.cpp:148-171 followed by the lazy transform_to_ntt_inplace of
 // database.cpp:190,222 applied to every selector.
 void expand_query_to_sv(pirgpu_ctx* c, Worker& w, const uint64_t* d_query, uint32_t nq, uint64_t* coeff_out_host) {
+  w.sv_cur = nullptr;
   const uint32_t N = c->N, k = c->k;
   const size_t ctw = c->ctw;
   uint64_t remaining = c->dim_sum;
@@ -427,7 +429,8 @@ void expand_query_to_sv(pirgpu_ctx* c, Worker& w, const uint64_t* d_query, uint3
 // selection vector already in NTT form in sv_ntt.  Leaves the reply in lvl[0].
 // selectors of the scanned (last) dimension for this worker's query
 const uint64_t* scan_selectors(pirgpu_ctx* c, Worker& w) {
-  return w.sv_ntt + (size_t)c->sv_off[c->d - 1] * c->ctw + (c->d == 1 ? (size_t)c->sb * c->ctw : 0);
+  const uint64_t* sv = w.sv_cur ? w.sv_cur : w.sv_ntt;
+  return sv + (size_t)c->sv_off[c->d - 1] * c->ctw + (c->d == 1 ? (size_t)c->sb * c->ctw : 0);
 }
 
 bool mq_usable(pirgpu_ctx* c) { return c->scan_nsplit == 1 && c->scan_rows >= 1 && c->scan_cols >= 1; }
@@ -483,7 +486,8 @@ void post_scan_on_device(pirgpu_ctx* c, Worker& w) {
     const uint64_t out_polys = rows * C * c->E * 2 * k;
     if (out_polys * n_chunks * N > c->pt_words)
       throw Fail{PIRGPU_INTERNAL, "upper-level scratch undersized"};
-    HIP_TRY(c->ops->upper_fused(w.stream, c->mode, c->dp, k, c->E, w.lvl[l + 1], w.sv_ntt, w.pt_buf,
+    HIP_TRY(c->ops->upper_fused(w.stream, c->mode, c->dp, k, c->E, w.lvl[l + 1], w.sv_cur ? w.sv_cur : w.sv_ntt,
+                                w.pt_buf,
                                 (uint32_t)rows, c->dims[l], (uint32_t)nch, sv_first, (uint32_t)C, chunk_len,
                                 n_chunks));
     if (l == 0) record(c, w, PH_FINAL);
@@ -954,6 +958,7 @@ int pirgpu_multiply(pirgpu_ctx* c, const uint64_t* sv, uint64_t sv_count, uint64
       HIP_TRY(hipStreamSynchronize(c->stream));
     }
     c->prof_cur = -1;
+    w.sv_cur = nullptr;
     multiply_on_device(c, w);
     HIP_TRY(hipMemcpyAsync(reply, w.lvl[0], c->reply_cts * c->ctw * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -997,66 +1002,117 @@ int pirgpu_batch_stage(pirgpu_ctx* c, const uint64_t* queries, uint32_t nq, uint
   });
 }
 
-int pirgpu_batch_run(pirgpu_ctx* c) {
-  return guarded(c, [&]() -> int {
-    if (!c->batch_count) return fail(c, PIRGPU_FAILED_PRECONDITION, "no batch has been staged");
-    const uint32_t nq = c->dim_sum / c->N + 1;
-    const size_t qwords = (size_t)nq * c->ctw, rwords = (size_t)c->reply_cts * c->ctw;
-    const uint32_t W = std::max<uint32_t>(1, std::min<uint32_t>(c->n_active, (uint32_t)c->workers.size()));
-    const uint32_t G = mq_usable(c) && c->pt_end > c->pt_begin ? std::min<uint32_t>(c->mq_nq, kMaxScanQueries) : 1;
-    c->prof_cur = -1;
-    // rounds of W queries (one per worker); inside a round, groups of G workers share one
-    // pass over the database (scan_mq_kernel), hand-offs between streams through events
-    for (uint32_t base = 0; base < c->batch_count; base += W) {
-      const uint32_t n = std::min<uint32_t>(W, c->batch_count - base);
-      for (uint32_t j = 0; j < n; ++j) {
-        Worker& w = c->workers[j];
+// Shared body of pirgpu_batch_run / pirgpu_batch_run_selectors: `count` queries in rounds of W
+// (one per worker); inside a round, groups of up to 4 workers share one pass over the
+// database (scan_mq_kernel), hand-offs between streams through events.  With ext_sv the
+// expansion is skipped and query i reads its NTT-form selection vector at ext_sv + i*dim_sum.
+static void batch_run_impl(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv) {
+  const uint32_t nq = c->dim_sum / c->N + 1;
+  const size_t qwords = (size_t)nq * c->ctw, rwords = (size_t)c->reply_cts * c->ctw;
+  const size_t svwords = (size_t)c->dim_sum * c->ctw;
+  const uint32_t W = std::max<uint32_t>(1, std::min<uint32_t>(c->n_active, (uint32_t)c->workers.size()));
+  const uint32_t G = mq_usable(c) && c->pt_end > c->pt_begin ? std::min<uint32_t>(c->mq_nq, kMaxScanQueries) : 1;
+  if (c->n_loaded != c->pt_end - c->pt_begin)
+    throw Fail{PIRGPU_FAILED_PRECONDITION, "database not fully loaded"};
+  c->prof_cur = -1;
+  for (uint32_t base = 0; base < count; base += W) {
+    const uint32_t n = std::min<uint32_t>(W, count - base);
+    for (uint32_t j = 0; j < n; ++j) {
+      Worker& w = c->workers[j];
+      if (ext_sv) {
+        w.sv_cur = ext_sv + (size_t)(base + j) * svwords;
+      } else {
         HIP_TRY(hipMemcpyAsync(w.d_query, c->d_bquery + (base + j) * qwords, qwords * 8, hipMemcpyDeviceToDevice,
                                w.stream));
         w.staged_nq = nq;
         expand_query_to_sv(c, w, w.d_query, nq, nullptr);
-        if (G > 1) HIP_TRY(hipEventRecord(w.ev_expanded, w.stream));
       }
-      for (uint32_t j0 = 0; j0 < n; j0 += G) {
-        const uint32_t g = std::min<uint32_t>(G, n - j0);
-        // group sizes the kernel is instantiated for: 4, 2, 1
-        uint32_t done = 0;
-        while (done < g) {
-          const uint32_t take = g - done >= 4 && G >= 4 ? 4 : (g - done >= 2 && G >= 2 ? 2 : 1);
-          Worker& lead = c->workers[j0 + done];
-          if (take == 1) {
-            scan_on_device(c, lead);
-            if (G > 1) HIP_TRY(hipEventRecord(lead.ev_scanned, lead.stream));
-          } else {
-            const uint64_t* svp[kMaxScanQueries];
-            uint64_t* outp[kMaxScanQueries];
-            for (uint32_t q = 0; q < take; ++q) {
-              Worker& m = c->workers[j0 + done + q];
-              if (q) HIP_TRY(hipStreamWaitEvent(lead.stream, m.ev_expanded, 0));
-              svp[q] = scan_selectors(c, m);
-              outp[q] = m.lvl[c->d - 1];
-            }
-            if (c->n_loaded != c->pt_end - c->pt_begin)
-              throw Fail{PIRGPU_FAILED_PRECONDITION, "database not fully loaded"};
-            const uint32_t rpw = take == 4 ? (c->mq_rows > 2 ? 1 : c->mq_rows) : (c->mq_rows > 2 ? 2 : c->mq_rows);
-            HIP_TRY(launch_scan_mq(lead.stream, c->dp, c->N, c->k, c->d_db, svp, outp, take, c->scan_rows,
-                                   c->scan_cols, rpw, c->scan_limb));
-            HIP_TRY(hipEventRecord(lead.ev_scanned, lead.stream));
-            for (uint32_t q = 1; q < take; ++q)
-              HIP_TRY(hipStreamWaitEvent(c->workers[j0 + done + q].stream, lead.ev_scanned, 0));
+      if (G > 1) HIP_TRY(hipEventRecord(w.ev_expanded, w.stream));
+    }
+    for (uint32_t j0 = 0; j0 < n; j0 += G) {
+      const uint32_t g = std::min<uint32_t>(G, n - j0);
+      uint32_t done = 0;
+      while (done < g) {  // group sizes the kernel is instantiated for: 4, 2, 1
+        const uint32_t take = g - done >= 4 && G >= 4 ? 4 : (g - done >= 2 && G >= 2 ? 2 : 1);
+        Worker& lead = c->workers[j0 + done];
+        if (take == 1) {
+          scan_on_device(c, lead);
+        } else {
+          const uint64_t* svp[kMaxScanQueries];
+          uint64_t* outp[kMaxScanQueries];
+          for (uint32_t q = 0; q < take; ++q) {
+            Worker& m = c->workers[j0 + done + q];
+            if (q) HIP_TRY(hipStreamWaitEvent(lead.stream, m.ev_expanded, 0));
+            svp[q] = scan_selectors(c, m);
+            outp[q] = m.lvl[c->d - 1];
           }
-          done += take;
+          const uint32_t rpw = take == 4 ? (c->mq_rows > 2 ? 1 : c->mq_rows) : (c->mq_rows > 2 ? 2 : c->mq_rows);
+          HIP_TRY(launch_scan_mq(lead.stream, c->dp, c->N, c->k, c->d_db, svp, outp, take, c->scan_rows,
+                                 c->scan_cols, rpw, c->scan_limb));
+          HIP_TRY(hipEventRecord(lead.ev_scanned, lead.stream));
+          for (uint32_t q = 1; q < take; ++q)
+            HIP_TRY(hipStreamWaitEvent(c->workers[j0 + done + q].stream, lead.ev_scanned, 0));
         }
-      }
-      for (uint32_t j = 0; j < n; ++j) {
-        Worker& w = c->workers[j];
-        post_scan_on_device(c, w);
-        HIP_TRY(hipMemcpyAsync(c->d_breply + (base + j) * rwords, w.lvl[0], rwords * 8, hipMemcpyDeviceToDevice,
-                               w.stream));
-        w.reply_valid = true;
+        done += take;
       }
     }
-    c->batch_valid = true;
+    for (uint32_t j = 0; j < n; ++j) {
+      Worker& w = c->workers[j];
+      post_scan_on_device(c, w);
+      HIP_TRY(hipMemcpyAsync(c->d_breply + (base + j) * rwords, w.lvl[0], rwords * 8, hipMemcpyDeviceToDevice,
+                             w.stream));
+      w.reply_valid = true;
+    }
+  }
+  c->batch_valid = true;
+}
+
+int pirgpu_batch_run(pirgpu_ctx* c) {
+  return guarded(c, [&]() -> int {
+    if (!c->batch_count) return fail(c, PIRGPU_FAILED_PRECONDITION, "no batch has been staged");
+    batch_run_impl(c, c->batch_count, nullptr);
+    return PIRGPU_OK;
+  });
+}
+
+// ---- query-parallel expansion for multi-GPU ----
+
+int pirgpu_batch_expand(pirgpu_ctx* c, uint32_t first, uint32_t count, uint64_t* device_dst) {
+  return guarded(c, [&]() -> int {
+    if (!c->batch_count || (uint64_t)first + count > c->batch_count)
+      return fail(c, PIRGPU_INVALID_ARGUMENT, "query range outside the staged batch");
+    if (!device_dst && count) return fail(c, PIRGPU_INVALID_ARGUMENT, "null buffer");
+    const uint32_t nq = c->dim_sum / c->N + 1;
+    const size_t qwords = (size_t)nq * c->ctw, svwords = (size_t)c->dim_sum * c->ctw;
+    const uint32_t W = std::max<uint32_t>(1, std::min<uint32_t>(c->n_active, (uint32_t)c->workers.size()));
+    c->prof_cur = -1;
+    for (uint32_t i = 0; i < count; ++i) {
+      Worker& w = c->workers[i % W];
+      HIP_TRY(hipMemcpyAsync(w.d_query, c->d_bquery + (size_t)(first + i) * qwords, qwords * 8,
+                             hipMemcpyDeviceToDevice, w.stream));
+      w.staged_nq = nq;
+      expand_query_to_sv(c, w, w.d_query, nq, nullptr);
+      HIP_TRY(hipMemcpyAsync(device_dst + (size_t)i * svwords, w.sv_ntt, svwords * 8, hipMemcpyDeviceToDevice,
+                             w.stream));
+    }
+    for (Worker& w : c->workers) HIP_TRY(hipStreamSynchronize(w.stream));
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_batch_run_selectors(pirgpu_ctx* c, const uint64_t* device_sv, uint32_t count) {
+  return guarded(c, [&]() -> int {
+    ensure_workspace(c);
+    if (!device_sv || count == 0 || count > 4096) return fail(c, PIRGPU_INVALID_ARGUMENT, "invalid batch");
+    if (count > c->batch_cap) {
+      const uint32_t nq = c->dim_sum / c->N + 1;
+      c->d_bquery = c->dalloc<uint64_t>((size_t)count * nq * c->ctw);
+      c->d_breply = c->dalloc<uint64_t>((size_t)count * c->reply_cts * c->ctw);
+      c->batch_cap = count;
+    }
+    c->batch_count = std::max(c->batch_count, count);
+    batch_run_impl(c, count, device_sv);
+    c->batch_count = count;
     return PIRGPU_OK;
   });
 }

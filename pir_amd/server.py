@@ -71,7 +71,10 @@ class PIRDatabase:
         p.use_ciphertext_multiplication = 1 if params.use_ciphertext_multiplication else 0
         p.device = device
         if shard is not None:
-            p.shard_begin, p.shard_end = int(shard[0]), int(shard[1])
+            b, e = int(shard[0]), int(shard[1])
+            if b == e:                      # empty shard: (0, 0) means "whole database" in the C ABI
+                b = e = params.dimensions[0]
+            p.shard_begin, p.shard_end = b, e
         self._cparams = p
         h = C.c_void_p()
         rc = self.lib.pirgpu_create(C.byref(p), C.byref(h))
@@ -254,6 +257,18 @@ class PIRServer:
         cnt = C.c_uint64(0)
         self._check(self.lib.pirgpu_batch_fetch(self.db.handle, _ptr(out), self._batch_count * n, C.byref(cnt)))
         return out
+
+    def batch_expand(self, first: int, count: int, device_ptr: int) -> None:
+        """Expansion + selector NTT of staged queries [first, first+count) into device memory."""
+        self._check(self.lib.pirgpu_batch_expand(self.db.handle, first, count, C.c_void_p(device_ptr)))
+
+    def batch_run_selectors(self, device_ptr: int, count: int) -> None:
+        """PIRDatabase::multiply for `count` queries whose NTT-form selection vectors are on the device."""
+        self._batch_count = count
+        self._check(self.lib.pirgpu_batch_run_selectors(self.db.handle, C.c_void_p(device_ptr), count))
+
+    def dim_sum(self) -> int:
+        return self.params.dim_sum
 
     def batch_reply_copy_to_device(self, device_ptr: int) -> None:
         self._check(self.lib.pirgpu_batch_reply_copy_to_device(self.db.handle, C.c_void_p(device_ptr),

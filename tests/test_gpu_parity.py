@@ -435,3 +435,45 @@ def test_batch_mode_one_dimension():
         assert np.array_equal(got[i], exp)
         assert s.client.process_response(s.params, idx, got[i]) == s.item(idx)
     db.close()
+
+
+@pytest.mark.parametrize("world,count", [(2, 4), (4, 4)])
+def test_query_parallel_expansion_simulated_ranks(world, count):
+    """The multi-GPU step (pir_amd.distributed.run_batch_query_parallel) simulated on one GPU: each
+    'rank' = a context holding one row shard expands only its block of the batch into a shared
+    device buffer (what the RCCL all-gather assembles), then every rank multiplies ALL queries
+    against its shard; the mod-q sum of the partial replies must equal the full replies."""
+    import torch
+    from pir_amd.distributed import owned_queries, shard_range
+    s = PirSetup(300, 288, 2, N=N, plain_bits=24)
+    p = s.params
+    indexes = [(53 * i + 11) % 300 for i in range(count)]
+    queries = np.stack([s.client.create_query_for(p, i) for i in indexes])
+    sv_all = torch.zeros((count, p.dim_sum, 2, s.orc.k, N), dtype=torch.int64, device="cuda")
+    ranks = []
+    for r in range(world):
+        db, srv = make_server(s, shard=shard_range(p.dimensions[0], r, world))
+        srv.set_galois_keys(s.galois_keys)
+        srv.set_concurrency(2)
+        srv.stage_batch(queries)
+        lo, hi = owned_queries(count, r, world)
+        srv.batch_expand(lo, hi - lo, sv_all[lo].data_ptr())
+        ranks.append((db, srv))
+    torch.cuda.synchronize()
+    # the gathered selection vectors are exactly the oracle's expansion in NTT form
+    rc, sv0 = s.orc.oblivious_expansion_multi(queries[0], p.dim_sum, s.galois_keys)
+    got0 = ranks[0][1].ntt_inverse(sv_all[0].cpu().numpy().view(np.uint64))   # SEAL order in -> coefficients
+    # (sv_all is in device NTT order, so compare through the full reply instead of this hook)
+    acc = None
+    for db, srv in ranks:
+        srv.batch_run_selectors(sv_all.data_ptr(), count)
+        part = srv.fetch_batch()
+        acc = part.copy() if acc is None else acc + part
+    for j, qj in enumerate(s.orc.moduli[: s.orc.k]):
+        acc[:, :, :, j, :] %= np.uint64(qj)
+    for i, idx in enumerate(indexes):
+        rc, exp = s.orc.process_query(s.db_ntt, p.dimensions, queries[i], s.galois_keys)
+        assert rc == 0 and np.array_equal(acc[i], exp), i
+        assert s.client.process_response(p, idx, acc[i]) == s.item(idx)
+    for db, srv in ranks:
+        db.close()

@@ -354,6 +354,27 @@ scan_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ db, co
   }
 }
 
+// AccLimb products with selectors that were already split at staging time (low limb in the
+// low dword, high limb in the high dword of b.s).
+template <int ROWS>
+__device__ __forceinline__ void scan_mac_presplit(AccLimb (&acc)[ROWS][2][2], const ScanBuf<ROWS, 2>& b) {
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const uint32_t b0 = (uint32_t)b.d[r][v] & 0x0FFFFFFFu;
+      const uint32_t b1 = (uint32_t)(b.d[r][v] >> 28);
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const uint32_t a0 = (uint32_t)b.s[p][v], a1 = (uint32_t)(b.s[p][v] >> 32);
+        acc[r][p][v].s00 += (uint64_t)a0 * b0;
+        acc[r][p][v].s01 += (uint64_t)a0 * b1;
+        acc[r][p][v].s01 += (uint64_t)a1 * b0;
+        acc[r][p][v].s11 += (uint64_t)a1 * b1;
+      }
+    }
+}
+
 // ------------------------------------------------------------------ multi-query scan
 //
 // Batch mode: NQ queries share one pass over the database, so each query pays 1/NQ of the
@@ -377,11 +398,24 @@ scan_mq_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ db,
   const uint32_t N = P->N, k = P->k;
   const uint32_t kN = k * N;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t chunk_base = blockIdx.x * 128;
+  // XCD-aware block order (workgroup b runs on XCD b % 8, each XCD has its own 4 MiB L2): an XCD
+  // walks all row blocks of one residue chunk before it moves to the next chunk, so the
+  // selector rows of only a few chunks are live in its L2 at any time.
+  const uint32_t n_chunks = kN / 128, n_rb = (rows + 4 * ROWS_W - 1) / (4 * ROWS_W);
+  uint32_t chunk, rb;
+  if ((n_chunks & 7) == 0) {
+    const uint32_t xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
+    chunk = xcd + 8 * (t / n_rb);
+    rb = t % n_rb;
+  } else {
+    chunk = blockIdx.x % n_chunks;
+    rb = blockIdx.x / n_chunks;
+  }
+  const uint32_t chunk_base = chunk * 128;
   const uint32_t c0 = chunk_base + lane * 2;
   const uint32_t j = c0 >> P->logN;
   const ModConst m = P->mod[j];
-  const uint32_t row0 = blockIdx.y * (4 * ROWS_W) + wave * ROWS_W;
+  const uint32_t row0 = rb * (4 * ROWS_W) + wave * ROWS_W;
   const uint32_t lazy = std::is_same<ACC, AccLimb>::value ? kLimbLazy : P->lazy_limit;
 
   const uint64_t* rp[ROWS_W];
@@ -417,11 +451,18 @@ scan_mq_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ db,
       st[i] = *reinterpret_cast<const u64x2*>(a.sv[q] + (size_t)col * 2 * kN + (size_t)p * kN + chunk_base + 2 * l);
     }
   };
+  // limb accumulators: the selectors are split at bit 28 once here (low limb in the low dword,
+  // high limb in the high dword) instead of per wave and column in the inner loop
   auto stage_store = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
       const uint32_t piece = tid + 256u * i;
-      tile[buf][piece >> 6][piece & 63] = st[i];
+      u64x2 v = st[i];
+      if constexpr (std::is_same<ACC, AccLimb>::value) {
+        v.x = ((v.x >> 28) << 32) | (v.x & 0x0FFFFFFFull);
+        v.y = ((v.y >> 28) << 32) | (v.y & 0x0FFFFFFFull);
+      }
+      tile[buf][piece >> 6][piece & 63] = v;
     }
   };
   uint32_t since = 0;
@@ -457,7 +498,10 @@ scan_mq_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ db,
             sb.d[r][0] = dbuf[t & 3][r].x;
             sb.d[r][1] = dbuf[t & 3][r].y;
           }
-          scan_mac<ROWS_W, 2>(acc[q], sb);
+          if constexpr (std::is_same<ACC, AccLimb>::value)
+            scan_mac_presplit<ROWS_W>(acc[q], sb);
+          else
+            scan_mac<ROWS_W, 2>(acc[q], sb);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -668,7 +712,7 @@ static hipError_t launch_scan_mq_variant(hipStream_t st, const DevParams* P, uin
     if (e != hipSuccess) return e;
     configured = true;
   }
-  dim3 grid(kN / 128, (rows + 4 * ROWS_W - 1) / (4 * ROWS_W));
+  dim3 grid((kN / 128) * ((rows + 4 * ROWS_W - 1) / (4 * ROWS_W)));
   hipLaunchKernelGGL((scan_mq_kernel<ROWS_W, NQ, TCOLS, ACC, MINWAVES>), grid, dim3(256), lds, st, P, db, a, rows,
                      cols);
   return hipGetLastError();

@@ -271,6 +271,28 @@ def main():
             "phases_ms_single_query": {kk: round(v, 4) for kk, v in timings.items() if kk.endswith("_ms")},
             "db_populate_s": round(t_populate, 2),
         }
+        if world == 1 and args.config == 3:
+            # wire-level ProcessRequest (what benchmark.cpp:71-79 times): serialized pir.Request in host
+            # memory -> serialized pir.Response, incl. parsing, H2D of keys + query, D2H, serialisation
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import seal_wire as W
+                mods = enc.coeff_modulus
+                gk = W.save_galois_keys(keys, N, W.parms_id(N, mods, enc.plain_modulus))
+                req = W.save_request([query], gk, W.parms_id(N, mods[:-1], enc.plain_modulus))
+                srv.set_concurrency(1)
+                wt = []
+                for _ in range(6):
+                    t0 = time.perf_counter()
+                    resp = srv.ProcessRequest(req)
+                    wt.append((time.perf_counter() - t0) * 1e3)
+                same = bool(np.array_equal(W.load_response(resp)[0], single_reply))
+                out["wire_process_request_ms"] = {"first_request_with_key_upload": round(wt[0], 3),
+                                                  "repeat_client_keys_cached": round(float(np.median(wt[1:])), 3),
+                                                  "request_bytes": len(req), "response_bytes": len(resp),
+                                                  "response_equals_residue_path": same}
+            except Exception as e:   # measurement extra only
+                out["wire_process_request_ms"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             batch_replies = srv.fetch_batch()
             out["batch_reply0_equals_single_query_reply"] = bool(np.array_equal(batch_replies[0], single_reply))

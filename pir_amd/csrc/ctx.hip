@@ -20,6 +20,7 @@
 #include "device_params.h"
 #include "host_math.h"
 #include "kernels.h"
+#include "wire.h"
 
 using namespace pirgpu;
 
@@ -87,6 +88,8 @@ struct pirgpu_ctx {
   std::vector<uint8_t> loaded;  // per local plaintext
   uint64_t n_loaded = 0;
   std::map<uint32_t, uint64_t*> keys;
+  bool keys_blob_valid = false;    // wire layer: the installed keys came from exactly this blob
+  std::vector<uint8_t> keys_blob;
 
   // workspace geometry (computed on first use) and the workers holding the buffers
   bool ws_ready = false;
@@ -757,6 +760,7 @@ int pirgpu_db_read_plaintext(pirgpu_ctx* c, uint64_t pt_index, uint64_t* out) {
 
 int pirgpu_set_galois_key(pirgpu_ctx* c, uint32_t g, const uint64_t* key) {
   return guarded(c, [&]() -> int {
+    c->keys_blob_valid = false;
     if (!key || !(g & 1) || g >= 2 * c->N) return fail(c, PIRGPU_INVALID_ARGUMENT, "invalid Galois element");
     const size_t words = (size_t)c->k * 2 * (c->k + 1) * c->N;
     uint64_t* dev = nullptr;
@@ -786,6 +790,7 @@ int pirgpu_set_galois_key(pirgpu_ctx* c, uint32_t g, const uint64_t* key) {
 
 int pirgpu_clear_galois_keys(pirgpu_ctx* c) {
   return guarded(c, [&]() -> int {
+    c->keys_blob_valid = false;
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (Worker& w : c->workers)
       if (w.stream) HIP_TRY(hipStreamSynchronize(w.stream));
@@ -1227,6 +1232,16 @@ int pirgpu_last_timings(pirgpu_ctx* c, float ms[6], uint32_t* runs) {
     memcpy(ms, c->timings, sizeof(c->timings));
     return PIRGPU_OK;
   });
+}
+
+int pirgpu_keys_blob_matches(pirgpu_ctx* c, const uint8_t* blob, size_t len) {
+  return c && c->keys_blob_valid && c->keys_blob.size() == len && memcmp(c->keys_blob.data(), blob, len) == 0;
+}
+
+void pirgpu_keys_blob_set(pirgpu_ctx* c, const uint8_t* blob, size_t len) {
+  if (!c) return;
+  c->keys_blob.assign(blob, blob + len);
+  c->keys_blob_valid = true;
 }
 
 void pirgpu_free(void* p) { free(p); }

@@ -22,14 +22,10 @@ struct NttOps {
                          uint32_t galois_elt, uint32_t nodes, uint64_t* dig);
   hipError_t (*ks_mac_intt)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* dig,
                             const uint64_t* key, uint32_t nodes, uint64_t* prod);
-  hipError_t (*reencode_lift_ntt)(hipStream_t st, int mode, const DevParams* P, uint32_t k, uint32_t enc_count,
-                                  const uint64_t* src, uint64_t n_src, uint64_t* pt);
   hipError_t (*upper_fused)(hipStream_t st, int mode, const DevParams* P, uint32_t k, uint32_t enc_count,
                             const uint64_t* src, const uint64_t* sv, uint64_t* part, uint32_t n_rows,
                             uint32_t n_dim, uint32_t n_children_total, uint32_t sv_first, uint32_t C,
                             uint32_t chunk_len, uint32_t n_chunks);
-  hipError_t (*sum_intt)(hipStream_t st, int mode, const DevParams* P, const uint64_t* part, uint32_t n_parts,
-                         uint64_t part_stride, uint64_t n_polys, uint64_t* out);
 };
 
 const NttOps* ntt_ops_for(uint32_t N);  // nullptr for unsupported degrees
@@ -50,8 +46,5 @@ hipError_t launch_scan_mq(hipStream_t st, const DevParams* P, uint32_t N, uint32
                           uint32_t cols, uint32_t rows_per_wave, bool limb);
 hipError_t launch_reduce_splits(hipStream_t st, const DevParams* P, const uint64_t* part, uint32_t nsplit,
                                 uint64_t words, uint64_t* out);
-hipError_t launch_upper_mac(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, uint32_t enc_count,
-                            const uint64_t* sv, const uint64_t* pt, uint32_t n_rows, uint32_t n_dim,
-                            uint32_t n_children_total, uint32_t sv_first, uint32_t C, uint64_t* out);
 
 }  // namespace pirgpu

@@ -12,8 +12,9 @@
 //   ks_combine_kernel         one level of oblivious_expansion           server.cpp:120-142 (apply_galois_inplace :71,
 //                                                                         negacyclic_shift :97, add_inplace :140-141)
 //   scan_kernel               multiply_plain + add_inplace base case     database.cpp:185-194,238-247
-//   reencode_lift_ntt_kernel  CiphertextReencoder::Encode + plain NTT    database.cpp:218,225-228, ct_reencoder.cpp:40-71
-//   upper_mac_kernel          multiply_plain + add_inplace upper levels  database.cpp:229-230,238-247
+//   scan_mq_kernel            the same, 1/2/4 queries per database pass, selectors shared through LDS
+//   reduce_splits_kernel      add_inplace of partial sums (column splits, chunk sums, multi-GPU fix-up)
+// (kernels that contain an NTT live in ntt_kernels.hip)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -567,48 +568,6 @@ __global__ void reduce_splits_kernel(const DevParams* __restrict__ P, const uint
   out[gid] = acc;
 }
 
-// ------------------------------------------------------------------ upper levels
-
-// Upper-level accumulate:  out[r][cc * E + e][p][j][i] =
-//    sum_{ii < nchild(r)} sv[ii][p][j][i] * pt[(child0(r) + ii) * C + cc][e][j][i]   mod q_j
-// where C = ciphertexts per child and E = enc_count.  One thread per output word.
-__global__ void upper_mac_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ sv,
-                                 const uint64_t* __restrict__ pt, uint32_t n_rows, uint32_t n_dim,
-                                 uint32_t n_children_total, uint32_t sv_first, uint32_t C,
-                                 uint64_t* __restrict__ out) {
-  const uint32_t N = P->N, k = P->k, E = P->enc_count;
-  const uint64_t words_per_row = (uint64_t)C * E * 2 * k * N;
-  const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= words_per_row * n_rows) return;
-  const uint32_t i = (uint32_t)(gid & (N - 1));
-  uint64_t rest = gid >> P->logN;
-  const uint32_t j = (uint32_t)(rest % k);
-  rest /= k;
-  const uint32_t p = (uint32_t)(rest & 1);
-  rest >>= 1;
-  const uint32_t e = (uint32_t)(rest % E);
-  rest /= E;
-  const uint32_t cc = (uint32_t)(rest % C);
-  const uint32_t r = (uint32_t)(rest / C);
-  const ModConst m = P->mod[j];
-  const uint32_t child0 = r * n_dim;
-  uint32_t nchild = n_children_total > child0 ? n_children_total - child0 : 0;
-  if (nchild > n_dim) nchild = n_dim;
-  const uint32_t lazy = P->lazy_limit;
-  u128 acc = 0;
-  uint32_t since = 0;
-  for (uint32_t ii = 0; ii < nchild; ++ii) {
-    uint64_t a = sv[(((size_t)(sv_first + ii) * 2 + p) * k + j) * N + i];
-    uint64_t b = pt[((((size_t)(child0 + ii) * C + cc) * E + e) * k + j) * N + i];
-    acc += (u128)a * b;
-    if (++since == lazy) {
-      since = 0;
-      acc = reduce128((uint64_t)acc, (uint64_t)(acc >> 64), m);
-    }
-  }
-  out[gid] = reduce128((uint64_t)acc, (uint64_t)(acc >> 64), m);
-}
-
 // ------------------------------------------------------------------ launchers
 
 #define PIRGPU_LAUNCH_CHECK()            \
@@ -690,12 +649,8 @@ hipError_t launch_scan(hipStream_t st, const DevParams* P, uint32_t N, uint32_t 
                 : launch_scan_variant<R, 2, AccWide>(st, P, kN, block, db, sv, out, rows, cols, num_pt, nsplit,     \
                                                      cols_per_split)
   switch (rows_per_thread) {
-    PIRGPU_SCAN_CASE(1);
     PIRGPU_SCAN_CASE(2);
-    PIRGPU_SCAN_CASE(3);
     PIRGPU_SCAN_CASE(4);
-    PIRGPU_SCAN_CASE(6);
-    PIRGPU_SCAN_CASE(8);
     default: return hipErrorInvalidValue;
   }
 #undef PIRGPU_SCAN_CASE
@@ -748,17 +703,6 @@ hipError_t launch_reduce_splits(hipStream_t st, const DevParams* P, const uint64
   if (!words) return hipSuccess;
   hipLaunchKernelGGL(reduce_splits_kernel, dim3((uint32_t)((words + 255) / 256)), dim3(256), 0, st, P, part, nsplit,
                      words, out);
-  PIRGPU_LAUNCH_CHECK();
-  return hipSuccess;
-}
-
-hipError_t launch_upper_mac(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, uint32_t enc_count,
-                            const uint64_t* sv, const uint64_t* pt, uint32_t n_rows, uint32_t n_dim,
-                            uint32_t n_children_total, uint32_t sv_first, uint32_t C, uint64_t* out) {
-  uint64_t total = (uint64_t)n_rows * C * enc_count * 2 * k * N;
-  if (!total) return hipSuccess;
-  hipLaunchKernelGGL(upper_mac_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, P, sv, pt, n_rows,
-                     n_dim, n_children_total, sv_first, C, out);
   PIRGPU_LAUNCH_CHECK();
   return hipSuccess;
 }

@@ -10,7 +10,8 @@
 //   db_encode_kernel          StringEncoder::encode + transform_to_ntt   database.cpp:100-106, string_encoder.cpp:58-122
 //   ks_digit_kernel,
 //   ks_mac_intt_kernel        Evaluator::apply_galois_inplace key switch server.cpp:71
-//   reencode_lift_ntt_kernel  CiphertextReencoder::Encode + plain NTT    database.cpp:218,225-228, ct_reencoder.cpp:40-71
+//   upper_fused_kernel        CiphertextReencoder::Encode + plain NTT +  database.cpp:218-247, ct_reencoder.cpp:40-71
+//                             multiply_plain + add_inplace (upper levels)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -221,36 +222,6 @@ ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
   for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
 }
 
-// CiphertextReencoder::Encode chunk e of source ciphertext c, lifted to residue
-// jt and forward-NTT'd: pt[c][e][jt][N] (device NTT order).  grid = (n_src, enc_count, k).
-template <int MODE>
-__global__ void __launch_bounds__(NT)
-reencode_lift_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ src,
-                         uint64_t* __restrict__ pt) {
-  using A = Arith<MODE>;
-  const uint32_t tid = threadIdx.x, k = P->k;
-  const uint32_t c = blockIdx.x, e_idx = blockIdx.y, jt = blockIdx.z;
-  const ModConst mc = P->mod[jt];
-  const typename A::Mod m = A::mod(P, jt);
-  const uint32_t sp = P->enc_poly[e_idx], sj = P->enc_res[e_idx], sh = P->enc_shift[e_idx];
-  const uint64_t mask = (1ull << P->enc_bits) - 1;
-  const uint64_t thr = P->plain_thr;
-  const uint64_t inc = P->lift_inc[jt] >= mc.q ? P->lift_inc[jt] - mc.q : P->lift_inc[jt];
-  const uint64_t* in = src + (((size_t)c * 2 + sp) * k + sj) * N;
-  typename A::T x[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    uint64_t v = (in[e * NT + tid] >> sh) & mask;
-    uint64_t r = reduce64(v, mc);
-    if (v >= thr) r = add_mod(r, inc, mc.q);
-    x[e] = A::in(r, m);
-  }
-  ntt_forward<MODE, LOGN>(x, smem_raw, P, jt, tid);
-  uint64_t* out = pt + (((size_t)c * P->enc_count + e_idx) * k + jt) * N;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
-}
-
 // Upper recursion level, fused: for output slot (row r, source ciphertext cc, Encode chunk
 // e_idx, target residue jt) and a chunk of the row's children,
 //   part[chunk][r][cc*E+e_idx][p][jt] = sum_{ii in chunk} sv[sv_first+ii][p][jt] (.)
@@ -258,7 +229,7 @@ reencode_lift_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __rest
 // i.e. CiphertextReencoder::Encode + transform_to_ntt_inplace(Plaintext) + multiply_plain +
 // add_inplace of database.cpp:218-247 without materialising the re-encoded plaintexts: the
 // transformed plaintext stays in registers and is multiplied into both polynomials of the
-// selector.  grid = (n_rows*C*n_chunks, E, k); partial sums are folded by sum_intt_kernel.
+// selector.  grid = (n_rows*C*n_chunks, E, k); partial sums are folded by reduce_splits_kernel, then ntt_batch_kernel (inverse).
 template <int MODE>
 __global__ void __launch_bounds__(NT)
 upper_fused_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ src,
@@ -354,35 +325,6 @@ upper_fused_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
   }
 }
 
-// out[poly] = INTT(sum_s part[s][poly] mod q): folds the chunk partial sums of
-// upper_fused_kernel (device NTT order) and leaves coefficient form (database.cpp:250-254).
-// grid = n_polys (ciphertext layout: modulus = poly % k).
-template <int MODE>
-__global__ void __launch_bounds__(NT)
-sum_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ part, uint32_t n_parts,
-                uint64_t part_stride, uint64_t* __restrict__ out) {
-  using A = Arith<MODE>;
-  const uint32_t tid = threadIdx.x;
-  const int mi = blockIdx.x % P->k;
-  const uint64_t q = P->mod[mi].q;
-  const typename A::Mod m = A::mod(P, mi);
-  const uint64_t* in = part + (size_t)blockIdx.x * N;
-  uint64_t sum[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) sum[e] = 0;
-  for (uint32_t s = 0; s < n_parts; ++s) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) sum[e] = add_mod(sum[e], in[(size_t)s * part_stride + e * NT + tid], q);
-  }
-  typename A::T x[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) x[e] = A::in(sum[e], m);
-  ntt_inverse<MODE, LOGN>(x, smem_raw, P, mi, tid);
-  uint64_t* o = out + (size_t)blockIdx.x * N;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) o[e * NT + tid] = A::out(x[e], m);
-}
-
 // ------------------------------------------------------------------ host side
 
 #define PIRGPU_BY_MODE(mode, EXPR)                                \
@@ -404,9 +346,7 @@ static hipError_t configure_mode() {
   PIRGPU_SET(db_encode_kernel<MODE>);
   PIRGPU_SET(ks_digit_kernel<MODE>);
   PIRGPU_SET(ks_mac_intt_kernel<MODE>);
-  PIRGPU_SET(reencode_lift_ntt_kernel<MODE>);
   PIRGPU_SET(upper_fused_kernel<MODE>);
-  PIRGPU_SET(sum_intt_kernel<MODE>);
 #undef PIRGPU_SET
   return hipSuccess;
 }
@@ -457,13 +397,6 @@ static hipError_t op_ks_mac_intt(hipStream_t st, int mode, const DevParams* P, u
   return hipGetLastError();
 }
 
-static hipError_t op_reencode(hipStream_t st, int mode, const DevParams* P, uint32_t k, uint32_t enc_count,
-                              const uint64_t* src, uint64_t n_src, uint64_t* pt) {
-  PIRGPU_BY_MODE(mode, hipLaunchKernelGGL(reencode_lift_ntt_kernel<MODE>, dim3((uint32_t)n_src, enc_count, k),
-                                          dim3(NT), kLdsBytes, st, P, src, pt));
-  return hipGetLastError();
-}
-
 static hipError_t op_upper_fused(hipStream_t st, int mode, const DevParams* P, uint32_t k, uint32_t enc_count,
                                  const uint64_t* src, const uint64_t* sv, uint64_t* part, uint32_t n_rows,
                                  uint32_t n_dim, uint32_t n_children_total, uint32_t sv_first, uint32_t C,
@@ -474,20 +407,13 @@ static hipError_t op_upper_fused(hipStream_t st, int mode, const DevParams* P, u
   return hipGetLastError();
 }
 
-static hipError_t op_sum_intt(hipStream_t st, int mode, const DevParams* P, const uint64_t* part, uint32_t n_parts,
-                              uint64_t part_stride, uint64_t n_polys, uint64_t* out) {
-  PIRGPU_BY_MODE(mode, hipLaunchKernelGGL(sum_intt_kernel<MODE>, dim3((uint32_t)n_polys), dim3(NT), kLdsBytes, st,
-                                          P, part, n_parts, part_stride, out));
-  return hipGetLastError();
-}
-
 }  // namespace PIRGPU_DEG_NS
 
 // host-only accessor (a namespace-scope const object would also be emitted for the device)
 const NttOps* PIRGPU_OPS_NAME() {
   using namespace PIRGPU_DEG_NS;
-  static const NttOps ops = {op_configure, op_ntt_batch,   op_ct_ntt_fwd_oop, op_db_encode,   op_ks_digit,
-                             op_ks_mac_intt, op_reencode,  op_upper_fused,    op_sum_intt};
+  static const NttOps ops = {op_configure, op_ntt_batch,   op_ct_ntt_fwd_oop, op_db_encode,
+                             op_ks_digit,  op_ks_mac_intt, op_upper_fused};
   return &ops;
 }
 

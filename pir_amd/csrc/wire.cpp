@@ -360,10 +360,16 @@ int pirgpu_process_request(pirgpu_ctx* ctx, const uint8_t* request, size_t reque
         throw Err{PIRGPU_INVALID_ARGUMENT, "malformed Request"};
       }
     }
-    // --- SEALDeserialize<GaloisKeys> (server.cpp:46-48): empty bytes -> load throws -> InvalidArgument
-    int rc = pirgpu_clear_galois_keys(ctx);
-    if (rc) throw Err{rc, pirgpu_last_error(ctx)};
-    load_galois_keys(ctx, sh, gk, gk_len);
+    // --- SEALDeserialize<GaloisKeys> (server.cpp:46-48): empty bytes -> load throws -> InvalidArgument.
+    // The reference re-parses the keys on every request; here a client that repeats its (multi-MB)
+    // key blob byte for byte keeps the device-resident keys of its previous request.
+    int rc = 0;
+    if (!gk_len || !pirgpu_keys_blob_matches(ctx, gk, gk_len)) {
+      rc = pirgpu_clear_galois_keys(ctx);
+      if (rc) throw Err{rc, pirgpu_last_error(ctx)};
+      load_galois_keys(ctx, sh, gk, gk_len);
+      pirgpu_keys_blob_set(ctx, gk, gk_len);
+    }
     // --- per query: LoadCiphertexts -> processQuery -> SaveCiphertexts (server.cpp:60-63,173-195)
     const uint64_t n_reply = pirgpu_reply_ct_count(ctx);
     std::vector<uint64_t> reply(n_reply * ctw), qbuf, one;

@@ -9,6 +9,11 @@ extern "C" {
 #endif
 void pirgpu_wire_parms_id(uint32_t N, const uint64_t* moduli, size_t n_moduli, uint64_t t, uint64_t out[4]);
 void pirgpu_wire_blake2b(uint8_t* out, size_t outlen, const uint8_t* in, size_t inlen);
+// Device-resident Galois key cache: the serialized key blob the installed keys came from
+// (forgotten by pirgpu_set_galois_key / pirgpu_clear_galois_keys); compared byte for byte.
+struct pirgpu_ctx;
+int pirgpu_keys_blob_matches(struct pirgpu_ctx* ctx, const uint8_t* blob, size_t len);
+void pirgpu_keys_blob_set(struct pirgpu_ctx* ctx, const uint8_t* blob, size_t len);
 #ifdef __cplusplus
 }
 #endif

@@ -80,7 +80,6 @@ struct pirgpu_ctx {
   hipStream_t stream = nullptr;
   const NttOps* ops = nullptr;  // NTT kernels for this ring degree
   int mode = kNttInt;           // arithmetic flavour of the NTT kernels (NttMode)
-  bool ks_fused = false;        // one-kernel expansion levels (ks_node_kernel: N <= 4096, k <= 2)
   DevParams hp{};
   DevParams* dp = nullptr;
   std::vector<void*> allocs;
@@ -393,15 +392,10 @@ uint64_t* expand_on_device(pirgpu_ctx* c, Worker& w, uint32_t n) {
   for (uint32_t j = 0; j < logm; ++j) {
     const uint32_t g = (N >> j) + 1;
     const uint64_t* key = find_key(c, g);
-    if (c->ks_fused) {
-      HIP_TRY(c->ops->ks_node(w.stream, c->mode, c->dp, k, cur, key, g, galois_inverse(g, N), 1u << j, 1u << j, true,
+    HIP_TRY(c->ops->ks_digit(w.stream, c->mode, c->dp, k, cur, g, 1u << j, w.dig));
+    HIP_TRY(c->ops->ks_mac_intt(w.stream, c->mode, c->dp, k, w.dig, key, 1u << j, w.prod));
+    HIP_TRY(launch_ks_combine(w.stream, c->dp, N, k, cur, w.prod, galois_inverse(g, N), 1u << j, 1u << j, true,
                               nxt));
-    } else {
-      HIP_TRY(c->ops->ks_digit(w.stream, c->mode, c->dp, k, cur, g, 1u << j, w.dig));
-      HIP_TRY(c->ops->ks_mac_intt(w.stream, c->mode, c->dp, k, w.dig, key, 1u << j, w.prod));
-      HIP_TRY(launch_ks_combine(w.stream, c->dp, N, k, cur, w.prod, galois_inverse(g, N), 1u << j, 1u << j, true,
-                                nxt));
-    }
     std::swap(cur, nxt);
   }
   return cur;
@@ -611,8 +605,6 @@ int pirgpu_create(const pirgpu_params* p, pirgpu_ctx** out) {
     if (!c->ops) return bail(PIRGPU_INVALID_ARGUMENT, "poly_modulus_degree must be 2048, 4096, 8192 or 16384");
     build_tables(c);
     HIP_TRY(c->ops->configure(c->mode));
-    // PIRGPU_KS_FUSED=0 forces the three-kernel expansion level
-    c->ks_fused = c->ops->has_ks_node && k <= 2 && !(getenv("PIRGPU_KS_FUSED") && atoi(getenv("PIRGPU_KS_FUSED")) == 0);
     c->reply_cts = 1;
     for (uint32_t l = 1; l < c->d; ++l) c->reply_cts *= c->E;
     const uint64_t shard_pts = c->pt_end - c->pt_begin;
@@ -929,15 +921,10 @@ int pirgpu_substitute_power_x(pirgpu_ctx* c, uint64_t* ct, uint32_t power) {
       return fail(c, PIRGPU_INTERNAL, "Galois element is not valid");
     const uint64_t* key = find_key(c, power);
     HIP_TRY(hipMemcpyAsync(w.res_a, ct, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
-    if (c->ks_fused) {
-      HIP_TRY(c->ops->ks_node(c->stream, c->mode, c->dp, c->k, w.res_a, key, power, galois_inverse(power, c->N), 1, 0,
+    HIP_TRY(c->ops->ks_digit(c->stream, c->mode, c->dp, c->k, w.res_a, power, 1, w.dig));
+    HIP_TRY(c->ops->ks_mac_intt(c->stream, c->mode, c->dp, c->k, w.dig, key, 1, w.prod));
+    HIP_TRY(launch_ks_combine(c->stream, c->dp, c->N, c->k, w.res_a, w.prod, galois_inverse(power, c->N), 1, 0,
                               false, w.res_b));
-    } else {
-      HIP_TRY(c->ops->ks_digit(c->stream, c->mode, c->dp, c->k, w.res_a, power, 1, w.dig));
-      HIP_TRY(c->ops->ks_mac_intt(c->stream, c->mode, c->dp, c->k, w.dig, key, 1, w.prod));
-      HIP_TRY(launch_ks_combine(c->stream, c->dp, c->N, c->k, w.res_a, w.prod, galois_inverse(power, c->N), 1, 0,
-                                false, w.res_b));
-    }
     HIP_TRY(hipMemcpyAsync(ct, w.res_b, c->ctw * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PIRGPU_OK;

@@ -26,11 +26,6 @@ struct NttOps {
                             const uint64_t* src, const uint64_t* sv, uint64_t* part, uint32_t n_rows,
                             uint32_t n_dim, uint32_t n_children_total, uint32_t sv_first, uint32_t C,
                             uint32_t chunk_len, uint32_t n_chunks);
-  // whole expansion level in one kernel (N <= 4096, k <= 2 only; see ks_node_kernel)
-  hipError_t (*ks_node)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* res_in,
-                        const uint64_t* key, uint32_t galois_elt, uint32_t galois_inv, uint32_t nodes,
-                        uint32_t shift_pow, bool expand_step, uint64_t* res_out);
-  bool has_ks_node;
 };
 
 const NttOps* ntt_ops_for(uint32_t N);  // nullptr for unsupported degrees

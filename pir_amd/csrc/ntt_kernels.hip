@@ -222,153 +222,6 @@ ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
   for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
 }
 
-// One level of the expansion tree in ONE kernel, for rings up to N = 4096 with k <= 2 data
-// primes (BASELINE configs 1-3): the whole key switch of a node stays inside a CU.
-//
-// grid = (nodes, k): workgroup (n, j) produces residue j of both output ciphertexts of node n.
-// It is four sub-blocks of N/16 threads, each with its own padded LDS region (4 x 34 KiB =
-// 136 KiB of the CU's 160 KiB at N = 4096), indexed s = (Isel, r):
-//   Isel in {data modulus j, special prime p}  -- the two key-level moduli residue j needs,
-//   r    = RNS digit J while transforming forward, = ciphertext component c afterwards.
-//  1. (Isel, J): sigma_g(c1)_J mod m_Isel -> forward NTT (4 transforms run concurrently);
-//  2. products with the key K[J][c][Isel]; the two digits of one Isel swap the partial product
-//     they do not own through LDS, so (Isel, c) ends with S[c][Isel] = sum_J dig_J (.) K[J][c][Isel];
-//  3. (Isel, c): inverse NTT of S[c][Isel];
-//  4. (j, c) reads the special-prime polynomial of its component from LDS, divides and rounds by
-//     p, adds sigma_g(c0) (c = 0) and applies the tree butterfly
-//     lo = a + g, hi = x^-2^j (a - g) straight into the next level's buffers.
-// No intermediate (digits, key products) ever reaches HBM: per node the kernel reads the input
-// ciphertext and writes the two outputs.  The special-prime chain is computed by both j
-// workgroups (+33 % arithmetic) in exchange for ~3x less memory traffic and one launch per
-// level instead of three.  Same arithmetic, same canonical residues as the three-kernel path.
-template <int MODE>
-__global__ void __launch_bounds__(4 * NT)
-ks_node_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ res_in,
-               const uint64_t* __restrict__ key_raw, uint32_t galois_elt, uint32_t galois_inv, uint32_t nodes,
-               uint32_t shift_pow, int expand_step, uint64_t* __restrict__ res_out) {
-  using A = Arith<MODE>;
-  using T = typename A::T;
-  constexpr int RW = Plan<LOGN>::LDS_WORDS;  // words per LDS region
-  uint64_t* lds = reinterpret_cast<uint64_t*>(smem_raw);
-  const uint32_t k = P->k, km = k + 1;
-  const uint32_t sub = threadIdx.x / NT, tid = threadIdx.x % NT;
-  const uint32_t isel = sub >> 1, r = sub & 1;  // isel: 0 = data modulus j, 1 = special prime
-  const uint32_t node = blockIdx.x, j = blockIdx.y;
-  const uint32_t I = isel ? k : j;              // key-level modulus index of this sub-block
-  const uint32_t J = k == 2 ? r : 0;            // digit transformed by this sub-block
-  const ModConst mI = P->mod[I];
-  const typename A::Mod m = A::mod(P, I);
-  uint64_t* my = lds + (size_t)sub * RW;
-  uint64_t* partner = lds + (size_t)(sub ^ 1) * RW;
-  const uint64_t* a_ct = res_in + (size_t)node * 2 * k * N;
-
-  // ---- 1. sigma_g(c1)_J mod m_I, forward NTT
-  {
-    const uint64_t qJ = P->mod[J].q;
-    const uint64_t* src = a_ct + ((size_t)k + J) * N;  // poly 1, residue J
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const uint32_t i = e * NT + tid;
-      const uint32_t raw = i * galois_elt;
-      uint64_t v = src[i];
-      if ((raw >> LOGN) & 1) v = neg_mod(v, qJ);
-      my[lds_idx(raw & (N - 1))] = reduce64(v, mI);
-    }
-  }
-  __syncthreads();
-  T x[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) x[e] = A::in(my[lds_idx(e * NT + tid)], m);
-  __syncthreads();
-  ntt_forward<MODE, LOGN>(x, my, P, I, tid);
-
-  // ---- 2. key products; component r is owned here, the other one goes to the partner (k == 2)
-  const T* key = reinterpret_cast<const T*>(key_raw);
-  T own[16];
-  {
-    const T* k_own = key + (((size_t)J * 2 + r) * km + I) * N;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      if constexpr (MODE == kNttInt)
-        own[e] = mul_mod(x[e], k_own[e * NT + tid], mI);
-      else
-        own[e] = f64_mulmod(x[e], k_own[e * NT + tid], m);
-    }
-  }
-  __syncthreads();  // every thread of the sub-block has left the forward transform's LDS reads
-  if (k == 2) {
-    T* mine_t = reinterpret_cast<T*>(my);
-    const T* k_oth = key + (((size_t)J * 2 + (r ^ 1)) * km + I) * N;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      T v;
-      if constexpr (MODE == kNttInt)
-        v = mul_mod(x[e], k_oth[e * NT + tid], mI);
-      else
-        v = f64_mulmod(x[e], k_oth[e * NT + tid], m);
-      mine_t[e * NT + tid] = v;
-    }
-  }
-  __syncthreads();
-  if (k == 2) {
-    const T* theirs = reinterpret_cast<const T*>(partner);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      if constexpr (MODE == kNttInt)
-        own[e] = add_mod(own[e], theirs[e * NT + tid], mI.q);
-      else
-        own[e] = f64_norm(own[e] + theirs[e * NT + tid], m);
-    }
-  }
-  __syncthreads();  // partner regions are free again
-
-  // ---- 3. inverse NTT of S[c = r][I]
-  ntt_inverse<MODE, LOGN>(own, my, P, I, tid);
-  uint64_t y[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) y[e] = A::out(own[e], m);
-
-  // ---- 4. special-prime polynomial of component c to LDS, then mod-down + butterfly on the data side
-  __syncthreads();
-  if (isel) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) my[e * NT + tid] = y[e];
-  }
-  __syncthreads();
-  if (!isel) {
-    const uint32_t c = r;
-    const uint64_t* special = lds + (size_t)(2 + c) * RW;
-    const ModConst mj = P->mod[j];
-    const uint64_t q = mj.q, pq = P->mod[k].q;
-    uint64_t* lo = res_out + (size_t)node * 2 * k * N;
-    uint64_t* hi = res_out + ((size_t)node + nodes) * 2 * k * N;
-    const size_t off = ((size_t)c * k + j) * N;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const uint32_t i = e * NT + tid;
-      const uint64_t rs = add_mod(special[i], P->p_half, pq);
-      const uint64_t delta = sub_mod(reduce64(rs, mj), P->p_half_mod[j], q);
-      uint64_t g = mul_shoup(sub_mod(y[e], delta, q), P->p_inv[j], P->p_inv_s[j], q);
-      if (c == 0) {  // + sigma_g(c0)[i]
-        const uint32_t raw = (i * galois_inv) & (2 * N - 1);
-        uint64_t c0 = a_ct[(size_t)j * N + (raw & (N - 1))];
-        if (raw >= (uint32_t)N) c0 = neg_mod(c0, q);
-        g = add_mod(g, c0, q);
-      }
-      if (!expand_step) {
-        lo[off + i] = g;
-      } else {
-        const uint64_t a = a_ct[off + i];
-        lo[off + i] = add_mod(a, g, q);
-        uint64_t d = sub_mod(a, g, q);
-        const uint32_t sraw = i + (2 * N - shift_pow);
-        if (sraw & N) d = neg_mod(d, q);
-        hi[off + (sraw & (N - 1))] = d;
-      }
-    }
-  }
-}
-
 // Upper recursion level, fused: for output slot (row r, source ciphertext cc, Encode chunk
 // e_idx, target residue jt) and a chunk of the row's children,
 //   part[chunk][r][cc*E+e_idx][p][jt] = sum_{ii in chunk} sv[sv_first+ii][p][jt] (.)
@@ -495,11 +348,6 @@ static hipError_t configure_mode() {
   PIRGPU_SET(ks_mac_intt_kernel<MODE>);
   PIRGPU_SET(upper_fused_kernel<MODE>);
 #undef PIRGPU_SET
-  if constexpr (LOGN <= 12) {  // fused expansion level: four LDS regions
-    if ((e = hipFuncSetAttribute((const void*)ks_node_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 4 * bytes)))
-      return e;
-  }
   return hipSuccess;
 }
 
@@ -549,20 +397,6 @@ static hipError_t op_ks_mac_intt(hipStream_t st, int mode, const DevParams* P, u
   return hipGetLastError();
 }
 
-static hipError_t op_ks_node(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* res_in,
-                             const uint64_t* key, uint32_t galois_elt, uint32_t galois_inv, uint32_t nodes,
-                             uint32_t shift_pow, bool expand_step, uint64_t* res_out) {
-  if constexpr (LOGN <= 12) {
-    if (k > 2) return hipErrorInvalidValue;
-    PIRGPU_BY_MODE(mode, hipLaunchKernelGGL(ks_node_kernel<MODE>, dim3(nodes, k), dim3(4 * NT), 4 * kLdsBytes, st, P,
-                                            res_in, key, galois_elt, galois_inv, nodes, shift_pow,
-                                            expand_step ? 1 : 0, res_out));
-    return hipGetLastError();
-  } else {
-    return hipErrorInvalidValue;
-  }
-}
-
 static hipError_t op_upper_fused(hipStream_t st, int mode, const DevParams* P, uint32_t k, uint32_t enc_count,
                                  const uint64_t* src, const uint64_t* sv, uint64_t* part, uint32_t n_rows,
                                  uint32_t n_dim, uint32_t n_children_total, uint32_t sv_first, uint32_t C,
@@ -579,7 +413,7 @@ static hipError_t op_upper_fused(hipStream_t st, int mode, const DevParams* P, u
 const NttOps* PIRGPU_OPS_NAME() {
   using namespace PIRGPU_DEG_NS;
   static const NttOps ops = {op_configure, op_ntt_batch,   op_ct_ntt_fwd_oop, op_db_encode,
-                             op_ks_digit,  op_ks_mac_intt, op_upper_fused,    op_ks_node, LOGN <= 12};
+                             op_ks_digit,  op_ks_mac_intt, op_upper_fused};
   return &ops;
 }
 

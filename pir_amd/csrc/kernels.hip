@@ -439,7 +439,7 @@ scan_mq_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ db,
   const uint32_t ntiles = (cols + TCOLS - 1) / TCOLS;
   const uint32_t last_col = cols - 1;
   u64x2 st[PIECES];
-  static_assert(TCOLS == 4, "the database ring below assumes 4-column tiles");
+  static_assert(TCOLS % 4 == 0, "the 4-slot database ring below needs tiles of a multiple of 4 columns");
   u64x2 dbuf[4][ROWS_W];  // ring of 4 columns, prefetch distance 2 (static indices: t is unrolled)
 
   auto stage_load = [&](uint32_t t0) {
@@ -686,8 +686,6 @@ hipError_t launch_scan_mq(hipStream_t st, const DevParams* P, uint32_t N, uint32
 #define PIRGPU_MQ(RW, NQ_, T)                                                                   \
   return limb ? launch_scan_mq_variant<RW, NQ_, T, AccLimb>(st, P, kN, db, a, rows, cols)        \
               : launch_scan_mq_variant<RW, NQ_, T, AccWide>(st, P, kN, db, a, rows, cols)
-  if (nq == 1 && rows_per_wave == 4 && !limb && getenv("PIRGPU_SCAN_OCC3"))  // experiment: 3 workgroups per CU
-    return launch_scan_mq_variant<4, 1, 4, AccWide, 3>(st, P, kN, db, a, rows, cols);
   if (nq == 1 && rows_per_wave == 4) { PIRGPU_MQ(4, 1, 4); }
   if (nq == 1 && rows_per_wave == 2) { PIRGPU_MQ(2, 1, 4); }
   if (nq == 2 && rows_per_wave == 2) { PIRGPU_MQ(2, 2, 4); }

@@ -139,37 +139,60 @@ __device__ __forceinline__ void lds_load16(const T* s, T (&x)[16], uint32_t tid)
   for (int e = 0; e < 16; ++e) x[e] = s[lds_idx(base | ((uint32_t)e << LB))];
 }
 
-// Cooley-Tukey stages on window LB for relative bits RHI..RLO (high to low).
+// The 15 twiddles of one 4-stage pass, in the order the stages consume them: relative bit rb
+// (3..0) owns slots (8 >> rb) - 1 ... ; loaded one pass AHEAD of their use so that their L2
+// latency hides under the previous pass's butterflies and LDS exchange.
 template <typename A, int LOGN, int LB, int RHI, int RLO>
-__device__ __forceinline__ void fwd_stages(typename A::T (&x)[16], const typename A::TW* __restrict__ tw,
-                                           uint32_t outer, const typename A::Mod& m) {
+__device__ __forceinline__ void load_twiddles(typename A::TW (&W)[15], const typename A::TW* __restrict__ tw,
+                                              uint32_t outer) {
 #pragma unroll
   for (int rb = RHI; rb >= RLO; --rb) {
     const uint32_t mm = 1u << (LOGN - 1 - (LB + rb));
 #pragma unroll
+    for (int g = 0; g < (8 >> rb); ++g) W[(8 >> rb) - 1 + g] = tw[mm + (outer << (3 - rb)) + g];
+  }
+}
+
+// Cooley-Tukey stages on window LB for relative bits RHI..RLO (high to low).
+template <typename A, int RHI, int RLO>
+__device__ __forceinline__ void fwd_stages(typename A::T (&x)[16], const typename A::TW (&W)[15],
+                                           const typename A::Mod& m) {
+#pragma unroll
+  for (int rb = RHI; rb >= RLO; --rb) {
+#pragma unroll
     for (int g = 0; g < (8 >> rb); ++g) {
-      const typename A::TW W = tw[mm + (outer << (3 - rb)) + g];
 #pragma unroll
       for (int l = 0; l < (1 << rb); ++l) {
         const int e0 = (g << (rb + 1)) | l, e1 = e0 | (1 << rb);
-        A::fwd(x[e0], x[e1], W, m);
+        A::fwd(x[e0], x[e1], W[(8 >> rb) - 1 + g], m);
       }
     }
   }
 }
 
-template <typename A, int LOGN, int LB>
-__device__ __forceinline__ void fwd_continue(typename A::T (&x)[16], typename A::T* s,
-                                             const typename A::TW* __restrict__ tw, const typename A::Mod& m,
-                                             uint32_t tid) {
+// Runs the pass whose twiddles are in Wcur on window LB (relative bits RHI..0), then the rest.
+// PF: load the next pass's twiddles before this pass's butterflies (hides their L2 latency, costs
+// 30-60 registers); without PF they are loaded at the start of their own pass.
+template <typename A, int LOGN, int LB, int RHI, bool PF>
+__device__ __forceinline__ void fwd_chain(typename A::T (&x)[16], typename A::T* s,
+                                          const typename A::TW* __restrict__ tw, const typename A::Mod& m,
+                                          uint32_t tid, const typename A::TW (&Wcur)[15]) {
   if constexpr (LB > 0) {
     constexpr int NLB = LB >= 4 ? LB - 4 : 0;
-    constexpr int RHI = LB >= 4 ? 3 : LB - 1;
+    constexpr int NRHI = LB >= 4 ? 3 : LB - 1;
+    typename A::TW Wnext[15];
+    if constexpr (PF) {
+      load_twiddles<A, LOGN, NLB, NRHI, 0>(Wnext, tw, tid >> NLB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    fwd_stages<A, RHI, 0>(x, Wcur, m);
     lds_store16<LB>(s, x, tid);
     __syncthreads();
+    if constexpr (!PF) load_twiddles<A, LOGN, NLB, NRHI, 0>(Wnext, tw, tid >> NLB);
     lds_load16<NLB>(s, x, tid);
-    fwd_stages<A, LOGN, NLB, RHI, 0>(x, tw, tid >> NLB, m);
-    fwd_continue<A, LOGN, NLB>(x, s, tw, m, tid);
+    fwd_chain<A, LOGN, NLB, NRHI, PF>(x, s, tw, m, tid, Wnext);
+  } else {
+    fwd_stages<A, RHI, 0>(x, Wcur, m);
   }
 }
 
@@ -177,65 +200,76 @@ __device__ __forceinline__ void fwd_continue(typename A::T (&x)[16], typename A:
 // Out: x[e] = SEAL NTT position 16*tid + e == device-order slot e*NT + tid, canonical
 // representative (A::out gives the residue).  The caller guarantees nobody still reads
 // `s` (barrier) when this is entered.
-template <int MODE, int LOGN>
+template <int MODE, int LOGN, bool PF = true>
 __device__ __forceinline__ void ntt_forward(typename Arith<MODE>::T (&x)[16], void* lds, const DevParams* P, int mi,
                                             uint32_t tid) {
   using A = Arith<MODE>;
   typename A::T* s = reinterpret_cast<typename A::T*>(lds);
   const typename A::Mod m = A::mod(P, mi);
   const typename A::TW* tw = A::tw(P, mi);
-  fwd_stages<A, LOGN, LOGN - 4, 3, 0>(x, tw, 0u, m);
-  fwd_continue<A, LOGN, LOGN - 4>(x, s, tw, m, tid);
+  typename A::TW W0[15];
+  load_twiddles<A, LOGN, LOGN - 4, 3, 0>(W0, tw, 0u);
+  fwd_chain<A, LOGN, LOGN - 4, 3, PF>(x, s, tw, m, tid, W0);
 #pragma unroll
   for (int e = 0; e < 16; ++e) x[e] = A::canon_fwd(x[e], m);
 }
 
-// Gentleman-Sande stages on window LB for relative bits RLO..RHI (low to high); with
-// LAST the final stage multiplies by N^-1 (folded into both outputs).
-template <typename A, int LOGN, int LB, int RLO, int RHI, bool LAST>
-__device__ __forceinline__ void inv_stages(typename A::T (&x)[16], const typename A::TW* __restrict__ itw,
-                                           const typename A::TW& ninv, const typename A::TW& iw1n, uint32_t outer,
+// Gentleman-Sande stages for relative bits RLO..3 (low to high) with preloaded twiddles; with
+// LAST the final stage multiplies by N^-1 (folded into both outputs, its own twiddle unused).
+template <typename A, int RLO, bool LAST>
+__device__ __forceinline__ void inv_stages(typename A::T (&x)[16], const typename A::TW (&W)[15],
+                                           const typename A::TW& ninv, const typename A::TW& iw1n,
                                            const typename A::Mod& m) {
 #pragma unroll
-  for (int rb = RLO; rb <= RHI; ++rb) {
-    const uint32_t h = 1u << (LOGN - 1 - (LB + rb));
-    if (LAST && rb == RHI) {
+  for (int rb = RLO; rb <= 3; ++rb) {
+    if (LAST && rb == 3) {
 #pragma unroll
       for (int l = 0; l < 8; ++l) A::inv_last(x[l], x[l | 8], ninv, iw1n, m);
     } else {
 #pragma unroll
       for (int g = 0; g < (8 >> rb); ++g) {
-        const typename A::TW W = itw[h + (outer << (3 - rb)) + g];
 #pragma unroll
         for (int l = 0; l < (1 << rb); ++l) {
           const int e0 = (g << (rb + 1)) | l, e1 = e0 | (1 << rb);
-          A::inv(x[e0], x[e1], W, m);
+          A::inv(x[e0], x[e1], W[(8 >> rb) - 1 + g], m);
         }
       }
     }
   }
 }
 
-template <typename A, int LOGN, int D, int PREV>  // D = index bits done; registers hold window PREV
-__device__ __forceinline__ void inv_continue(typename A::T (&x)[16], typename A::T* s,
-                                             const typename A::TW* __restrict__ itw, const typename A::TW& ninv,
-                                             const typename A::TW& iw1n, const typename A::Mod& m, uint32_t tid) {
-  if constexpr (D < LOGN) {
-    constexpr int LB = (LOGN - D >= 4) ? D : LOGN - 4;
-    constexpr int RLO = D - LB;
-    constexpr bool LAST = (LB + 4 == LOGN);
-    lds_store16<PREV>(s, x, tid);
+// Runs the pass on window LB (relative bits RLO..3) whose twiddles are in Wcur; D = index bits
+// done once this pass completes.
+template <typename A, int LOGN, int LB, int RLO, bool PF>
+__device__ __forceinline__ void inv_chain(typename A::T (&x)[16], typename A::T* s,
+                                          const typename A::TW* __restrict__ itw, const typename A::TW& ninv,
+                                          const typename A::TW& iw1n, const typename A::Mod& m, uint32_t tid,
+                                          const typename A::TW (&Wcur)[15]) {
+  constexpr int D = LB + 4;
+  constexpr bool LAST = (D == LOGN);
+  if constexpr (!LAST) {
+    constexpr int NLB = (LOGN - D >= 4) ? D : LOGN - 4;
+    constexpr int NRLO = D - NLB;
+    typename A::TW Wnext[15];
+    if constexpr (PF) {  // one pass ahead
+      load_twiddles<A, LOGN, NLB, 3, NRLO>(Wnext, itw, tid >> NLB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    inv_stages<A, RLO, false>(x, Wcur, ninv, iw1n, m);
+    lds_store16<LB>(s, x, tid);
     __syncthreads();
-    lds_load16<LB>(s, x, tid);
-    inv_stages<A, LOGN, LB, RLO, 3, LAST>(x, itw, ninv, iw1n, tid >> LB, m);
-    inv_continue<A, LOGN, LB + 4, LB>(x, s, itw, ninv, iw1n, m, tid);
+    if constexpr (!PF) load_twiddles<A, LOGN, NLB, 3, NRLO>(Wnext, itw, tid >> NLB);
+    lds_load16<NLB>(s, x, tid);
+    inv_chain<A, LOGN, NLB, NRLO, PF>(x, s, itw, ninv, iw1n, m, tid, Wnext);
+  } else {
+    inv_stages<A, RLO, true>(x, Wcur, ninv, iw1n, m);
   }
 }
 
 // Inverse NTT.  In: x[e] = NTT position 16*tid + e (any representative the flavour
 // accepts: < 2q for integers, |v| <= 4q for fp64).  Out: x[e] = coefficient e*NT + tid,
 // canonical, scaled by N^-1.
-template <int MODE, int LOGN>
+template <int MODE, int LOGN, bool PF = true>
 __device__ __forceinline__ void ntt_inverse(typename Arith<MODE>::T (&x)[16], void* lds, const DevParams* P, int mi,
                                             uint32_t tid) {
   static_assert(LOGN >= 8, "at least two passes expected");
@@ -244,8 +278,9 @@ __device__ __forceinline__ void ntt_inverse(typename Arith<MODE>::T (&x)[16], vo
   const typename A::Mod m = A::mod(P, mi);
   const typename A::TW* itw = A::itw(P, mi);
   const typename A::TW ninv = A::ninv(P, mi), iw1n = A::iw1n(P, mi);
-  inv_stages<A, LOGN, 0, 0, 3, false>(x, itw, ninv, iw1n, tid, m);
-  inv_continue<A, LOGN, 4, 0>(x, s, itw, ninv, iw1n, m, tid);
+  typename A::TW W0[15];
+  load_twiddles<A, LOGN, 0, 3, 0>(W0, itw, tid);
+  inv_chain<A, LOGN, 0, 0, PF>(x, s, itw, ninv, iw1n, m, tid, W0);
 #pragma unroll
   for (int e = 0; e < 16; ++e) x[e] = A::canon_inv(x[e], m);
 }

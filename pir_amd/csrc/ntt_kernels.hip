@@ -277,7 +277,7 @@ upper_fused_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
       x[e] = A::in(rr, m);
     }
     __syncthreads();  // previous iteration's transform may still be reading LDS
-    ntt_forward<MODE, LOGN>(x, smem_raw, P, jt, tid);
+    ntt_forward<MODE, LOGN, false>(x, smem_raw, P, jt, tid);  // no twiddle prefetch: accumulators need the registers
     const uint64_t* s0 = sv + (((size_t)(sv_first + ii) * 2 + 0) * k + jt) * N;
     const uint64_t* s1 = sv + (((size_t)(sv_first + ii) * 2 + 1) * k + jt) * N;
     if constexpr (MODE == kNttInt) {

@@ -33,6 +33,10 @@ struct Plan {
 
 __device__ __forceinline__ uint32_t lds_idx(uint32_t i) { return i + (i >> 4); }
 
+// Twiddle tables are reached through pointers stored in DevParams; typing them as global
+// (address space 1) makes hipcc emit global_load instead of flat_load for them.
+#define PIRGPU_GLOBAL __attribute__((address_space(1)))
+
 // ------------------------------------------------------------------ arithmetic policies
 
 template <int MODE>
@@ -49,8 +53,10 @@ struct Arith<kNttInt> {
     const uint64_t q = P->mod[mi].q;
     return Mod{q, q << 1};
   }
-  static __device__ __forceinline__ const TW* tw(const DevParams* P, int mi) { return P->tab[mi].tw; }
-  static __device__ __forceinline__ const TW* itw(const DevParams* P, int mi) { return P->tab[mi].itw; }
+  using TWPtr = const PIRGPU_GLOBAL TW*;
+  static __device__ __forceinline__ TW load_tw(TWPtr p, uint32_t i) { return TW{p[i].w, p[i].ws}; }
+  static __device__ __forceinline__ TWPtr tw(const DevParams* P, int mi) { return (TWPtr)P->tab[mi].tw; }
+  static __device__ __forceinline__ TWPtr itw(const DevParams* P, int mi) { return (TWPtr)P->tab[mi].itw; }
   static __device__ __forceinline__ TW ninv(const DevParams* P, int mi) { return P->tab[mi].ninv; }
   static __device__ __forceinline__ TW iw1n(const DevParams* P, int mi) { return P->tab[mi].iw1n; }
   // canonical residue < q  <->  register element
@@ -88,8 +94,10 @@ struct ArithF64 {
   static __device__ __forceinline__ Mod mod(const DevParams* P, int mi) {
     return Mod{P->tab[mi].qd, P->tab[mi].qinvd};
   }
-  static __device__ __forceinline__ const TW* tw(const DevParams* P, int mi) { return P->tab[mi].twf; }
-  static __device__ __forceinline__ const TW* itw(const DevParams* P, int mi) { return P->tab[mi].itwf; }
+  using TWPtr = const PIRGPU_GLOBAL TW*;
+  static __device__ __forceinline__ TW load_tw(TWPtr p, uint32_t i) { return p[i]; }
+  static __device__ __forceinline__ TWPtr tw(const DevParams* P, int mi) { return (TWPtr)P->tab[mi].twf; }
+  static __device__ __forceinline__ TWPtr itw(const DevParams* P, int mi) { return (TWPtr)P->tab[mi].itwf; }
   static __device__ __forceinline__ TW ninv(const DevParams* P, int mi) { return P->tab[mi].ninv_f; }
   static __device__ __forceinline__ TW iw1n(const DevParams* P, int mi) { return P->tab[mi].iw1n_f; }
   static __device__ __forceinline__ T in(uint64_t v, const Mod&) { return f64_from_u64(v); }
@@ -143,13 +151,13 @@ __device__ __forceinline__ void lds_load16(const T* s, T (&x)[16], uint32_t tid)
 // (3..0) owns slots (8 >> rb) - 1 ... ; loaded one pass AHEAD of their use so that their L2
 // latency hides under the previous pass's butterflies and LDS exchange.
 template <typename A, int LOGN, int LB, int RHI, int RLO>
-__device__ __forceinline__ void load_twiddles(typename A::TW (&W)[15], const typename A::TW* __restrict__ tw,
+__device__ __forceinline__ void load_twiddles(typename A::TW (&W)[15], typename A::TWPtr tw,
                                               uint32_t outer) {
 #pragma unroll
   for (int rb = RHI; rb >= RLO; --rb) {
     const uint32_t mm = 1u << (LOGN - 1 - (LB + rb));
 #pragma unroll
-    for (int g = 0; g < (8 >> rb); ++g) W[(8 >> rb) - 1 + g] = tw[mm + (outer << (3 - rb)) + g];
+    for (int g = 0; g < (8 >> rb); ++g) W[(8 >> rb) - 1 + g] = A::load_tw(tw, mm + (outer << (3 - rb)) + g);
   }
 }
 
@@ -175,7 +183,7 @@ __device__ __forceinline__ void fwd_stages(typename A::T (&x)[16], const typenam
 // 30-60 registers); without PF they are loaded at the start of their own pass.
 template <typename A, int LOGN, int LB, int RHI, bool PF>
 __device__ __forceinline__ void fwd_chain(typename A::T (&x)[16], typename A::T* s,
-                                          const typename A::TW* __restrict__ tw, const typename A::Mod& m,
+                                          typename A::TWPtr tw, const typename A::Mod& m,
                                           uint32_t tid, const typename A::TW (&Wcur)[15]) {
   if constexpr (LB > 0) {
     constexpr int NLB = LB >= 4 ? LB - 4 : 0;
@@ -206,7 +214,7 @@ __device__ __forceinline__ void ntt_forward(typename Arith<MODE>::T (&x)[16], vo
   using A = Arith<MODE>;
   typename A::T* s = reinterpret_cast<typename A::T*>(lds);
   const typename A::Mod m = A::mod(P, mi);
-  const typename A::TW* tw = A::tw(P, mi);
+  const typename A::TWPtr tw = A::tw(P, mi);
   typename A::TW W0[15];
   load_twiddles<A, LOGN, LOGN - 4, 3, 0>(W0, tw, 0u);
   fwd_chain<A, LOGN, LOGN - 4, 3, PF>(x, s, tw, m, tid, W0);
@@ -242,7 +250,7 @@ __device__ __forceinline__ void inv_stages(typename A::T (&x)[16], const typenam
 // done once this pass completes.
 template <typename A, int LOGN, int LB, int RLO, bool PF>
 __device__ __forceinline__ void inv_chain(typename A::T (&x)[16], typename A::T* s,
-                                          const typename A::TW* __restrict__ itw, const typename A::TW& ninv,
+                                          typename A::TWPtr itw, const typename A::TW& ninv,
                                           const typename A::TW& iw1n, const typename A::Mod& m, uint32_t tid,
                                           const typename A::TW (&Wcur)[15]) {
   constexpr int D = LB + 4;
@@ -276,7 +284,7 @@ __device__ __forceinline__ void ntt_inverse(typename Arith<MODE>::T (&x)[16], vo
   using A = Arith<MODE>;
   typename A::T* s = reinterpret_cast<typename A::T*>(lds);
   const typename A::Mod m = A::mod(P, mi);
-  const typename A::TW* itw = A::itw(P, mi);
+  const typename A::TWPtr itw = A::itw(P, mi);
   const typename A::TW ninv = A::ninv(P, mi), iw1n = A::iw1n(P, mi);
   typename A::TW W0[15];
   load_twiddles<A, LOGN, 0, 3, 0>(W0, itw, tid);

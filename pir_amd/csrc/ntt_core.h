@@ -84,6 +84,7 @@ struct Arith<kNttInt> {
     return v >= m.q ? v - m.q : v;
   }
   static __device__ __forceinline__ T canon_inv(T v, const Mod& m) { return v >= m.q ? v - m.q : v; }
+  static __device__ __forceinline__ T pass_norm(T v, const Mod&) { return v; }
 };
 
 template <int MODE>
@@ -109,12 +110,16 @@ struct ArithF64 {
     b = a - t;
     a = a + t;
   }
-  // inverse: the sum is renormalised every stage, so |values| <= 0.7 q throughout
+  // inverse: sums double per stage.  kNttF64 (q < 2^46) lets them grow through the 4 stages of a
+  // pass (|values| <= 16 q < 2^50, quotient estimates stay exact to < 0.1) and renormalises once
+  // per pass (pass_norm); kNttF64Wide renormalises every stage, |values| <= 0.7 q throughout.
+  static constexpr bool kNormPerPass = MODE == kNttF64;
   static __device__ __forceinline__ void inv(T& a, T& b, const TW& w, const Mod& m) {
     const T u = a + b, d = a - b;
-    a = f64_norm(u, m);
+    a = kNormPerPass ? u : f64_norm(u, m);
     b = f64_mulmod(d, w, m);
   }
+  static __device__ __forceinline__ T pass_norm(T v, const Mod& m) { return kNormPerPass ? f64_norm(v, m) : v; }
   static __device__ __forceinline__ void inv_last(T& a, T& b, const TW& ninv, const TW& iw1n, const Mod& m) {
     const T u = a + b, d = a - b;
     a = f64_mulmod(u, ninv, m);
@@ -264,6 +269,8 @@ __device__ __forceinline__ void inv_chain(typename A::T (&x)[16], typename A::T*
       __builtin_amdgcn_sched_barrier(0);
     }
     inv_stages<A, RLO, false>(x, Wcur, ninv, iw1n, m);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x[e] = A::pass_norm(x[e], m);
     lds_store16<LB>(s, x, tid);
     __syncthreads();
     if constexpr (!PF) load_twiddles<A, LOGN, NLB, 3, NRLO>(Wnext, itw, tid >> NLB);

@@ -439,8 +439,12 @@ scan_mq_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ db,
   const uint32_t ntiles = (cols + TCOLS - 1) / TCOLS;
   const uint32_t last_col = cols - 1;
   u64x2 st[PIECES];
-  static_assert(TCOLS % 4 == 0, "the 4-slot database ring below needs tiles of a multiple of 4 columns");
-  u64x2 dbuf[4][ROWS_W];  // ring of 4 columns, prefetch distance 2 (static indices: t is unrolled)
+  static_assert(TCOLS == 4, "the database ring below assumes 4-column tiles");
+  // ring of database columns with prefetch distance RING/2 (static indices: t is unrolled and the
+  // tile parity BUF is a template constant).  One row per wave needs the deeper ring to keep
+  // enough bytes in flight (4 x 1 KiB per wave).
+  constexpr int RING = ROWS_W == 1 ? 8 : 4, DIST = RING / 2;
+  u64x2 dbuf[RING][ROWS_W];
 
   auto stage_load = [&](uint32_t t0) {
 #pragma unroll
@@ -476,11 +480,11 @@ scan_mq_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ db,
     stage_load(t0 + TCOLS);
 #pragma unroll
     for (int t = 0; t < TCOLS; ++t) {
-      {  // database column t+2 -> ring slot (t+2)&3, two columns ahead of its use
-        const uint32_t col = t0 + t + 2 < last_col ? t0 + t + 2 : last_col;
+      {  // database column t+DIST -> its ring slot, DIST columns ahead of its use
+        const uint32_t col = t0 + t + DIST < last_col ? t0 + t + DIST : last_col;
 #pragma unroll
         for (int r = 0; r < ROWS_W; ++r)
-          dbuf[(t + 2) & 3][r] =
+          dbuf[(BUF * TCOLS + t + DIST) % RING][r] =
               __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(rp[r] + (size_t)col * kN));
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -496,8 +500,8 @@ scan_mq_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ db,
           sb.s[1][1] = s1.y;
 #pragma unroll
           for (int r = 0; r < ROWS_W; ++r) {
-            sb.d[r][0] = dbuf[t & 3][r].x;
-            sb.d[r][1] = dbuf[t & 3][r].y;
+            sb.d[r][0] = dbuf[(BUF * TCOLS + t) % RING][r].x;
+            sb.d[r][1] = dbuf[(BUF * TCOLS + t) % RING][r].y;
           }
           if constexpr (std::is_same<ACC, AccLimb>::value)
             scan_mac_presplit<ROWS_W>(acc[q], sb);
@@ -527,7 +531,7 @@ scan_mq_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ db,
 
   stage_load(0);
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
+  for (int t = 0; t < DIST; ++t) {
     const uint32_t col = (uint32_t)t < last_col ? (uint32_t)t : last_col;
 #pragma unroll
     for (int r = 0; r < ROWS_W; ++r)

@@ -303,9 +303,76 @@ static void load_galois_keys(pirgpu_ctx* ctx, const Shape& sh, const uint8_t* da
       memcpy(key.data() + (size_t)j * 2 * km * sh.N, tmp.data(), tmp.size() * 8);
       o.p = pk_end;
     }
-    int rc = pirgpu_set_galois_key(ctx, (uint32_t)(2 * index + 1), key.data());
-    if (rc) throw Err{rc, pirgpu_last_error(ctx)};
+    if (ctx) {  // ctx == nullptr: validation only (pirgpu_wire_validate_request)
+      int rc = pirgpu_set_galois_key(ctx, (uint32_t)(2 * index + 1), key.data());
+      if (rc) throw Err{rc, pirgpu_last_error(ctx)};
+    }
   }
+}
+
+static Shape make_shape(const pirgpu_params& prm) {
+  Shape sh;
+  sh.N = prm.poly_modulus_degree;
+  sh.k = prm.num_data_primes;
+  for (uint32_t i = 0; i < sh.k; ++i) sh.q[i] = prm.coeff_modulus[i];
+  sh.q[sh.k] = prm.special_prime;
+  sh.t = prm.plain_modulus;
+  parms_id(sh.N, sh.q, sh.k, sh.t, sh.data_id);
+  parms_id(sh.N, sh.q, sh.k + 1, sh.t, sh.key_id);
+  return sh;
+}
+
+struct ParsedRequest {
+  std::vector<std::pair<const uint8_t*, size_t>> queries;  // Ciphertexts sub-messages
+  const uint8_t* galois_keys = nullptr;
+  size_t galois_keys_len = 0;
+};
+
+// pir.Request (payload.proto:27-36)
+static ParsedRequest parse_request(const uint8_t* request, size_t request_len) {
+  ParsedRequest pr;
+  Reader r{request, request + request_len};
+  while (r.p < r.end) {
+    uint64_t tag;
+    if (!r.varint(tag)) throw Err{PIRGPU_INVALID_ARGUMENT, "malformed Request"};
+    const uint32_t field = (uint32_t)(tag >> 3), wt = (uint32_t)(tag & 7);
+    const uint8_t* d;
+    size_t l;
+    if (field == 1 && wt == 2) {
+      if (!r.bytes(d, l)) throw Err{PIRGPU_INVALID_ARGUMENT, "malformed Request.query"};
+      pr.queries.emplace_back(d, l);
+    } else if (field == 2 && wt == 2) {
+      if (!r.bytes(pr.galois_keys, pr.galois_keys_len))
+        throw Err{PIRGPU_INVALID_ARGUMENT, "malformed Request.galois_keys"};
+    } else if (!r.skip(wt)) {  // relin_keys (field 3) are only used by CT-multiplication mode
+      throw Err{PIRGPU_INVALID_ARGUMENT, "malformed Request"};
+    }
+  }
+  return pr;
+}
+
+// LoadCiphertexts (serialization.cpp:32-42) of one Ciphertexts message -> residues, count
+static uint32_t load_query(const Shape& sh, const uint8_t* data, size_t len, std::vector<uint64_t>& qbuf) {
+  Reader qr{data, data + len};
+  std::vector<uint64_t> one;
+  qbuf.clear();
+  uint32_t nq = 0;
+  while (qr.p < qr.end) {
+    uint64_t tag;
+    if (!qr.varint(tag)) throw Err{PIRGPU_INVALID_ARGUMENT, "malformed Ciphertexts"};
+    const uint8_t* d;
+    size_t l;
+    if ((tag >> 3) == 1 && (tag & 7) == 2) {
+      if (!qr.bytes(d, l)) throw Err{PIRGPU_INVALID_ARGUMENT, "malformed Ciphertexts.ct"};
+      Cursor c{d, d + l};
+      load_ciphertext(c, sh, false, one);
+      qbuf.insert(qbuf.end(), one.begin(), one.end());
+      ++nq;
+    } else if (!qr.skip((uint32_t)(tag & 7))) {
+      throw Err{PIRGPU_INVALID_ARGUMENT, "malformed Ciphertexts"};
+    }
+  }
+  return nq;
 }
 
 }  // namespace wire
@@ -323,6 +390,27 @@ void pirgpu_wire_blake2b(uint8_t* out, size_t outlen, const uint8_t* in, size_t 
   blake2b(out, outlen, in, inlen);
 }
 
+// Parses and validates a serialized pir.Request against `params` exactly as pirgpu_process_request
+// does (framing, SEAL headers, parms_id, shapes, coefficient ranges) without touching a device:
+// 0 if it would be accepted, else the status code it would fail with.  *n_queries = number of queries.
+int pirgpu_wire_validate_request(const pirgpu_params* params, const uint8_t* request, size_t request_len,
+                                 uint32_t* n_queries) {
+  if (!params || (!request && request_len)) return PIRGPU_INVALID_ARGUMENT;
+  try {
+    const Shape sh = make_shape(*params);
+    ParsedRequest pr = parse_request(request, request_len);
+    load_galois_keys(nullptr, sh, pr.galois_keys, pr.galois_keys_len);
+    std::vector<uint64_t> qbuf;
+    for (auto& qm : pr.queries) (void)load_query(sh, qm.first, qm.second, qbuf);
+    if (n_queries) *n_queries = (uint32_t)pr.queries.size();
+    return PIRGPU_OK;
+  } catch (const Err& e) {
+    return e.code;
+  } catch (const std::exception&) {
+    return PIRGPU_INTERNAL;
+  }
+}
+
 int pirgpu_process_request(pirgpu_ctx* ctx, const uint8_t* request, size_t request_len, uint8_t** response,
                            size_t* response_len) {
   if (!ctx || (!request && request_len) || !response || !response_len) return PIRGPU_INVALID_ARGUMENT;
@@ -330,69 +418,26 @@ int pirgpu_process_request(pirgpu_ctx* ctx, const uint8_t* request, size_t reque
   *response_len = 0;
   pirgpu_params prm;
   if (pirgpu_get_params(ctx, &prm)) return PIRGPU_INVALID_ARGUMENT;
-  Shape sh;
-  sh.N = prm.poly_modulus_degree;
-  sh.k = prm.num_data_primes;
-  for (uint32_t i = 0; i < sh.k; ++i) sh.q[i] = prm.coeff_modulus[i];
-  sh.q[sh.k] = prm.special_prime;
-  sh.t = prm.plain_modulus;
-  parms_id(sh.N, sh.q, sh.k, sh.t, sh.data_id);
-  parms_id(sh.N, sh.q, sh.k + 1, sh.t, sh.key_id);
+  const Shape sh = make_shape(prm);
   const size_t ctw = (size_t)2 * sh.k * sh.N;
   try {
-    // --- parse pir.Request (payload.proto:27-36)
-    std::vector<std::pair<const uint8_t*, size_t>> queries;
-    const uint8_t* gk = nullptr;
-    size_t gk_len = 0;
-    Reader r{request, request + request_len};
-    while (r.p < r.end) {
-      uint64_t tag;
-      if (!r.varint(tag)) throw Err{PIRGPU_INVALID_ARGUMENT, "malformed Request"};
-      const uint32_t field = (uint32_t)(tag >> 3), wt = (uint32_t)(tag & 7);
-      const uint8_t* d;
-      size_t l;
-      if (field == 1 && wt == 2) {
-        if (!r.bytes(d, l)) throw Err{PIRGPU_INVALID_ARGUMENT, "malformed Request.query"};
-        queries.emplace_back(d, l);
-      } else if (field == 2 && wt == 2) {
-        if (!r.bytes(gk, gk_len)) throw Err{PIRGPU_INVALID_ARGUMENT, "malformed Request.galois_keys"};
-      } else if (!r.skip(wt)) {  // relin_keys (field 3) are only used by CT-multiplication mode
-        throw Err{PIRGPU_INVALID_ARGUMENT, "malformed Request"};
-      }
-    }
+    ParsedRequest pr = parse_request(request, request_len);
     // --- SEALDeserialize<GaloisKeys> (server.cpp:46-48): empty bytes -> load throws -> InvalidArgument.
     // The reference re-parses the keys on every request; here a client that repeats its (multi-MB)
     // key blob byte for byte keeps the device-resident keys of its previous request.
     int rc = 0;
-    if (!gk_len || !pirgpu_keys_blob_matches(ctx, gk, gk_len)) {
+    if (!pr.galois_keys_len || !pirgpu_keys_blob_matches(ctx, pr.galois_keys, pr.galois_keys_len)) {
       rc = pirgpu_clear_galois_keys(ctx);
       if (rc) throw Err{rc, pirgpu_last_error(ctx)};
-      load_galois_keys(ctx, sh, gk, gk_len);
-      pirgpu_keys_blob_set(ctx, gk, gk_len);
+      load_galois_keys(ctx, sh, pr.galois_keys, pr.galois_keys_len);
+      pirgpu_keys_blob_set(ctx, pr.galois_keys, pr.galois_keys_len);
     }
     // --- per query: LoadCiphertexts -> processQuery -> SaveCiphertexts (server.cpp:60-63,173-195)
     const uint64_t n_reply = pirgpu_reply_ct_count(ctx);
-    std::vector<uint64_t> reply(n_reply * ctw), qbuf, one;
+    std::vector<uint64_t> reply(n_reply * ctw), qbuf;
     std::string out;
-    for (auto& qm : queries) {
-      Reader qr{qm.first, qm.first + qm.second};
-      qbuf.clear();
-      uint32_t nq = 0;
-      while (qr.p < qr.end) {
-        uint64_t tag;
-        if (!qr.varint(tag)) throw Err{PIRGPU_INVALID_ARGUMENT, "malformed Ciphertexts"};
-        const uint8_t* d;
-        size_t l;
-        if ((tag >> 3) == 1 && (tag & 7) == 2) {
-          if (!qr.bytes(d, l)) throw Err{PIRGPU_INVALID_ARGUMENT, "malformed Ciphertexts.ct"};
-          Cursor c{d, d + l};
-          load_ciphertext(c, sh, false, one);
-          qbuf.insert(qbuf.end(), one.begin(), one.end());
-          ++nq;
-        } else if (!qr.skip((uint32_t)(tag & 7))) {
-          throw Err{PIRGPU_INVALID_ARGUMENT, "malformed Ciphertexts"};
-        }
-      }
+    for (auto& qm : pr.queries) {
+      const uint32_t nq = load_query(sh, qm.first, qm.second, qbuf);
       uint64_t got = 0;
       rc = pirgpu_process_query(ctx, qbuf.data(), nq, reply.data(), n_reply, &got);
       if (rc) throw Err{rc, pirgpu_last_error(ctx)};

@@ -9,6 +9,10 @@ extern "C" {
 #endif
 void pirgpu_wire_parms_id(uint32_t N, const uint64_t* moduli, size_t n_moduli, uint64_t t, uint64_t out[4]);
 void pirgpu_wire_blake2b(uint8_t* out, size_t outlen, const uint8_t* in, size_t inlen);
+// Device-free validation of a serialized pir.Request (same checks as pirgpu_process_request).
+struct pirgpu_params;
+int pirgpu_wire_validate_request(const struct pirgpu_params* params, const uint8_t* request, size_t request_len,
+                                 uint32_t* n_queries);
 // Device-resident Galois key cache: the serialized key blob the installed keys came from
 // (forgotten by pirgpu_set_galois_key / pirgpu_clear_galois_keys); compared byte for byte.
 struct pirgpu_ctx;

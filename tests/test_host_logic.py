@@ -111,3 +111,57 @@ def test_wire_blake2b_and_parms_id_match_hashlib():
         out = (C.c_uint64 * 4)()
         lib.pirgpu_wire_parms_id(4096, (C.c_uint64 * len(mods))(*mods), len(mods), 0xFFC001, out)
         assert bytes(out) == parms_id(4096, mods, 0xFFC001)
+
+
+def _wire_fixture():
+    """A valid serialized pir.Request (N=2048 golden vector: small) and its pirgpu_params."""
+    import seal_wire as W
+    z = np.load(os.path.join(ROOT, "tests", "golden", "cfg1_n2048.npz"))
+    N, moduli, t = int(z["N"]), [int(x) for x in z["moduli"]], int(z["t"])
+    keys = {int(g): z["galois_keys"][i] for i, g in enumerate(z["galois_elts"])}
+    gk = W.save_galois_keys(keys, N, W.parms_id(N, moduli, t))
+    req = W.save_request([z["query"]], gk, W.parms_id(N, moduli[:-1], t))
+    p = capi.Params()
+    p.poly_modulus_degree, p.num_data_primes = N, len(moduli) - 1
+    p.coeff_modulus[0], p.special_prime, p.plain_modulus = moduli[0], moduli[1], t
+    p.num_dimensions, p.num_pt = 1, 10
+    p.dimensions[0] = 10
+    return req, p
+
+
+def _validate(lib, p, data):
+    n = C.c_uint32(0)
+    buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data if data else b"\0")
+    return lib.pirgpu_wire_validate_request(C.byref(p), buf, len(data), C.byref(n)), n.value
+
+
+def test_wire_request_validation_and_fuzz():
+    """The server parses untrusted client bytes: a valid Request validates, and truncations, bit flips and
+    spliced garbage are rejected with a status code (never a crash, never accepted when structurally broken)."""
+    lib = capi.load()
+    lib.pirgpu_wire_validate_request.argtypes = [C.POINTER(capi.Params), C.POINTER(C.c_uint8), C.c_size_t,
+                                                 C.POINTER(C.c_uint32)]
+    lib.pirgpu_wire_validate_request.restype = C.c_int
+    req, p = _wire_fixture()
+    assert _validate(lib, p, req) == (0, 1)
+    assert _validate(lib, p, b"")[0] == 3                       # no galois keys -> InvalidArgument
+    rng = np.random.default_rng(11)
+    allowed = {0, 3, 12}
+    for cut in [1, 2, 7, 16, 17, 48, 100, 1000, len(req) // 2, len(req) - 9, len(req) - 1]:
+        rc, _ = _validate(lib, p, req[:cut])
+        assert rc in (3, 12), cut                               # truncated objects never validate
+    data = bytearray(req)
+    for _ in range(300):
+        m = bytearray(data)
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(0, len(m)))
+            m[pos] ^= 1 << int(rng.integers(0, 8))
+        rc, _ = _validate(lib, p, bytes(m))
+        assert rc in allowed
+    for _ in range(50):                                         # random garbage of assorted lengths
+        g = rng.integers(0, 256, int(rng.integers(1, 4096)), dtype=np.uint8).tobytes()
+        assert _validate(lib, p, g)[0] in allowed
+    # wrong parameters (different plain modulus) -> parms_id mismatch
+    p2 = capi.Params.from_buffer_copy(p)
+    p2.plain_modulus = 40961
+    assert _validate(lib, p2, req)[0] == 3

@@ -48,6 +48,8 @@ def load(native: bool = False) -> C.CDLL:
         return _LIBS[key]
     name = "libpir_oracle_native.so" if native else "libpir_oracle.so"
     path = os.path.join(_HERE, name)
+    if os.environ.get("PIR_ORACLE_LIB"):      # e.g. the ASan/UBSan build (make -C oracle asan) under LD_PRELOAD
+        path = os.environ["PIR_ORACLE_LIB"]
     src = os.path.join(_HERE, "pir_oracle.c")
     if not os.path.exists(path) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(path)):
         try:

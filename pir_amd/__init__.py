@@ -13,7 +13,8 @@ from .parameters import (BFV_DEFAULT, EncryptionParams, PIRParameters, create_pi
                          generate_encryption_params, generate_galois_elts, next_power_two,
                          plain_modulus_batching, coeff_modulus_create)
 from .server import PIRDatabase, PIRServer, PirGpuError, StatusCode
+from .client import PIRClient
 
 __all__ = ["capi", "BFV_DEFAULT", "EncryptionParams", "PIRParameters", "create_pir_parameters",
            "generate_encryption_params", "generate_galois_elts", "next_power_two", "plain_modulus_batching",
-           "coeff_modulus_create", "PIRDatabase", "PIRServer", "PirGpuError", "StatusCode"]
+           "coeff_modulus_create", "PIRDatabase", "PIRServer", "PIRClient", "PirGpuError", "StatusCode"]

@@ -8,10 +8,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpirgpu.so")
-SOURCES = ["kernels.hip", "ctx.hip", "wire.cpp"]
+SOURCES = ["kernels.hip", "ctx.hip", "wire.cpp", "wire_codec.cpp"]
 NTT_SOURCE = "ntt_kernels.hip"      # compiled once per ring degree (-DPIRGPU_LOGN)
 NTT_LOGNS = [11, 12, 13, 14]
-HEADERS = ["device_params.h", "kernels.h", "host_math.h", "wire.h", "arith.h", "ntt_core.h", NTT_SOURCE, os.path.join("..", "..", "include", "pirgpu.h")]
+HEADERS = ["device_params.h", "kernels.h", "host_math.h", "wire.h", "wire_codec.h", "arith.h", "ntt_core.h", NTT_SOURCE, os.path.join("..", "..", "include", "pirgpu.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -56,5 +56,27 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+CLIENT_LIB = os.path.join(HERE, "libpirclient.so")
+CLIENT_SOURCES = ["client.cpp", "wire_codec.cpp"]
+CLIENT_HEADERS = ["host_math.h", "wire_codec.h", os.path.join("..", "..", "include", "pirgpu.h"),
+                  os.path.join("..", "..", "include", "pirclient.h")]
+CXX = os.environ.get("CXX", "g++")
+
+
+def build_client(force: bool = False, verbose: bool = False) -> str:
+    """libpirclient.so (include/pirclient.h): host-only C++, no HIP -- the CPU PIR client."""
+    deps = [os.path.join(CSRC, f) for f in CLIENT_SOURCES + CLIENT_HEADERS] + [os.path.abspath(__file__)]
+    if not force and os.path.exists(CLIENT_LIB) and all(
+            os.path.getmtime(d) <= os.path.getmtime(CLIENT_LIB) for d in deps if os.path.exists(d)):
+        return CLIENT_LIB
+    cmd = [CXX, "-O2", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-shared"] + \
+          [os.path.join(CSRC, s) for s in CLIENT_SOURCES] + ["-o", CLIENT_LIB]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return CLIENT_LIB
+
+
 if __name__ == "__main__":
+    print(build_client(force="--force" in sys.argv, verbose=True))
     print(build(force="--force" in sys.argv, verbose=True))

@@ -35,6 +35,34 @@ class Params(C.Structure):
     ]
 
 
+def make_params(params, device: int = 0, shard=None) -> Params:
+    """PIRParameters (+ device / first-dimension shard) -> the pirgpu_params struct of include/pirgpu.h."""
+    enc = params.encryption_parameters
+    p = Params()
+    p.poly_modulus_degree = enc.poly_modulus_degree
+    p.num_data_primes = len(enc.coeff_modulus) - 1
+    for i, q in enumerate(enc.coeff_modulus[:-1]):
+        p.coeff_modulus[i] = q
+    p.special_prime = enc.coeff_modulus[-1] if len(enc.coeff_modulus) > 1 else 0
+    p.plain_modulus = enc.plain_modulus
+    p.num_dimensions = len(params.dimensions)
+    for i, d in enumerate(params.dimensions):
+        p.dimensions[i] = d
+    p.num_pt = params.num_pt
+    p.num_items = params.num_items
+    p.bytes_per_item = params.bytes_per_item
+    p.items_per_plaintext = params.items_per_plaintext
+    p.bits_per_coeff = params.bits_per_coeff
+    p.use_ciphertext_multiplication = 1 if params.use_ciphertext_multiplication else 0
+    p.device = device
+    if shard is not None:
+        b, e = int(shard[0]), int(shard[1])
+        if b == e:                      # empty shard: (0, 0) means "whole database" in the C ABI
+            b = e = params.dimensions[0]
+        p.shard_begin, p.shard_end = b, e
+    return p
+
+
 # every symbol include/pirgpu.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "pirgpu_create": (C.c_int, [C.POINTER(Params), C.POINTER(C.c_void_p)]),
@@ -98,4 +126,51 @@ def load() -> C.CDLL:
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    return lib
+
+
+# ---------------------------------------------------------------------------------------------------
+# libpirclient.so (include/pirclient.h): CPU-only client library, no device dependency.
+CLIENT_LIB_PATH = os.path.join(HERE, "libpirclient.so")
+i64p = C.POINTER(C.c_int64)
+
+CLIENT_SIGNATURES = {
+    "pirclient_create": (C.c_int, [C.POINTER(Params), u8p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "pirclient_destroy": (None, [C.c_void_p]),
+    "pirclient_last_error": (C.c_char_p, [C.c_void_p]),
+    "pirclient_create_error": (C.c_char_p, []),
+    "pirclient_create_request": (C.c_int, [C.c_void_p, u64p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "pirclient_process_response": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u8p, C.c_size_t, u8p, C.c_size_t]),
+    "pirclient_process_response_integer": (C.c_int, [C.c_void_p, u8p, C.c_size_t, i64p, C.c_size_t,
+                                                      C.POINTER(C.c_size_t)]),
+    "pirclient_free": (None, [C.c_void_p]),
+    "pirclient_query_ct_count": (C.c_uint32, [C.c_void_p]),
+    "pirclient_create_query": (C.c_int, [C.c_void_p, C.c_uint64, u64p, C.c_size_t, C.POINTER(C.c_uint32)]),
+    "pirclient_galois_key": (C.c_int, [C.c_void_p, C.c_uint32, u64p]),
+    "pirclient_process_reply": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p]),
+    "pirclient_reply_ct_count": (C.c_uint64, [C.c_void_p]),
+    "pirclient_encrypt": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p]),
+    "pirclient_decrypt": (C.c_int, [C.c_void_p, u64p, u64p]),
+    "pirclient_noise_budget": (C.c_int, [C.c_void_p, u64p, C.POINTER(C.c_int)]),
+    "pirclient_reencode": (C.c_int, [C.c_void_p, u64p, u64p, C.c_size_t, C.POINTER(C.c_uint32)]),
+    "pirclient_string_decode": (C.c_int, [C.c_void_p, u64p, C.c_size_t, C.c_size_t, u8p]),
+}
+
+_client_lib = None
+
+
+def load_client() -> C.CDLL:
+    """Load libpirclient.so (g++-built, runs without a GPU)."""
+    global _client_lib
+    if _client_lib is not None:
+        return _client_lib
+    if not os.path.exists(CLIENT_LIB_PATH):
+        from . import build as _build       # host-only g++ build, a few seconds
+        _build.build_client()
+    lib = C.CDLL(CLIENT_LIB_PATH)
+    for name, (res, args) in CLIENT_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _client_lib = lib
     return lib

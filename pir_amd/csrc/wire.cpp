@@ -10,6 +10,7 @@
 // expanded objects (galois_keys_local + SaveRequest, as server_test.cpp builds
 // them) are accepted.
 #include "wire.h"
+#include "wire_codec.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -22,305 +23,6 @@
 
 namespace pirgpu {
 namespace wire {
-
-// ------------------------------------------------------------------ BLAKE2b (RFC 7693)
-
-static const uint64_t kIV[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL,
-                                0xa54ff53a5f1d36f1ULL, 0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL,
-                                0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
-static const uint8_t kSigma[12][16] = {
-    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
-    {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
-    {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
-    {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
-    {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0},
-    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3}};
-
-static inline uint64_t rotr64(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
-
-static void b2_compress(uint64_t h[8], const uint8_t block[128], uint64_t t0, bool last) {
-  uint64_t m[16], v[16];
-  for (int i = 0; i < 16; ++i) memcpy(&m[i], block + 8 * i, 8);
-  for (int i = 0; i < 8; ++i) {
-    v[i] = h[i];
-    v[i + 8] = kIV[i];
-  }
-  v[12] ^= t0;
-  if (last) v[14] = ~v[14];
-#define B2G(a, b, c, d, x, y)    \
-  v[a] = v[a] + v[b] + (x);      \
-  v[d] = rotr64(v[d] ^ v[a], 32); \
-  v[c] = v[c] + v[d];            \
-  v[b] = rotr64(v[b] ^ v[c], 24); \
-  v[a] = v[a] + v[b] + (y);      \
-  v[d] = rotr64(v[d] ^ v[a], 16); \
-  v[c] = v[c] + v[d];            \
-  v[b] = rotr64(v[b] ^ v[c], 63);
-  for (int r = 0; r < 12; ++r) {
-    const uint8_t* s = kSigma[r];
-    B2G(0, 4, 8, 12, m[s[0]], m[s[1]])
-    B2G(1, 5, 9, 13, m[s[2]], m[s[3]])
-    B2G(2, 6, 10, 14, m[s[4]], m[s[5]])
-    B2G(3, 7, 11, 15, m[s[6]], m[s[7]])
-    B2G(0, 5, 10, 15, m[s[8]], m[s[9]])
-    B2G(1, 6, 11, 12, m[s[10]], m[s[11]])
-    B2G(2, 7, 8, 13, m[s[12]], m[s[13]])
-    B2G(3, 4, 9, 14, m[s[14]], m[s[15]])
-  }
-#undef B2G
-  for (int i = 0; i < 8; ++i) h[i] ^= v[i] ^ v[i + 8];
-}
-
-// unkeyed BLAKE2b with outlen <= 64
-void blake2b(uint8_t* out, size_t outlen, const uint8_t* in, size_t inlen) {
-  uint64_t h[8];
-  for (int i = 0; i < 8; ++i) h[i] = kIV[i];
-  h[0] ^= 0x01010000ULL ^ (uint64_t)outlen;
-  uint8_t block[128];
-  uint64_t t = 0;
-  while (inlen > 128) {
-    t += 128;
-    b2_compress(h, in, t, false);
-    in += 128;
-    inlen -= 128;
-  }
-  memset(block, 0, 128);
-  if (inlen) memcpy(block, in, inlen);
-  t += inlen;
-  b2_compress(h, block, t, true);
-  uint8_t full[64];
-  memcpy(full, h, 64);
-  memcpy(out, full, outlen);
-}
-
-// EncryptionParameters::compute_parms_id: BLAKE2b-256 over
-// [scheme = BFV(1), N, q..., t] as little-endian u64.
-void parms_id(uint32_t N, const uint64_t* moduli, size_t n_moduli, uint64_t t, uint64_t out[4]) {
-  std::vector<uint64_t> data;
-  data.push_back(1);
-  data.push_back(N);
-  for (size_t i = 0; i < n_moduli; ++i) data.push_back(moduli[i]);
-  data.push_back(t);
-  blake2b(reinterpret_cast<uint8_t*>(out), 32, reinterpret_cast<const uint8_t*>(data.data()), data.size() * 8);
-}
-
-// ------------------------------------------------------------------ proto3 primitives
-
-struct Reader {
-  const uint8_t* p;
-  const uint8_t* end;
-  bool varint(uint64_t& v) {
-    v = 0;
-    for (int shift = 0; shift < 64 && p < end; shift += 7) {
-      uint8_t b = *p++;
-      v |= (uint64_t)(b & 0x7f) << shift;
-      if (!(b & 0x80)) return true;
-    }
-    return false;
-  }
-  bool bytes(const uint8_t*& data, size_t& len) {
-    uint64_t n;
-    if (!varint(n) || n > (uint64_t)(end - p)) return false;
-    data = p;
-    len = (size_t)n;
-    p += n;
-    return true;
-  }
-  bool skip(uint32_t wt) {
-    uint64_t v;
-    const uint8_t* d;
-    size_t l;
-    switch (wt) {
-      case 0: return varint(v);
-      case 1: if (end - p < 8) return false; p += 8; return true;
-      case 2: return bytes(d, l);
-      case 5: if (end - p < 4) return false; p += 4; return true;
-      default: return false;
-    }
-  }
-};
-
-static void put_varint(std::string& s, uint64_t v) {
-  while (v >= 0x80) {
-    s.push_back((char)(v | 0x80));
-    v >>= 7;
-  }
-  s.push_back((char)v);
-}
-
-static void put_bytes_field(std::string& s, uint32_t field, const std::string& payload) {
-  put_varint(s, (field << 3) | 2);
-  put_varint(s, payload.size());
-  s.append(payload);
-}
-
-// ------------------------------------------------------------------ SEAL 3.5.6 objects
-
-constexpr uint16_t kSealMagic = 0xA15E;
-constexpr size_t kHeader = 16;
-
-struct Err {
-  int code;
-  std::string msg;
-};
-
-static void put_u64(std::string& s, uint64_t v) { s.append(reinterpret_cast<const char*>(&v), 8); }
-
-static void put_header(std::string& s, uint64_t total_size) {
-  uint8_t h[kHeader] = {0};
-  h[0] = (uint8_t)(kSealMagic & 0xff);
-  h[1] = (uint8_t)(kSealMagic >> 8);
-  h[2] = 0x10;  // header size
-  h[3] = 3;     // version major
-  h[4] = 5;     // version minor
-  h[5] = 0;     // compr_mode_type::none (seal.BUILD:15: zlib off)
-  memcpy(h + 8, &total_size, 8);
-  s.append(reinterpret_cast<const char*>(h), kHeader);
-}
-
-struct Cursor {
-  const uint8_t* p;
-  const uint8_t* end;
-  void need(size_t n) const {
-    if ((size_t)(end - p) < n) throw Err{PIRGPU_INVALID_ARGUMENT, "SEAL object truncated"};
-  }
-  uint64_t u64() {
-    need(8);
-    uint64_t v;
-    memcpy(&v, p, 8);
-    p += 8;
-    return v;
-  }
-  uint8_t u8() {
-    need(1);
-    return *p++;
-  }
-  // returns the end of the object the header describes
-  const uint8_t* header() {
-    need(kHeader);
-    uint16_t magic = (uint16_t)(p[0] | (p[1] << 8));
-    if (magic != kSealMagic || p[2] != 0x10) throw Err{PIRGPU_INVALID_ARGUMENT, "loaded SEALHeader is invalid"};
-    if (p[3] != 3) throw Err{PIRGPU_INVALID_ARGUMENT, "incompatible SEAL version"};
-    if (p[5] != 0)
-      throw Err{PIRGPU_UNIMPLEMENTED, "compressed SEAL objects are not supported (reference builds SEAL without zlib)"};
-    uint64_t size;
-    memcpy(&size, p + 8, 8);
-    if (size < kHeader || size > (uint64_t)(end - p)) throw Err{PIRGPU_INVALID_ARGUMENT, "SEAL object size mismatch"};
-    const uint8_t* obj_end = p + size;
-    p += kHeader;
-    return obj_end;
-  }
-};
-
-struct Shape {
-  uint32_t N, k;
-  uint64_t q[PIRGPU_MAX_PRIMES + 1];  // data primes then special
-  uint64_t t;
-  uint64_t data_id[4], key_id[4];
-};
-
-// Ciphertext::load (+ is_valid_for): returns residues [2][nres][N].
-static void load_ciphertext(Cursor& c, const Shape& sh, bool key_level, std::vector<uint64_t>& out) {
-  const uint8_t* obj_end = c.header();
-  Cursor o{c.p, obj_end};
-  uint64_t id[4];
-  for (int i = 0; i < 4; ++i) id[i] = o.u64();
-  const uint64_t* want = key_level ? sh.key_id : sh.data_id;
-  if (memcmp(id, want, 32) != 0) throw Err{PIRGPU_INVALID_ARGUMENT, "ciphertext data is invalid (parms_id mismatch)"};
-  uint8_t is_ntt = o.u8();
-  uint64_t size = o.u64(), N = o.u64(), cm = o.u64();
-  (void)o.u64();  // scale (double); BFV requires 1.0, SEAL does not reject others on load
-  const uint32_t nres = key_level ? sh.k + 1 : sh.k;
-  if (size != 2) throw Err{PIRGPU_INVALID_ARGUMENT, "ciphertext size must be 2"};
-  if (N != sh.N || cm != nres) throw Err{PIRGPU_INVALID_ARGUMENT, "ciphertext data is invalid (shape mismatch)"};
-  if ((is_ntt != 0) != key_level) throw Err{PIRGPU_INVALID_ARGUMENT, "ciphertext NTT form does not match its level"};
-  // IntArray<ct_coeff_type>
-  const uint8_t* arr_end = Cursor{o.p, o.end}.header();
-  Cursor a{o.p + kHeader, arr_end};
-  uint64_t count = a.u64();
-  const uint64_t full = 2ull * nres * sh.N;
-  if (count == full / 2)
-    throw Err{PIRGPU_UNIMPLEMENTED,
-              "seed-compressed SEAL object: expanding it needs SEAL's Blake2xb PRNG (not implemented)"};
-  if (count != full) throw Err{PIRGPU_INVALID_ARGUMENT, "ciphertext data is invalid (coefficient count)"};
-  a.need(count * 8);
-  out.resize(count);
-  memcpy(out.data(), a.p, count * 8);
-  // is_data_valid_for: every coefficient below its modulus
-  for (uint32_t poly = 0; poly < 2; ++poly)
-    for (uint32_t j = 0; j < nres; ++j) {
-      const uint64_t q = (key_level && j == sh.k) ? sh.q[sh.k] : sh.q[j];
-      const uint64_t* v = out.data() + ((size_t)poly * nres + j) * sh.N;
-      for (uint32_t i = 0; i < sh.N; ++i)
-        if (v[i] >= q) throw Err{PIRGPU_INVALID_ARGUMENT, "ciphertext data is invalid (coefficient out of range)"};
-    }
-  c.p = obj_end;
-}
-
-static std::string save_ciphertext(const Shape& sh, const uint64_t* ct) {
-  const uint64_t count = 2ull * sh.k * sh.N;
-  std::string arr;
-  put_header(arr, kHeader + 8 + count * 8);
-  put_u64(arr, count);
-  arr.append(reinterpret_cast<const char*>(ct), count * 8);
-  std::string body;
-  for (int i = 0; i < 4; ++i) put_u64(body, sh.data_id[i]);
-  body.push_back(0);  // is_ntt_form
-  put_u64(body, 2);
-  put_u64(body, sh.N);
-  put_u64(body, sh.k);
-  double scale = 1.0;
-  uint64_t sbits;
-  memcpy(&sbits, &scale, 8);
-  put_u64(body, sbits);
-  body.append(arr);
-  std::string out;
-  put_header(out, kHeader + body.size());
-  out.append(body);
-  return out;
-}
-
-// GaloisKeys::load: installs every present key on the device context.
-static void load_galois_keys(pirgpu_ctx* ctx, const Shape& sh, const uint8_t* data, size_t len) {
-  Cursor c{data, data + len};
-  const uint8_t* obj_end = c.header();
-  Cursor o{c.p, obj_end};
-  uint64_t id[4];
-  for (int i = 0; i < 4; ++i) id[i] = o.u64();
-  if (memcmp(id, sh.key_id, 32) != 0) throw Err{PIRGPU_INVALID_ARGUMENT, "GaloisKeys data is invalid (parms_id mismatch)"};
-  uint64_t dim1 = o.u64();
-  if (dim1 > sh.N) throw Err{PIRGPU_INVALID_ARGUMENT, "GaloisKeys data is invalid"};
-  const uint32_t km = sh.k + 1;
-  std::vector<uint64_t> key((size_t)sh.k * 2 * km * sh.N), tmp;
-  for (uint64_t index = 0; index < dim1; ++index) {
-    uint64_t dim2 = o.u64();
-    if (dim2 == 0) continue;
-    if (dim2 != sh.k) throw Err{PIRGPU_INVALID_ARGUMENT, "GaloisKeys data is invalid (decomposition count)"};
-    for (uint64_t j = 0; j < dim2; ++j) {
-      const uint8_t* pk_end = o.header();  // PublicKey wrapper
-      Cursor pk{o.p, pk_end};
-      load_ciphertext(pk, sh, true, tmp);  // [2][k+1][N]
-      memcpy(key.data() + (size_t)j * 2 * km * sh.N, tmp.data(), tmp.size() * 8);
-      o.p = pk_end;
-    }
-    if (ctx) {  // ctx == nullptr: validation only (pirgpu_wire_validate_request)
-      int rc = pirgpu_set_galois_key(ctx, (uint32_t)(2 * index + 1), key.data());
-      if (rc) throw Err{rc, pirgpu_last_error(ctx)};
-    }
-  }
-}
-
-static Shape make_shape(const pirgpu_params& prm) {
-  Shape sh;
-  sh.N = prm.poly_modulus_degree;
-  sh.k = prm.num_data_primes;
-  for (uint32_t i = 0; i < sh.k; ++i) sh.q[i] = prm.coeff_modulus[i];
-  sh.q[sh.k] = prm.special_prime;
-  sh.t = prm.plain_modulus;
-  parms_id(sh.N, sh.q, sh.k, sh.t, sh.data_id);
-  parms_id(sh.N, sh.q, sh.k + 1, sh.t, sh.key_id);
-  return sh;
-}
 
 struct ParsedRequest {
   std::vector<std::pair<const uint8_t*, size_t>> queries;  // Ciphertexts sub-messages
@@ -351,30 +53,6 @@ static ParsedRequest parse_request(const uint8_t* request, size_t request_len) {
   return pr;
 }
 
-// LoadCiphertexts (serialization.cpp:32-42) of one Ciphertexts message -> residues, count
-static uint32_t load_query(const Shape& sh, const uint8_t* data, size_t len, std::vector<uint64_t>& qbuf) {
-  Reader qr{data, data + len};
-  std::vector<uint64_t> one;
-  qbuf.clear();
-  uint32_t nq = 0;
-  while (qr.p < qr.end) {
-    uint64_t tag;
-    if (!qr.varint(tag)) throw Err{PIRGPU_INVALID_ARGUMENT, "malformed Ciphertexts"};
-    const uint8_t* d;
-    size_t l;
-    if ((tag >> 3) == 1 && (tag & 7) == 2) {
-      if (!qr.bytes(d, l)) throw Err{PIRGPU_INVALID_ARGUMENT, "malformed Ciphertexts.ct"};
-      Cursor c{d, d + l};
-      load_ciphertext(c, sh, false, one);
-      qbuf.insert(qbuf.end(), one.begin(), one.end());
-      ++nq;
-    } else if (!qr.skip((uint32_t)(tag & 7))) {
-      throw Err{PIRGPU_INVALID_ARGUMENT, "malformed Ciphertexts"};
-    }
-  }
-  return nq;
-}
-
 }  // namespace wire
 }  // namespace pirgpu
 
@@ -399,7 +77,7 @@ int pirgpu_wire_validate_request(const pirgpu_params* params, const uint8_t* req
   try {
     const Shape sh = make_shape(*params);
     ParsedRequest pr = parse_request(request, request_len);
-    load_galois_keys(nullptr, sh, pr.galois_keys, pr.galois_keys_len);
+    load_kswitch_keys(sh, pr.galois_keys, pr.galois_keys_len, nullptr);
     std::vector<uint64_t> qbuf;
     for (auto& qm : pr.queries) (void)load_query(sh, qm.first, qm.second, qbuf);
     if (n_queries) *n_queries = (uint32_t)pr.queries.size();
@@ -429,7 +107,10 @@ int pirgpu_process_request(pirgpu_ctx* ctx, const uint8_t* request, size_t reque
     if (!pr.galois_keys_len || !pirgpu_keys_blob_matches(ctx, pr.galois_keys, pr.galois_keys_len)) {
       rc = pirgpu_clear_galois_keys(ctx);
       if (rc) throw Err{rc, pirgpu_last_error(ctx)};
-      load_galois_keys(ctx, sh, pr.galois_keys, pr.galois_keys_len);
+      load_kswitch_keys(sh, pr.galois_keys, pr.galois_keys_len, [&](uint64_t index, const uint64_t* key) {
+        int krc = pirgpu_set_galois_key(ctx, (uint32_t)(2 * index + 1), key);
+        if (krc) throw Err{krc, pirgpu_last_error(ctx)};
+      });
       pirgpu_keys_blob_set(ctx, pr.galois_keys, pr.galois_keys_len);
     }
     // --- per query: LoadCiphertexts -> processQuery -> SaveCiphertexts (server.cpp:60-63,173-195)

@@ -1,0 +1,131 @@
+// wire_codec.h -- internal header: pir/proto framing primitives + SEAL 3.5.6 object codec.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../include/pirgpu.h"
+
+namespace pirgpu {
+namespace wire {
+
+void blake2b(uint8_t* out, size_t outlen, const uint8_t* in, size_t inlen);
+void parms_id(uint32_t N, const uint64_t* moduli, size_t n_moduli, uint64_t t, uint64_t out[4]);
+
+// ------------------------------------------------------------------ proto3 primitives
+
+struct Reader {
+  const uint8_t* p;
+  const uint8_t* end;
+  bool varint(uint64_t& v) {
+    v = 0;
+    for (int shift = 0; shift < 64 && p < end; shift += 7) {
+      uint8_t b = *p++;
+      v |= (uint64_t)(b & 0x7f) << shift;
+      if (!(b & 0x80)) return true;
+    }
+    return false;
+  }
+  bool bytes(const uint8_t*& data, size_t& len) {
+    uint64_t n;
+    if (!varint(n) || n > (uint64_t)(end - p)) return false;
+    data = p;
+    len = (size_t)n;
+    p += n;
+    return true;
+  }
+  bool skip(uint32_t wt) {
+    uint64_t v;
+    const uint8_t* d;
+    size_t l;
+    switch (wt) {
+      case 0: return varint(v);
+      case 1: if (end - p < 8) return false; p += 8; return true;
+      case 2: return bytes(d, l);
+      case 5: if (end - p < 4) return false; p += 4; return true;
+      default: return false;
+    }
+  }
+};
+
+void put_varint(std::string& s, uint64_t v);
+void put_bytes_field(std::string& s, uint32_t field, const std::string& payload);
+
+// ------------------------------------------------------------------ SEAL 3.5.6 objects
+
+constexpr uint16_t kSealMagic = 0xA15E;
+constexpr size_t kHeader = 16;
+
+struct Err {
+  int code;
+  std::string msg;
+};
+
+void put_u64(std::string& s, uint64_t v);
+void put_header(std::string& s, uint64_t total_size);
+
+struct Cursor {
+  const uint8_t* p;
+  const uint8_t* end;
+  void need(size_t n) const {
+    if ((size_t)(end - p) < n) throw Err{PIRGPU_INVALID_ARGUMENT, "SEAL object truncated"};
+  }
+  uint64_t u64() {
+    need(8);
+    uint64_t v;
+    memcpy(&v, p, 8);
+    p += 8;
+    return v;
+  }
+  uint8_t u8() {
+    need(1);
+    return *p++;
+  }
+  // returns the end of the object the header describes
+  const uint8_t* header() {
+    need(kHeader);
+    uint16_t magic = (uint16_t)(p[0] | (p[1] << 8));
+    if (magic != kSealMagic || p[2] != 0x10) throw Err{PIRGPU_INVALID_ARGUMENT, "loaded SEALHeader is invalid"};
+    if (p[3] != 3) throw Err{PIRGPU_INVALID_ARGUMENT, "incompatible SEAL version"};
+    if (p[5] != 0)
+      throw Err{PIRGPU_UNIMPLEMENTED, "compressed SEAL objects are not supported (reference builds SEAL without zlib)"};
+    uint64_t size;
+    memcpy(&size, p + 8, 8);
+    if (size < kHeader || size > (uint64_t)(end - p)) throw Err{PIRGPU_INVALID_ARGUMENT, "SEAL object size mismatch"};
+    const uint8_t* obj_end = p + size;
+    p += kHeader;
+    return obj_end;
+  }
+};
+
+struct Shape {
+  uint32_t N, k;
+  uint64_t q[PIRGPU_MAX_PRIMES + 1];  // data primes then special
+  uint64_t t;
+  uint64_t data_id[4], key_id[4];
+};
+
+Shape make_shape(const pirgpu_params& prm);
+
+// Ciphertext::load (+ is_valid_for): residues [2][nres][N]; key_level = (k+1)-prime NTT-form object.
+void load_ciphertext(Cursor& c, const Shape& sh, bool key_level, std::vector<uint64_t>& out);
+// Ciphertext::save of a size-2 ciphertext: data level (k primes, coefficient form) or, with
+// key_level, the (k+1)-prime NTT-form body of a PublicKey.
+std::string save_ciphertext(const Shape& sh, const uint64_t* ct, bool key_level = false);
+// PublicKey::save = header + Ciphertext::save(key level).
+std::string save_public_key(const Shape& sh, const uint64_t* pk);
+// KSwitchKeys::load (GaloisKeys / RelinKeys): calls sink(index, key [k][2][k+1][N]) per present entry.
+void load_kswitch_keys(const Shape& sh, const uint8_t* data, size_t len,
+                       const std::function<void(uint64_t, const uint64_t*)>& sink);
+// KSwitchKeys::save: entries[i] = key [k][2][k+1][N] or nullptr (absent), i < dim1.
+std::string save_kswitch_keys(const Shape& sh, const std::vector<const uint64_t*>& entries);
+
+// LoadCiphertexts (serialization.cpp:32-42) of one pir.Ciphertexts message -> residues [n][2][k][N]; returns n.
+uint32_t load_query(const Shape& sh, const uint8_t* data, size_t len, std::vector<uint64_t>& qbuf);
+
+}  // namespace wire
+}  // namespace pirgpu

@@ -53,28 +53,7 @@ class PIRDatabase:
         self.N = enc.poly_modulus_degree
         self.k = len(enc.coeff_modulus) - 1
         self.lib = capi.load()
-        p = capi.Params()
-        p.poly_modulus_degree = self.N
-        p.num_data_primes = self.k
-        for i, q in enumerate(enc.coeff_modulus[:-1]):
-            p.coeff_modulus[i] = q
-        p.special_prime = enc.coeff_modulus[-1] if len(enc.coeff_modulus) > 1 else 0
-        p.plain_modulus = enc.plain_modulus
-        p.num_dimensions = len(params.dimensions)
-        for i, d in enumerate(params.dimensions):
-            p.dimensions[i] = d
-        p.num_pt = params.num_pt
-        p.num_items = params.num_items
-        p.bytes_per_item = params.bytes_per_item
-        p.items_per_plaintext = params.items_per_plaintext
-        p.bits_per_coeff = params.bits_per_coeff
-        p.use_ciphertext_multiplication = 1 if params.use_ciphertext_multiplication else 0
-        p.device = device
-        if shard is not None:
-            b, e = int(shard[0]), int(shard[1])
-            if b == e:                      # empty shard: (0, 0) means "whole database" in the C ABI
-                b = e = params.dimensions[0]
-            p.shard_begin, p.shard_end = b, e
+        p = capi.make_params(params, device=device, shard=shard)
         self._cparams = p
         h = C.c_void_p()
         rc = self.lib.pirgpu_create(C.byref(p), C.byref(h))

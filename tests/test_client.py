@@ -323,3 +323,36 @@ def test_request_passes_server_side_validation():
     lib.pirgpu_wire_validate_request.restype = C.c_int
     assert lib.pirgpu_wire_validate_request(C.byref(p), buf, len(req), C.byref(n)) == 0
     assert n.value == 2
+
+
+# ---------------------------------------------------------------- the oracle's own client, same tables
+
+ORACLE_LAYOUT = [  # (dbsize, d, index, [(ct, slot, m)])  client_test.cpp:67-267,321-348
+    (100, 1, 5, [(0, 5, 128)]),
+    (82, 2, 42, [(0, 4, 32), (0, 16, 32)]),
+    (82, 3, 42, [(0, 2, 16), (0, 5, 16), (0, 12, 16)]),
+    (20000000, 2, 12345679, [(0, 2760, N), (1, 2959 + 4473 - N, N)]),
+    (20000000, 2, 12346679, [(0, 2760, N), (2, 3959 + 4473 - 2 * N, 1024)]),
+    (10000, 1, 8192, [(2, 0, 2048)]),
+    (10000, 1, 4097, [(1, 1, N)]),
+    (16384, 1, 16383, [(3, 4095, 4096)]),
+]
+
+
+@pytest.mark.parametrize("dbsize,d,index,expected", ORACLE_LAYOUT)
+def test_oracle_client_query_layout(dbsize, d, index, expected):
+    """The test-side client (oracle/client.py) follows the same reference tables as the product client."""
+    from oracle.client import Client
+    op = oracle.create_pir_parameters(dbsize, 0, d, N=N, plain_bits=16)
+    orc = oracle.Oracle.from_params(op)
+    cl = Client(orc, seed=3)
+    q = cl.create_query_for(op, index)
+    assert q.shape[0] == sum(op.dimensions) // N + 1
+    want = {}
+    for ct, slot, m in expected:
+        want.setdefault(ct, {})[slot] = m
+    for c in range(q.shape[0]):
+        pt = cl.decrypt(q[c])
+        assert set(np.nonzero(pt)[0].tolist()) == set(want.get(c, {}))
+        for slot, m in want.get(c, {}).items():
+            assert int(pt[slot]) * m % op.t == 1

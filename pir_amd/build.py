@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpirgpu.so")
-SOURCES = ["kernels.hip", "ctx.hip", "wire.cpp", "wire_codec.cpp"]
+SOURCES = ["kernels.hip", "scan_mfma.hip", "ctx.hip", "wire.cpp", "wire_codec.cpp"]
 NTT_SOURCE = "ntt_kernels.hip"      # compiled once per ring degree (-DPIRGPU_LOGN)
 NTT_LOGNS = [11, 12, 13, 14]
 HEADERS = ["device_params.h", "kernels.h", "host_math.h", "wire.h", "wire_codec.h", "arith.h", "ntt_core.h", NTT_SOURCE, os.path.join("..", "..", "include", "pirgpu.h")]

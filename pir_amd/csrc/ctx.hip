@@ -57,6 +57,7 @@ struct Worker {
   std::vector<uint64_t*> lvl;  // per level results; lvl[0] = reply
   uint64_t* pt_buf = nullptr;
   uint64_t* scan_part = nullptr;
+  uint8_t* selp = nullptr;           // digit-packed selectors of the group this worker leads (MFMA scan)
   bool reply_valid = false;
   hipEvent_t ev_expanded = nullptr, ev_scanned = nullptr;  // batch mode: cross-stream hand-offs
 };
@@ -111,6 +112,12 @@ struct pirgpu_ctx {
   uint32_t mq_single_rows = 4;              // rows per wave of that kernel for a single query (2 or 4)
   bool mq_single_limb = false;              // single query: 128-bit accumulators need fewer registers (3 WG/CU)
   uint64_t scan_npt = 0;
+  // digit-sliced int8-MFMA scan (scan_mfma.hip): d >= 2, database additionally held in operand layout
+  bool mfma_on = false;
+  MfmaGeom mg{};
+  uint32_t mfma_nq = kMaxMfmaQueries;       // queries per database pass in batch mode
+  uint8_t* d_dbp = nullptr;
+  bool packed_valid = false;
 
   bool prof = false;
   static constexpr int kMaxProfRuns = 256;
@@ -320,6 +327,12 @@ void ensure_workspace(pirgpu_ctx* c) {
     want = std::max<uint32_t>(1, std::min<uint32_t>(want, std::max<uint32_t>(c->scan_cols, 1)));
     c->scan_cps = (uint32_t)ceil_div(std::max<uint32_t>(c->scan_cols, 1), want);
     c->scan_nsplit = (uint32_t)ceil_div(std::max<uint32_t>(c->scan_cols, 1), c->scan_cps);
+    //   PIRGPU_SCAN_MFMA=0 keeps the 64-bit multiply-accumulate kernels for d >= 2 as well
+    //   PIRGPU_SCAN_MFMA_NQ queries per database pass of the MFMA scan in batch mode (1..8)
+    c->mg = mfma_geometry(c->hp, c->scan_rows, c->scan_cols);
+    c->mfma_on = env_u32("PIRGPU_SCAN_MFMA", 1) != 0 && d >= 2 && c->mg.L != 0 && c->scan_rows >= 8 && shard_pts > 0;
+    c->mfma_nq = std::max<uint32_t>(1, std::min<uint32_t>(env_u32("PIRGPU_SCAN_MFMA_NQ", kMaxMfmaQueries),
+                                                          kMaxMfmaQueries));
   }
   c->ws_ready = true;
   if (c->workers.empty()) c->workers.emplace_back();
@@ -342,8 +355,8 @@ void alloc_worker(pirgpu_ctx* c, Worker& w) {
   w.lvl.assign(c->d, nullptr);
   for (uint32_t l = 0; l < c->d; ++l) w.lvl[l] = c->dalloc<uint64_t>(c->lvl_cts[l] * ctw);
   if (c->pt_words) w.pt_buf = c->dalloc<uint64_t>(c->pt_words);
-  if (c->scan_nsplit > 1)
-    w.scan_part = c->dalloc<uint64_t>((size_t)c->scan_nsplit * std::max<uint32_t>(c->scan_rows, 1) * ctw);
+  const uint32_t parts = std::max<uint32_t>(c->scan_nsplit, c->mfma_on ? c->mg.nchunks : 1);
+  if (parts > 1) w.scan_part = c->dalloc<uint64_t>((size_t)parts * std::max<uint32_t>(c->scan_rows, 1) * ctw);
   HIP_TRY(hipEventCreateWithFlags(&w.ev_expanded, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&w.ev_scanned, hipEventDisableTiming));
 }
@@ -438,6 +451,36 @@ const uint64_t* scan_selectors(pirgpu_ctx* c, Worker& w) {
 
 bool mq_usable(pirgpu_ctx* c) { return c->scan_nsplit == 1 && c->scan_rows >= 1 && c->scan_cols >= 1; }
 
+// Brings the operand-layout copy of the database up to date (after loads); one-time cost per load.
+void ensure_packed(pirgpu_ctx* c) {
+  if (!c->mfma_on || c->packed_valid) return;
+  if (!c->d_dbp) c->d_dbp = c->dalloc<uint8_t>(c->mg.db_bytes);
+  HIP_TRY(launch_db_pack(c->stream, c->dp, c->mg, c->d_db, c->d_dbp, c->scan_rows, c->scan_cols, c->k * c->N));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->packed_valid = true;
+}
+
+// One pass of the MFMA scan for up to 8 queries (the workers in `members`, expanded already and
+// synchronised with lead.stream by the caller): pack the selectors, scan, fold column chunks.
+void scan_group_mfma(pirgpu_ctx* c, Worker& lead, Worker* const* members, uint32_t n) {
+  const uint32_t kN = c->k * c->N;
+  const uint64_t words = (uint64_t)c->scan_rows * c->ctw;
+  ensure_packed(c);
+  if (!lead.selp) lead.selp = c->dalloc<uint8_t>(c->mg.sel_bytes);
+  MfmaPtrs sv{}, out{};
+  for (uint32_t q = 0; q < n; ++q) {
+    sv.p[q] = scan_selectors(c, *members[q]);
+    out.p[q] = c->mg.nchunks > 1 ? members[q]->scan_part : members[q]->lvl[c->d - 1];
+  }
+  HIP_TRY(launch_sel_pack(lead.stream, c->dp, c->mg, sv, n, lead.selp, c->scan_cols, kN));
+  record(c, lead, PH_SCAN);  // selector packing counts as selector preparation, not as the scan
+  HIP_TRY(launch_scan_mfma(lead.stream, c->dp, c->mg, c->d_dbp, lead.selp, out, n, c->scan_rows, kN, words));
+  if (c->mg.nchunks > 1)
+    for (uint32_t q = 0; q < n; ++q)
+      HIP_TRY(launch_reduce_splits(lead.stream, c->dp, members[q]->scan_part, c->mg.nchunks, words,
+                                   members[q]->lvl[c->d - 1]));
+}
+
 // Base case of PIRDatabase::multiply (reference database.cpp:185-194,238-247): one fused
 // multiply_plain + add_inplace pass over the database.  Leaves NTT-form row sums in lvl[d-1].
 void scan_on_device(pirgpu_ctx* c, Worker& w) {
@@ -446,6 +489,11 @@ void scan_on_device(pirgpu_ctx* c, Worker& w) {
   if (c->n_loaded != c->pt_end - c->pt_begin)
     throw Fail{PIRGPU_FAILED_PRECONDITION, "database not fully loaded"};
   if (c->pt_end == c->pt_begin) return;
+  if (c->mfma_on) {
+    Worker* one = &w;
+    scan_group_mfma(c, w, &one, 1);
+    return;
+  }
   const uint64_t* sv_base = scan_selectors(c, w);
   uint64_t* base_out = w.lvl[d - 1];
   if (c->mq_single && mq_usable(c)) {
@@ -662,7 +710,18 @@ int pirgpu_get_params(const pirgpu_ctx* c, pirgpu_params* out) {
 uint64_t pirgpu_db_size(const pirgpu_ctx* c) { return c ? c->n_loaded : 0; }
 uint64_t pirgpu_reply_ct_count(const pirgpu_ctx* c) { return c ? c->reply_cts : 0; }
 uint32_t pirgpu_expansion_ratio(const pirgpu_ctx* c) { return c ? c->er : 0; }
-uint64_t pirgpu_scan_bytes(const pirgpu_ctx* c) { return c ? (c->pt_end - c->pt_begin) * c->k * c->N * 8 : 0; }
+uint64_t pirgpu_scan_bytes(const pirgpu_ctx* cc) {
+  pirgpu_ctx* c = const_cast<pirgpu_ctx*>(cc);
+  if (!c) return 0;
+  try {
+    c->use_device();
+    ensure_workspace(c);
+  } catch (...) {
+    return 0;
+  }
+  // bytes one pass over the database must read: the operand-layout copy when the MFMA scan is active
+  return c->mfma_on ? (uint64_t)c->mg.db_bytes : (c->pt_end - c->pt_begin) * c->k * c->N * 8;
+}
 
 int pirgpu_db_load_items(pirgpu_ctx* c, const uint8_t* items, uint64_t num_items, uint32_t bytes_per_item) {
   return guarded(c, [&]() -> int {
@@ -675,6 +734,7 @@ int pirgpu_db_load_items(pirgpu_ctx* c, const uint8_t* items, uint64_t num_items
       return fail(c, PIRGPU_INVALID_ARGUMENT, "item size does not match parameters");
     const uint64_t ipp = p.items_per_plaintext;
     const uint64_t bytes_per_pt = ipp * bytes_per_item;
+    c->packed_valid = false;
     // StringEncoder::calc_num_coeff (reference string_encoder.cpp:88-95)
     if ((uint64_t)std::ceil((double)(bytes_per_pt * 8) / c->bits) > c->N)
       return fail(c, PIRGPU_INVALID_ARGUMENT, "Number of coefficients needed greater than poly modulus degree");
@@ -712,6 +772,7 @@ int pirgpu_db_load_coeffs(pirgpu_ctx* c, uint64_t first_pt, uint64_t n_pt, const
     if (first_pt + n_pt > c->P || (!coeffs && n_pt)) return fail(c, PIRGPU_INVALID_ARGUMENT, "plaintext range out of bounds");
     const uint64_t lo = std::max(first_pt, c->pt_begin), hi = std::min(first_pt + n_pt, c->pt_end);
     if (lo >= hi) return PIRGPU_OK;
+    c->packed_valid = false;
     const uint64_t chunk = std::max<uint64_t>(1, (64ull << 20) / (c->N * 8));
     uint64_t* d_coeffs = nullptr;
     HIP_TRY(hipMalloc((void**)&d_coeffs, chunk * c->N * 8));
@@ -1016,9 +1077,11 @@ static void batch_run_impl(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
   const size_t qwords = (size_t)nq * c->ctw, rwords = (size_t)c->reply_cts * c->ctw;
   const size_t svwords = (size_t)c->dim_sum * c->ctw;
   const uint32_t W = std::max<uint32_t>(1, std::min<uint32_t>(c->n_active, (uint32_t)c->workers.size()));
-  const uint32_t G = mq_usable(c) && c->pt_end > c->pt_begin ? std::min<uint32_t>(c->mq_nq, kMaxScanQueries) : 1;
+  const uint32_t G = c->mfma_on ? c->mfma_nq
+                   : mq_usable(c) && c->pt_end > c->pt_begin ? std::min<uint32_t>(c->mq_nq, kMaxScanQueries) : 1;
   if (c->n_loaded != c->pt_end - c->pt_begin)
     throw Fail{PIRGPU_FAILED_PRECONDITION, "database not fully loaded"};
+  ensure_packed(c);
   c->prof_cur = -1;
   for (uint32_t base = 0; base < count; base += W) {
     const uint32_t n = std::min<uint32_t>(W, count - base);
@@ -1037,10 +1100,22 @@ static void batch_run_impl(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
     for (uint32_t j0 = 0; j0 < n; j0 += G) {
       const uint32_t g = std::min<uint32_t>(G, n - j0);
       uint32_t done = 0;
-      while (done < g) {  // group sizes the kernel is instantiated for: 4, 2, 1
-        const uint32_t take = g - done >= 4 && G >= 4 ? 4 : (g - done >= 2 && G >= 2 ? 2 : 1);
+      while (done < g) {  // group sizes the kernel is instantiated for: 4, 2, 1 (MFMA scan: any size up to 8)
+        const uint32_t take = c->mfma_on ? g - done
+                                         : (g - done >= 4 && G >= 4 ? 4 : (g - done >= 2 && G >= 2 ? 2 : 1));
         Worker& lead = c->workers[j0 + done];
-        if (take == 1) {
+        if (c->mfma_on) {
+          Worker* members[kMaxMfmaQueries];
+          for (uint32_t q = 0; q < take; ++q) {
+            members[q] = &c->workers[j0 + done + q];
+            if (q) HIP_TRY(hipStreamWaitEvent(lead.stream, members[q]->ev_expanded, 0));
+          }
+          scan_group_mfma(c, lead, members, take);
+          if (take > 1) {
+            HIP_TRY(hipEventRecord(lead.ev_scanned, lead.stream));
+            for (uint32_t q = 1; q < take; ++q) HIP_TRY(hipStreamWaitEvent(members[q]->stream, lead.ev_scanned, 0));
+          }
+        } else if (take == 1) {
           scan_on_device(c, lead);
         } else {
           const uint64_t* svp[kMaxScanQueries];
@@ -1212,7 +1287,7 @@ int pirgpu_last_timings(pirgpu_ctx* c, float ms[6], uint32_t* runs) {
       for (int r = 0; r < c->prof_runs; ++r) {
         hipEvent_t* e = &c->ev[(size_t)r * (PH_COUNT + 1)];
         float t;
-        HIP_TRY(hipEventElapsedTime(&t, e[PH_EXPAND], e[PH_SVNTT]));
+        HIP_TRY(hipEventElapsedTime(&t, e[PH_EXPAND], e[PH_SCAN]));
         acc[0] += t;
         HIP_TRY(hipEventElapsedTime(&t, e[PH_SCAN], e[PH_UPPER]));
         acc[2] += t;

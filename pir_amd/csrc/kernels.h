@@ -47,4 +47,30 @@ hipError_t launch_scan_mq(hipStream_t st, const DevParams* P, uint32_t N, uint32
 hipError_t launch_reduce_splits(hipStream_t st, const DevParams* P, const uint64_t* part, uint32_t nsplit,
                                 uint64_t words, uint64_t* out);
 
+
+// ---- digit-sliced int8-MFMA scan (scan_mfma.hip) ----
+constexpr int kMaxMfmaQueries = 8;   // (query, comp) pairs fill the 16 columns of one MFMA tile
+
+struct MfmaPtrs {                    // per query: selectors in / row sums out (by value kernel argument)
+  const void* p[kMaxMfmaQueries];
+};
+
+struct MfmaGeom {
+  uint32_t L;        // balanced base-256 digits per residue (5, 6, 7); 0 = not applicable
+  uint32_t RT;       // row tiles (16 rows)
+  uint32_t KG;       // column groups (16 columns)
+  uint32_t KS;       // k-steps (64 columns) per chunk, selectors of one chunk live in registers
+  uint32_t nchunks;  // column chunks (grid.y); > 1 leaves partial sums to reduce_splits_kernel
+  size_t db_bytes, sel_bytes;
+};
+
+MfmaGeom mfma_geometry(const DevParams& hp, uint32_t rows, uint32_t cols);
+hipError_t launch_db_pack(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint64_t* db, uint8_t* dbp,
+                          uint32_t rows, uint32_t cols, uint32_t kN);
+hipError_t launch_sel_pack(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const MfmaPtrs& sv, uint32_t nq,
+                           uint8_t* selp, uint32_t cols, uint32_t kN);
+hipError_t launch_scan_mfma(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp,
+                            const uint8_t* selp, const MfmaPtrs& out, uint32_t nq, uint32_t rows, uint32_t kN,
+                            uint64_t chunk_stride);
+
 }  // namespace pirgpu

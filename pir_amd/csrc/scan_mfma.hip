@@ -1,0 +1,280 @@
+// scan_mfma.hip -- digit-sliced database scan on the int8 matrix cores (gfx950).
+//
+// Base case of PIRDatabase::multiply (reference database.cpp:185-194,238-247) for d >= 2: for every
+// residue slot j (kN of them) and every database row r
+//     out[query][r][comp][j] = sum_c  DB[r][c][j] * S[query][c][comp][j]   (mod q_j)
+// i.e. per slot j an exact integer matrix product [rows x cols] * [cols x (2 * queries)].  The plain
+// 64-bit multiply-accumulate kernels (kernels.hip) are HBM-bound for one query but VALU-bound as soon
+// as several queries share a database pass (each 36x36-bit product costs four v_mad_u64_u32).  Here
+// both operands are stored as balanced base-256 digits (signed bytes, L per residue) and the L*L
+// digit products run on v_mfma_i32_16x16x64_i8:
+//     A tile = 16 rows x 64 columns of digit a of the database      (one 16-byte load per lane)
+//     B tile = 64 columns x 16 (query, comp) pairs of digit b of the selectors
+//     T[a+b] += A_a * B_b      (the K accumulation and the digit diagonal share one int32 accumulator)
+// then value = sum_s T[s] 2^(8 s) is folded and reduced modulo q_j exactly.  All arithmetic is integer
+// and exact (|T| < L * 2^14 * 64 * KS < 2^25), so replies stay bit-identical to the reference.  The
+// database is stored ONCE in the operand layout of the instruction, which also shrinks it from
+// 8 to L bytes per residue (5 for the 36-bit moduli of N = 4096): the pass reads 0.74x the bytes of
+// the u64 layout (incl. padding to 16 x 16 tiles) and serves up to 8 queries.
+//
+// Layouts (bytes):
+//   database   [j][rt = r / 16][kg = c / 16][a][r % 16][c % 16]
+//   selectors  [j][kg][b][x = 2 * query + comp][c % 16]
+// A workgroup is 8 waves = 8 consecutive slots j (one per wave); results are staged through LDS so
+// that each (row, x) is written as one 64-byte run of 8 slots.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "arith.h"
+#include "kernels.h"
+
+namespace pirgpu {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef unsigned __int128 u128;
+
+// centred residue -> L balanced base-256 digits
+template <int L>
+__device__ __forceinline__ void to_digits(uint64_t x, uint64_t q, int8_t (&d)[L]) {
+  int64_t v = x > (q >> 1) ? (int64_t)x - (int64_t)q : (int64_t)x;
+#pragma unroll
+  for (int a = 0; a < L; ++a) {
+    d[a] = (int8_t)(v & 0xFF);
+    v = (v - d[a]) >> 8;
+  }
+}
+
+// database u64 [rows][cols][kN] (zero-padded rows) -> packed.  block = 16 rows x 16 slots; grid = (kN/16, RT, KG)
+template <int L>
+__global__ void __launch_bounds__(256)
+db_pack_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ db, uint8_t* __restrict__ dbp,
+               uint32_t rows, uint32_t cols, uint32_t kN, uint32_t RT, uint32_t KG) {
+  const uint32_t j = blockIdx.x * 16 + (threadIdx.x & 15);
+  const uint32_t r16 = threadIdx.x >> 4;
+  const uint32_t rt = blockIdx.y, kg = blockIdx.z;
+  const uint32_t r = rt * 16 + r16;
+  const uint64_t q = P->mod[j >> P->logN].q;
+  uint8_t o[L][16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const uint32_t c = kg * 16 + t;
+    uint64_t x = 0;
+    if (r < rows && c < cols) x = db[((size_t)r * cols + c) * kN + j];
+    int8_t d[L];
+    to_digits<L>(x, q, d);
+#pragma unroll
+    for (int a = 0; a < L; ++a) o[a][t] = (uint8_t)d[a];
+  }
+#pragma unroll
+  for (int a = 0; a < L; ++a) {
+    v4i v;
+    __builtin_memcpy(&v, o[a], 16);
+    *reinterpret_cast<v4i*>(dbp + ((((size_t)j * RT + rt) * KG + kg) * L + a) * 256 + r16 * 16) = v;
+  }
+}
+
+// selectors (per query u64 [cols][2][kN], NTT form) -> packed.  block = 16 x * 16 slots; grid = (kN/16, KG)
+template <int L>
+__global__ void __launch_bounds__(256)
+sel_pack_kernel(const DevParams* __restrict__ P, MfmaPtrs sv, uint32_t nq, uint8_t* __restrict__ selp, uint32_t cols,
+                uint32_t kN, uint32_t KG) {
+  const uint32_t j = blockIdx.x * 16 + (threadIdx.x & 15);
+  const uint32_t x = threadIdx.x >> 4;
+  const uint32_t kg = blockIdx.y;
+  const uint64_t q = P->mod[j >> P->logN].q;
+  const uint32_t qi = x >> 1, comp = x & 1;
+  const uint64_t* src = qi < nq ? (const uint64_t*)sv.p[qi] : nullptr;
+  uint8_t o[L][16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const uint32_t c = kg * 16 + t;
+    uint64_t v = 0;
+    if (src && c < cols) v = src[((size_t)c * 2 + comp) * kN + j];
+    int8_t d[L];
+    to_digits<L>(v, q, d);
+#pragma unroll
+    for (int b = 0; b < L; ++b) o[b][t] = (uint8_t)d[b];
+  }
+#pragma unroll
+  for (int b = 0; b < L; ++b) {
+    v4i v;
+    __builtin_memcpy(&v, o[b], 16);
+    *reinterpret_cast<v4i*>(selp + (((size_t)j * KG + kg) * L + b) * 256 + x * 16) = v;
+  }
+}
+
+__device__ __forceinline__ v4i load_tile(const uint8_t* p) {
+  return __builtin_nontemporal_load(reinterpret_cast<const v4i*>(p));
+}
+
+// grid = (kN / 8, nchunks); block = 512 (wave w <-> slot j0 + w).  Chunk ch covers column groups
+// [ch * 4 * KS, (ch + 1) * 4 * KS) and writes to out.p[q] + ch * chunk_stride (partial sums when nchunks > 1).
+template <int L, int KS>
+__global__ void __launch_bounds__(512)
+scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ dbp, const uint8_t* __restrict__ selp,
+                 MfmaPtrs out, uint32_t nq, uint32_t rows, uint32_t RT, uint32_t KG, uint32_t kN,
+                 uint64_t chunk_stride) {
+  constexpr int NS = 2 * L - 1;        // digit diagonals
+  constexpr int NG = (NS + 4) / 5;     // groups of five diagonals (40 bits)
+  __shared__ uint64_t stage[2][16][16][8];
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int g = l >> 4, i16 = l & 15;
+  const uint32_t j0 = blockIdx.x * 8;
+  const uint32_t j = j0 + w;
+  const uint32_t kg0 = blockIdx.y * 4 * KS;
+  const ModConst m = P->mod[j >> P->logN];
+  // multiple of q that makes every 40-bit group positive: 2^57 <= bias < 2^58, |group| < 2^56.1
+  const uint64_t bias = m.q << (58 - (64 - __builtin_clzll(m.q)));
+
+  v4i B[KS][L];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const uint32_t kg = kg0 + ks * 4 + g;
+#pragma unroll
+    for (int b = 0; b < L; ++b) {
+      B[ks][b] = v4i{0, 0, 0, 0};
+      if (kg < KG) B[ks][b] = *reinterpret_cast<const v4i*>(selp + (((size_t)j * KG + kg) * L + b) * 256 + i16 * 16);
+    }
+  }
+  const uint8_t* abase = dbp + (size_t)j * RT * KG * L * 256 + i16 * 16;
+  const uint32_t nx = 2 * nq;
+
+  // ring of KS k-steps of A tiles: slot ks is refilled with the next row tile's step right after use
+  v4i A[KS][L];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const uint32_t kg = kg0 + ks * 4 + g;
+#pragma unroll
+    for (int a = 0; a < L; ++a) {
+      A[ks][a] = v4i{0, 0, 0, 0};
+      if (kg < KG) A[ks][a] = load_tile(abase + ((size_t)kg * L + a) * 256);
+    }
+  }
+
+  for (uint32_t rt = 0; rt < RT; ++rt) {
+    v4i T[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) T[s] = v4i{0, 0, 0, 0};
+    const uint32_t rtn = rt + 1 < RT ? rt + 1 : rt;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      // the L*L digit products, ordered so that consecutive MFMAs accumulate into different diagonals
+#pragma unroll
+      for (int off = 0; off < L; ++off)
+#pragma unroll
+        for (int a = 0; a < L; ++a) {
+          const int b = (a + off) % L;
+          T[a + b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks][a], B[ks][b], T[a + b], 0, 0, 0);
+        }
+      const uint32_t kg = kg0 + ks * 4 + g;
+      if (kg < KG) {
+#pragma unroll
+        for (int a = 0; a < L; ++a) A[ks][a] = load_tile(abase + (((size_t)rtn * KG + kg) * L + a) * 256);
+      }
+    }
+    // lane (g, i16) holds rows rt*16 + g*4 + i (i < 4) of column x = i16:  value = sum_s T[s] 2^(8 s)
+    const int buf = rt & 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint64_t r = 0;
+#pragma unroll
+      for (int grp = NG - 1; grp >= 0; --grp) {
+        int64_t G = 0;
+#pragma unroll
+        for (int s = grp * 5; s < grp * 5 + 5 && s < NS; ++s) G += (int64_t)T[s][i] << (8 * (s - grp * 5));
+        const u128 v = ((u128)r << 40) + (uint64_t)(G + (int64_t)bias);
+        r = reduce128((uint64_t)v, (uint64_t)(v >> 64), m);
+      }
+      stage[buf][g * 4 + i][i16][w] = r;
+    }
+    __syncthreads();
+    // 256 (row, x) runs of 8 slots = 64 B each; 512 threads x 16 B, two rounds
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+      const int run = round * 128 + (threadIdx.x >> 2);
+      const int part = threadIdx.x & 3;
+      const int r16 = run >> 4, x = run & 15;
+      const uint32_t r = rt * 16 + r16;
+      if (x < (int)nx && r < rows) {
+        const v4i v = *reinterpret_cast<const v4i*>(&stage[buf][r16][x][part * 2]);
+        uint64_t* dst = (uint64_t*)out.p[x >> 1] + blockIdx.y * chunk_stride + ((size_t)r * 2 + (x & 1)) * kN + j0 +
+                        part * 2;
+        *reinterpret_cast<v4i*>(dst) = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ host side
+
+MfmaGeom mfma_geometry(const DevParams& hp, uint32_t rows, uint32_t cols) {
+  MfmaGeom gm{};
+  uint32_t bits = 0;
+  for (uint32_t i = 0; i < hp.k; ++i) bits = std::max<uint32_t>(bits, 64 - (uint32_t)__builtin_clzll(hp.mod[i].q));
+  // L balanced digits cover |v| <= 127 (256^L - 1) / 255 > 2^(8L - 2); centred residues are < 2^(bits - 1)
+  if (bits <= 39) gm.L = 5;
+  else if (bits <= 47) gm.L = 6;
+  else if (bits <= 55) gm.L = 7;
+  else return gm;                       // L = 0: not applicable
+  if (rows < 1 || cols < 1) { gm.L = 0; return gm; }
+  gm.RT = (rows + 15) / 16;
+  gm.KG = (cols + 15) / 16;
+  const uint32_t max_ks = gm.L == 5 ? 3 : 2;
+  const uint32_t steps = (gm.KG + 3) / 4;
+  gm.KS = std::min(max_ks, steps);
+  gm.nchunks = (steps + gm.KS - 1) / gm.KS;
+  const size_t kN = (size_t)hp.k * hp.N;
+  gm.db_bytes = kN * gm.RT * gm.KG * gm.L * 256;
+  gm.sel_bytes = kN * gm.KG * gm.L * 256;
+  return gm;
+}
+
+hipError_t launch_db_pack(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint64_t* db, uint8_t* dbp,
+                          uint32_t rows, uint32_t cols, uint32_t kN) {
+  const dim3 grid(kN / 16, gm.RT, gm.KG);
+  switch (gm.L) {
+    case 5: hipLaunchKernelGGL(db_pack_kernel<5>, grid, dim3(256), 0, st, P, db, dbp, rows, cols, kN, gm.RT, gm.KG); break;
+    case 6: hipLaunchKernelGGL(db_pack_kernel<6>, grid, dim3(256), 0, st, P, db, dbp, rows, cols, kN, gm.RT, gm.KG); break;
+    case 7: hipLaunchKernelGGL(db_pack_kernel<7>, grid, dim3(256), 0, st, P, db, dbp, rows, cols, kN, gm.RT, gm.KG); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_sel_pack(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const MfmaPtrs& sv, uint32_t nq,
+                           uint8_t* selp, uint32_t cols, uint32_t kN) {
+  const dim3 grid(kN / 16, gm.KG);
+  switch (gm.L) {
+    case 5: hipLaunchKernelGGL(sel_pack_kernel<5>, grid, dim3(256), 0, st, P, sv, nq, selp, cols, kN, gm.KG); break;
+    case 6: hipLaunchKernelGGL(sel_pack_kernel<6>, grid, dim3(256), 0, st, P, sv, nq, selp, cols, kN, gm.KG); break;
+    case 7: hipLaunchKernelGGL(sel_pack_kernel<7>, grid, dim3(256), 0, st, P, sv, nq, selp, cols, kN, gm.KG); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+template <int L, int KS>
+static void launch_scan_mfma_variant(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp,
+                                     const uint8_t* selp, const MfmaPtrs& out, uint32_t nq, uint32_t rows, uint32_t kN,
+                                     uint64_t chunk_stride) {
+  hipLaunchKernelGGL((scan_mfma_kernel<L, KS>), dim3(kN / 8, gm.nchunks), dim3(512), 0, st, P, dbp, selp, out, nq, rows,
+                     gm.RT, gm.KG, kN, chunk_stride);
+}
+
+hipError_t launch_scan_mfma(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp,
+                            const uint8_t* selp, const MfmaPtrs& out, uint32_t nq, uint32_t rows, uint32_t kN,
+                            uint64_t chunk_stride) {
+#define PIRGPU_MFMA_CASE(L_, KS_)                                                                     \
+  if (gm.L == L_ && gm.KS == KS_) {                                                                   \
+    launch_scan_mfma_variant<L_, KS_>(st, P, gm, dbp, selp, out, nq, rows, kN, chunk_stride);         \
+    return hipGetLastError();                                                                         \
+  }
+  PIRGPU_MFMA_CASE(5, 1) PIRGPU_MFMA_CASE(5, 2) PIRGPU_MFMA_CASE(5, 3)
+  PIRGPU_MFMA_CASE(6, 1) PIRGPU_MFMA_CASE(6, 2)
+  PIRGPU_MFMA_CASE(7, 1) PIRGPU_MFMA_CASE(7, 2)
+#undef PIRGPU_MFMA_CASE
+  return hipErrorInvalidValue;
+}
+
+}  // namespace pirgpu

@@ -60,6 +60,18 @@ struct Worker {
   uint8_t* selp = nullptr;           // digit-packed selectors of the group this worker leads (MFMA scan)
   bool reply_valid = false;
   hipEvent_t ev_expanded = nullptr, ev_scanned = nullptr;  // batch mode: cross-stream hand-offs
+  hipEvent_t ev_done = nullptr;      // batch mode: this worker's reply is complete (its buffers may be reused)
+};
+
+// Batch mode with the MFMA scan: a group of up to 8 queries is expanded TOGETHER on one lane (the
+// expansion kernels run over nodes x queries, ciphertext index = node * B + query), scanned in one
+// database pass, and finished per query on the workers' own streams.  Two lanes alternate so that the
+// bandwidth-bound scan of one group overlaps the compute-bound expansion of the next.
+struct BatchLane {
+  hipStream_t stream = nullptr;
+  uint64_t *res_a = nullptr, *res_b = nullptr, *prod = nullptr, *dig = nullptr;
+  uint8_t* selp = nullptr;
+  hipEvent_t ev_scanned = nullptr;
 };
 
 struct pirgpu_ctx {
@@ -118,6 +130,8 @@ struct pirgpu_ctx {
   uint32_t mfma_nq = kMaxMfmaQueries;       // queries per database pass in batch mode
   uint8_t* d_dbp = nullptr;
   bool packed_valid = false;
+  std::vector<BatchLane> lanes;             // created on the first batch
+  uint64_t groups_run = 0;
 
   bool prof = false;
   static constexpr int kMaxProfRuns = 256;
@@ -359,6 +373,7 @@ void alloc_worker(pirgpu_ctx* c, Worker& w) {
   if (parts > 1) w.scan_part = c->dalloc<uint64_t>((size_t)parts * std::max<uint32_t>(c->scan_rows, 1) * ctw);
   HIP_TRY(hipEventCreateWithFlags(&w.ev_expanded, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&w.ev_scanned, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming));
 }
 
 uint32_t galois_inverse(uint32_t g, uint32_t N) {
@@ -397,21 +412,28 @@ void begin_profiled_run(pirgpu_ctx* c) {
 // oblivious_expansion(ct, n) on the device (reference server.cpp:105-146).
 // Input ciphertext must already be in res_a[0]; returns the buffer holding the
 // next_power_two(n) results.
-uint64_t* expand_on_device(pirgpu_ctx* c, Worker& w, uint32_t n) {
+// B queries at once: ciphertext index = node * B + query, so every level is the same three launches
+// over B times the nodes (the per-level Galois element and monomial shift are uniform).
+uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* res_b, uint64_t* dig, uint64_t* prod,
+                      uint32_t n, uint32_t B) {
   const uint32_t N = c->N, k = c->k;
   if (n > N) throw Fail{PIRGPU_INVALID_ARGUMENT, "Cannot expand more items from a CT than poly modulus degree"};
   const uint32_t logm = hm::ceil_log2(n);
-  uint64_t *cur = w.res_a, *nxt = w.res_b;
+  uint64_t *cur = res_a, *nxt = res_b;
   for (uint32_t j = 0; j < logm; ++j) {
     const uint32_t g = (N >> j) + 1;
     const uint64_t* key = find_key(c, g);
-    HIP_TRY(c->ops->ks_digit(w.stream, c->mode, c->dp, k, cur, g, 1u << j, w.dig));
-    HIP_TRY(c->ops->ks_mac_intt(w.stream, c->mode, c->dp, k, w.dig, key, 1u << j, w.prod));
-    HIP_TRY(launch_ks_combine(w.stream, c->dp, N, k, cur, w.prod, galois_inverse(g, N), 1u << j, 1u << j, true,
-                              nxt));
+    const uint32_t nodes = (1u << j) * B;
+    HIP_TRY(c->ops->ks_digit(st, c->mode, c->dp, k, cur, g, nodes, dig));
+    HIP_TRY(c->ops->ks_mac_intt(st, c->mode, c->dp, k, dig, key, nodes, prod));
+    HIP_TRY(launch_ks_combine(st, c->dp, N, k, cur, prod, galois_inverse(g, N), nodes, 1u << j, true, nxt));
     std::swap(cur, nxt);
   }
   return cur;
+}
+
+uint64_t* expand_on_device(pirgpu_ctx* c, Worker& w, uint32_t n) {
+  return expand_core(c, w.stream, w.res_a, w.res_b, w.dig, w.prod, n, 1);
 }
 
 // expansion of all staged query ciphertexts into sv_ntt (NTT form) -- reference
@@ -460,25 +482,25 @@ void ensure_packed(pirgpu_ctx* c) {
   c->packed_valid = true;
 }
 
-// One pass of the MFMA scan for up to 8 queries (the workers in `members`, expanded already and
-// synchronised with lead.stream by the caller): pack the selectors, scan, fold column chunks.
-void scan_group_mfma(pirgpu_ctx* c, Worker& lead, Worker* const* members, uint32_t n) {
+// One pass of the MFMA scan for up to 8 queries (the workers in `members`, expanded already; the
+// caller has ordered stream `st` after their expansions): pack the selectors, scan, fold column chunks.
+void scan_group_mfma(pirgpu_ctx* c, hipStream_t st, uint8_t*& selp, Worker* const* members, uint32_t n,
+                     Worker* profiled) {
   const uint32_t kN = c->k * c->N;
   const uint64_t words = (uint64_t)c->scan_rows * c->ctw;
   ensure_packed(c);
-  if (!lead.selp) lead.selp = c->dalloc<uint8_t>(c->mg.sel_bytes);
+  if (!selp) selp = c->dalloc<uint8_t>(c->mg.sel_bytes);
   MfmaPtrs sv{}, out{};
   for (uint32_t q = 0; q < n; ++q) {
     sv.p[q] = scan_selectors(c, *members[q]);
     out.p[q] = c->mg.nchunks > 1 ? members[q]->scan_part : members[q]->lvl[c->d - 1];
   }
-  HIP_TRY(launch_sel_pack(lead.stream, c->dp, c->mg, sv, n, lead.selp, c->scan_cols, kN));
-  record(c, lead, PH_SCAN);  // selector packing counts as selector preparation, not as the scan
-  HIP_TRY(launch_scan_mfma(lead.stream, c->dp, c->mg, c->d_dbp, lead.selp, out, n, c->scan_rows, kN, words));
+  HIP_TRY(launch_sel_pack(st, c->dp, c->mg, sv, n, selp, c->scan_cols, kN));
+  if (profiled) record(c, *profiled, PH_SCAN);  // selector packing counts as selector preparation, not as the scan
+  HIP_TRY(launch_scan_mfma(st, c->dp, c->mg, c->d_dbp, selp, out, n, c->scan_rows, kN, words));
   if (c->mg.nchunks > 1)
     for (uint32_t q = 0; q < n; ++q)
-      HIP_TRY(launch_reduce_splits(lead.stream, c->dp, members[q]->scan_part, c->mg.nchunks, words,
-                                   members[q]->lvl[c->d - 1]));
+      HIP_TRY(launch_reduce_splits(st, c->dp, members[q]->scan_part, c->mg.nchunks, words, members[q]->lvl[c->d - 1]));
 }
 
 // Base case of PIRDatabase::multiply (reference database.cpp:185-194,238-247): one fused
@@ -491,7 +513,7 @@ void scan_on_device(pirgpu_ctx* c, Worker& w) {
   if (c->pt_end == c->pt_begin) return;
   if (c->mfma_on) {
     Worker* one = &w;
-    scan_group_mfma(c, w, &one, 1);
+    scan_group_mfma(c, w.stream, w.selp, &one, 1, &w);
     return;
   }
   const uint64_t* sv_base = scan_selectors(c, w);
@@ -677,6 +699,8 @@ void pirgpu_destroy(pirgpu_ctx* c) {
   if (c->stream) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    for (BatchLane& ln : c->lanes)
+      if (ln.stream) (void)hipStreamSynchronize(ln.stream);
     for (size_t i = 1; i < c->workers.size(); ++i)
       if (c->workers[i].stream) (void)hipStreamSynchronize(c->workers[i].stream);
   }
@@ -686,6 +710,11 @@ void pirgpu_destroy(pirgpu_ctx* c) {
   for (Worker& w : c->workers) {
     if (w.ev_expanded) (void)hipEventDestroy(w.ev_expanded);
     if (w.ev_scanned) (void)hipEventDestroy(w.ev_scanned);
+    if (w.ev_done) (void)hipEventDestroy(w.ev_done);
+  }
+  for (BatchLane& ln : c->lanes) {
+    if (ln.ev_scanned) (void)hipEventDestroy(ln.ev_scanned);
+    if (ln.stream) (void)hipStreamDestroy(ln.stream);
   }
   for (size_t i = 1; i < c->workers.size(); ++i)
     if (c->workers[i].stream) (void)hipStreamDestroy(c->workers[i].stream);
@@ -886,6 +915,8 @@ int pirgpu_query_run(pirgpu_ctx* c) {
 int pirgpu_sync(pirgpu_ctx* c) {
   return guarded(c, [&]() -> int {
     HIP_TRY(hipStreamSynchronize(c->stream));
+    for (BatchLane& ln : c->lanes)
+      if (ln.stream) HIP_TRY(hipStreamSynchronize(ln.stream));
     for (Worker& w : c->workers)
       if (w.stream) HIP_TRY(hipStreamSynchronize(w.stream));
     return PIRGPU_OK;
@@ -1072,17 +1103,89 @@ int pirgpu_batch_stage(pirgpu_ctx* c, const uint64_t* queries, uint32_t nq, uint
 // (one per worker); inside a round, groups of up to 4 workers share one pass over the
 // database (scan_mq_kernel), hand-offs between streams through events.  With ext_sv the
 // expansion is skipped and query i reads its NTT-form selection vector at ext_sv + i*dim_sum.
+// Batch mode with the MFMA scan (see BatchLane): groups of up to mfma_nq queries share one batched
+// expansion and one database pass; consecutive groups alternate between two lanes.
+static void batch_run_mfma(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv) {
+  const uint32_t N = c->N, k = c->k;
+  const uint32_t nq = c->dim_sum / N + 1;
+  const size_t ctw = c->ctw;
+  const size_t qwords = (size_t)nq * ctw, rwords = (size_t)c->reply_cts * ctw, svwords = (size_t)c->dim_sum * ctw;
+  const uint32_t W = std::max<uint32_t>(1, std::min<uint32_t>(c->n_active, (uint32_t)c->workers.size()));
+  const uint32_t G = std::min<uint32_t>(c->mfma_nq, W);
+  if (c->lanes.empty()) {
+    c->lanes.resize(2);
+    for (BatchLane& ln : c->lanes) {
+      HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&ln.ev_scanned, hipEventDisableTiming));
+    }
+  }
+  if (!ext_sv && !c->lanes[0].res_a) {
+    const uint64_t half = std::max<uint64_t>(c->m_max / 2, 1);
+    for (BatchLane& ln : c->lanes) {
+      ln.res_a = c->dalloc<uint64_t>((size_t)c->mfma_nq * c->m_max * ctw);
+      ln.res_b = c->dalloc<uint64_t>((size_t)c->mfma_nq * c->m_max * ctw);
+      ln.prod = c->dalloc<uint64_t>((size_t)c->mfma_nq * half * 2 * (k + 1) * N);
+      ln.dig = c->dalloc<uint64_t>((size_t)c->mfma_nq * half * (k + 1) * k * N);
+    }
+  }
+  for (uint32_t base = 0; base < count; base += W) {
+    const uint32_t n = std::min<uint32_t>(W, count - base);
+    for (uint32_t j0 = 0; j0 < n; j0 += G) {
+      const uint32_t B = std::min<uint32_t>(G, n - j0);
+      BatchLane& ln = c->lanes[c->groups_run++ % c->lanes.size()];
+      Worker* members[kMaxMfmaQueries];
+      for (uint32_t q = 0; q < B; ++q) {
+        members[q] = &c->workers[j0 + q];
+        HIP_TRY(hipStreamWaitEvent(ln.stream, members[q]->ev_done, 0));  // its buffers are free again
+      }
+      if (ext_sv) {
+        for (uint32_t q = 0; q < B; ++q) members[q]->sv_cur = ext_sv + (size_t)(base + j0 + q) * svwords;
+      } else {
+        // batched oblivious expansion: B queries interleaved (ciphertext index = node * B + query)
+        uint64_t remaining = c->dim_sum, produced = 0;
+        for (uint32_t qc = 0; qc < nq && remaining; ++qc) {
+          const uint32_t slots = (uint32_t)std::min<uint64_t>(remaining, N);
+          HIP_TRY(hipMemcpy2DAsync(ln.res_a, ctw * 8, c->d_bquery + (size_t)(base + j0) * qwords + (size_t)qc * ctw,
+                                   qwords * 8, ctw * 8, B, hipMemcpyDeviceToDevice, ln.stream));
+          uint64_t* res = expand_core(c, ln.stream, ln.res_a, ln.res_b, ln.dig, ln.prod, slots, B);
+          MfmaPtrs dst{};
+          for (uint32_t q = 0; q < B; ++q) dst.p[q] = members[q]->sv_ntt + produced * ctw;
+          HIP_TRY(c->ops->ct_ntt_fwd_split(ln.stream, c->mode, c->dp, k, res, dst, B, (uint64_t)slots * B));
+          produced += slots;
+          remaining -= slots;
+        }
+        for (uint32_t q = 0; q < B; ++q) members[q]->sv_cur = nullptr;
+      }
+      scan_group_mfma(c, ln.stream, ln.selp, members, B, nullptr);
+      HIP_TRY(hipEventRecord(ln.ev_scanned, ln.stream));
+      for (uint32_t q = 0; q < B; ++q) {
+        Worker& w = *members[q];
+        HIP_TRY(hipStreamWaitEvent(w.stream, ln.ev_scanned, 0));
+        post_scan_on_device(c, w);
+        HIP_TRY(hipMemcpyAsync(c->d_breply + (size_t)(base + j0 + q) * rwords, w.lvl[0], rwords * 8,
+                               hipMemcpyDeviceToDevice, w.stream));
+        HIP_TRY(hipEventRecord(w.ev_done, w.stream));
+        w.reply_valid = true;
+      }
+    }
+  }
+}
+
 static void batch_run_impl(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv) {
   const uint32_t nq = c->dim_sum / c->N + 1;
   const size_t qwords = (size_t)nq * c->ctw, rwords = (size_t)c->reply_cts * c->ctw;
   const size_t svwords = (size_t)c->dim_sum * c->ctw;
   const uint32_t W = std::max<uint32_t>(1, std::min<uint32_t>(c->n_active, (uint32_t)c->workers.size()));
-  const uint32_t G = c->mfma_on ? c->mfma_nq
-                   : mq_usable(c) && c->pt_end > c->pt_begin ? std::min<uint32_t>(c->mq_nq, kMaxScanQueries) : 1;
+  const uint32_t G = mq_usable(c) && c->pt_end > c->pt_begin ? std::min<uint32_t>(c->mq_nq, kMaxScanQueries) : 1;
   if (c->n_loaded != c->pt_end - c->pt_begin)
     throw Fail{PIRGPU_FAILED_PRECONDITION, "database not fully loaded"};
   ensure_packed(c);
   c->prof_cur = -1;
+  if (c->mfma_on) {
+    batch_run_mfma(c, count, ext_sv);
+    c->batch_valid = true;
+    return;
+  }
   for (uint32_t base = 0; base < count; base += W) {
     const uint32_t n = std::min<uint32_t>(W, count - base);
     for (uint32_t j = 0; j < n; ++j) {
@@ -1100,22 +1203,10 @@ static void batch_run_impl(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
     for (uint32_t j0 = 0; j0 < n; j0 += G) {
       const uint32_t g = std::min<uint32_t>(G, n - j0);
       uint32_t done = 0;
-      while (done < g) {  // group sizes the kernel is instantiated for: 4, 2, 1 (MFMA scan: any size up to 8)
-        const uint32_t take = c->mfma_on ? g - done
-                                         : (g - done >= 4 && G >= 4 ? 4 : (g - done >= 2 && G >= 2 ? 2 : 1));
+      while (done < g) {  // group sizes the kernel is instantiated for: 4, 2, 1
+        const uint32_t take = g - done >= 4 && G >= 4 ? 4 : (g - done >= 2 && G >= 2 ? 2 : 1);
         Worker& lead = c->workers[j0 + done];
-        if (c->mfma_on) {
-          Worker* members[kMaxMfmaQueries];
-          for (uint32_t q = 0; q < take; ++q) {
-            members[q] = &c->workers[j0 + done + q];
-            if (q) HIP_TRY(hipStreamWaitEvent(lead.stream, members[q]->ev_expanded, 0));
-          }
-          scan_group_mfma(c, lead, members, take);
-          if (take > 1) {
-            HIP_TRY(hipEventRecord(lead.ev_scanned, lead.stream));
-            for (uint32_t q = 1; q < take; ++q) HIP_TRY(hipStreamWaitEvent(members[q]->stream, lead.ev_scanned, 0));
-          }
-        } else if (take == 1) {
+        if (take == 1) {
           scan_on_device(c, lead);
         } else {
           const uint64_t* svp[kMaxScanQueries];

@@ -7,6 +7,12 @@
 
 namespace pirgpu {
 
+constexpr int kMaxMfmaQueries = 8;   // (query, comp) pairs fill the 16 columns of one MFMA tile
+
+struct MfmaPtrs {                    // one pointer per query of a group (by-value kernel argument)
+  const void* p[kMaxMfmaQueries];
+};
+
 // Kernels that contain an NTT, for one ring degree (ntt_kernels.hip is compiled once
 // per degree).  `mode` is an NttMode.
 struct NttOps {
@@ -15,6 +21,9 @@ struct NttOps {
                           uint32_t mod_period, uint32_t mod_base, bool inverse);
   hipError_t (*ct_ntt_fwd_oop)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* src,
                                uint64_t* dst, uint64_t n_cts);
+  // same transform for B interleaved queries (source ciphertext i*B + q -> dst.p[q] + i): batched expansion
+  hipError_t (*ct_ntt_fwd_split)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* src,
+                                 const MfmaPtrs& dst, uint32_t B, uint64_t n_cts_total);
   hipError_t (*db_encode)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* coeffs,
                           const uint8_t* bytes, uint64_t bytes_per_pt, uint64_t total_bytes, uint32_t bits,
                           uint64_t n_pt, uint64_t* db);
@@ -49,12 +58,6 @@ hipError_t launch_reduce_splits(hipStream_t st, const DevParams* P, const uint64
 
 
 // ---- digit-sliced int8-MFMA scan (scan_mfma.hip) ----
-constexpr int kMaxMfmaQueries = 8;   // (query, comp) pairs fill the 16 columns of one MFMA tile
-
-struct MfmaPtrs {                    // per query: selectors in / row sums out (by value kernel argument)
-  const void* p[kMaxMfmaQueries];
-};
-
 struct MfmaGeom {
   uint32_t L;        // balanced base-256 digits per residue (5, 6, 7); 0 = not applicable
   uint32_t RT;       // row tiles (16 rows)

@@ -81,6 +81,28 @@ ct_ntt_fwd_oop_kernel(const DevParams* __restrict__ P, const uint64_t* __restric
   for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
 }
 
+// The same transform for B queries expanded together: source ciphertext index = slot * B + query
+// (batched expansion keeps the queries interleaved), destination = that query's own selection vector.
+template <int MODE>
+__global__ void __launch_bounds__(NT)
+ct_ntt_fwd_split_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ src, MfmaPtrs dst, uint32_t B) {
+  using A = Arith<MODE>;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t k2 = 2 * P->k;
+  const int mi = blockIdx.x % P->k;
+  const typename A::Mod m = A::mod(P, mi);
+  const uint32_t ct = blockIdx.x / k2, rem = blockIdx.x % k2;
+  const uint32_t slot = ct / B, q = ct % B;
+  const uint64_t* in = src + (size_t)blockIdx.x * N;
+  uint64_t* out = (uint64_t*)dst.p[q] + ((size_t)slot * k2 + rem) * N;
+  typename A::T x[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) x[e] = A::in(in[e * NT + tid], m);
+  ntt_forward<MODE, LOGN>(x, smem_raw, P, mi, tid);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
+}
+
 // grid = (n_pt, k).  Source is either pre-encoded coefficients (coeffs != null)
 // or raw item bytes packed MSB-first into bits-wide coefficients
 // (reference string_encoder.cpp:58-122); then plain lift + forward NTT.
@@ -343,6 +365,7 @@ static hipError_t configure_mode() {
   PIRGPU_SET((ntt_batch_kernel<MODE, false>));
   PIRGPU_SET((ntt_batch_kernel<MODE, true>));
   PIRGPU_SET(ct_ntt_fwd_oop_kernel<MODE>);
+  PIRGPU_SET(ct_ntt_fwd_split_kernel<MODE>);
   PIRGPU_SET(db_encode_kernel<MODE>);
   PIRGPU_SET(ks_digit_kernel<MODE>);
   PIRGPU_SET(ks_mac_intt_kernel<MODE>);
@@ -372,6 +395,13 @@ static hipError_t op_ct_ntt_fwd_oop(hipStream_t st, int mode, const DevParams* P
                                     uint64_t* dst, uint64_t n_cts) {
   PIRGPU_BY_MODE(mode, hipLaunchKernelGGL(ct_ntt_fwd_oop_kernel<MODE>, dim3((uint32_t)(n_cts * 2 * k)), dim3(NT),
                                           kLdsBytes, st, P, src, dst));
+  return hipGetLastError();
+}
+
+static hipError_t op_ct_ntt_fwd_split(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* src,
+                                      const MfmaPtrs& dst, uint32_t B, uint64_t n_cts_total) {
+  PIRGPU_BY_MODE(mode, hipLaunchKernelGGL(ct_ntt_fwd_split_kernel<MODE>, dim3((uint32_t)(n_cts_total * 2 * k)),
+                                          dim3(NT), kLdsBytes, st, P, src, dst, B));
   return hipGetLastError();
 }
 
@@ -412,7 +442,7 @@ static hipError_t op_upper_fused(hipStream_t st, int mode, const DevParams* P, u
 // host-only accessor (a namespace-scope const object would also be emitted for the device)
 const NttOps* PIRGPU_OPS_NAME() {
   using namespace PIRGPU_DEG_NS;
-  static const NttOps ops = {op_configure, op_ntt_batch,   op_ct_ntt_fwd_oop, op_db_encode,
+  static const NttOps ops = {op_configure, op_ntt_batch,   op_ct_ntt_fwd_oop, op_ct_ntt_fwd_split, op_db_encode,
                              op_ks_digit,  op_ks_mac_intt, op_upper_fused};
   return &ops;
 }

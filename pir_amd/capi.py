@@ -106,6 +106,7 @@ SIGNATURES = {
     "pirgpu_reply_copy_to_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "pirgpu_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "pirgpu_scan_bytes": (C.c_uint64, [C.c_void_p]),
+    "pirgpu_scan_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
 }
 
 _lib = None

@@ -752,6 +752,22 @@ uint64_t pirgpu_scan_bytes(const pirgpu_ctx* cc) {
   return c->mfma_on ? (uint64_t)c->mg.db_bytes : (c->pt_end - c->pt_begin) * c->k * c->N * 8;
 }
 
+int pirgpu_scan_info(pirgpu_ctx* c, uint32_t info[8]) {
+  return guarded(c, [&]() -> int {
+    if (!info) return fail(c, PIRGPU_INVALID_ARGUMENT, "null info");
+    ensure_workspace(c);
+    info[0] = c->mfma_on ? 1 : 0;
+    info[1] = c->mfma_on ? c->mg.L : 0;
+    info[2] = c->mfma_on ? c->mg.nchunks : c->scan_nsplit;
+    info[3] = c->mfma_on ? c->mg.KS : 0;
+    info[4] = c->mfma_on ? c->mfma_nq : (mq_usable(c) ? std::min<uint32_t>(c->mq_nq, kMaxScanQueries) : 1);
+    info[5] = c->scan_rows;
+    info[6] = c->scan_cols;
+    info[7] = 0;
+    return PIRGPU_OK;
+  });
+}
+
 int pirgpu_db_load_items(pirgpu_ctx* c, const uint8_t* items, uint64_t num_items, uint32_t bytes_per_item) {
   return guarded(c, [&]() -> int {
     const pirgpu_params& p = c->prm;

@@ -289,6 +289,13 @@ class PIRServer:
     def scan_bytes(self) -> int:
         return int(self.lib.pirgpu_scan_bytes(self.db.handle))
 
+    def scan_info(self) -> dict:
+        """How the database is scanned (pirgpu_scan_info): MFMA digit-sliced path or 64-bit MAC kernels."""
+        info = (C.c_uint32 * 8)()
+        self._check(self.lib.pirgpu_scan_info(self.db.handle, info))
+        return {"mfma": bool(info[0]), "digits": info[1], "chunks": info[2], "ksteps": info[3],
+                "queries_per_pass": info[4], "rows": info[5], "cols": info[6]}
+
     # -- test-visible helpers (server.h:66-131) -----------------------------------------
     def substitute_power_x_inplace(self, ct: np.ndarray, power: int) -> np.ndarray:
         """server.cpp:67-76; returns the substituted ciphertext (ct itself is updated too)."""

@@ -1,0 +1,174 @@
+"""GPU parity of the digit-sliced int8-MFMA database scan (pir_amd/csrc/scan_mfma.hip) across its
+geometry variants -- digits per residue (5 / 6 / 7), k-steps per chunk, column chunks, ragged row and
+column tiles -- and of the batch pipeline built on it (batched expansion, groups of up to 8 queries,
+two lanes).  Every reply is compared bit for bit with the CPU oracle; `scan_info` proves which path ran."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import pir_amd
+from gpu_helpers import to_product_params
+from pir_fixtures import PirSetup
+
+pytestmark = pytest.mark.gpu
+
+
+def make(setup, shard=None):
+    pp = to_product_params(setup.params)
+    db = pir_amd.PIRDatabase.Create(pp, shard=shard)
+    db.populate(setup.raw)
+    srv = pir_amd.PIRServer(db, pp)
+    srv.set_galois_keys(setup.galois_keys)
+    return db, srv
+
+
+def setup_with_dims(short, elem, dims, **kw):
+    """PirSetup with an explicit (non-square) dimension vector and prod(dims) plaintexts minus `short`
+    items: the reference accepts any dimensions whose product covers num_pt (database.cpp:140-168 only
+    uses them as given)."""
+    probe = oracle.create_pir_parameters(10, elem, 1, **{k: v for k, v in kw.items() if k in
+                                                          ("N", "plain_bits", "moduli", "t")})
+    pts = int(np.prod(dims))
+    s = PirSetup(pts * probe.items_per_plaintext - short, elem, len(dims), **kw)
+    assert s.params.num_pt == pts
+    s.params.dimensions = list(dims)
+    return s
+
+
+def check_queries(s, srv, indexes, decode=True):
+    for idx in indexes:
+        q = s.client.create_query_for(s.params, idx)
+        rc, exp = s.orc.process_query(s.db_ntt, s.params.dimensions, q, s.galois_keys)
+        assert rc == 0
+        got = srv.process_query(q)
+        assert np.array_equal(got, exp), idx
+        if decode:
+            assert s.client.process_response(s.params, idx, got) == s.item(idx)
+
+
+# (label, setup kwargs, expected digits, expected chunks, expected ksteps)
+GEOMETRIES = [
+    # N=4096, 36-bit primes -> 5 digits
+    ("L5 17x70 (2 k-steps, ragged tiles)", dict(dbsize=0, elem=2048, dims=[17, 70], N=4096, plain_bits=24), 5, 1, 2),
+    ("L5 33x9 (1 k-step)", dict(dbsize=0, elem=2048, dims=[33, 9], N=4096, plain_bits=24), 5, 1, 1),
+    ("L5 9x200 (2 column chunks)", dict(dbsize=3, elem=2048, dims=[9, 200], N=4096, plain_bits=24), 5, 2, 3),
+    ("L5 d=3 4x4x40 (rows = 16)", dict(dbsize=1, elem=2048, dims=[4, 4, 40], N=4096, plain_bits=20), 5, 1, 1),
+]
+
+
+@pytest.mark.parametrize("label,kw,digits,chunks,ksteps", GEOMETRIES, ids=[g[0] for g in GEOMETRIES])
+def test_mfma_scan_geometries(label, kw, digits, chunks, ksteps):
+    kw = dict(kw)
+    s = setup_with_dims(kw.pop("dbsize"), kw.pop("elem"), kw.pop("dims"), **kw)
+    db, srv = make(s)
+    info = srv.scan_info()
+    assert info["mfma"] and info["digits"] == digits and info["chunks"] == chunks and info["ksteps"] == ksteps, info
+    n = s.params.num_items
+    check_queries(s, srv, [0, n // 2 + 1, n - 1])
+    # the same through the batch pipeline (one group of 3)
+    idx = [1, n // 3, n - 2]
+    queries = np.stack([s.client.create_query_for(s.params, i) for i in idx])
+    got = srv.process_batch(queries, n_workers=4)
+    for i, j in enumerate(idx):
+        rc, exp = s.orc.process_query(s.db_ntt, s.params.dimensions, queries[i], s.galois_keys)
+        assert np.array_equal(got[i], exp)
+    db.close()
+
+
+def test_mfma_scan_six_digits_n8192():
+    # BFVDefault(8192): 43-bit data primes -> 6 digits, 2 k-steps per chunk
+    m = oracle.BFV_DEFAULT[8192]
+    s = setup_with_dims(2, 1024, [9, 130], N=8192, moduli=m[:3] + [m[4]],
+                        t=oracle.plain_modulus_batching(8192, 24))
+    db, srv = make(s)
+    info = srv.scan_info()
+    assert info["mfma"] and info["digits"] == 6 and info["ksteps"] == 2 and info["chunks"] == 2, info
+    check_queries(s, srv, [5, s.params.num_items - 1])
+    db.close()
+
+
+def test_mfma_scan_seven_digits_n16384():
+    # BFVDefault(16384): 48/49-bit data primes -> 7 digits
+    m = oracle.BFV_DEFAULT[16384]
+    s = setup_with_dims(0, 288, [9, 10], N=16384, moduli=m[:4] + [m[8]],
+                        t=oracle.plain_modulus_batching(16384, 24))
+    db, srv = make(s)
+    info = srv.scan_info()
+    assert info["mfma"] and info["digits"] == 7, info
+    check_queries(s, srv, [163 * 45 + 7], decode=False)
+    db.close()
+
+
+def test_valu_scan_still_selectable(monkeypatch):
+    """PIRGPU_SCAN_MFMA=0 keeps the 64-bit multiply-accumulate kernels (read when the context is created)."""
+    monkeypatch.setenv("PIRGPU_SCAN_MFMA", "0")
+    s = setup_with_dims(0, 2048, [17, 17], N=4096, plain_bits=24)
+    db, srv = make(s)
+    assert not srv.scan_info()["mfma"]
+    check_queries(s, srv, [3, s.params.num_items - 1])
+    db.close()
+
+
+def test_small_row_counts_use_the_valu_scan():
+    s = PirSetup(300, 2048, 2, N=4096, plain_bits=24)        # 60 plaintexts -> dims [8, 8]: rows = 8 -> MFMA
+    db, srv = make(s)
+    assert srv.scan_info()["rows"] == 8 and srv.scan_info()["mfma"]
+    db.close()
+    s = PirSetup(100, 2048, 2, N=4096, plain_bits=24)        # 20 plaintexts -> dims [5, 4]: too few rows
+    db, srv = make(s)
+    assert not srv.scan_info()["mfma"]
+    check_queries(s, srv, [99])
+    db.close()
+
+
+@pytest.mark.parametrize("count,workers", [(11, 16), (19, 16), (9, 3), (8, 8)])
+def test_batch_groups_and_lanes(count, workers):
+    """Ragged groups (8 + 3), several rounds and both lanes: every reply equals the single-query reply."""
+    s = setup_with_dims(4, 2048, [20, 21], N=4096, plain_bits=24)
+    db, srv = make(s)
+    n = s.params.num_items
+    idx = [(97 * i + 13) % n for i in range(count)]
+    queries = np.stack([s.client.create_query_for(s.params, i) for i in idx])
+    got = srv.process_batch(queries, n_workers=workers)
+    assert got.shape[0] == count
+    for i in (0, count // 2, count - 1):
+        rc, exp = s.orc.process_query(s.db_ntt, s.params.dimensions, queries[i], s.galois_keys)
+        assert np.array_equal(got[i], exp)
+    for i in range(count):
+        assert np.array_equal(got[i], srv.process_query(queries[i])), i
+    # a second batch on the same context (lanes and workers reused)
+    got2 = srv.process_batch(queries[::-1].copy(), n_workers=workers)
+    assert np.array_equal(got2[::-1], got)
+    db.close()
+
+
+def test_repopulate_after_packing():
+    """Loading new contents after the first query re-packs the operand-layout copy."""
+    s1 = setup_with_dims(0, 2048, [16, 16], N=4096, plain_bits=24, seed=1)
+    s2 = setup_with_dims(0, 2048, [16, 16], N=4096, plain_bits=24, seed=2)
+    db, srv = make(s1)
+    check_queries(s1, srv, [77])
+    db.populate(s2.raw)
+    srv.set_galois_keys(s2.galois_keys)
+    check_queries(s2, srv, [77, 1000])
+    assert np.array_equal(db.read_plaintext(5), s2.db_ntt[5])
+    db.close()
+
+
+def test_row_shards_with_mfma_scan():
+    """Row shards of 24 + 24 rows, each MFMA-scanned; partial replies add up to the full reply (mod q)."""
+    s = setup_with_dims(0, 2048, [48, 10], N=4096, plain_bits=24)
+    q = s.client.create_query_for(s.params, 1234)
+    rc, exp = s.orc.process_query(s.db_ntt, s.params.dimensions, q, s.galois_keys)
+    acc = None
+    for shard in ((0, 24), (24, 48)):
+        db, srv = make(s, shard=shard)
+        assert srv.scan_info()["mfma"] and srv.scan_info()["rows"] == 24
+        part = srv.process_query(q)
+        acc = part.copy() if acc is None else acc + part
+        db.close()
+    for j, qj in enumerate(s.orc.moduli[: s.orc.k]):
+        acc[:, :, j, :] %= np.uint64(qj)
+    assert np.array_equal(acc, exp)

@@ -4,11 +4,12 @@
 One "step" = one pass of the hot path (PIRServer::ProcessRequest's query loop, reference
 server.cpp:60-63 -> processQuery :173-195: oblivious expansion -> database scan ->
 recursive re-encode / multiply-accumulate) over one batch of `--batch` independent
-queries (default 8, different synthetic query ciphertexts), with the encoded database,
-the Galois keys and the query ciphertexts already resident in HBM.  The queries of a
-batch run concurrently on `--workers` working sets (HIP streams), so the latency-bound
-expansion of one query overlaps the bandwidth-bound scan of another; every query does
-the full work.  `value` = queries/s over the timed steps; the single-query latency
+queries (default 16, different synthetic query ciphertexts), with the encoded database,
+the Galois keys and the query ciphertexts already resident in HBM.  Groups of up to 8
+queries are expanded together and share one pass over the database (the digit-sliced
+int8-MFMA scan serves 8 queries per pass); two groups alternate on two lanes so the
+bandwidth-bound scan of one overlaps the compute-bound expansion of the other; every
+query does the full work.  `value` = queries/s over the timed steps; the single-query latency
 (`--batch 1` behaviour, what benchmark.cpp:71-79 times per request) is measured as well
 and reported as `latency_ms_single_query`, and the scan kernel's roofline comes from
 those single-query runs (one scan launch per query, HIP events on the library's stream).
@@ -39,6 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+PMC_FILE = "r01_pmc_scan_mfma_traffic.json"
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -104,8 +106,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="queries per step (per request)")
-    ap.add_argument("--workers", type=int, default=0, help="queries in flight on the GPU (0 = min(batch, 8))")
+    ap.add_argument("--batch", type=int, default=16, help="queries per step (per request)")
+    ap.add_argument("--workers", type=int, default=0, help="queries in flight on the GPU (0 = min(batch, 16): two "
+                                                           "groups of 8 share one database pass each and overlap)")
     ap.add_argument("--latency-runs", type=int, default=30, help="single-query runs for latency + roofline")
     ap.add_argument("--log-items", type=int, default=20, help="database = 2^log_items x 288 B")
     ap.add_argument("--dims", type=int, default=2)
@@ -114,6 +117,12 @@ def main():
                     help="BASELINE.json config (1-based as in SURVEY.md section 8): 3 = the headline workload; "
                          "2/4/5 are reference points (other ring degrees / database shapes)")
     args = ap.parse_args()
+
+    # stdout carries exactly one JSON line: anything native libraries print there (RCCL's version banner)
+    # is sent to stderr instead
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -153,7 +162,7 @@ def main():
         enc = pir_amd.generate_encryption_params(4096, 24)
     pp = pir_amd.create_pir_parameters(1 << args.log_items, item_bytes, args.dims, enc)
     batch = max(1, args.batch)
-    workers = args.workers if args.workers > 0 else min(batch, 8)
+    workers = args.workers if args.workers > 0 else min(batch, 16)
     raw, keys, queries = synthetic_inputs(pp, n_queries=batch)
     query = queries[0]
 
@@ -233,13 +242,14 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         qps = args.steps * batch / elapsed
-        scan_bytes = srv.scan_bytes()                   # algorithmic: num_pt(shard) * k * N * 8
+        scan_bytes = srv.scan_bytes()                   # bytes one database pass must read
+        info = srv.scan_info()
         scan_ms = timings["scan_ms"]
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         traffic = None
         try:   # HBM bytes per scan launch from the committed PMC passes (profiles/), same workload only
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_scan_traffic.json")))
-            if args.config == 3 and args.log_items == 20 and args.dims == 2 and world == 1:
+            pm = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
+            if args.config == 3 and args.log_items == 20 and args.dims == 2 and world == 1 and info["mfma"]:
                 traffic = pm["traffic_bytes_per_launch"]
         except Exception:
             pass
@@ -262,8 +272,11 @@ def main():
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, profiles/r01_pmc_scan_traffic.json",
-                         "kernel": "scan_mq_kernel<4 rows/wave, 1 query>" if args.dims > 1 else "scan_kernel + reduce_splits (column split)",
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, profiles/" + PMC_FILE,
+                         "kernel": ("scan_mfma_kernel<%d digits, %d k-steps> (int8 MFMA digit products, 1 query; "
+                                    "the same pass serves up to 8)" % (info["digits"], info["ksteps"])) if info["mfma"]
+                         else ("scan_mq_kernel<4 rows/wave, 1 query>" if args.dims > 1
+                               else "scan_kernel + reduce_splits (column split)"),
                          "kernel_ms": scan_ms, "algorithmic_bytes": scan_bytes,
                          "launches_averaged": timings["runs"]},
             "latency_ms_single_query": round(latency_ms, 4),
@@ -298,7 +311,8 @@ def main():
             out["batch_reply0_equals_single_query_reply"] = bool(np.array_equal(batch_replies[0], single_reply))
             out["cpu_baseline"] = cpu_baseline(pp, raw, keys, query, single_reply)
             out["speedup_vs_cpu_baseline"] = qps / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        print(json.dumps(out), file=result_out)
+        result_out.flush()
     if use_dist:
         if world == 1 and rank == 0:   # forced single-rank run: the reduced replies must equal the plain ones
             ok = bool(np.array_equal(redb.cpu().numpy().view(np.uint64), srv.fetch_batch()))

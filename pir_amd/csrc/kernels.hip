@@ -60,7 +60,8 @@ __global__ void ntt_reorder_kernel(const uint64_t* __restrict__ in, uint64_t* __
 // substitute_power_x_inplace).  One thread per (node, residue, coefficient).
 __global__ void ks_combine_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ res_in,
                                   const uint64_t* __restrict__ prod, uint32_t galois_inv, uint32_t nodes,
-                                  uint32_t shift_pow, int expand_step, uint64_t* __restrict__ res_out) {
+                                  uint32_t shift_pow, int expand_step, uint32_t hi_limit,
+                                  uint64_t* __restrict__ res_out) {
   const uint32_t N = P->N, k = P->k, km = k + 1;
   const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t total = (uint64_t)nodes * k * N;
@@ -100,11 +101,13 @@ __global__ void ks_combine_kernel(const DevParams* __restrict__ P, const uint64_
   bool sneg = (sraw & N) != 0;
   uint64_t* lo = res_out + (size_t)node * 2 * k * N;
   uint64_t* hi = res_out + ((size_t)node + nodes) * 2 * k * N;
+  const bool want_hi = node + nodes < hi_limit;  // last level: outputs past the requested count are never read
 #pragma unroll
   for (int comp = 0; comp < 2; ++comp) {
     size_t off = ((size_t)comp * k + j) * N;
     uint64_t a = a_ct[off + i];
     lo[off + i] = add_mod(a, g[comp], q);
+    if (!want_hi) continue;
     uint64_t d = sub_mod(a, g[comp], q);
     if (sneg) d = neg_mod(d, q);
     hi[off + sidx] = d;
@@ -614,10 +617,10 @@ hipError_t launch_ntt_reorder(hipStream_t st, uint32_t N, const uint64_t* in, ui
 
 hipError_t launch_ks_combine(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* res_in,
                              const uint64_t* prod, uint32_t galois_inv, uint32_t nodes, uint32_t shift_pow,
-                             bool expand_step, uint64_t* res_out) {
+                             bool expand_step, uint32_t hi_limit, uint64_t* res_out) {
   uint64_t total = (uint64_t)nodes * k * N;
   hipLaunchKernelGGL(ks_combine_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, P, res_in, prod,
-                     galois_inv, nodes, shift_pow, expand_step ? 1 : 0, res_out);
+                     galois_inv, nodes, shift_pow, expand_step ? 1 : 0, hi_limit, res_out);
   PIRGPU_LAUNCH_CHECK();
   return hipSuccess;
 }

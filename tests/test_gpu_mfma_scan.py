@@ -172,3 +172,39 @@ def test_row_shards_with_mfma_scan():
     for j, qj in enumerate(s.orc.moduli[: s.orc.k]):
         acc[:, :, j, :] %= np.uint64(qj)
     assert np.array_equal(acc, exp)
+
+
+def test_query_parallel_ranks_with_mfma_scan():
+    """The multi-GPU step simulated on one GPU with MFMA-scanned shards: each 'rank' expands its block of the
+    batch into the shared buffer, every rank runs ALL queries from the gathered selection vectors
+    (pirgpu_batch_run_selectors -> the ext_sv path of the batch pipeline), partial replies add up mod q."""
+    import torch
+    from pir_amd.distributed import owned_queries
+    s = setup_with_dims(0, 2048, [48, 10], N=4096, plain_bits=24)
+    p = s.params
+    count, world = 6, 2
+    idx = [(211 * i + 17) % p.num_items for i in range(count)]
+    queries = np.stack([s.client.create_query_for(p, i) for i in idx])
+    sv_all = torch.zeros((count, p.dim_sum, 2, s.orc.k, 4096), dtype=torch.int64, device="cuda")
+    ranks = []
+    for r, shard in enumerate(((0, 24), (24, 48))):
+        db, srv = make(s, shard=shard)
+        assert srv.scan_info()["mfma"]
+        srv.set_concurrency(3)
+        srv.stage_batch(queries)
+        lo, hi = owned_queries(count, r, world)
+        srv.batch_expand(lo, hi - lo, sv_all[lo].data_ptr())
+        ranks.append((db, srv))
+    torch.cuda.synchronize()
+    acc = None
+    for db, srv in ranks:
+        srv.batch_run_selectors(sv_all.data_ptr(), count)
+        part = srv.fetch_batch()
+        acc = part.copy() if acc is None else acc + part
+    for j, qj in enumerate(s.orc.moduli[: s.orc.k]):
+        acc[:, :, :, j, :] %= np.uint64(qj)
+    for i in range(count):
+        rc, exp = s.orc.process_query(s.db_ntt, p.dimensions, queries[i], s.galois_keys)
+        assert rc == 0 and np.array_equal(acc[i], exp), i
+    for db, srv in ranks:
+        db.close()

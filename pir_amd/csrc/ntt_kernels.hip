@@ -37,6 +37,7 @@ constexpr int LOGN = PIRGPU_LOGN;
 constexpr int NT = Plan<LOGN>::NT;
 constexpr int N = Plan<LOGN>::N;
 constexpr size_t kLdsBytes = (size_t)Plan<LOGN>::LDS_WORDS * 8;
+constexpr uint32_t kWideLevel = 256;  // nodes per launch from which the key-switch kernels use the XCD-aware 1-D grid
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
@@ -171,7 +172,16 @@ ks_digit_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ re
   uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
   const uint32_t tid = threadIdx.x;
   const uint32_t k = P->k;
-  const uint32_t node = blockIdx.x, I = blockIdx.y, J = blockIdx.z;
+  uint32_t node = blockIdx.x, I = blockIdx.y, J = blockIdx.z;
+  if (gridDim.y == 1) {
+    // wide levels, 1-D grid: the k+1 target moduli of one (node, J) source polynomial run back to back on
+    // the same XCD (block b -> XCD b % 8), so the source is fetched from HBM once and re-read from L2
+    const uint32_t xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
+    I = t % (k + 1);
+    const uint32_t u = t / (k + 1);
+    J = u % k;
+    node = (u / k) * 8 + xcd;
+  }
   const ModConst mI = P->mod[I];
   const typename A::Mod m = A::mod(P, I);
   const uint64_t qJ = P->mod[J].q;
@@ -208,7 +218,16 @@ ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
   using T = typename A::T;
   const uint32_t tid = threadIdx.x;
   const uint32_t k = P->k, km = k + 1;
-  const uint32_t node = blockIdx.x, I = blockIdx.y, comp = blockIdx.z;
+  uint32_t node = blockIdx.x, I = blockIdx.y, comp = blockIdx.z;
+  if (gridDim.y == 1) {
+    // wide levels, 1-D grid: both components of one (node, I) run back to back on the same XCD, so the
+    // second one finds the digits in L2 instead of re-reading them from HBM
+    const uint32_t xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
+    comp = t & 1;
+    const uint32_t u = t >> 1;
+    I = u % km;
+    node = (u / km) * 8 + xcd;
+  }
   const ModConst mI = P->mod[I];
   const typename A::Mod m = A::mod(P, I);
   const T* d0 = reinterpret_cast<const T*>(dig_raw) + ((size_t)node * km + I) * k * N;
@@ -415,15 +434,17 @@ static hipError_t op_db_encode(hipStream_t st, int mode, const DevParams* P, uin
 
 static hipError_t op_ks_digit(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* res_in,
                               uint32_t galois_elt, uint32_t nodes, uint64_t* dig) {
-  PIRGPU_BY_MODE(mode, hipLaunchKernelGGL(ks_digit_kernel<MODE>, dim3(nodes, k + 1, k), dim3(NT), kLdsBytes, st, P,
-                                          res_in, galois_elt, dig));
+  const dim3 grid = nodes >= kWideLevel && nodes % 8 == 0 ? dim3(nodes * (k + 1) * k) : dim3(nodes, k + 1, k);
+  PIRGPU_BY_MODE(mode, hipLaunchKernelGGL(ks_digit_kernel<MODE>, grid, dim3(NT), kLdsBytes, st, P, res_in,
+                                          galois_elt, dig));
   return hipGetLastError();
 }
 
 static hipError_t op_ks_mac_intt(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* dig,
                                  const uint64_t* key, uint32_t nodes, uint64_t* prod) {
-  PIRGPU_BY_MODE(mode, hipLaunchKernelGGL(ks_mac_intt_kernel<MODE>, dim3(nodes, k + 1, 2), dim3(NT), kLdsBytes, st,
-                                          P, dig, key, prod));
+  const dim3 grid = nodes >= kWideLevel && nodes % 8 == 0 ? dim3(nodes * (k + 1) * 2) : dim3(nodes, k + 1, 2);
+  PIRGPU_BY_MODE(mode, hipLaunchKernelGGL(ks_mac_intt_kernel<MODE>, grid, dim3(NT), kLdsBytes, st, P, dig, key,
+                                          prod));
   return hipGetLastError();
 }
 

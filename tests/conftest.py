@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+# torch first: it bundles its own HIP runtime, which must be the one the process loads (importing it after
+# libpirgpu.so has pulled in /opt/rocm's copy leaves torch.cuda unable to initialise)
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -16,10 +16,17 @@ those single-query runs (one scan launch per query, HIP events on the library's 
 Workload = BASELINE.json configs[2]: N=4096, 2 RNS primes, DB = 2^20 x 288 B, d=2 (the
 reference's own benchmark parameters, benchmark.cpp:17-23).
 
-Multi-GPU (launched by torch.distributed.run, one rank per GPU): the database is
-row-sharded across ranks, every rank expands the query, scans its rows and the
-per-shard reply ciphertexts are summed with one RCCL all-reduce + a mod-q fix-up.
-Total work is fixed as N grows -> "scaling": "strong".
+Multi-GPU (launched by torch.distributed.run, one rank per GPU), two modes:
+  --dist-mode queries (default): queries are independent, so they are the unit that is sharded --
+      every GPU holds the whole packed database (1.27 GB of 288 GB at this workload) and serves
+      its own `--batch` queries per step; no collective on the data path (the barrier and the
+      max-over-ranks timing are the only communication); per-GPU work is fixed as N grows ->
+      "scaling": "weak", value = all ranks' queries / time.
+  --dist-mode rows: the database is row-sharded across ranks (for databases larger than one
+      GPU), every rank expands its share of the batch, the selection vectors are all-gathered,
+      every rank scans its rows and the per-shard reply ciphertexts are summed with one RCCL
+      all-reduce + a mod-q fix-up.  Total work is fixed as N grows -> "scaling": "strong".
+DESIGN.md section 7 explains why `queries` is the default at this database size.
 
 The GPU leg uses synthetic inputs of the right shape (uniform residues); the
 cpu_baseline leg (rank 0, N=1 only) times the CPU oracle -- the restatement of the
@@ -44,8 +51,9 @@ PMC_FILE = "r01_pmc_scan_mfma_traffic.json"
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def synthetic_inputs(pp, seed=42, n_queries=1):
-    """DB bytes, Galois keys and n_queries queries: uniform random of the right shape."""
+def synthetic_inputs(pp, seed=42, n_queries=1, query_seed=None):
+    """DB bytes, Galois keys and n_queries queries: uniform random of the right shape.
+    query_seed (per rank in query-sharded multi-GPU runs) changes the queries only."""
     enc = pp.encryption_parameters
     N, q = enc.poly_modulus_degree, enc.coeff_modulus
     k = len(q) - 1
@@ -53,8 +61,9 @@ def synthetic_inputs(pp, seed=42, n_queries=1):
     raw = rng.integers(0, 256, size=(pp.num_items, pp.bytes_per_item), dtype=np.uint8)
     nq = pp.dim_sum // N + 1
     query = np.empty((n_queries, nq, 2, k, N), dtype=np.uint64)
+    qrng = rng if query_seed is None else np.random.default_rng(query_seed)
     for j in range(k):
-        query[:, :, :, j, :] = rng.integers(0, q[j], size=(n_queries, nq, 2, N), dtype=np.uint64)
+        query[:, :, :, j, :] = qrng.integers(0, q[j], size=(n_queries, nq, 2, N), dtype=np.uint64)
     keys = {}
     import pir_amd
     for g in pir_amd.generate_galois_elts(N):
@@ -113,6 +122,11 @@ def main():
     ap.add_argument("--log-items", type=int, default=20, help="database = 2^log_items x 288 B")
     ap.add_argument("--dims", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-mode", choices=["queries", "rows"], default=os.environ.get("PIRGPU_DIST_MODE", "queries"),
+                    help="multi-GPU: 'queries' = every GPU holds the whole database and serves its own batch "
+                         "(independent queries, no data-path collective, weak scaling); 'rows' = the database is "
+                         "row-sharded, replies summed with an RCCL all-reduce (strong scaling; for databases "
+                         "larger than one GPU)")
     ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5],
                     help="BASELINE.json config (1-based as in SURVEY.md section 8): 3 = the headline workload; "
                          "2/4/5 are reference points (other ring degrees / database shapes)")
@@ -134,8 +148,14 @@ def main():
     import pir_amd
 
     dist = None
-    # PIRGPU_FORCE_DIST=1 exercises the RCCL reduce path with a single rank (1-GPU boxes)
-    use_dist = world > 1 or os.environ.get("PIRGPU_FORCE_DIST") == "1"
+    # PIRGPU_FORCE_DIST=1 / =queries: run the multi-GPU code path (rows / queries mode) with a single rank
+    force = os.environ.get("PIRGPU_FORCE_DIST", "")
+    use_dist = world > 1 or force in ("1", "rows", "queries")
+    if force in ("1", "rows"):
+        args.dist_mode = "rows"
+    elif force == "queries":
+        args.dist_mode = "queries"
+    row_sharded = use_dist and args.dist_mode == "rows"
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -163,12 +183,14 @@ def main():
     pp = pir_amd.create_pir_parameters(1 << args.log_items, item_bytes, args.dims, enc)
     batch = max(1, args.batch)
     workers = args.workers if args.workers > 0 else min(batch, 16)
-    raw, keys, queries = synthetic_inputs(pp, n_queries=batch)
+    # query-sharded runs: same database and keys everywhere, every rank draws its own queries
+    raw, keys, queries = synthetic_inputs(pp, n_queries=batch,
+                                          query_seed=1000 + rank if use_dist and not row_sharded else None)
     query = queries[0]
 
     from pir_amd.distributed import (all_reduce_batch_replies, all_reduce_reply, run_batch_query_parallel,
                                      shard_range)
-    shard = shard_range(pp.dimensions[0], rank, world) if world > 1 else None
+    shard = shard_range(pp.dimensions[0], rank, world) if world > 1 and row_sharded else None
     db = pir_amd.PIRDatabase.Create(pp, device=local_rank, shard=shard)
     t0 = time.perf_counter()
     db.populate(raw)
@@ -182,8 +204,8 @@ def main():
     red1 = redb = sv_all = None
     # multi-GPU: query-parallel expansion + all-gather of the selection vectors when the batch
     # divides evenly over the ranks; otherwise every rank expands every query (replicated)
-    query_parallel = use_dist and batch % world == 0 and os.environ.get("PIRGPU_REPLICATED_EXPANSION") != "1"
-    if use_dist:
+    query_parallel = row_sharded and batch % world == 0 and os.environ.get("PIRGPU_REPLICATED_EXPANSION") != "1"
+    if row_sharded:
         red1 = torch.empty((reply_cts, 2, k, N), dtype=torch.int64, device=dev)
         redb = torch.empty((batch, reply_cts, 2, k, N), dtype=torch.int64, device=dev)
         if query_parallel:
@@ -199,14 +221,14 @@ def main():
     srv.stage_query(query)
     for _ in range(3):
         srv.run_staged()
-        if use_dist:
+        if row_sharded:
             all_reduce_reply(srv, red1, dist)
     srv.set_profiling(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.latency_runs):
         srv.run_staged()
-        if use_dist:
+        if row_sharded:
             all_reduce_reply(srv, red1, dist)
     barrier()
     latency_ms = (time.perf_counter() - t0) / args.latency_runs * 1e3
@@ -223,7 +245,7 @@ def main():
             run_batch_query_parallel(srv, sv_all, redb, dist, rank, world)
         else:
             srv.run_batch()
-            if use_dist:
+            if row_sharded:
                 all_reduce_batch_replies(srv, redb, dist)
 
     for _ in range(args.warmup):
@@ -241,7 +263,9 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        qps = args.steps * batch / elapsed
+        # query-sharded: every rank served its own `batch` queries per step
+        total_batch = batch * world if use_dist and not row_sharded else batch
+        qps = args.steps * total_batch / elapsed
         scan_bytes = srv.scan_bytes()                   # bytes one database pass must read
         info = srv.scan_info()
         scan_ms = timings["scan_ms"]
@@ -257,7 +281,8 @@ def main():
             "metric": "PIR queries/sec (ms/query in ms_per_step), N=%d DB=2^%d x %dB d=%d"
                       % (enc.poly_modulus_degree, args.log_items, item_bytes, args.dims),
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong" if row_sharded or world == 1 else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": "N=%d, %d RNS data primes (%s bit | special %d bit), t=24 bit, DB=2^%d x %dB, "
                                    "d=%d, dims=%s, num_pt=%d, %d queries/step, %d in flight (BASELINE.json configs[%d])"
@@ -265,11 +290,13 @@ def main():
                                       ",".join(str(q.bit_length()) for q in enc.coeff_modulus[:-1]),
                                       enc.coeff_modulus[-1].bit_length(), args.log_items, item_bytes, args.dims,
                                       pp.dimensions, pp.num_pt, batch, workers, args.config - 1),
-                       "queries_per_step": batch, "workers": workers,
-                       "parallelism": ("rows sharded over %d GPU(s), %s, RCCL all-reduce of replies"
-                                       % (world, "query-parallel expansion + RCCL all-gather of selection vectors"
-                                          if query_parallel else "replicated expansion"))
-                       if world > 1 else "single GPU"},
+                       "queries_per_step": total_batch, "queries_per_step_per_gpu": batch, "workers": workers,
+                       "parallelism": ("single GPU" if world == 1 else
+                                       ("rows sharded over %d GPU(s), %s, RCCL all-reduce of replies"
+                                        % (world, "query-parallel expansion + RCCL all-gather of selection vectors"
+                                           if query_parallel else "replicated expansion")) if row_sharded else
+                                       ("queries sharded over %d GPUs: every GPU holds the whole database and "
+                                        "serves its own %d queries per step, no data-path collective" % (world, batch)))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, profiles/" + PMC_FILE,
@@ -314,7 +341,7 @@ def main():
         print(json.dumps(out), file=result_out)
         result_out.flush()
     if use_dist:
-        if world == 1 and rank == 0:   # forced single-rank run: the reduced replies must equal the plain ones
+        if world == 1 and rank == 0 and row_sharded:   # forced single-rank run: the reduced replies must equal the plain ones
             ok = bool(np.array_equal(redb.cpu().numpy().view(np.uint64), srv.fetch_batch()))
             print("forced-dist check: all-reduced batch replies equal plain replies: %s" % ok, file=sys.stderr)
         dist.barrier()

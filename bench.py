@@ -273,7 +273,7 @@ def main():
         traffic = None
         try:   # HBM bytes per scan launch from the committed PMC passes (profiles/), same workload only
             pm = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
-            if args.config == 3 and args.log_items == 20 and args.dims == 2 and world == 1 and info["mfma"]:
+            if args.config == 3 and args.log_items == 20 and args.dims == 2 and world == 1 and info["single_query_mfma"]:
                 traffic = pm["traffic_bytes_per_launch"]
         except Exception:
             pass
@@ -301,7 +301,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, profiles/" + PMC_FILE,
                          "kernel": ("scan_mfma_kernel<%d digits, %d k-steps> (int8 MFMA digit products, 1 query; "
-                                    "the same pass serves up to 8)" % (info["digits"], info["ksteps"])) if info["mfma"]
+                                    "the same pass serves up to 8)" % (info["digits"], info["ksteps"])) if info["single_query_mfma"]
                          else ("scan_mq_kernel<4 rows/wave, 1 query>" if args.dims > 1
                                else "scan_kernel + reduce_splits (column split)"),
                          "kernel_ms": scan_ms, "algorithmic_bytes": scan_bytes,

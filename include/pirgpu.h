@@ -191,13 +191,14 @@ void pirgpu_free(void* p);
 int pirgpu_last_timings(pirgpu_ctx* ctx, float phase_ms[6], uint32_t* runs);
 /* Enable/disable the phase events above (default off: zero overhead). */
 int pirgpu_set_profiling(pirgpu_ctx* ctx, int enabled);
-/* Bytes one pass over the database reads: the digit-packed operand-layout copy when the int8-MFMA
- * scan is active (d >= 2), else num_pt(shard) * k * N * 8. */
+/* Bytes a single-query pass over the database reads: the digit-packed operand-layout copy when that pass
+ * is the int8-MFMA scan (info[7] of pirgpu_scan_info), else num_pt(shard) * k * N * 8. */
 uint64_t pirgpu_scan_bytes(const pirgpu_ctx* ctx);
 /* How this context scans its database.  info[0] = 1 if the digit-sliced int8-MFMA scan is active
  * (0: 64-bit multiply-accumulate kernels), info[1] = digits per residue, info[2] = column chunks per
  * pass, info[3] = k-steps (64 columns) per chunk, info[4] = queries per database pass in batch mode,
- * info[5] = rows, info[6] = columns of the scanned matrix, info[7] = reserved (0). */
+ * info[5] = rows, info[6] = columns of the scanned matrix, info[7] = 1 if single queries use the MFMA
+ * scan as well (matrices wider than one column chunk scan single queries with the 64-bit kernels). */
 int pirgpu_scan_info(pirgpu_ctx* ctx, uint32_t info[8]);
 
 #ifdef __cplusplus

@@ -128,6 +128,7 @@ struct pirgpu_ctx {
   bool mfma_on = false;
   MfmaGeom mg{};
   uint32_t mfma_nq = kMaxMfmaQueries;       // queries per database pass in batch mode
+  bool mfma_single = true;                  // single queries use it too (off for matrices wider than one chunk)
   uint8_t* d_dbp = nullptr;
   bool packed_valid = false;
   std::vector<BatchLane> lanes;             // created on the first batch
@@ -347,6 +348,9 @@ void ensure_workspace(pirgpu_ctx* c) {
     c->mfma_on = env_u32("PIRGPU_SCAN_MFMA", 1) != 0 && d >= 2 && c->mg.L != 0 && c->scan_rows >= 8 && shard_pts > 0;
     c->mfma_nq = std::max<uint32_t>(1, std::min<uint32_t>(env_u32("PIRGPU_SCAN_MFMA_NQ", kMaxMfmaQueries),
                                                           kMaxMfmaQueries));
+    //   PIRGPU_SCAN_MFMA_SINGLE: a single query on a matrix wider than one column chunk pays the partial-sum
+    //   round trip for one query only; there the 64-bit kernels on the u64 copy are faster (cfg 4: 5.6 vs 6.4 ms)
+    c->mfma_single = env_u32("PIRGPU_SCAN_MFMA_SINGLE", c->mg.nchunks == 1 ? 1 : 0) != 0;
   }
   c->ws_ready = true;
   if (c->workers.empty()) c->workers.emplace_back();
@@ -513,7 +517,7 @@ void scan_on_device(pirgpu_ctx* c, Worker& w) {
   if (c->n_loaded != c->pt_end - c->pt_begin)
     throw Fail{PIRGPU_FAILED_PRECONDITION, "database not fully loaded"};
   if (c->pt_end == c->pt_begin) return;
-  if (c->mfma_on) {
+  if (c->mfma_on && c->mfma_single) {
     Worker* one = &w;
     scan_group_mfma(c, w.stream, w.selp, &one, 1, &w);
     return;
@@ -750,8 +754,8 @@ uint64_t pirgpu_scan_bytes(const pirgpu_ctx* cc) {
   } catch (...) {
     return 0;
   }
-  // bytes one pass over the database must read: the operand-layout copy when the MFMA scan is active
-  return c->mfma_on ? (uint64_t)c->mg.db_bytes : (c->pt_end - c->pt_begin) * c->k * c->N * 8;
+  // bytes a single-query pass over the database must read: the operand-layout copy when that pass is the MFMA scan
+  return c->mfma_on && c->mfma_single ? (uint64_t)c->mg.db_bytes : (c->pt_end - c->pt_begin) * c->k * c->N * 8;
 }
 
 int pirgpu_scan_info(pirgpu_ctx* c, uint32_t info[8]) {
@@ -765,7 +769,7 @@ int pirgpu_scan_info(pirgpu_ctx* c, uint32_t info[8]) {
     info[4] = c->mfma_on ? c->mfma_nq : (mq_usable(c) ? std::min<uint32_t>(c->mq_nq, kMaxScanQueries) : 1);
     info[5] = c->scan_rows;
     info[6] = c->scan_cols;
-    info[7] = 0;
+    info[7] = c->mfma_on && c->mfma_single ? 1 : 0;
     return PIRGPU_OK;
   });
 }

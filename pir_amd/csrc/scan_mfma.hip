@@ -220,7 +220,7 @@ MfmaGeom mfma_geometry(const DevParams& hp, uint32_t rows, uint32_t cols) {
   if (rows < 1 || cols < 1) { gm.L = 0; return gm; }
   gm.RT = (rows + 15) / 16;
   gm.KG = (cols + 15) / 16;
-  const uint32_t max_ks = gm.L == 5 ? 3 : 2;
+  const uint32_t max_ks = gm.L <= 6 ? 3 : 2;
   const uint32_t steps = (gm.KG + 3) / 4;
   gm.KS = std::min(max_ks, steps);
   gm.nchunks = (steps + gm.KS - 1) / gm.KS;
@@ -271,7 +271,7 @@ hipError_t launch_scan_mfma(hipStream_t st, const DevParams* P, const MfmaGeom& 
     return hipGetLastError();                                                                         \
   }
   PIRGPU_MFMA_CASE(5, 1) PIRGPU_MFMA_CASE(5, 2) PIRGPU_MFMA_CASE(5, 3)
-  PIRGPU_MFMA_CASE(6, 1) PIRGPU_MFMA_CASE(6, 2)
+  PIRGPU_MFMA_CASE(6, 1) PIRGPU_MFMA_CASE(6, 2) PIRGPU_MFMA_CASE(6, 3)
   PIRGPU_MFMA_CASE(7, 1) PIRGPU_MFMA_CASE(7, 2)
 #undef PIRGPU_MFMA_CASE
   return hipErrorInvalidValue;

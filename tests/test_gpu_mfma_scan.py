@@ -77,6 +77,21 @@ def test_mfma_scan_geometries(label, kw, digits, chunks, ksteps):
     db.close()
 
 
+def test_single_query_through_chunked_mfma_scan(monkeypatch):
+    """Matrices wider than one chunk scan single queries with the 64-bit kernels by default; forced onto the
+    MFMA scan they fold the per-chunk partial sums (reduce_splits_kernel) to the same bits."""
+    s = setup_with_dims(3, 2048, [9, 200], N=4096, plain_bits=24)
+    db, srv = make(s)
+    assert srv.scan_info()["mfma"] and not srv.scan_info()["single_query_mfma"]
+    check_queries(s, srv, [11])
+    db.close()
+    monkeypatch.setenv("PIRGPU_SCAN_MFMA_SINGLE", "1")
+    db, srv = make(s)
+    assert srv.scan_info()["single_query_mfma"] and srv.scan_info()["chunks"] == 2
+    check_queries(s, srv, [11, s.params.num_items - 1])
+    db.close()
+
+
 def test_mfma_scan_six_digits_n8192():
     # BFVDefault(8192): 43-bit data primes -> 6 digits, 2 k-steps per chunk
     m = oracle.BFV_DEFAULT[8192]
@@ -84,7 +99,7 @@ def test_mfma_scan_six_digits_n8192():
                         t=oracle.plain_modulus_batching(8192, 24))
     db, srv = make(s)
     info = srv.scan_info()
-    assert info["mfma"] and info["digits"] == 6 and info["ksteps"] == 2 and info["chunks"] == 2, info
+    assert info["mfma"] and info["digits"] == 6 and info["ksteps"] == 3 and info["chunks"] == 1, info
     check_queries(s, srv, [5, s.params.num_items - 1])
     db.close()
 

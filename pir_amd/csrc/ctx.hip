@@ -129,6 +129,7 @@ struct pirgpu_ctx {
   MfmaGeom mg{};
   uint32_t mfma_nq = kMaxMfmaQueries;       // queries per database pass in batch mode
   bool mfma_single = true;                  // single queries use it too (off for matrices wider than one chunk)
+  bool pack40 = false;                      // key-switch digits stored in 5 bytes (all moduli < 2^40; PIRGPU_PACK40)
   uint8_t* d_dbp = nullptr;
   bool packed_valid = false;
   std::vector<BatchLane> lanes;             // created on the first batch
@@ -344,6 +345,8 @@ void ensure_workspace(pirgpu_ctx* c) {
     c->scan_nsplit = (uint32_t)ceil_div(std::max<uint32_t>(c->scan_cols, 1), c->scan_cps);
     //   PIRGPU_SCAN_MFMA=0 keeps the 64-bit multiply-accumulate kernels for d >= 2 as well
     //   PIRGPU_SCAN_MFMA_NQ queries per database pass of the MFMA scan in batch mode (1..8)
+    c->pack40 = env_u32("PIRGPU_PACK40", 1) != 0;
+    for (uint32_t j = 0; j <= k; ++j) c->pack40 = c->pack40 && (c->hp.mod[j].q >> 40) == 0;
     c->mg = mfma_geometry(c->hp, c->scan_rows, c->scan_cols);
     c->mfma_on = env_u32("PIRGPU_SCAN_MFMA", 1) != 0 && d >= 2 && c->mg.L != 0 && c->scan_rows >= 8 && shard_pts > 0;
     c->mfma_nq = std::max<uint32_t>(1, std::min<uint32_t>(env_u32("PIRGPU_SCAN_MFMA_NQ", kMaxMfmaQueries),
@@ -428,8 +431,8 @@ uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* 
     const uint32_t g = (N >> j) + 1;
     const uint64_t* key = find_key(c, g);
     const uint32_t nodes = (1u << j) * B;
-    HIP_TRY(c->ops->ks_digit(st, c->mode, c->dp, k, cur, g, nodes, dig));
-    HIP_TRY(c->ops->ks_mac_intt(st, c->mode, c->dp, k, dig, key, nodes, prod));
+    HIP_TRY(c->ops->ks_digit(st, c->mode, c->dp, k, cur, g, nodes, dig, c->pack40));
+    HIP_TRY(c->ops->ks_mac_intt(st, c->mode, c->dp, k, dig, key, nodes, prod, c->pack40));
     // outputs n*B.. of the last level are never read (only the first n results per query are used)
     const uint32_t hi_limit = j + 1 == logm ? n * B : UINT32_MAX;
     HIP_TRY(launch_ks_combine(st, c->dp, N, k, cur, prod, galois_inverse(g, N), nodes, 1u << j, true, hi_limit, nxt));
@@ -1035,8 +1038,8 @@ int pirgpu_substitute_power_x(pirgpu_ctx* c, uint64_t* ct, uint32_t power) {
       return fail(c, PIRGPU_INTERNAL, "Galois element is not valid");
     const uint64_t* key = find_key(c, power);
     HIP_TRY(hipMemcpyAsync(w.res_a, ct, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c->ops->ks_digit(c->stream, c->mode, c->dp, c->k, w.res_a, power, 1, w.dig));
-    HIP_TRY(c->ops->ks_mac_intt(c->stream, c->mode, c->dp, c->k, w.dig, key, 1, w.prod));
+    HIP_TRY(c->ops->ks_digit(c->stream, c->mode, c->dp, c->k, w.res_a, power, 1, w.dig, c->pack40));
+    HIP_TRY(c->ops->ks_mac_intt(c->stream, c->mode, c->dp, c->k, w.dig, key, 1, w.prod, c->pack40));
     HIP_TRY(launch_ks_combine(c->stream, c->dp, c->N, c->k, w.res_a, w.prod, galois_inverse(power, c->N), 1, 0,
                               false, /*hi_limit: unused without the expand step*/ 0, w.res_b));
     HIP_TRY(hipMemcpyAsync(ct, w.res_b, c->ctw * 8, hipMemcpyDeviceToHost, c->stream));

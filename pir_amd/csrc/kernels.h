@@ -28,9 +28,9 @@ struct NttOps {
                           const uint8_t* bytes, uint64_t bytes_per_pt, uint64_t total_bytes, uint32_t bits,
                           uint64_t n_pt, uint64_t* db);
   hipError_t (*ks_digit)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* res_in,
-                         uint32_t galois_elt, uint32_t nodes, uint64_t* dig);
+                         uint32_t galois_elt, uint32_t nodes, uint64_t* dig, bool pack40);
   hipError_t (*ks_mac_intt)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* dig,
-                            const uint64_t* key, uint32_t nodes, uint64_t* prod);
+                            const uint64_t* key, uint32_t nodes, uint64_t* prod, bool pack40);
   hipError_t (*upper_fused)(hipStream_t st, int mode, const DevParams* P, uint32_t k, uint32_t enc_count,
                             const uint64_t* src, const uint64_t* sv, uint64_t* part, uint32_t n_rows,
                             uint32_t n_dim, uint32_t n_children_total, uint32_t sv_first, uint32_t C,

@@ -41,6 +41,18 @@ constexpr uint32_t kWideLevel = 256;  // nodes per launch from which the key-swi
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
+// 40-bit polynomial storage for the key-switch intermediates (all moduli < 2^40): N low words (u32)
+// followed by N high bytes = 5 N bytes per polynomial instead of 8 N.  The wide expansion levels are
+// bound by the traffic of these intermediates, not by the transforms.
+constexpr size_t kPoly40 = (size_t)5 * N;
+__device__ __forceinline__ uint64_t load40(const uint8_t* poly, uint32_t i) {
+  return (uint64_t)reinterpret_cast<const uint32_t*>(poly)[i] | ((uint64_t)poly[4 * N + i] << 32);
+}
+__device__ __forceinline__ void store40(uint8_t* poly, uint32_t i, uint64_t v) {
+  reinterpret_cast<uint32_t*>(poly)[i] = (uint32_t)v;
+  poly[4 * N + i] = (uint8_t)(v >> 32);
+}
+
 // One workgroup per polynomial; modulus index = mod_base + (poly % mod_period).
 // Forward: natural coefficients -> device NTT order; inverse: the reverse.  In place.
 template <int MODE, bool INVERSE>
@@ -164,7 +176,7 @@ db_encode_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ c
 // One level of the expansion tree, part 1a: for node n, key-level modulus I and
 // RNS digit J:  dig[n][I][J] = NTT_I(sigma_g(c1)_J mod m_I)  (device NTT order, stored in
 // the flavour's register type).  grid = (nodes, k+1, k).
-template <int MODE>
+template <int MODE, bool P40>
 __global__ void __launch_bounds__(NT)
 ks_digit_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ res_in, uint32_t galois_elt,
                 uint64_t* __restrict__ dig) {
@@ -201,16 +213,23 @@ ks_digit_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ re
   for (int e = 0; e < 16; ++e) x[e] = A::in(s[lds_idx(e * NT + tid)], m);
   __syncthreads();  // the transform reuses the same LDS words with its own element type
   ntt_forward<MODE, LOGN>(x, smem_raw, P, I, tid);
-  typename A::T* out = reinterpret_cast<typename A::T*>(dig) + (((size_t)node * (k + 1) + I) * k + J) * N;
+  const size_t poly = ((size_t)node * (k + 1) + I) * k + J;
+  if constexpr (P40) {
+    uint8_t* out = reinterpret_cast<uint8_t*>(dig) + poly * kPoly40;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) out[e * NT + tid] = x[e];
+    for (int e = 0; e < 16; ++e) store40(out, e * NT + tid, A::out(x[e], m));
+  } else {
+    typename A::T* out = reinterpret_cast<typename A::T*>(dig) + poly * N;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) out[e * NT + tid] = x[e];
+  }
 }
 
 // Part 1b: S[c][I] = sum_J dig[n][I][J] (.) K[J][c][I], then INTT_I -> prod[n][c][I]
 // (coefficient order, canonical u64).  The key is in device NTT order (and in the
 // flavour's register type), so the dyadic products are formed directly in the register
 // layout the inverse transform starts from.  grid = (nodes, k+1, 2).
-template <int MODE>
+template <int MODE, bool P40>
 __global__ void __launch_bounds__(NT)
 ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ dig_raw,
                    const uint64_t* __restrict__ key_raw, uint64_t* __restrict__ prod) {
@@ -230,18 +249,24 @@ ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
   }
   const ModConst mI = P->mod[I];
   const typename A::Mod m = A::mod(P, I);
-  const T* d0 = reinterpret_cast<const T*>(dig_raw) + ((size_t)node * km + I) * k * N;
+  const size_t poly0 = ((size_t)node * km + I) * k;
+  const T* d0 = reinterpret_cast<const T*>(dig_raw) + poly0 * N;
+  const uint8_t* d40 = reinterpret_cast<const uint8_t*>(dig_raw) + poly0 * kPoly40;
   const T* key = reinterpret_cast<const T*>(key_raw);
+  // digit J, element i, in the flavour's register type
+  auto digit = [&](uint32_t J, uint32_t i) -> T {
+    if constexpr (P40) return A::in(load40(d40 + (size_t)J * kPoly40, i), m);
+    else return d0[(size_t)J * N + i];
+  };
   T x[16];
   if constexpr (MODE == kNttInt) {
     u128 acc[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0;
     for (uint32_t J = 0; J < k; ++J) {  // k <= 8 products of two residues < 2^61 fit 128 bits
-      const T* dj = d0 + (size_t)J * N;
       const T* kj = key + (((size_t)J * 2 + comp) * km + I) * N;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[e] += (u128)dj[e * NT + tid] * kj[e * NT + tid];
+      for (int e = 0; e < 16; ++e) acc[e] += (u128)digit(J, e * NT + tid) * kj[e * NT + tid];
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) x[e] = reduce128((uint64_t)acc[e], (uint64_t)(acc[e] >> 64), mI);
@@ -249,10 +274,9 @@ ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
 #pragma unroll
     for (int e = 0; e < 16; ++e) x[e] = 0.0;
     for (uint32_t J = 0; J < k; ++J) {
-      const T* dj = d0 + (size_t)J * N;
       const T* kj = key + (((size_t)J * 2 + comp) * km + I) * N;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) x[e] += f64_mulmod(dj[e * NT + tid], kj[e * NT + tid], m);
+      for (int e = 0; e < 16; ++e) x[e] += f64_mulmod(digit(J, e * NT + tid), kj[e * NT + tid], m);
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) x[e] = f64_norm(x[e], m);
@@ -386,8 +410,10 @@ static hipError_t configure_mode() {
   PIRGPU_SET(ct_ntt_fwd_oop_kernel<MODE>);
   PIRGPU_SET(ct_ntt_fwd_split_kernel<MODE>);
   PIRGPU_SET(db_encode_kernel<MODE>);
-  PIRGPU_SET(ks_digit_kernel<MODE>);
-  PIRGPU_SET(ks_mac_intt_kernel<MODE>);
+  PIRGPU_SET((ks_digit_kernel<MODE, false>));
+  PIRGPU_SET((ks_digit_kernel<MODE, true>));
+  PIRGPU_SET((ks_mac_intt_kernel<MODE, false>));
+  PIRGPU_SET((ks_mac_intt_kernel<MODE, true>));
   PIRGPU_SET(upper_fused_kernel<MODE>);
 #undef PIRGPU_SET
   return hipSuccess;
@@ -433,18 +459,28 @@ static hipError_t op_db_encode(hipStream_t st, int mode, const DevParams* P, uin
 }
 
 static hipError_t op_ks_digit(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* res_in,
-                              uint32_t galois_elt, uint32_t nodes, uint64_t* dig) {
+                              uint32_t galois_elt, uint32_t nodes, uint64_t* dig, bool pack40) {
   const dim3 grid = nodes >= kWideLevel && nodes % 8 == 0 ? dim3(nodes * (k + 1) * k) : dim3(nodes, k + 1, k);
-  PIRGPU_BY_MODE(mode, hipLaunchKernelGGL(ks_digit_kernel<MODE>, grid, dim3(NT), kLdsBytes, st, P, res_in,
-                                          galois_elt, dig));
+  if (pack40) {
+    PIRGPU_BY_MODE(mode, hipLaunchKernelGGL((ks_digit_kernel<MODE, true>), grid, dim3(NT), kLdsBytes, st, P, res_in,
+                                            galois_elt, dig));
+  } else {
+    PIRGPU_BY_MODE(mode, hipLaunchKernelGGL((ks_digit_kernel<MODE, false>), grid, dim3(NT), kLdsBytes, st, P, res_in,
+                                            galois_elt, dig));
+  }
   return hipGetLastError();
 }
 
 static hipError_t op_ks_mac_intt(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* dig,
-                                 const uint64_t* key, uint32_t nodes, uint64_t* prod) {
+                                 const uint64_t* key, uint32_t nodes, uint64_t* prod, bool pack40) {
   const dim3 grid = nodes >= kWideLevel && nodes % 8 == 0 ? dim3(nodes * (k + 1) * 2) : dim3(nodes, k + 1, 2);
-  PIRGPU_BY_MODE(mode, hipLaunchKernelGGL(ks_mac_intt_kernel<MODE>, grid, dim3(NT), kLdsBytes, st, P, dig, key,
-                                          prod));
+  if (pack40) {
+    PIRGPU_BY_MODE(mode, hipLaunchKernelGGL((ks_mac_intt_kernel<MODE, true>), grid, dim3(NT), kLdsBytes, st, P, dig,
+                                            key, prod));
+  } else {
+    PIRGPU_BY_MODE(mode, hipLaunchKernelGGL((ks_mac_intt_kernel<MODE, false>), grid, dim3(NT), kLdsBytes, st, P, dig,
+                                            key, prod));
+  }
   return hipGetLastError();
 }
 

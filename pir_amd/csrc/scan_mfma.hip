@@ -24,6 +24,8 @@
 // that each (row, x) is written as one 64-byte run of 8 slots.
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "arith.h"
@@ -108,8 +110,12 @@ __device__ __forceinline__ v4i load_tile(const uint8_t* p) {
   return __builtin_nontemporal_load(reinterpret_cast<const v4i*>(p));
 }
 
-// grid = (kN / 8, nchunks); block = 512 (wave w <-> slot j0 + w).  Chunk ch covers column groups
-// [ch * 4 * KS, (ch + 1) * 4 * KS) and writes to out.p[q] + ch * chunk_stride (partial sums when nchunks > 1).
+// grid = (workgroups, nchunks); block = 512 (wave w <-> slot j0 + w).  A workgroup is persistent: it walks
+// the slot blocks blk = blockIdx.x, blockIdx.x + gridDim.x, ... and, while it folds and stores the last row
+// tile of one block, the selector tiles and the first database tiles of its next block are already in
+// flight (one workgroup per CU at this register count, so nothing else would hide that latency).
+// Chunk ch covers column groups [ch * 4 * KS, (ch + 1) * 4 * KS) and writes to out.p[q] + ch * chunk_stride
+// (partial sums when nchunks > 1).
 template <int L, int KS>
 __global__ void __launch_bounds__(512)
 scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ dbp, const uint8_t* __restrict__ selp,
@@ -120,87 +126,108 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
   __shared__ uint64_t stage[2][16][16][8];
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int g = l >> 4, i16 = l & 15;
-  const uint32_t j0 = blockIdx.x * 8;
-  const uint32_t j = j0 + w;
+  const uint32_t nblocks = kN >> 3;
   const uint32_t kg0 = blockIdx.y * 4 * KS;
-  const ModConst m = P->mod[j >> P->logN];
-  // multiple of q that makes every 40-bit group positive: 2^57 <= bias < 2^58, |group| < 2^56.1
-  const uint64_t bias = m.q << (58 - (64 - __builtin_clzll(m.q)));
-
-  v4i B[KS][L];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    const uint32_t kg = kg0 + ks * 4 + g;
-#pragma unroll
-    for (int b = 0; b < L; ++b) {
-      B[ks][b] = v4i{0, 0, 0, 0};
-      if (kg < KG) B[ks][b] = *reinterpret_cast<const v4i*>(selp + (((size_t)j * KG + kg) * L + b) * 256 + i16 * 16);
-    }
-  }
-  const uint8_t* abase = dbp + (size_t)j * RT * KG * L * 256 + i16 * 16;
   const uint32_t nx = 2 * nq;
+  const size_t slab = (size_t)RT * KG * L * 256;   // database bytes of one slot
 
-  // ring of KS k-steps of A tiles: slot ks is refilled with the next row tile's step right after use
-  v4i A[KS][L];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    const uint32_t kg = kg0 + ks * 4 + g;
-#pragma unroll
-    for (int a = 0; a < L; ++a) {
-      A[ks][a] = v4i{0, 0, 0, 0};
-      if (kg < KG) A[ks][a] = load_tile(abase + ((size_t)kg * L + a) * 256);
-    }
-  }
-
-  for (uint32_t rt = 0; rt < RT; ++rt) {
-    v4i T[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) T[s] = v4i{0, 0, 0, 0};
-    const uint32_t rtn = rt + 1 < RT ? rt + 1 : rt;
+  v4i B[KS][L], A[KS][L];
+  auto load_B = [&](uint32_t j) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      // the L*L digit products, ordered so that consecutive MFMAs accumulate into different diagonals
-#pragma unroll
-      for (int off = 0; off < L; ++off)
-#pragma unroll
-        for (int a = 0; a < L; ++a) {
-          const int b = (a + off) % L;
-          T[a + b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks][a], B[ks][b], T[a + b], 0, 0, 0);
-        }
       const uint32_t kg = kg0 + ks * 4 + g;
-      if (kg < KG) {
 #pragma unroll
-        for (int a = 0; a < L; ++a) A[ks][a] = load_tile(abase + (((size_t)rtn * KG + kg) * L + a) * 256);
+      for (int b = 0; b < L; ++b) {
+        B[ks][b] = v4i{0, 0, 0, 0};
+        if (kg < KG) B[ks][b] = *reinterpret_cast<const v4i*>(selp + (((size_t)j * KG + kg) * L + b) * 256 + i16 * 16);
       }
     }
-    // lane (g, i16) holds rows rt*16 + g*4 + i (i < 4) of column x = i16:  value = sum_s T[s] 2^(8 s)
-    const int buf = rt & 1;
+  };
+
+  uint32_t blk = blockIdx.x;
+  if (blk >= nblocks) return;
+  load_B(blk * 8 + w);
+  {
+    const uint8_t* abase = dbp + (size_t)(blk * 8 + w) * slab + i16 * 16;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      uint64_t r = 0;
+    for (int ks = 0; ks < KS; ++ks) {
+      const uint32_t kg = kg0 + ks * 4 + g;
 #pragma unroll
-      for (int grp = NG - 1; grp >= 0; --grp) {
-        int64_t G = 0;
-#pragma unroll
-        for (int s = grp * 5; s < grp * 5 + 5 && s < NS; ++s) G += (int64_t)T[s][i] << (8 * (s - grp * 5));
-        const u128 v = ((u128)r << 40) + (uint64_t)(G + (int64_t)bias);
-        r = reduce128((uint64_t)v, (uint64_t)(v >> 64), m);
+      for (int a = 0; a < L; ++a) {
+        A[ks][a] = v4i{0, 0, 0, 0};
+        if (kg < KG) A[ks][a] = load_tile(abase + ((size_t)kg * L + a) * 256);
       }
-      stage[buf][g * 4 + i][i16][w] = r;
     }
-    __syncthreads();
-    // 256 (row, x) runs of 8 slots = 64 B each; 512 threads x 16 B, two rounds
+  }
+
+  uint32_t parity = 0;
+  for (; blk < nblocks; blk += gridDim.x) {
+    const uint32_t j0 = blk * 8;
+    const uint32_t j = j0 + w;
+    const ModConst m = P->mod[j >> P->logN];
+    // multiple of q that makes every 40-bit group positive: 2^57 <= bias < 2^58, |group| < 2^56.1
+    const uint64_t bias = m.q << (58 - (64 - __builtin_clzll(m.q)));
+    const uint8_t* abase = dbp + (size_t)j * slab + i16 * 16;
+    const uint32_t nblk = blk + gridDim.x;
+    const bool has_next = nblk < nblocks;
+    const uint8_t* nbase = dbp + (size_t)(nblk * 8 + w) * slab + i16 * 16;
+
+    for (uint32_t rt = 0; rt < RT; ++rt) {
+      v4i T[NS];
 #pragma unroll
-    for (int round = 0; round < 2; ++round) {
-      const int run = round * 128 + (threadIdx.x >> 2);
-      const int part = threadIdx.x & 3;
-      const int r16 = run >> 4, x = run & 15;
-      const uint32_t r = rt * 16 + r16;
-      if (x < (int)nx && r < rows) {
-        const v4i v = *reinterpret_cast<const v4i*>(&stage[buf][r16][x][part * 2]);
-        uint64_t* dst = (uint64_t*)out.p[x >> 1] + blockIdx.y * chunk_stride + ((size_t)r * 2 + (x & 1)) * kN + j0 +
-                        part * 2;
-        *reinterpret_cast<v4i*>(dst) = v;
+      for (int s = 0; s < NS; ++s) T[s] = v4i{0, 0, 0, 0};
+      const bool last = rt + 1 == RT;   // wave-uniform
+      // ring of KS k-steps of A tiles: slot ks is refilled right after use with the same step of the next
+      // row tile (or of the next block's first row tile)
+      const uint8_t* next_tile = last ? nbase : abase + (size_t)(rt + 1) * KG * L * 256;
+      const bool refill = !last || has_next;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        // the L*L digit products, ordered so that consecutive MFMAs accumulate into different diagonals
+#pragma unroll
+        for (int off = 0; off < L; ++off)
+#pragma unroll
+          for (int a = 0; a < L; ++a) {
+            const int b = (a + off) % L;
+            T[a + b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks][a], B[ks][b], T[a + b], 0, 0, 0);
+          }
+        const uint32_t kg = kg0 + ks * 4 + g;
+        if (refill && kg < KG) {
+#pragma unroll
+          for (int a = 0; a < L; ++a) A[ks][a] = load_tile(next_tile + ((size_t)kg * L + a) * 256);
+        }
+      }
+      if (last && has_next) load_B(nblk * 8 + w);   // all MFMAs of this block are issued: B is free
+      // lane (g, i16) holds rows rt*16 + g*4 + i (i < 4) of column x = i16:  value = sum_s T[s] 2^(8 s)
+      const int buf = parity;
+      parity ^= 1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint64_t r = 0;
+#pragma unroll
+        for (int grp = NG - 1; grp >= 0; --grp) {
+          int64_t G = 0;
+#pragma unroll
+          for (int s = grp * 5; s < grp * 5 + 5 && s < NS; ++s) G += (int64_t)T[s][i] << (8 * (s - grp * 5));
+          const u128 v = ((u128)r << 40) + (uint64_t)(G + (int64_t)bias);
+          r = reduce128((uint64_t)v, (uint64_t)(v >> 64), m);
+        }
+        stage[buf][g * 4 + i][i16][w] = r;
+      }
+      __syncthreads();
+      // 256 (row, x) runs of 8 slots = 64 B each; 512 threads x 16 B, two rounds
+#pragma unroll
+      for (int round = 0; round < 2; ++round) {
+        const int run = round * 128 + (threadIdx.x >> 2);
+        const int part = threadIdx.x & 3;
+        const int r16 = run >> 4, x = run & 15;
+        const uint32_t r = rt * 16 + r16;
+        if (x < (int)nx && r < rows) {
+          const v4i v = *reinterpret_cast<const v4i*>(&stage[buf][r16][x][part * 2]);
+          uint64_t* dst = (uint64_t*)out.p[x >> 1] + blockIdx.y * chunk_stride + ((size_t)r * 2 + (x & 1)) * kN + j0 +
+                          part * 2;
+          *reinterpret_cast<v4i*>(dst) = v;
+        }
       }
     }
   }
@@ -258,7 +285,17 @@ template <int L, int KS>
 static void launch_scan_mfma_variant(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp,
                                      const uint8_t* selp, const MfmaPtrs& out, uint32_t nq, uint32_t rows, uint32_t kN,
                                      uint64_t chunk_stride) {
-  hipLaunchKernelGGL((scan_mfma_kernel<L, KS>), dim3(kN / 8, gm.nchunks), dim3(512), 0, st, P, dbp, selp, out, nq, rows,
+  // persistent workgroups: one per CU and chunk (at most), each walking its share of the kN/8 slot blocks
+  static const uint32_t wgs = [] {
+    const char* v = getenv("PIRGPU_SCAN_MFMA_WGS");
+    if (v && *v) return (uint32_t)strtoul(v, nullptr, 10);
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256u;
+    return (uint32_t)prop.multiProcessorCount;
+  }();
+  const uint32_t gx = std::min<uint32_t>(kN / 8, std::max<uint32_t>(1, wgs / std::min<uint32_t>(gm.nchunks, wgs)));
+  hipLaunchKernelGGL((scan_mfma_kernel<L, KS>), dim3(gx, gm.nchunks), dim3(512), 0, st, P, dbp, selp, out, nq, rows,
                      gm.RT, gm.KG, kN, chunk_stride);
 }
 

@@ -1435,6 +1435,8 @@ void pirgpu_keys_blob_set(pirgpu_ctx* c, const uint8_t* blob, size_t len) {
   c->keys_blob_valid = true;
 }
 
+uint32_t pirgpu_get_concurrency(pirgpu_ctx* c) { return c ? c->n_active : 0; }
+
 void pirgpu_free(void* p) { free(p); }
 
 }  // extern "C"

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -115,16 +116,56 @@ int pirgpu_process_request(pirgpu_ctx* ctx, const uint8_t* request, size_t reque
     }
     // --- per query: LoadCiphertexts -> processQuery -> SaveCiphertexts (server.cpp:60-63,173-195)
     const uint64_t n_reply = pirgpu_reply_ct_count(ctx);
-    std::vector<uint64_t> reply(n_reply * ctw), qbuf;
+    std::vector<uint64_t> reply, qbuf;
     std::string out;
-    for (auto& qm : pr.queries) {
-      const uint32_t nq = load_query(sh, qm.first, qm.second, qbuf);
-      uint64_t got = 0;
-      rc = pirgpu_process_query(ctx, qbuf.data(), nq, reply.data(), n_reply, &got);
-      if (rc) throw Err{rc, pirgpu_last_error(ctx)};
+    auto append_reply = [&](const uint64_t* cts_words, uint64_t n) {
       std::string cts;
-      for (uint64_t i = 0; i < got; ++i) put_bytes_field(cts, 1, save_ciphertext(sh, reply.data() + i * ctw));
+      for (uint64_t i = 0; i < n; ++i) put_bytes_field(cts, 1, save_ciphertext(sh, cts_words + i * ctw));
       put_bytes_field(out, 1, cts);  // Response.reply (payload.proto:39-42)
+    };
+    // Several queries in one request (the loop of server.cpp:60-63): run them through the batch pipeline
+    // (grouped expansion, shared database passes) when they all have the same ciphertext count; a request
+    // with a malformed query takes the sequential path so that it fails at that query like the reference.
+    bool batched = false;
+    if (pr.queries.size() > 1) {
+      std::vector<uint64_t> all;
+      uint32_t nq0 = 0;
+      bool uniform = true;
+      for (size_t i = 0; i < pr.queries.size() && uniform; ++i) {
+        const uint32_t nq = load_query(sh, pr.queries[i].first, pr.queries[i].second, qbuf);
+        if (i == 0) nq0 = nq;
+        uniform = nq == nq0 && nq > 0;
+        all.insert(all.end(), qbuf.begin(), qbuf.end());
+      }
+      if (uniform) {
+        const uint32_t count = (uint32_t)pr.queries.size();
+        const uint32_t before = pirgpu_get_concurrency(ctx);
+        rc = pirgpu_set_concurrency(ctx, std::max<uint32_t>(before, std::min<uint32_t>(count, 16)));
+        if (!rc) rc = pirgpu_batch_stage(ctx, all.data(), nq0, count);
+        if (!rc) rc = pirgpu_batch_run(ctx);
+        reply.resize((size_t)count * n_reply * ctw);
+        uint64_t got = 0;
+        if (!rc) rc = pirgpu_batch_fetch(ctx, reply.data(), (uint64_t)count * n_reply, &got);
+        (void)pirgpu_set_concurrency(ctx, before);
+        if (rc == PIRGPU_INVALID_ARGUMENT) {
+          // e.g. wrong ciphertext count for the dimensions: let the sequential path report it per query
+          out.clear();
+        } else {
+          if (rc) throw Err{rc, pirgpu_last_error(ctx)};
+          for (uint32_t i = 0; i < count; ++i) append_reply(reply.data() + (size_t)i * n_reply * ctw, n_reply);
+          batched = true;
+        }
+      }
+    }
+    if (!batched) {
+      reply.resize(n_reply * ctw);
+      for (auto& qm : pr.queries) {
+        const uint32_t nq = load_query(sh, qm.first, qm.second, qbuf);
+        uint64_t got = 0;
+        rc = pirgpu_process_query(ctx, qbuf.data(), nq, reply.data(), n_reply, &got);
+        if (rc) throw Err{rc, pirgpu_last_error(ctx)};
+        append_reply(reply.data(), got);
+      }
     }
     uint8_t* buf = (uint8_t*)malloc(out.size() ? out.size() : 1);
     if (!buf) return PIRGPU_INTERNAL;

@@ -18,6 +18,8 @@ int pirgpu_wire_validate_request(const struct pirgpu_params* params, const uint8
 struct pirgpu_ctx;
 int pirgpu_keys_blob_matches(struct pirgpu_ctx* ctx, const uint8_t* blob, size_t len);
 void pirgpu_keys_blob_set(struct pirgpu_ctx* ctx, const uint8_t* blob, size_t len);
+// Queries in flight as last set with pirgpu_set_concurrency (1 by default).
+uint32_t pirgpu_get_concurrency(struct pirgpu_ctx* ctx);
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,7 @@ CASES = [
     (4096, 24, 64, 0, 10, 1, [0]),
     (4096, 24, 64, 0, 1000, 1, [42, 999]),
     (4096, 24, 288, 0, 3000, 2, [0, 1234, 2999]),
+    (4096, 24, 288, 0, 3200, 2, [(173 * i + 5) % 3200 for i in range(19)]),   # one request, 19 queries: batch pipeline
     (4096, 24, 64, 10, 1500, 2, [7, 1499]),
     (4096, 20, 64, 0, 500, 3, [321]),
     (8192, 24, 256, 0, 2000, 2, [5, 1999]),

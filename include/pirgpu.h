@@ -92,6 +92,12 @@ int pirgpu_db_load_items(pirgpu_ctx* ctx, const uint8_t* items, uint64_t num_ite
 int pirgpu_db_load_coeffs(pirgpu_ctx* ctx, uint64_t first_pt, uint64_t n_pt, const uint64_t* coeffs);
 /* PIRDatabase::size() (reference database.h:97) -- plaintexts loaded so far. */
 uint64_t pirgpu_db_size(const pirgpu_ctx* ctx);
+/* Optional: bring the scan's operand-layout copy of the database up to date now (otherwise done lazily
+ * by the first query after a load).  With release_staging != 0 (d >= 2 only) the u64 staging copy that
+ * loads write into is freed afterwards: the database then occupies L/8 of its u64 size (plus tile
+ * padding) and cannot be reloaded (FailedPrecondition); pirgpu_db_read_plaintext keeps working.
+ * No reference counterpart (the reference keeps one vector<Plaintext>, database.h:126-133). */
+int pirgpu_db_finalize(pirgpu_ctx* ctx, int release_staging);
 /* Test hook: read back one encoded plaintext [k][N] (NTT form) from HBM. */
 int pirgpu_db_read_plaintext(pirgpu_ctx* ctx, uint64_t pt_index, uint64_t* out);
 

@@ -132,6 +132,7 @@ struct pirgpu_ctx {
   bool pack40 = false;                      // key-switch digits stored in 5 bytes (all moduli < 2^40; PIRGPU_PACK40)
   uint8_t* d_dbp = nullptr;
   bool packed_valid = false;
+  bool staging_released = false;            // pirgpu_db_finalize(release): only the operand-layout copy is left
   std::vector<BatchLane> lanes;             // created on the first batch
   uint64_t groups_run = 0;
 
@@ -788,6 +789,8 @@ int pirgpu_db_load_items(pirgpu_ctx* c, const uint8_t* items, uint64_t num_items
       return fail(c, PIRGPU_INVALID_ARGUMENT, "item size does not match parameters");
     const uint64_t ipp = p.items_per_plaintext;
     const uint64_t bytes_per_pt = ipp * bytes_per_item;
+    if (c->staging_released)
+      return fail(c, PIRGPU_FAILED_PRECONDITION, "database staging was released by pirgpu_db_finalize; it cannot be reloaded");
     c->packed_valid = false;
     // StringEncoder::calc_num_coeff (reference string_encoder.cpp:88-95)
     if ((uint64_t)std::ceil((double)(bytes_per_pt * 8) / c->bits) > c->N)
@@ -826,6 +829,8 @@ int pirgpu_db_load_coeffs(pirgpu_ctx* c, uint64_t first_pt, uint64_t n_pt, const
     if (first_pt + n_pt > c->P || (!coeffs && n_pt)) return fail(c, PIRGPU_INVALID_ARGUMENT, "plaintext range out of bounds");
     const uint64_t lo = std::max(first_pt, c->pt_begin), hi = std::min(first_pt + n_pt, c->pt_end);
     if (lo >= hi) return PIRGPU_OK;
+    if (c->staging_released)
+      return fail(c, PIRGPU_FAILED_PRECONDITION, "database staging was released by pirgpu_db_finalize; it cannot be reloaded");
     c->packed_valid = false;
     const uint64_t chunk = std::max<uint64_t>(1, (64ull << 20) / (c->N * 8));
     uint64_t* d_coeffs = nullptr;
@@ -853,15 +858,42 @@ int pirgpu_db_load_coeffs(pirgpu_ctx* c, uint64_t first_pt, uint64_t n_pt, const
   });
 }
 
+int pirgpu_db_finalize(pirgpu_ctx* c, int release_staging) {
+  return guarded(c, [&]() -> int {
+    ensure_workspace(c);
+    if (c->n_loaded != c->pt_end - c->pt_begin) return fail(c, PIRGPU_FAILED_PRECONDITION, "database not fully loaded");
+    ensure_packed(c);
+    if (release_staging && c->mfma_on && c->d_db) {
+      for (Worker& w : c->workers)
+        if (w.stream) HIP_TRY(hipStreamSynchronize(w.stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      auto it = std::find(c->allocs.begin(), c->allocs.end(), (void*)c->d_db);
+      if (it != c->allocs.end()) c->allocs.erase(it);
+      HIP_TRY(hipFree(c->d_db));
+      c->d_db = nullptr;
+      c->staging_released = true;
+      c->mfma_single = true;  // the 64-bit kernels read the staging copy
+    }
+    return PIRGPU_OK;
+  });
+}
+
 int pirgpu_db_read_plaintext(pirgpu_ctx* c, uint64_t pt_index, uint64_t* out) {
   return guarded(c, [&]() -> int {
     if (pt_index < c->pt_begin || pt_index >= c->pt_end || !out)
       return fail(c, PIRGPU_INVALID_ARGUMENT, "plaintext index outside this shard");
     uint64_t* stage = nullptr;
-    HIP_TRY(hipMalloc((void**)&stage, (size_t)c->k * c->N * 8));
+    HIP_TRY(hipMalloc((void**)&stage, (size_t)2 * c->k * c->N * 8));
     try {
-      HIP_TRY(launch_ntt_reorder(c->stream, c->N, c->d_db + (pt_index - c->pt_begin) * c->k * c->N, stage, c->k, false,
-                                 false));
+      const uint64_t* src = c->d_db ? c->d_db + (pt_index - c->pt_begin) * c->k * c->N : nullptr;
+      if (!src) {  // staging released: gather the digits of this plaintext from the operand layout
+        const uint64_t local = pt_index - c->pt_begin;
+        uint64_t* tmp = stage + (size_t)c->k * c->N;
+        HIP_TRY(launch_db_unpack(c->stream, c->dp, c->mg, c->d_dbp, tmp, (uint32_t)(local / c->scan_cols),
+                                 (uint32_t)(local % c->scan_cols), c->k * c->N));
+        src = tmp;
+      }
+      HIP_TRY(launch_ntt_reorder(c->stream, c->N, src, stage, c->k, false, false));
       HIP_TRY(hipMemcpyAsync(out, stage, (size_t)c->k * c->N * 8, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(hipStreamSynchronize(c->stream));
     } catch (...) {

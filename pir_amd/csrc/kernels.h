@@ -70,6 +70,8 @@ struct MfmaGeom {
 MfmaGeom mfma_geometry(const DevParams& hp, uint32_t rows, uint32_t cols);
 hipError_t launch_db_pack(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint64_t* db, uint8_t* dbp,
                           uint32_t rows, uint32_t cols, uint32_t kN);
+hipError_t launch_db_unpack(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp, uint64_t* out,
+                            uint32_t row, uint32_t col, uint32_t kN);
 hipError_t launch_sel_pack(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const MfmaPtrs& sv, uint32_t nq,
                            uint8_t* selp, uint32_t cols, uint32_t kN);
 hipError_t launch_scan_mfma(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp,

@@ -106,6 +106,21 @@ sel_pack_kernel(const DevParams* __restrict__ P, MfmaPtrs sv, uint32_t nq, uint8
   }
 }
 
+// one plaintext (row r, column c) back from the operand layout: out[j] = residue in [0, q_j), device slot order
+template <int L>
+__global__ void __launch_bounds__(256)
+db_unpack_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ dbp, uint64_t* __restrict__ out,
+                 uint32_t r, uint32_t c, uint32_t kN, uint32_t RT, uint32_t KG) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= kN) return;
+  const uint64_t q = P->mod[j >> P->logN].q;
+  const uint8_t* p = dbp + (((size_t)j * RT + (r >> 4)) * KG + (c >> 4)) * L * 256 + (r & 15) * 16 + (c & 15);
+  int64_t v = 0;
+#pragma unroll
+  for (int a = L - 1; a >= 0; --a) v = v * 256 + (int8_t)p[(size_t)a * 256];
+  out[j] = v < 0 ? (uint64_t)(v + (int64_t)q) : (uint64_t)v;
+}
+
 __device__ __forceinline__ v4i load_tile(const uint8_t* p) {
   return __builtin_nontemporal_load(reinterpret_cast<const v4i*>(p));
 }
@@ -264,6 +279,18 @@ hipError_t launch_db_pack(hipStream_t st, const DevParams* P, const MfmaGeom& gm
     case 5: hipLaunchKernelGGL(db_pack_kernel<5>, grid, dim3(256), 0, st, P, db, dbp, rows, cols, kN, gm.RT, gm.KG); break;
     case 6: hipLaunchKernelGGL(db_pack_kernel<6>, grid, dim3(256), 0, st, P, db, dbp, rows, cols, kN, gm.RT, gm.KG); break;
     case 7: hipLaunchKernelGGL(db_pack_kernel<7>, grid, dim3(256), 0, st, P, db, dbp, rows, cols, kN, gm.RT, gm.KG); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_db_unpack(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp, uint64_t* out,
+                            uint32_t row, uint32_t col, uint32_t kN) {
+  const dim3 grid((kN + 255) / 256);
+  switch (gm.L) {
+    case 5: hipLaunchKernelGGL(db_unpack_kernel<5>, grid, dim3(256), 0, st, P, dbp, out, row, col, kN, gm.RT, gm.KG); break;
+    case 6: hipLaunchKernelGGL(db_unpack_kernel<6>, grid, dim3(256), 0, st, P, dbp, out, row, col, kN, gm.RT, gm.KG); break;
+    case 7: hipLaunchKernelGGL(db_unpack_kernel<7>, grid, dim3(256), 0, st, P, dbp, out, row, col, kN, gm.RT, gm.KG); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

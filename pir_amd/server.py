@@ -117,6 +117,10 @@ class PIRDatabase:
     def size(self) -> int:
         return int(self.lib.pirgpu_db_size(self._h))
 
+    def finalize(self, release_staging: bool = False) -> None:
+        """Pack the operand-layout copy now; optionally free the u64 staging copy (no reloads afterwards)."""
+        self._check(self.lib.pirgpu_db_finalize(self._h, 1 if release_staging else 0))
+
     def read_plaintext(self, index: int) -> np.ndarray:
         out = np.empty((self.k, self.N), dtype=np.uint64)
         self._check(self.lib.pirgpu_db_read_plaintext(self._h, index, _ptr(out)))

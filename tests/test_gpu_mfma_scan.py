@@ -223,3 +223,33 @@ def test_query_parallel_ranks_with_mfma_scan():
         assert rc == 0 and np.array_equal(acc[i], exp), i
     for db, srv in ranks:
         db.close()
+
+
+def test_finalize_and_release_staging():
+    """pirgpu_db_finalize(release_staging): only the operand-layout copy stays resident; queries (single and
+    batch) and read_plaintext keep working bit-exactly, reloading is refused."""
+    s = setup_with_dims(2, 2048, [17, 19], N=4096, plain_bits=24)
+    db, srv = make(s)
+    db.finalize(release_staging=True)
+    assert srv.scan_info()["single_query_mfma"]
+    check_queries(s, srv, [0, s.params.num_items - 1])
+    for i in (0, 18, 19, s.params.num_pt - 1):
+        assert np.array_equal(db.read_plaintext(i), s.db_ntt[i]), i
+    idx = [3, 500, 1000]
+    queries = np.stack([s.client.create_query_for(s.params, i) for i in idx])
+    got = srv.process_batch(queries, n_workers=4)
+    for i in range(len(idx)):
+        rc, exp = s.orc.process_query(s.db_ntt, s.params.dimensions, queries[i], s.galois_keys)
+        assert np.array_equal(got[i], exp)
+    with pytest.raises(pir_amd.PirGpuError) as e:
+        db.populate(s.raw)
+    assert e.value.code == pir_amd.StatusCode.FAILED_PRECONDITION
+    db.close()
+    # chunked geometry: releasing the staging copy moves single queries onto the MFMA scan as well
+    s = setup_with_dims(3, 2048, [9, 200], N=4096, plain_bits=24)
+    db, srv = make(s)
+    assert not srv.scan_info()["single_query_mfma"]
+    db.finalize(release_staging=True)
+    assert srv.scan_info()["single_query_mfma"]
+    check_queries(s, srv, [77])
+    db.close()

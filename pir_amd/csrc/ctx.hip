@@ -1156,19 +1156,9 @@ int pirgpu_batch_stage(pirgpu_ctx* c, const uint64_t* queries, uint32_t nq, uint
   });
 }
 
-// Shared body of pirgpu_batch_run / pirgpu_batch_run_selectors: `count` queries in rounds of W
-// (one per worker); inside a round, groups of up to 4 workers share one pass over the
-// database (scan_mq_kernel), hand-offs between streams through events.  With ext_sv the
-// expansion is skipped and query i reads its NTT-form selection vector at ext_sv + i*dim_sum.
-// Batch mode with the MFMA scan (see BatchLane): groups of up to mfma_nq queries share one batched
-// expansion and one database pass; consecutive groups alternate between two lanes.
-static void batch_run_mfma(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv) {
+// Lanes (stream + expansion buffers for up to 8 interleaved queries), created on the first batch.
+static void ensure_lanes(pirgpu_ctx* c, bool with_expansion_buffers) {
   const uint32_t N = c->N, k = c->k;
-  const uint32_t nq = c->dim_sum / N + 1;
-  const size_t ctw = c->ctw;
-  const size_t qwords = (size_t)nq * ctw, rwords = (size_t)c->reply_cts * ctw, svwords = (size_t)c->dim_sum * ctw;
-  const uint32_t W = std::max<uint32_t>(1, std::min<uint32_t>(c->n_active, (uint32_t)c->workers.size()));
-  const uint32_t G = std::min<uint32_t>(c->mfma_nq, W);
   if (c->lanes.empty()) {
     c->lanes.resize(2);
     for (BatchLane& ln : c->lanes) {
@@ -1176,15 +1166,45 @@ static void batch_run_mfma(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
       HIP_TRY(hipEventCreateWithFlags(&ln.ev_scanned, hipEventDisableTiming));
     }
   }
-  if (!ext_sv && !c->lanes[0].res_a) {
+  if (with_expansion_buffers && !c->lanes[0].res_a) {
     const uint64_t half = std::max<uint64_t>(c->m_max / 2, 1);
     for (BatchLane& ln : c->lanes) {
-      ln.res_a = c->dalloc<uint64_t>((size_t)c->mfma_nq * c->m_max * ctw);
-      ln.res_b = c->dalloc<uint64_t>((size_t)c->mfma_nq * c->m_max * ctw);
-      ln.prod = c->dalloc<uint64_t>((size_t)c->mfma_nq * half * 2 * (k + 1) * N);
-      ln.dig = c->dalloc<uint64_t>((size_t)c->mfma_nq * half * (k + 1) * k * N);
+      ln.res_a = c->dalloc<uint64_t>((size_t)kMaxMfmaQueries * c->m_max * c->ctw);
+      ln.res_b = c->dalloc<uint64_t>((size_t)kMaxMfmaQueries * c->m_max * c->ctw);
+      ln.prod = c->dalloc<uint64_t>((size_t)kMaxMfmaQueries * half * 2 * (k + 1) * N);
+      ln.dig = c->dalloc<uint64_t>((size_t)kMaxMfmaQueries * half * (k + 1) * k * N);
     }
   }
+}
+
+// Batched oblivious expansion of the staged queries first .. first+B-1 on lane `ln`, B queries interleaved
+// (ciphertext index = node * B + query), into the members' own selection vectors (NTT form).
+static void expand_group_on_lane(pirgpu_ctx* c, BatchLane& ln, Worker* const* members, uint32_t B, uint32_t first) {
+  const uint32_t N = c->N, k = c->k;
+  const uint32_t nq = c->dim_sum / N + 1;
+  const size_t ctw = c->ctw, qwords = (size_t)nq * ctw;
+  uint64_t remaining = c->dim_sum, produced = 0;
+  for (uint32_t qc = 0; qc < nq && remaining; ++qc) {
+    const uint32_t slots = (uint32_t)std::min<uint64_t>(remaining, N);
+    HIP_TRY(hipMemcpy2DAsync(ln.res_a, ctw * 8, c->d_bquery + (size_t)first * qwords + (size_t)qc * ctw, qwords * 8,
+                             ctw * 8, B, hipMemcpyDeviceToDevice, ln.stream));
+    uint64_t* res = expand_core(c, ln.stream, ln.res_a, ln.res_b, ln.dig, ln.prod, slots, B);
+    MfmaPtrs dst{};
+    for (uint32_t q = 0; q < B; ++q) dst.p[q] = members[q]->sv_ntt + produced * ctw;
+    HIP_TRY(c->ops->ct_ntt_fwd_split(ln.stream, c->mode, c->dp, k, res, dst, B, (uint64_t)slots * B));
+    produced += slots;
+    remaining -= slots;
+  }
+  for (uint32_t q = 0; q < B; ++q) members[q]->sv_cur = nullptr;
+}
+
+// Batch mode with the MFMA scan (see BatchLane): groups of up to mfma_nq queries share one batched
+// expansion and one database pass; consecutive groups alternate between two lanes.
+static void batch_run_mfma(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv) {
+  const size_t rwords = (size_t)c->reply_cts * c->ctw, svwords = (size_t)c->dim_sum * c->ctw;
+  const uint32_t W = std::max<uint32_t>(1, std::min<uint32_t>(c->n_active, (uint32_t)c->workers.size()));
+  const uint32_t G = std::min<uint32_t>(c->mfma_nq, W);
+  ensure_lanes(c, !ext_sv);
   for (uint32_t base = 0; base < count; base += W) {
     const uint32_t n = std::min<uint32_t>(W, count - base);
     for (uint32_t j0 = 0; j0 < n; j0 += G) {
@@ -1198,20 +1218,7 @@ static void batch_run_mfma(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
       if (ext_sv) {
         for (uint32_t q = 0; q < B; ++q) members[q]->sv_cur = ext_sv + (size_t)(base + j0 + q) * svwords;
       } else {
-        // batched oblivious expansion: B queries interleaved (ciphertext index = node * B + query)
-        uint64_t remaining = c->dim_sum, produced = 0;
-        for (uint32_t qc = 0; qc < nq && remaining; ++qc) {
-          const uint32_t slots = (uint32_t)std::min<uint64_t>(remaining, N);
-          HIP_TRY(hipMemcpy2DAsync(ln.res_a, ctw * 8, c->d_bquery + (size_t)(base + j0) * qwords + (size_t)qc * ctw,
-                                   qwords * 8, ctw * 8, B, hipMemcpyDeviceToDevice, ln.stream));
-          uint64_t* res = expand_core(c, ln.stream, ln.res_a, ln.res_b, ln.dig, ln.prod, slots, B);
-          MfmaPtrs dst{};
-          for (uint32_t q = 0; q < B; ++q) dst.p[q] = members[q]->sv_ntt + produced * ctw;
-          HIP_TRY(c->ops->ct_ntt_fwd_split(ln.stream, c->mode, c->dp, k, res, dst, B, (uint64_t)slots * B));
-          produced += slots;
-          remaining -= slots;
-        }
-        for (uint32_t q = 0; q < B; ++q) members[q]->sv_cur = nullptr;
+        expand_group_on_lane(c, ln, members, B, base + j0);
       }
       scan_group_mfma(c, ln.stream, ln.selp, members, B, nullptr);
       HIP_TRY(hipEventRecord(ln.ev_scanned, ln.stream));
@@ -1228,9 +1235,13 @@ static void batch_run_mfma(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
   }
 }
 
+// Shared body of pirgpu_batch_run / pirgpu_batch_run_selectors: `count` queries in rounds of W (one worker
+// per query).  Expansion is batched per group of up to 8 queries on a lane; with the MFMA scan the group
+// also shares the database pass (batch_run_mfma), otherwise groups of up to 4 workers share one pass of
+// scan_mq_kernel (d = 1 / few rows), hand-offs between streams through events.  With ext_sv the expansion
+// is skipped and query i reads its NTT-form selection vector at ext_sv + i*dim_sum.
 static void batch_run_impl(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv) {
-  const uint32_t nq = c->dim_sum / c->N + 1;
-  const size_t qwords = (size_t)nq * c->ctw, rwords = (size_t)c->reply_cts * c->ctw;
+  const size_t rwords = (size_t)c->reply_cts * c->ctw;
   const size_t svwords = (size_t)c->dim_sum * c->ctw;
   const uint32_t W = std::max<uint32_t>(1, std::min<uint32_t>(c->n_active, (uint32_t)c->workers.size()));
   const uint32_t G = mq_usable(c) && c->pt_end > c->pt_begin ? std::min<uint32_t>(c->mq_nq, kMaxScanQueries) : 1;
@@ -1243,19 +1254,30 @@ static void batch_run_impl(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
     c->batch_valid = true;
     return;
   }
+  if (!ext_sv) ensure_lanes(c, true);
   for (uint32_t base = 0; base < count; base += W) {
     const uint32_t n = std::min<uint32_t>(W, count - base);
-    for (uint32_t j = 0; j < n; ++j) {
-      Worker& w = c->workers[j];
-      if (ext_sv) {
+    if (ext_sv) {
+      for (uint32_t j = 0; j < n; ++j) {
+        Worker& w = c->workers[j];
         w.sv_cur = ext_sv + (size_t)(base + j) * svwords;
-      } else {
-        HIP_TRY(hipMemcpyAsync(w.d_query, c->d_bquery + (base + j) * qwords, qwords * 8, hipMemcpyDeviceToDevice,
-                               w.stream));
-        w.staged_nq = nq;
-        expand_query_to_sv(c, w, w.d_query, nq, nullptr);
+        HIP_TRY(hipEventRecord(w.ev_expanded, w.stream));
       }
-      if (G > 1) HIP_TRY(hipEventRecord(w.ev_expanded, w.stream));
+    } else {
+      for (uint32_t j0 = 0; j0 < n; j0 += kMaxMfmaQueries) {
+        const uint32_t B = std::min<uint32_t>(kMaxMfmaQueries, n - j0);
+        BatchLane& ln = c->lanes[c->groups_run++ % c->lanes.size()];
+        Worker* members[kMaxMfmaQueries];
+        for (uint32_t q = 0; q < B; ++q) {
+          members[q] = &c->workers[j0 + q];
+          HIP_TRY(hipStreamWaitEvent(ln.stream, members[q]->ev_done, 0));  // its selection vector is free again
+        }
+        expand_group_on_lane(c, ln, members, B, base + j0);
+        for (uint32_t q = 0; q < B; ++q) {
+          HIP_TRY(hipEventRecord(members[q]->ev_expanded, ln.stream));
+          HIP_TRY(hipStreamWaitEvent(members[q]->stream, members[q]->ev_expanded, 0));
+        }
+      }
     }
     for (uint32_t j0 = 0; j0 < n; j0 += G) {
       const uint32_t g = std::min<uint32_t>(G, n - j0);
@@ -1289,6 +1311,7 @@ static void batch_run_impl(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
       post_scan_on_device(c, w);
       HIP_TRY(hipMemcpyAsync(c->d_breply + (base + j) * rwords, w.lvl[0], rwords * 8, hipMemcpyDeviceToDevice,
                              w.stream));
+      HIP_TRY(hipEventRecord(w.ev_done, w.stream));
       w.reply_valid = true;
     }
   }

@@ -128,8 +128,11 @@ int pirgpu_sync(pirgpu_ctx* ctx);
  * PIRServer::ProcessRequest (reference server.cpp:60-63) with several queries in flight:
  * set_concurrency gives the context n_workers independent working sets (stream +
  * intermediates, ~0.4 GB each at N=4096 / dim_sum=324); batch_stage uploads `count`
- * queries of nq ciphertexts each; batch_run enqueues all of them round-robin over the
- * workers (asynchronous); batch_fetch waits and downloads count x reply_ct_count
+ * queries of nq ciphertexts each; batch_run enqueues all of them (asynchronous) in rounds of
+ * n_workers queries: groups of up to 8 queries are expanded together (the expansion kernels run
+ * over nodes x queries) and, with the int8-MFMA scan (d >= 2), share one pass over the database;
+ * consecutive groups alternate between two streams so that scan and expansion overlap
+ * (n_workers = 16 keeps both busy); batch_fetch waits and downloads count x reply_ct_count
  * ciphertexts, reply i answering query i. */
 int pirgpu_set_concurrency(pirgpu_ctx* ctx, uint32_t n_workers);
 int pirgpu_batch_stage(pirgpu_ctx* ctx, const uint64_t* queries, uint32_t nq, uint32_t count);

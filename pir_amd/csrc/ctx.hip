@@ -436,7 +436,8 @@ uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* 
     HIP_TRY(c->ops->ks_mac_intt(st, c->mode, c->dp, k, dig, key, nodes, prod, c->pack40));
     // outputs n*B.. of the last level are never read (only the first n results per query are used)
     const uint32_t hi_limit = j + 1 == logm ? n * B : UINT32_MAX;
-    HIP_TRY(launch_ks_combine(st, c->dp, N, k, cur, prod, galois_inverse(g, N), nodes, 1u << j, true, hi_limit, nxt));
+    HIP_TRY(launch_ks_combine(st, c->dp, N, k, cur, prod, galois_inverse(g, N), nodes, 1u << j, true, hi_limit, c->pack40,
+                              nxt));
     std::swap(cur, nxt);
   }
   return cur;
@@ -1073,7 +1074,7 @@ int pirgpu_substitute_power_x(pirgpu_ctx* c, uint64_t* ct, uint32_t power) {
     HIP_TRY(c->ops->ks_digit(c->stream, c->mode, c->dp, c->k, w.res_a, power, 1, w.dig, c->pack40));
     HIP_TRY(c->ops->ks_mac_intt(c->stream, c->mode, c->dp, c->k, w.dig, key, 1, w.prod, c->pack40));
     HIP_TRY(launch_ks_combine(c->stream, c->dp, c->N, c->k, w.res_a, w.prod, galois_inverse(power, c->N), 1, 0,
-                              false, /*hi_limit: unused without the expand step*/ 0, w.res_b));
+                              false, /*hi_limit: unused without the expand step*/ 0, c->pack40, w.res_b));
     HIP_TRY(hipMemcpyAsync(ct, w.res_b, c->ctw * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PIRGPU_OK;

@@ -58,6 +58,7 @@ __global__ void ntt_reorder_kernel(const uint64_t* __restrict__ in, uint64_t* __
 // (identical residues to the reference's two negacyclic shifts + adds, since
 // x^-(N+2^j) = -x^(-2^j)).  With expand_step == 0 only g is written (plain
 // substitute_power_x_inplace).  One thread per (node, residue, coefficient).
+template <bool P40>
 __global__ void ks_combine_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ res_in,
                                   const uint64_t* __restrict__ prod, uint32_t galois_inv, uint32_t nodes,
                                   uint32_t shift_pow, int expand_step, uint32_t hi_limit,
@@ -79,10 +80,21 @@ __global__ void ks_combine_kernel(const DevParams* __restrict__ P, const uint64_
   uint64_t g[2];
 #pragma unroll
   for (int comp = 0; comp < 2; ++comp) {
-    const uint64_t* pr = prod + ((size_t)node * 2 + comp) * km * N;
-    uint64_t r = add_mod(pr[(size_t)k * N + i], P->p_half, mp.q);
+    uint64_t sp, dj;  // special-prime and data-prime residues of the key-switch product
+    if constexpr (P40) {  // 5-byte polynomials: N low words, then N high bytes (ntt_kernels.hip load40/store40)
+      const uint8_t* pr = reinterpret_cast<const uint8_t*>(prod) + ((size_t)node * 2 + comp) * km * 5 * N;
+      const uint8_t* ps = pr + (size_t)k * 5 * N;
+      const uint8_t* pj = pr + (size_t)j * 5 * N;
+      sp = (uint64_t)reinterpret_cast<const uint32_t*>(ps)[i] | ((uint64_t)ps[4 * (size_t)N + i] << 32);
+      dj = (uint64_t)reinterpret_cast<const uint32_t*>(pj)[i] | ((uint64_t)pj[4 * (size_t)N + i] << 32);
+    } else {
+      const uint64_t* pr = prod + ((size_t)node * 2 + comp) * km * N;
+      sp = pr[(size_t)k * N + i];
+      dj = pr[(size_t)j * N + i];
+    }
+    uint64_t r = add_mod(sp, P->p_half, mp.q);
     uint64_t delta = sub_mod(reduce64(r, mj), P->p_half_mod[j], q);
-    uint64_t v = sub_mod(pr[(size_t)j * N + i], delta, q);
+    uint64_t v = sub_mod(dj, delta, q);
     g[comp] = mul_shoup(v, P->p_inv[j], P->p_inv_s[j], q);
   }
   const uint64_t* a_ct = res_in + (size_t)node * 2 * k * N;
@@ -617,10 +629,14 @@ hipError_t launch_ntt_reorder(hipStream_t st, uint32_t N, const uint64_t* in, ui
 
 hipError_t launch_ks_combine(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* res_in,
                              const uint64_t* prod, uint32_t galois_inv, uint32_t nodes, uint32_t shift_pow,
-                             bool expand_step, uint32_t hi_limit, uint64_t* res_out) {
+                             bool expand_step, uint32_t hi_limit, bool pack40, uint64_t* res_out) {
   uint64_t total = (uint64_t)nodes * k * N;
-  hipLaunchKernelGGL(ks_combine_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, P, res_in, prod,
-                     galois_inv, nodes, shift_pow, expand_step ? 1 : 0, hi_limit, res_out);
+  if (pack40)
+    hipLaunchKernelGGL(ks_combine_kernel<true>, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, P, res_in,
+                       prod, galois_inv, nodes, shift_pow, expand_step ? 1 : 0, hi_limit, res_out);
+  else
+    hipLaunchKernelGGL(ks_combine_kernel<false>, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, P, res_in,
+                       prod, galois_inv, nodes, shift_pow, expand_step ? 1 : 0, hi_limit, res_out);
   PIRGPU_LAUNCH_CHECK();
   return hipSuccess;
 }

@@ -282,9 +282,16 @@ ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
     for (int e = 0; e < 16; ++e) x[e] = f64_norm(x[e], m);
   }
   ntt_inverse<MODE, LOGN>(x, smem_raw, P, I, tid);
-  uint64_t* out = prod + (((size_t)node * 2 + comp) * km + I) * N;
+  const size_t opoly = ((size_t)node * 2 + comp) * km + I;
+  if constexpr (P40) {
+    uint8_t* out = reinterpret_cast<uint8_t*>(prod) + opoly * kPoly40;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
+    for (int e = 0; e < 16; ++e) store40(out, e * NT + tid, A::out(x[e], m));
+  } else {
+    uint64_t* out = prod + opoly * N;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
+  }
 }
 
 // Upper recursion level, fused: for output slot (row r, source ciphertext cc, Encode chunk

@@ -50,3 +50,54 @@ def test_facade_process_request_matches_oracle(tmp_path):
         rc, exp = o.process_query(s.db_ntt, p.dimensions, q, s.galois_keys)
         assert rc == 0 and np.array_equal(rep, exp)
         assert s.client.process_response(p, idx, rep) == s.item(idx)
+
+
+# ---------------------------------------------------------------- C++ mirror of PIRClient
+
+CLIENT_SRC = os.path.join(ROOT, "tests", "cpp", "client_facade_test.cpp")
+
+
+def _write_params(path, pp):
+    enc = pp.encryption_parameters
+    with open(path, "w") as f:
+        f.write("%d %d %d %d %d %d %d %d %d\n" % (enc.poly_modulus_degree, enc.plain_modulus, pp.num_items, pp.num_pt,
+                                                   pp.bytes_per_item, pp.items_per_plaintext, pp.bits_per_coeff,
+                                                   len(enc.coeff_modulus), len(pp.dimensions)))
+        f.write(" ".join(str(q) for q in enc.coeff_modulus) + "\n" + " ".join(str(d) for d in pp.dimensions) + "\n")
+
+
+def _build_client_test(tmp_path, with_server):
+    import pir_amd.capi as capi
+    capi.load_client()
+    exe = str(tmp_path / "client_facade_test")
+    lib_dir = os.path.join(ROOT, "pir_amd")
+    libs = ["-lpirclient"] + (["-lpirgpu", "-Wl,-rpath,/opt/rocm/lib"] if with_server else [])
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", CLIENT_SRC, "-o", exe, "-L" + lib_dir] + libs +
+                   ["-Wl,-rpath," + lib_dir] + ([] if with_server else ["-Wl,--unresolved-symbols=ignore-in-object-files"]),
+                   check=True)
+    return exe
+
+
+def test_client_facade_cpu(tmp_path):
+    """client_test.cpp's D2 layout, invalid index and reply-count checks through the C++ PIRClient mirror."""
+    import pir_amd
+    pp = pir_amd.create_pir_parameters(82, 0, 2, pir_amd.generate_encryption_params(4096, 16))
+    _write_params(tmp_path / "params.txt", pp)
+    exe = _build_client_test(tmp_path, with_server=False)
+    r = subprocess.run([exe, str(tmp_path / "params.txt")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "client_facade_test OK" in r.stdout
+
+
+@pytest.mark.gpu
+def test_client_server_round_trip_in_cpp(tmp_path):
+    """correctness_test.cpp:95-113 with C++ on both sides: pir::PIRClient -> pir::PIRServer -> pir::PIRClient."""
+    import pir_amd
+    pp = pir_amd.create_pir_parameters(3000, 288, 2, pir_amd.generate_encryption_params(4096, 24))
+    _write_params(tmp_path / "params.txt", pp)
+    raw = np.random.default_rng(11).integers(0, 256, size=(3000, 288), dtype=np.uint8)
+    (tmp_path / "db.bin").write_bytes(raw.tobytes())
+    exe = _build_client_test(tmp_path, with_server=True)
+    r = subprocess.run([exe, str(tmp_path / "params.txt"), str(tmp_path / "db.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "round trip OK" in r.stdout

@@ -275,6 +275,7 @@ void build_tables(pirgpu_ctx* c) {
 uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
 void alloc_worker(pirgpu_ctx* c, Worker& w);
+void ensure_expansion_buffers(pirgpu_ctx* c, Worker& w);
 
 void ensure_workspace(pirgpu_ctx* c) {
   if (c->ws_ready) return;
@@ -360,20 +361,28 @@ void ensure_workspace(pirgpu_ctx* c) {
   if (c->workers.empty()) c->workers.emplace_back();
   c->workers[0].stream = c->stream;
   for (Worker& w : c->workers) alloc_worker(c, w);
+  ensure_expansion_buffers(c, c->workers[0]);  // worker 0 serves the single-query entry points and test hooks
+}
+
+// Expansion tree (ping/pong) and key-switch scratch of one worker, on first use.
+void ensure_expansion_buffers(pirgpu_ctx* c, Worker& w) {
+  if (w.res_a) return;
+  const uint32_t N = c->N, k = c->k;
+  w.res_a = c->dalloc<uint64_t>(c->m_max * c->ctw);
+  w.res_b = c->dalloc<uint64_t>(c->m_max * c->ctw);
+  w.prod = c->dalloc<uint64_t>(std::max<uint64_t>(c->m_max / 2, 1) * 2 * (k + 1) * N);
+  w.dig = c->dalloc<uint64_t>(std::max<uint64_t>(c->m_max / 2, 1) * (k + 1) * k * N);
 }
 
 // Allocates one worker's buffers (and its stream unless it is the context's main stream).
 void alloc_worker(pirgpu_ctx* c, Worker& w) {
-  if (w.res_a) return;
-  const uint32_t N = c->N, k = c->k;
+  if (w.sv_ntt) return;
   const size_t ctw = c->ctw;
   if (!w.stream) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
-  w.res_a = c->dalloc<uint64_t>(c->m_max * ctw);
-  w.res_b = c->dalloc<uint64_t>(c->m_max * ctw);
-  w.prod = c->dalloc<uint64_t>(std::max<uint64_t>(c->m_max / 2, 1) * 2 * (k + 1) * N);
-  w.dig = c->dalloc<uint64_t>(std::max<uint64_t>(c->m_max / 2, 1) * (k + 1) * k * N);
+  // the expansion tree / key-switch scratch is allocated on first use (ensure_expansion_buffers): in batch
+  // mode the lanes expand, so only a worker that runs single queries needs its own
   w.sv_ntt = c->dalloc<uint64_t>((size_t)std::max<uint32_t>(c->dim_sum, 1) * ctw);
-  w.d_query = c->dalloc<uint64_t>((size_t)(c->dim_sum / N + 1) * ctw);
+  w.d_query = c->dalloc<uint64_t>((size_t)(c->dim_sum / c->N + 1) * ctw);
   w.lvl.assign(c->d, nullptr);
   for (uint32_t l = 0; l < c->d; ++l) w.lvl[l] = c->dalloc<uint64_t>(c->lvl_cts[l] * ctw);
   if (c->pt_words) w.pt_buf = c->dalloc<uint64_t>(c->pt_words);
@@ -444,6 +453,7 @@ uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* 
 }
 
 uint64_t* expand_on_device(pirgpu_ctx* c, Worker& w, uint32_t n) {
+  ensure_expansion_buffers(c, w);
   return expand_core(c, w.stream, w.res_a, w.res_b, w.dig, w.prod, n, 1);
 }
 
@@ -451,6 +461,7 @@ uint64_t* expand_on_device(pirgpu_ctx* c, Worker& w, uint32_t n) {
 // server.cpp:148-171 followed by the lazy transform_to_ntt_inplace of
 // database.cpp:190,222 applied to every selector.
 void expand_query_to_sv(pirgpu_ctx* c, Worker& w, const uint64_t* d_query, uint32_t nq, uint64_t* coeff_out_host) {
+  ensure_expansion_buffers(c, w);
   w.sv_cur = nullptr;
   const uint32_t N = c->N, k = c->k;
   const size_t ctw = c->ctw;

@@ -30,12 +30,22 @@ __device__ __forceinline__ uint64_t hash64(uint64_t x) {
   x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x;
 }
 
-__global__ void fill_kernel(uint64_t* p, size_t n, uint64_t q0, uint64_t q1, uint32_t N, uint32_t kN, uint64_t seed) {
+// edge != 0: residues drawn from the boundary cases of the centring / digit decomposition instead of uniform
+__global__ void fill_kernel(uint64_t* p, size_t n, uint64_t q0, uint64_t q1, uint32_t N, uint32_t kN, uint64_t seed,
+                            int edge) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t j = (uint32_t)(i % kN);
   uint64_t q = j < N ? q0 : q1;
-  p[i] = hash64(i * 0x9E3779B97F4A7C15ULL + seed) % q;
+  uint64_t h = hash64(i * 0x9E3779B97F4A7C15ULL + seed);
+  if (!edge) { p[i] = h % q; return; }
+  const uint64_t half = q >> 1;
+  const uint64_t cases[16] = {0, 1, q - 1, q - 2, half, half + 1, half - 1, half + 2,
+                              0x7F, 0x80, 0x81, 0x7F7F7F7F7FULL % q, 0x8080808080ULL % q, 0x807F807F80ULL % q,
+                              q - 0x80, q - 0x8080};
+  uint64_t v = cases[h & 15];
+  if ((h >> 4) & 1) v = (v + (((h >> 8) & 3) << 8)) % q;   // perturb a middle digit
+  p[i] = v;
 }
 
 // reference: one thread per (q, r, comp, j)
@@ -267,8 +277,9 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&db, db_words * 8)); CK(hipMalloc(&sel, sel_words * 8));
   CK(hipMalloc(&out, out_words * 8)); CK(hipMalloc(&ref, out_words * 8));
   CK(hipMalloc(&dbp, dbp_bytes)); CK(hipMalloc(&selp, selp_bytes));
-  fill_kernel<<<(db_words + 255) / 256, 256>>>(db, db_words, q0, q1, N, kN, 1);
-  fill_kernel<<<(sel_words + 255) / 256, 256>>>(sel, sel_words, q0, q1, N, kN, 2);
+  const int edge = argc > 5 ? atoi(argv[5]) : 0;
+  fill_kernel<<<(db_words + 255) / 256, 256>>>(db, db_words, q0, q1, N, kN, 1, edge);
+  fill_kernel<<<(sel_words + 255) / 256, 256>>>(sel, sel_words, q0, q1, N, kN, 2, edge);
   CK(hipMemset(out, 0xFF, out_words * 8));
   ref_kernel<<<(out_words + 255) / 256, 256>>>(db, sel, ref, R, C, kN, N, NQ, q0, q1);
   hipEvent_t e0, e1;

@@ -253,3 +253,36 @@ def test_finalize_and_release_staging():
     assert srv.scan_info()["single_query_mfma"]
     check_queries(s, srv, [77])
     db.close()
+
+
+def test_mfma_and_valu_scan_agree_on_boundary_selectors(monkeypatch):
+    """Selection vectors made of the boundary residues of the centring / digit decomposition (0, 1, q-1, q/2,
+    q/2 +- 1, 0x7F / 0x80 byte patterns ...), injected in NTT form through pirgpu_batch_run_selectors: the
+    int8-MFMA scan and the 64-bit multiply-accumulate scan must produce identical replies."""
+    import torch
+    s = setup_with_dims(1, 2048, [17, 19], N=4096, plain_bits=24)
+    p = s.params
+    k, N = s.orc.k, 4096
+    count = 5
+    rng = np.random.default_rng(123)
+    sv = np.empty((count, p.dim_sum, 2, k, N), dtype=np.uint64)
+    for j in range(k):
+        q = int(s.orc.moduli[j])
+        half = q >> 1
+        cases = np.array([0, 1, q - 1, q - 2, half, half + 1, half - 1, half + 2, 0x7F, 0x80, 0x81,
+                          0x7F7F7F7F7F % q, 0x8080808080 % q, 0x807F807F80 % q, q - 0x80, q - 0x8080], dtype=np.uint64)
+        pick = rng.integers(0, len(cases), size=(count, p.dim_sum, 2, N))
+        sv[:, :, :, j, :] = cases[pick]
+    sv_dev = torch.from_numpy(sv.view(np.int64)).cuda()
+    replies = []
+    for mfma in ("1", "0"):
+        monkeypatch.setenv("PIRGPU_SCAN_MFMA", mfma)
+        db, srv = make(s)
+        assert srv.scan_info()["mfma"] == (mfma == "1")
+        srv.set_concurrency(8)
+        srv.stage_batch(np.zeros((count, 1, 2, k, N), dtype=np.uint64))   # sizes the reply buffers
+        srv.batch_run_selectors(sv_dev.data_ptr(), count)
+        replies.append(srv.fetch_batch())
+        db.close()
+    assert np.array_equal(replies[0], replies[1])
+    assert replies[0].any()

@@ -212,10 +212,11 @@ def main():
             sv_all = torch.empty((batch, pp.dim_sum, 2, k, N), dtype=torch.int64, device=dev)
 
     def barrier():
+        srv.sync()                      # the library's own streams (not torch's current stream)
+        torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
-        srv.sync()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     # ---- (1) single-query latency + scan-kernel roofline (one scan launch per query)
     srv.stage_query(query)

@@ -86,13 +86,14 @@ sel_pack_kernel(const DevParams* __restrict__ P, MfmaPtrs sv, uint32_t nq, uint8
   const uint32_t kg = blockIdx.y;
   const uint64_t q = P->mod[j >> P->logN].q;
   const uint32_t qi = x >> 1, comp = x & 1;
-  const uint64_t* src = qi < nq ? (const uint64_t*)sv.p[qi] : nullptr;
+  if (qi >= nq) return;   // scan_mfma_kernel does not read the columns of absent queries
+  const uint64_t* src = (const uint64_t*)sv.p[qi];
   uint8_t o[L][16];
 #pragma unroll
   for (int t = 0; t < 16; ++t) {
     const uint32_t c = kg * 16 + t;
     uint64_t v = 0;
-    if (src && c < cols) v = src[((size_t)c * 2 + comp) * kN + j];
+    if (c < cols) v = src[((size_t)c * 2 + comp) * kN + j];
     int8_t d[L];
     to_digits<L>(v, q, d);
 #pragma unroll
@@ -153,8 +154,9 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
       const uint32_t kg = kg0 + ks * 4 + g;
 #pragma unroll
       for (int b = 0; b < L; ++b) {
-        B[ks][b] = v4i{0, 0, 0, 0};
-        if (kg < KG) B[ks][b] = *reinterpret_cast<const v4i*>(selp + (((size_t)j * KG + kg) * L + b) * 256 + i16 * 16);
+        B[ks][b] = v4i{0, 0, 0, 0};   // columns beyond the group's queries stay zero and are neither packed nor read
+        if (kg < KG && (uint32_t)i16 < nx)
+          B[ks][b] = *reinterpret_cast<const v4i*>(selp + (((size_t)j * KG + kg) * L + b) * 256 + i16 * 16);
       }
     }
   };

@@ -14,6 +14,9 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #ifndef NTS
 #define NTS 0
 #endif
+#ifndef NO_MFMA
+#define NO_MFMA 0
+#endif
 #ifndef NO_STORE
 #define NO_STORE 0
 #endif
@@ -204,6 +207,7 @@ scan_mfma_kernel(const uint8_t* __restrict__ dbp, const uint8_t* __restrict__ se
 #pragma unroll
         for (int a = 0; a < L; ++a) {
           const int b = (a + off) % L;
+          if (NO_MFMA) { if (b == 0) T[a] ^= A[ks][a]; } else
           T[a + b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks][a], B[ks][b], T[a + b], 0, 0, 0);
         }
       // refill this ring slot with the next row tile's step

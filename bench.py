@@ -17,7 +17,7 @@ Workload = BASELINE.json configs[2]: N=4096, 2 RNS primes, DB = 2^20 x 288 B, d=
 reference's own benchmark parameters, benchmark.cpp:17-23).
 
 Multi-GPU (launched by torch.distributed.run, one rank per GPU), two modes:
-  --dist-mode queries (default): queries are independent, so they are the unit that is sharded --
+  --dist-mode queries (what the default `auto` resolves to while the database fits one GPU): queries are independent, so they are the unit that is sharded --
       every GPU holds the whole packed database (1.27 GB of 288 GB at this workload) and serves
       its own `--batch` queries per step; no collective on the data path (the barrier and the
       max-over-ranks timing are the only communication); per-GPU work is fixed as N grows ->
@@ -142,11 +142,13 @@ def main():
     ap.add_argument("--log-items", type=int, default=20, help="database = 2^log_items x 288 B")
     ap.add_argument("--dims", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dist-mode", choices=["queries", "rows"], default=os.environ.get("PIRGPU_DIST_MODE", "queries"),
+    ap.add_argument("--dist-mode", choices=["auto", "queries", "rows"],
+                    default=os.environ.get("PIRGPU_DIST_MODE", "auto"),
                     help="multi-GPU: 'queries' = every GPU holds the whole database and serves its own batch "
                          "(independent queries, no data-path collective, weak scaling); 'rows' = the database is "
                          "row-sharded, replies summed with an RCCL all-reduce (strong scaling; for databases "
-                         "larger than one GPU)")
+                         "larger than one GPU); 'auto' = queries while the encoded database (both layouts) takes "
+                         "less than half of one GPU's memory, else rows")
     ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5],
                     help="BASELINE.json config (1-based as in SURVEY.md section 8): 3 = the headline workload; "
                          "2/4/5 are reference points (other ring degrees / database shapes)")
@@ -175,7 +177,8 @@ def main():
         args.dist_mode = "rows"
     elif force == "queries":
         args.dist_mode = "queries"
-    row_sharded = use_dist and args.dist_mode == "rows"
+    dist_mode_requested = args.dist_mode
+    row_sharded = use_dist and args.dist_mode == "rows"   # 'auto' is resolved once the database size is known
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -201,6 +204,12 @@ def main():
     else:
         enc = pir_amd.generate_encryption_params(4096, 24)
     pp = pir_amd.create_pir_parameters(1 << args.log_items, item_bytes, args.dims, enc)
+    if args.dist_mode == "auto":
+        # u64 staging copy + operand-layout copy (at most 7/8 of it, plus tile padding)
+        db_bytes = pp.num_pt * (len(enc.coeff_modulus) - 1) * enc.poly_modulus_degree * 8 * 2
+        hbm = torch.cuda.get_device_properties(local_rank).total_memory
+        args.dist_mode = "rows" if db_bytes > hbm // 2 else "queries"
+        row_sharded = use_dist and args.dist_mode == "rows"
     batch = max(1, args.batch)
     workers = args.workers if args.workers > 0 else min(batch, 16)
     # query-sharded runs: same database and keys everywhere, every rank draws its own queries
@@ -313,6 +322,7 @@ def main():
                                       enc.coeff_modulus[-1].bit_length(), args.log_items, item_bytes, args.dims,
                                       pp.dimensions, pp.num_pt, batch, workers, args.config - 1),
                        "queries_per_step": total_batch, "queries_per_step_per_gpu": batch, "workers": workers,
+                       "dist_mode": "%s (requested: %s)" % (args.dist_mode, dist_mode_requested),
                        "parallelism": ("single GPU" if world == 1 else
                                        ("rows sharded over %d GPU(s), %s, RCCL all-reduce of replies"
                                         % (world, "query-parallel expansion + RCCL all-gather of selection vectors"

@@ -758,7 +758,14 @@ int pirclient_create(const pirgpu_params* params, const uint8_t* seed, size_t se
   return PIRGPU_OK;
 }
 
-void pirclient_destroy(pirclient* c) { delete c; }
+void pirclient_destroy(pirclient* c) {
+  if (!c) return;
+  // wipe the secret key and the generator state before the memory is returned
+  if (!c->s_ntt.empty()) explicit_bzero(c->s_ntt.data(), c->s_ntt.size() * sizeof(uint64_t));
+  if (!c->s_signed.empty()) explicit_bzero(c->s_signed.data(), c->s_signed.size());
+  explicit_bzero(&c->rng, sizeof(c->rng));
+  delete c;
+}
 const char* pirclient_last_error(const pirclient* c) { return c ? c->err.c_str() : "null client"; }
 const char* pirclient_create_error(void) { return g_create_error.c_str(); }
 void pirclient_free(void* p) { free(p); }

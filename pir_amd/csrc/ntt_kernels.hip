@@ -37,6 +37,9 @@ constexpr int LOGN = PIRGPU_LOGN;
 constexpr int NT = Plan<LOGN>::NT;
 constexpr int N = Plan<LOGN>::N;
 constexpr size_t kLdsBytes = (size_t)Plan<LOGN>::LDS_WORDS * 8;
+// twiddle prefetch one pass ahead costs ~30 VGPRs: not affordable under the 128-VGPR cap of the 1024-thread
+// workgroups of N = 16384 (it spills)
+constexpr bool kPF = LOGN < 14;
 constexpr uint32_t kWideLevel = 256;  // nodes per launch from which the key-switch kernels use the XCD-aware 1-D grid
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -68,9 +71,9 @@ ntt_batch_kernel(const DevParams* __restrict__ P, uint64_t* __restrict__ data, u
 #pragma unroll
   for (int e = 0; e < 16; ++e) x[e] = A::in(poly[e * NT + tid], m);
   if constexpr (INVERSE)
-    ntt_inverse<MODE, LOGN>(x, smem_raw, P, mi, tid);
+    ntt_inverse<MODE, LOGN, kPF>(x, smem_raw, P, mi, tid);
   else
-    ntt_forward<MODE, LOGN>(x, smem_raw, P, mi, tid);
+    ntt_forward<MODE, LOGN, kPF>(x, smem_raw, P, mi, tid);
 #pragma unroll
   for (int e = 0; e < 16; ++e) poly[e * NT + tid] = A::out(x[e], m);
 }
@@ -89,7 +92,7 @@ ct_ntt_fwd_oop_kernel(const DevParams* __restrict__ P, const uint64_t* __restric
   typename A::T x[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) x[e] = A::in(in[e * NT + tid], m);
-  ntt_forward<MODE, LOGN>(x, smem_raw, P, mi, tid);
+  ntt_forward<MODE, LOGN, kPF>(x, smem_raw, P, mi, tid);
 #pragma unroll
   for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
 }
@@ -111,7 +114,7 @@ ct_ntt_fwd_split_kernel(const DevParams* __restrict__ P, const uint64_t* __restr
   typename A::T x[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) x[e] = A::in(in[e * NT + tid], m);
-  ntt_forward<MODE, LOGN>(x, smem_raw, P, mi, tid);
+  ntt_forward<MODE, LOGN, kPF>(x, smem_raw, P, mi, tid);
 #pragma unroll
   for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
 }
@@ -167,7 +170,7 @@ db_encode_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ c
     if (v >= thr) r = add_mod(r, inc, mc.q);
     x[e] = A::in(r, m);
   }
-  ntt_forward<MODE, LOGN>(x, smem_raw, P, j, tid);
+  ntt_forward<MODE, LOGN, kPF>(x, smem_raw, P, j, tid);
   uint64_t* out = db + (pt * k + j) * N;
 #pragma unroll
   for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
@@ -212,7 +215,7 @@ ks_digit_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ re
 #pragma unroll
   for (int e = 0; e < 16; ++e) x[e] = A::in(s[lds_idx(e * NT + tid)], m);
   __syncthreads();  // the transform reuses the same LDS words with its own element type
-  ntt_forward<MODE, LOGN>(x, smem_raw, P, I, tid);
+  ntt_forward<MODE, LOGN, kPF>(x, smem_raw, P, I, tid);
   const size_t poly = ((size_t)node * (k + 1) + I) * k + J;
   if constexpr (P40) {
     uint8_t* out = reinterpret_cast<uint8_t*>(dig) + poly * kPoly40;
@@ -281,7 +284,7 @@ ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
 #pragma unroll
     for (int e = 0; e < 16; ++e) x[e] = f64_norm(x[e], m);
   }
-  ntt_inverse<MODE, LOGN>(x, smem_raw, P, I, tid);
+  ntt_inverse<MODE, LOGN, kPF>(x, smem_raw, P, I, tid);
   const size_t opoly = ((size_t)node * 2 + comp) * km + I;
   if constexpr (P40) {
     uint8_t* out = reinterpret_cast<uint8_t*>(prod) + opoly * kPoly40;

@@ -133,7 +133,7 @@ def load() -> C.CDLL:
 
 # ---------------------------------------------------------------------------------------------------
 # libpirclient.so (include/pirclient.h): CPU-only client library, no device dependency.
-CLIENT_LIB_PATH = os.path.join(HERE, "libpirclient.so")
+CLIENT_LIB_PATH = os.environ.get("PIR_CLIENT_LIB", os.path.join(HERE, "libpirclient.so"))   # override: sanitizer builds
 i64p = C.POINTER(C.c_int64)
 
 CLIENT_SIGNATURES = {

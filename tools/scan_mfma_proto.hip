@@ -14,6 +14,11 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #ifndef NTS
 #define NTS 0
 #endif
+#ifndef LAYOUT2
+#define LAYOUT2 0
+#endif
+// LAYOUT2: database tiles stored [j][rt][ks][a][g][r16][16B] (a whole A tile = 1 KB contiguous, K padded to 64)
+#define DBOFF(rt, kg, a) (LAYOUT2 ? ((((size_t)(rt) * KSTEPS + ((kg) >> 2)) * L + (a)) * 1024 + ((kg) & 3) * 256) : (((size_t)(rt) * KG + (kg)) * L + (a)) * 256)
 #ifndef NO_MFMA
 #define NO_MFMA 0
 #endif
@@ -105,7 +110,9 @@ db_pack_kernel(const uint64_t* __restrict__ db, uint8_t* __restrict__ dbp, uint3
   for (int a = 0; a < L; ++a) {
     uint4 v;
     __builtin_memcpy(&v, o[a], 16);
-    *reinterpret_cast<uint4*>(dbp + ((((size_t)j * RT + rt) * KG + kg) * L + a) * 256 + r16 * 16) = v;
+    const uint32_t KSTEPS = (KG + 3) / 4;
+    const size_t slab = LAYOUT2 ? (size_t)RT * KSTEPS * L * 1024 : (size_t)RT * KG * L * 256;
+    *reinterpret_cast<uint4*>(dbp + (size_t)j * slab + DBOFF(rt, kg, a) + r16 * 16) = v;
   }
 }
 
@@ -179,7 +186,8 @@ scan_mfma_kernel(const uint8_t* __restrict__ dbp, const uint8_t* __restrict__ se
       if (kg < KG) B[ks][b] = *reinterpret_cast<const v4i*>(selp + (((size_t)j * KG + kg) * L + b) * 256 + i16 * 16);
     }
   }
-  const uint8_t* abase = dbp + (size_t)j * RT * KG * L * 256 + i16 * 16;
+  const uint32_t KSTEPS = (KG + 3) / 4;
+  const uint8_t* abase = dbp + (size_t)j * (LAYOUT2 ? (size_t)RT * KSTEPS * L * 1024 : (size_t)RT * KG * L * 256) + i16 * 16;
   const uint32_t nx = 2 * NQ;
 
   v4i A[KS][L];
@@ -189,7 +197,7 @@ scan_mfma_kernel(const uint8_t* __restrict__ dbp, const uint8_t* __restrict__ se
 #pragma unroll
     for (int a = 0; a < L; ++a) {
       A[ks][a] = v4i{0, 0, 0, 0};
-      if (kg < KG) A[ks][a] = load16(abase + ((size_t)(0 * KG + kg) * L + a) * 256);
+      if (kg < KG) A[ks][a] = load16(abase + DBOFF(0, kg, a));
     }
   }
 
@@ -214,7 +222,7 @@ scan_mfma_kernel(const uint8_t* __restrict__ dbp, const uint8_t* __restrict__ se
       const uint32_t kg = ks * 4 + g;
       if (kg < KG) {
 #pragma unroll
-        for (int a = 0; a < L; ++a) A[ks][a] = load16(abase + ((size_t)(rtn * KG + kg) * L + a) * 256);
+        for (int a = 0; a < L; ++a) A[ks][a] = load16(abase + DBOFF(rtn, kg, a));
       }
     }
     // value = sum_s T_s 2^(8 s) = G0 + G1 2^40, reduced mod q
@@ -275,7 +283,7 @@ int main(int argc, char** argv) {
     m[i].mu = (uint64_t)((((u128)1) << 64) / q);
   }
   const size_t db_words = (size_t)R * C * kN, sel_words = (size_t)NQ * C * 2 * kN, out_words = (size_t)NQ * R * 2 * kN;
-  const size_t dbp_bytes = (size_t)kN * RT * KG * L * 256, selp_bytes = (size_t)kN * KG * L * 256;
+  const size_t dbp_bytes = LAYOUT2 ? (size_t)kN * RT * ((KG + 3) / 4) * L * 1024 : (size_t)kN * RT * KG * L * 256, selp_bytes = (size_t)kN * KG * L * 256;
   uint64_t *db, *sel, *out, *ref;
   uint8_t *dbp, *selp;
   CK(hipMalloc(&db, db_words * 8)); CK(hipMalloc(&sel, sel_words * 8));

@@ -117,6 +117,7 @@ def cpu_baseline(pp, raw, keys, query, gpu_reply, budget_s=25.0):
                 oks = list(ex.map(one, range(threads)))
             dt = time.perf_counter() - t0
             all_cores = {"value": threads / dt, "unit": "queries/s", "cores": threads,
+                         "speedup_over_one_core": (threads / dt) * sec,   # < cores when a CPU quota caps the box
                          "sample": "%d concurrent single-threaded queries (one per core), wall %.2f s; all bit-exact=%s"
                                    % (threads, dt, all(oks))}
     except Exception as e:   # reported extra only

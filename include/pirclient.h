@@ -53,6 +53,10 @@ int pirclient_process_response(pirclient* c, const uint64_t* indexes, size_t n_i
 int pirclient_process_response_integer(pirclient* c, const uint8_t* response, size_t response_len, int64_t* out,
                                        size_t out_cap, size_t* n_out);
 void pirclient_free(void* p);
+/* Key fields of the requests: seed-compressed (default; what SEAL 3.5.6's Serializable<GaloisKeys> /
+ * Serializable<RelinKeys> of PIRClient::initialize produce, client.cpp:47-54: every key sample carries c0 and the
+ * 64-byte seed its uniform half is re-sampled from) or, with enabled == 0, fully expanded objects. */
+int pirclient_set_seeded_keys(pirclient* c, int enabled);
 
 /* ---- residue-level halves of the same calls (what sits between SEAL objects in the reference) ---- */
 

@@ -19,9 +19,14 @@
  *   - every function returns 0 on success or the numeric absl::StatusCode the
  *     reference would have returned (3 InvalidArgument, 9 FailedPrecondition,
  *     12 Unimplemented, 13 Internal); pirgpu_last_error() gives the message;
- *   - one context drives one GPU; calls on one context are serialised
- *     internally; every result is a canonical residue in [0, q_j) and is
- *     bit-identical to the reference's SEAL CPU path on the same inputs.
+ *   - one context drives one GPU; every entry point takes the context's lock
+ *     for its own duration, and pirgpu_process_request holds it for the whole
+ *     request (key installation + every query), so concurrent requests on one
+ *     context are serialised as units.  Sequences the CALLER composes out of
+ *     several calls (set keys + query, stage / run / fetch) are only atomic if
+ *     the caller serialises them itself;
+ *   - every result is a canonical residue in [0, q_j) and is bit-identical to
+ *     the reference's SEAL CPU path on the same inputs.
  */
 #ifndef PIRGPU_H_
 #define PIRGPU_H_
@@ -73,6 +78,8 @@ typedef struct pirgpu_params {
  * database.cpp:40-44): validates the parameters, builds NTT tables on the device. */
 int pirgpu_create(const pirgpu_params* params, pirgpu_ctx** out);
 void pirgpu_destroy(pirgpu_ctx* ctx);
+/* Message of the calling thread's last failed call on this context (falls back to the context's last
+ * failure when this thread has none). */
 const char* pirgpu_last_error(const pirgpu_ctx* ctx);
 /* Records an error message on the context (used by the wire-level layer). */
 void pirgpu_set_error(pirgpu_ctx* ctx, const char* message);
@@ -98,6 +105,11 @@ uint64_t pirgpu_db_size(const pirgpu_ctx* ctx);
  * padding) and cannot be reloaded (FailedPrecondition); pirgpu_db_read_plaintext keeps working.
  * No reference counterpart (the reference keeps one vector<Plaintext>, database.h:126-133). */
 int pirgpu_db_finalize(pirgpu_ctx* ctx, int release_staging);
+/* SEAL's default build throws logic_error("result ciphertext is transparent") from multiply_plain when a
+ * database plaintext is identically zero, which the reference surfaces as InternalError for every query
+ * (database.cpp:308-315).  Default (allow == 0): same status.  allow != 0: return the mathematically defined
+ * reply instead (what a SEAL built without SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT computes). */
+int pirgpu_set_transparent_policy(pirgpu_ctx* ctx, int allow);
 /* Test hook: read back one encoded plaintext [k][N] (NTT form) from HBM. */
 int pirgpu_db_read_plaintext(pirgpu_ctx* ctx, uint64_t pt_index, uint64_t* out);
 
@@ -186,7 +198,9 @@ int pirgpu_reply_copy_to_device(pirgpu_ctx* ctx, uint64_t* device_dst, uint64_t 
 /* Wire-level entry: PIRServer::ProcessRequest (reference server.cpp:44-65).
  * request = serialized pir.Request (pir/proto/payload.proto:27-36); on success
  * *response points to a malloc'd serialized pir.Response (payload.proto:39-42)
- * that the caller releases with pirgpu_free. */
+ * that the caller releases with pirgpu_free.  The SEAL 3.5.6 objects inside the bytes fields may be fully
+ * expanded or seed-compressed (Serializable<>, what the reference client sends for its keys); relin_keys, when
+ * present, are parsed and validated like server.cpp:53-58.  Atomic on the context (see Conventions). */
 int pirgpu_process_request(pirgpu_ctx* ctx, const uint8_t* request, size_t request_len, uint8_t** response,
                            size_t* response_len);
 void pirgpu_free(void* p);

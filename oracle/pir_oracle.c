@@ -575,7 +575,20 @@ typedef struct {
   uint64_t* sv;
   uint8_t* sv_ntt;
   uint32_t er;
+  int transparent; /* a multiply_plain / add_inplace result had an all-zero c1: SEAL throws (App. A.5) */
 } dbm_t;
+
+/* Ciphertext::is_transparent for a size-2 ciphertext: every coefficient of c1 is zero.  SEAL's default build
+ * (SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT) makes Evaluator::multiply_plain / add_inplace throw
+ * logic_error("result ciphertext is transparent") on such a result; reference database.cpp:308-315 turns any
+ * exception of the multiplication into InternalError. */
+static int ct_is_transparent(const orc_ctx* c, const uint64_t* ct) {
+  const size_t n = (size_t)c->k * c->N;
+  const uint64_t* c1 = ct + n;
+  for (size_t i = 0; i < n; ++i)
+    if (c1[i]) return 0;
+  return 1;
+}
 
 static void ensure_sv_ntt(dbm_t* m, uint64_t idx) {
   if (!m->sv_ntt[idx]) {
@@ -604,6 +617,7 @@ static uint64_t* dbm_multiply(dbm_t* m, const uint32_t* dims, uint32_t nd, uint6
       if (!temp) temp = (uint64_t*)malloc(sizeof(uint64_t) * ctw);
       ensure_sv_ntt(m, sv_off + i);
       orc_multiply_plain_ntt(c, m->sv + (sv_off + i) * ctw, m->db + m->pos * (size_t)k * N, temp);
+      if (ct_is_transparent(c, temp)) m->transparent = 1;
       ++m->pos;
     } else {
       uint64_t lcount;
@@ -619,6 +633,7 @@ static uint64_t* dbm_multiply(dbm_t* m, const uint32_t* dims, uint32_t nd, uint6
           ensure_sv_ntt(m, sv_off + i);                      /* :221-224 */
           orc_plain_lift_ntt(c, pts + (size_t)e * N, N, ptn); /* :225-228 */
           orc_multiply_plain_ntt(c, m->sv + (sv_off + i) * ctw, ptn, temp + ti * ctw); /* :229 */
+          if (ct_is_transparent(c, temp + ti * ctw)) m->transparent = 1;
           ++ti;
         }
       }
@@ -632,7 +647,10 @@ static uint64_t* dbm_multiply(dbm_t* m, const uint32_t* dims, uint32_t nd, uint6
       memcpy(result, temp, sizeof(uint64_t) * ctw * rcount);
       first = 0;
     } else {
-      for (uint64_t j = 0; j < rcount; ++j) orc_ct_add_inplace(c, result + j * ctw, temp + j * ctw);
+      for (uint64_t j = 0; j < rcount; ++j) {
+        orc_ct_add_inplace(c, result + j * ctw, temp + j * ctw);
+        if (ct_is_transparent(c, result + j * ctw)) m->transparent = 1;
+      }
     }
   }
   free(temp);
@@ -647,13 +665,13 @@ int orc_db_multiply(const orc_ctx* c, const uint64_t* db_ntt, uint64_t P, const 
   uint64_t dim_sum = 0;
   for (uint32_t i = 0; i < nd; ++i) dim_sum += dims[i];
   if (sv_count != dim_sum) return ORC_INVALID_ARGUMENT;
-  dbm_t m = {c, db_ntt, P, 0, sv, sv_is_ntt, orc_expansion_ratio(c)};
+  dbm_t m = {c, db_ntt, P, 0, sv, sv_is_ntt, orc_expansion_ratio(c), 0};
   uint64_t count = 0;
   uint64_t* r = dbm_multiply(&m, dims, nd, 0, &count);
   if (r) memcpy(out, r, sizeof(uint64_t) * 2 * c->k * c->N * count);
   free(r);
   if (out_count) *out_count = count;
-  return ORC_OK;
+  return m.transparent ? ORC_INTERNAL : ORC_OK; /* database.cpp:313-315 */
 }
 
 /* reference server.cpp:173-195 without the (de)serialisation at either end */

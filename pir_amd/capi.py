@@ -74,6 +74,7 @@ SIGNATURES = {
     "pirgpu_db_size": (C.c_uint64, [C.c_void_p]),
     "pirgpu_db_read_plaintext": (C.c_int, [C.c_void_p, C.c_uint64, u64p]),
     "pirgpu_db_finalize": (C.c_int, [C.c_void_p, C.c_int]),
+    "pirgpu_set_transparent_policy": (C.c_int, [C.c_void_p, C.c_int]),
     "pirgpu_set_galois_key": (C.c_int, [C.c_void_p, C.c_uint32, u64p]),
     "pirgpu_clear_galois_keys": (C.c_int, [C.c_void_p]),
     "pirgpu_process_query": (C.c_int, [C.c_void_p, u64p, C.c_uint32, u64p, C.c_uint64, u64p]),
@@ -146,6 +147,7 @@ CLIENT_SIGNATURES = {
     "pirclient_process_response_integer": (C.c_int, [C.c_void_p, u8p, C.c_size_t, i64p, C.c_size_t,
                                                       C.POINTER(C.c_size_t)]),
     "pirclient_free": (None, [C.c_void_p]),
+    "pirclient_set_seeded_keys": (C.c_int, [C.c_void_p, C.c_int]),
     "pirclient_query_ct_count": (C.c_uint32, [C.c_void_p]),
     "pirclient_create_query": (C.c_int, [C.c_void_p, C.c_uint64, u64p, C.c_size_t, C.POINTER(C.c_uint32)]),
     "pirclient_galois_key": (C.c_int, [C.c_void_p, C.c_uint32, u64p]),

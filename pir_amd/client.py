@@ -65,6 +65,11 @@ class PIRClient:
         if rc != 0:
             raise PirGpuError(rc, self.lib.pirclient_last_error(self._h).decode())
 
+    def set_seeded_keys(self, enabled: bool = True) -> None:
+        """Key fields of CreateRequest: seed-compressed Serializable<> objects (default, what the reference client
+        sends, client.cpp:47-54) or fully expanded ones."""
+        self._check(self.lib.pirclient_set_seeded_keys(self._h, 1 if enabled else 0))
+
     # -- reference interface -------------------------------------------------------
     def CreateRequest(self, indexes: Sequence[int]) -> bytes:
         """client.cpp:80-90 -> serialized pir.Request."""

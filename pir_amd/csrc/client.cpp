@@ -244,7 +244,10 @@ struct pirclient {
   std::vector<uint64_t> pk;     // [2][km][N] NTT form
   std::map<uint32_t, std::vector<uint64_t>> galois;  // elt -> [k][2][km][N]
   std::vector<uint64_t> relin;  // [k][2][km][N]
-  std::string galois_blob, relin_blob;  // serialized once (client.cpp:49-54)
+  std::string galois_blob, relin_blob;  // serialized once (client.cpp:49-54), fully expanded
+  std::string galois_blob_seeded, relin_blob_seeded;  // the same keys, seed-compressed (the default on the wire)
+  std::map<uint32_t, std::vector<uint8_t>> galois_seeds;
+  bool seeded_keys = true;
 
   // decryption / encryption constants
   std::vector<uint64_t> inv_punct;   // (Q/q_j)^-1 mod q_j
@@ -334,12 +337,25 @@ struct pirclient {
     for (auto& v : e) v = rng.noise();
     return e;
   }
-  // (-(a s + e), a) at key level, NTT form: out [2][km][N]
-  void rlwe_zero_sym(uint64_t* out) {
+  // (-(a s + e), a) at key level, NTT form: out [2][km][N].  `a` is sampled the way SEAL 3.5.6 samples the
+  // public half of a symmetric-key sample (encrypt_zero_symmetric): a fresh 64-byte public seed, BlakePRNG,
+  // sample_poly_uniform over the key-level moduli -- so that the object can be sent seed-compressed
+  // (Serializable<>, reference client.cpp:47-54).  seed_out (optional) receives that seed.
+  void rlwe_zero_sym(uint64_t* out, uint8_t* seed_out = nullptr) {
     uint64_t* c0 = out;
     uint64_t* c1 = out + (size_t)km * N;
-    for (uint32_t j = 0; j < km; ++j)
-      for (uint32_t i = 0; i < N; ++i) c1[(size_t)j * N + i] = rng.below(mod[j].q);
+    uint8_t seed[wire::kSeedBytes];
+    for (size_t i = 0; i < wire::kSeedBytes; i += 8) {
+      const uint64_t v = rng.u64();
+      memcpy(seed + i, &v, 8);
+    }
+    if (seed_out) memcpy(seed_out, seed, wire::kSeedBytes);
+    {
+      wire::SealPrng pub(seed);
+      uint64_t mods[PIRGPU_MAX_PRIMES + 1];
+      for (uint32_t j = 0; j < km; ++j) mods[j] = mod[j].q;
+      wire::sample_poly_uniform(pub, mods, km, N, c1);
+    }
     small_to_ntt(sample_noise(), c0);
     for (uint32_t j = 0; j < km; ++j) {
       const Modulus& m = mod[j];
@@ -349,11 +365,11 @@ struct pirclient {
       }
     }
   }
-  // KSwitchKey for new_key (NTT form [km][N]): out [k][2][km][N]
-  void make_kswitch_key(const uint64_t* new_key, uint64_t* out) {
+  // KSwitchKey for new_key (NTT form [km][N]): out [k][2][km][N]; seeds_out: k seeds of kSeedBytes
+  void make_kswitch_key(const uint64_t* new_key, uint64_t* out, uint8_t* seeds_out) {
     for (uint32_t j = 0; j < k; ++j) {
       uint64_t* smp = out + (size_t)j * 2 * km * N;
-      rlwe_zero_sym(smp);
+      rlwe_zero_sym(smp, seeds_out + (size_t)j * wire::kSeedBytes);
       const Modulus& m = mod[j];
       uint64_t* c0j = smp + (size_t)j * N;
       const uint64_t* nk = new_key + (size_t)j * N;
@@ -385,7 +401,9 @@ struct pirclient {
       }
       auto& key = galois[g];
       key.resize(key_words());
-      make_kswitch_key(rotated.data(), key.data());
+      auto& sd = galois_seeds[g];
+      sd.resize((size_t)k * wire::kSeedBytes);
+      make_kswitch_key(rotated.data(), key.data(), sd.data());
       max_index = std::max<uint64_t>(max_index, (g - 1) >> 1);
     }
     // relinearisation key: s^2
@@ -395,10 +413,21 @@ struct pirclient {
         rotated[o] = mod[j].mul(s_ntt[o], s_ntt[o]);
       }
     relin.resize(key_words());
-    make_kswitch_key(rotated.data(), relin.data());
-    // serialize once
+    std::vector<uint8_t> relin_seed((size_t)k * wire::kSeedBytes);
+    make_kswitch_key(rotated.data(), relin.data(), relin_seed.data());
+    explicit_bzero(rotated.data(), rotated.size() * 8);  // held sigma_g(s) / s^2
+    explicit_bzero(s.data(), s.size() * sizeof(int));
+    // serialize once (client.cpp:49-54): seed-compressed like SEAL's Serializable<GaloisKeys>/<RelinKeys>,
+    // and fully expanded (what galois_keys_local + SaveRequest produce, server_test.cpp) on request
     std::vector<const uint64_t*> entries(max_index + 1, nullptr);
-    for (auto& kv : galois) entries[(kv.first - 1) >> 1] = kv.second.data();
+    std::vector<const uint8_t*> seeds(max_index + 1, nullptr);
+    for (auto& kv : galois) {
+      entries[(kv.first - 1) >> 1] = kv.second.data();
+      seeds[(kv.first - 1) >> 1] = galois_seeds[kv.first].data();
+    }
+    std::vector<const uint8_t*> rseeds{relin_seed.data()};
+    galois_blob_seeded = wire::save_kswitch_keys(sh, entries, &seeds);
+    relin_blob_seeded = wire::save_kswitch_keys(sh, {relin.data()}, &rseeds);
     galois_blob = wire::save_kswitch_keys(sh, entries);
     relin_blob = wire::save_kswitch_keys(sh, {relin.data()});
   }
@@ -641,14 +670,18 @@ struct pirclient {
   // StringEncoder::decode (string_encoder.cpp:124-163), same shift/or sequence on 8-bit chars
   void string_decode(const uint64_t* pt, size_t length, size_t byte_offset, uint8_t* out) const {
     const size_t bpc = bits_per_coeff;
-    if (byte_offset + length > (size_t)N * bpc / 8)
+    // pt.coeff_count() of a decrypted SEAL plaintext: Decryptor::decrypt trims the result to its significant
+    // coefficients (at least one), and the reference's bound (string_encoder.cpp:126) is taken on that count
+    size_t coeff_count = N;
+    while (coeff_count > 1 && !pt[coeff_count - 1]) --coeff_count;
+    if (byte_offset + length > coeff_count * bpc / 8)
       throw Err{PIRGPU_INVALID_ARGUMENT, "Requested decode beyond end of data in polynomial"};
     if (length == 0) return;
     const size_t start = byte_offset * 8 / bpc;
     size_t coeff_bits = (start + 1) * bpc - byte_offset * 8;
     memset(out, 0, length);
     size_t idx = 0, remain = 8;
-    for (size_t i = start; i < N; ++i) {
+    for (size_t i = start; i < coeff_count; ++i) {
       while (coeff_bits > 0) {
         const size_t n = std::min(coeff_bits, remain);
         out[idx] = (uint8_t)((out[idx] << n) | (uint8_t)(pt[i] >> (coeff_bits - n)));
@@ -689,8 +722,8 @@ struct pirclient {
       for (uint32_t c = 0; c < nq; ++c) wire::put_bytes_field(cts, 1, wire::save_ciphertext(sh, q.data() + c * ct_words()));
       wire::put_bytes_field(out, 1, cts);
     }
-    wire::put_bytes_field(out, 2, galois_blob);
-    wire::put_bytes_field(out, 3, relin_blob);
+    wire::put_bytes_field(out, 2, seeded_keys ? galois_blob_seeded : galois_blob);
+    wire::put_bytes_field(out, 3, seeded_keys ? relin_blob_seeded : relin_blob);
     return out;
   }
   // pir.Response (payload.proto:39-42): the Ciphertexts sub-messages
@@ -768,6 +801,12 @@ void pirclient_destroy(pirclient* c) {
 }
 const char* pirclient_last_error(const pirclient* c) { return c ? c->err.c_str() : "null client"; }
 const char* pirclient_create_error(void) { return g_create_error.c_str(); }
+int pirclient_set_seeded_keys(pirclient* c, int enabled) {
+  if (!c) return PIRGPU_INVALID_ARGUMENT;
+  c->seeded_keys = enabled != 0;
+  return PIRGPU_OK;
+}
+
 void pirclient_free(void* p) { free(p); }
 
 int pirclient_create_request(pirclient* c, const uint64_t* indexes, size_t n_indexes, uint8_t** request,

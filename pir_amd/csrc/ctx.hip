@@ -27,6 +27,10 @@ using namespace pirgpu;
 namespace {
 
 thread_local std::string g_create_error;
+// last failure of THIS thread (and the context it happened on): pirgpu_last_error stays meaningful when other
+// threads use the same context in between
+thread_local std::string t_last_error;
+thread_local const pirgpu_ctx* t_last_error_ctx = nullptr;
 
 struct Fail {
   int code;
@@ -144,7 +148,9 @@ struct pirgpu_ctx {
   float timings[6]{};
 
   std::string err;
-  std::mutex mu;
+  std::recursive_mutex mu;  // per ABI call; pirgpu_process_request holds it across its whole body
+  uint64_t zero_pts = 0;    // all-zero database plaintexts in this shard (SEAL: "result ciphertext is transparent")
+  bool allow_transparent = false;
 
   template <typename T>
   T* dalloc(size_t count) {
@@ -159,14 +165,19 @@ struct pirgpu_ctx {
 namespace {
 
 int fail(pirgpu_ctx* c, int code, const std::string& msg) {
-  if (c) c->err = msg;
+  if (c) {
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    c->err = msg;
+    t_last_error = msg;
+    t_last_error_ctx = c;
+  }
   return code;
 }
 
 template <typename F>
 int guarded(pirgpu_ctx* c, F&& f) {
   if (!c) return PIRGPU_INVALID_ARGUMENT;
-  std::lock_guard<std::mutex> lock(c->mu);
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   try {
     c->use_device();
     return f();
@@ -273,6 +284,31 @@ void build_tables(pirgpu_ctx* c) {
 }
 
 uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+
+bool all_zero_bytes(const uint8_t* p, size_t n) {
+  for (size_t i = 0; i < n; ++i)
+    if (p[i]) return false;
+  return true;
+}
+
+// loaded[] per local plaintext: 0 = not loaded, 1 = loaded, 2 = loaded and identically zero
+void note_plaintext(pirgpu_ctx* c, uint64_t local, bool zero) {
+  uint8_t& st = c->loaded[local];
+  if (!st) ++c->n_loaded;
+  if (st == 2) --c->zero_pts;
+  st = zero ? 2 : 1;
+  if (zero) ++c->zero_pts;
+}
+
+// Evaluator::multiply_plain throws logic_error("result ciphertext is transparent") when its result has an
+// all-zero c1 (SEAL's default build, SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT), which happens for every query as
+// soon as one database plaintext is identically zero; PIRDatabase::multiply maps it to InternalError
+// (reference database.cpp:308-315).  pirgpu_set_transparent_policy(ctx, 1) returns the mathematically defined
+// reply instead.
+void check_transparent(pirgpu_ctx* c) {
+  if (c->zero_pts && !c->allow_transparent)
+    throw Fail{PIRGPU_INTERNAL, "result ciphertext is transparent"};
+}
 
 void alloc_worker(pirgpu_ctx* c, Worker& w);
 void ensure_expansion_buffers(pirgpu_ctx* c, Worker& w);
@@ -532,6 +568,7 @@ void scan_on_device(pirgpu_ctx* c, Worker& w) {
   const size_t ctw = c->ctw;
   if (c->n_loaded != c->pt_end - c->pt_begin)
     throw Fail{PIRGPU_FAILED_PRECONDITION, "database not fully loaded"};
+  check_transparent(c);
   if (c->pt_end == c->pt_begin) return;
   if (c->mfma_on && c->mfma_single) {
     Worker* one = &w;
@@ -744,10 +781,26 @@ void pirgpu_destroy(pirgpu_ctx* c) {
   delete c;
 }
 
-const char* pirgpu_last_error(const pirgpu_ctx* c) { return c ? c->err.c_str() : "null context"; }
+const char* pirgpu_last_error(const pirgpu_ctx* c) {
+  if (!c) return "null context";
+  if (t_last_error_ctx == c) return t_last_error.c_str();  // this thread's own last failure on this context
+  return c->err.c_str();
+}
 
-void pirgpu_set_error(pirgpu_ctx* c, const char* message) {
-  if (c) c->err = message ? message : "";
+void pirgpu_set_error(pirgpu_ctx* c, const char* message) { (void)fail(c, 0, message ? message : ""); }
+
+void pirgpu_request_lock(pirgpu_ctx* c) {
+  if (c) c->mu.lock();
+}
+void pirgpu_request_unlock(pirgpu_ctx* c) {
+  if (c) c->mu.unlock();
+}
+
+int pirgpu_set_transparent_policy(pirgpu_ctx* c, int allow) {
+  return guarded(c, [&]() -> int {
+    c->allow_transparent = allow != 0;
+    return PIRGPU_OK;
+  });
 }
 
 int pirgpu_get_params(const pirgpu_ctx* c, pirgpu_params* out) {
@@ -818,14 +871,14 @@ int pirgpu_db_load_items(pirgpu_ctx* c, const uint8_t* items, uint64_t num_items
         const uint64_t b0 = std::min<uint64_t>(pt * bytes_per_pt, total_bytes);
         const uint64_t b1 = std::min<uint64_t>((pt + n) * bytes_per_pt, total_bytes);
         if (b1 > b0) HIP_TRY(hipMemcpyAsync(d_bytes, items + b0, b1 - b0, hipMemcpyHostToDevice, c->stream));
+        for (uint64_t i = 0; i < n; ++i) {  // all-zero plaintexts (host scan while the copy is in flight)
+          const uint64_t p0 = std::min<uint64_t>((pt + i) * bytes_per_pt, total_bytes);
+          const uint64_t p1 = std::min<uint64_t>((pt + i + 1) * bytes_per_pt, total_bytes);
+          note_plaintext(c, pt - c->pt_begin + i, all_zero_bytes(items + p0, p1 - p0));
+        }
         HIP_TRY(c->ops->db_encode(c->stream, c->mode, c->dp, c->k, nullptr, d_bytes, bytes_per_pt, b1 - b0, c->bits,
                                   n, c->d_db + (pt - c->pt_begin) * c->k * c->N));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        for (uint64_t i = 0; i < n; ++i)
-          if (!c->loaded[pt - c->pt_begin + i]) {
-            c->loaded[pt - c->pt_begin + i] = 1;
-            ++c->n_loaded;
-          }
       }
     } catch (...) {
       (void)hipFree(d_bytes);
@@ -852,14 +905,13 @@ int pirgpu_db_load_coeffs(pirgpu_ctx* c, uint64_t first_pt, uint64_t n_pt, const
         const uint64_t n = std::min<uint64_t>(chunk, hi - pt);
         HIP_TRY(hipMemcpyAsync(d_coeffs, coeffs + (pt - first_pt) * c->N, n * c->N * 8, hipMemcpyHostToDevice,
                                c->stream));
+        for (uint64_t i = 0; i < n; ++i)
+          note_plaintext(c, pt - c->pt_begin + i,
+                         all_zero_bytes(reinterpret_cast<const uint8_t*>(coeffs + (pt - first_pt + i) * c->N),
+                                        (size_t)c->N * 8));
         HIP_TRY(c->ops->db_encode(c->stream, c->mode, c->dp, c->k, d_coeffs, nullptr, 0, 0, c->bits, n,
                                   c->d_db + (pt - c->pt_begin) * c->k * c->N));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        for (uint64_t i = 0; i < n; ++i)
-          if (!c->loaded[pt - c->pt_begin + i]) {
-            c->loaded[pt - c->pt_begin + i] = 1;
-            ++c->n_loaded;
-          }
       }
     } catch (...) {
       (void)hipFree(d_coeffs);
@@ -1148,6 +1200,8 @@ int pirgpu_set_concurrency(pirgpu_ctx* c, uint32_t n_workers) {
   });
 }
 
+static void ensure_batch_capacity(pirgpu_ctx* c, uint32_t count);
+
 int pirgpu_batch_stage(pirgpu_ctx* c, const uint64_t* queries, uint32_t nq, uint32_t count) {
   return guarded(c, [&]() -> int {
     ensure_workspace(c);
@@ -1155,17 +1209,41 @@ int pirgpu_batch_stage(pirgpu_ctx* c, const uint64_t* queries, uint32_t nq, uint
       return fail(c, PIRGPU_INVALID_ARGUMENT,
                   "Number of ciphertexts doesn't match number of items for oblivious expansion.");
     if (count == 0 || count > 4096) return fail(c, PIRGPU_INVALID_ARGUMENT, "batch size must be in [1, 4096]");
-    if (count > c->batch_cap) {
-      c->d_bquery = c->dalloc<uint64_t>((size_t)count * nq * c->ctw);
-      c->d_breply = c->dalloc<uint64_t>((size_t)count * c->reply_cts * c->ctw);
-      c->batch_cap = count;
-    }
+    ensure_batch_capacity(c, count);
     HIP_TRY(hipMemcpyAsync(c->d_bquery, queries, (size_t)count * nq * c->ctw * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->batch_count = count;
     c->batch_valid = false;
     return PIRGPU_OK;
   });
+}
+
+// Batch staging (queries + replies, device resident) for at least `count` queries.  Growth frees the old pair
+// (after every stream that may still touch it has drained) and at least doubles, so a peer that sends ever
+// larger requests cannot accumulate stale buffers.
+static void ensure_batch_capacity(pirgpu_ctx* c, uint32_t count) {
+  if (count <= c->batch_cap) return;
+  const uint32_t nq = c->dim_sum / c->N + 1;
+  if (c->d_bquery || c->d_breply) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (BatchLane& ln : c->lanes)
+      if (ln.stream) HIP_TRY(hipStreamSynchronize(ln.stream));
+    for (Worker& w : c->workers)
+      if (w.stream) HIP_TRY(hipStreamSynchronize(w.stream));
+    for (uint64_t* p : {c->d_bquery, c->d_breply}) {
+      if (!p) continue;
+      auto it = std::find(c->allocs.begin(), c->allocs.end(), (void*)p);
+      if (it != c->allocs.end()) c->allocs.erase(it);
+      HIP_TRY(hipFree(p));
+    }
+    c->d_bquery = c->d_breply = nullptr;
+    c->batch_cap = 0;
+    c->batch_valid = false;
+  }
+  const uint32_t cap = std::max<uint32_t>(count, std::min<uint32_t>(4096, 2 * c->batch_cap));
+  c->d_bquery = c->dalloc<uint64_t>((size_t)cap * nq * c->ctw);
+  c->d_breply = c->dalloc<uint64_t>((size_t)cap * c->reply_cts * c->ctw);
+  c->batch_cap = cap;
 }
 
 // Lanes (stream + expansion buffers for up to 8 interleaved queries), created on the first batch.
@@ -1259,6 +1337,7 @@ static void batch_run_impl(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
   const uint32_t G = mq_usable(c) && c->pt_end > c->pt_begin ? std::min<uint32_t>(c->mq_nq, kMaxScanQueries) : 1;
   if (c->n_loaded != c->pt_end - c->pt_begin)
     throw Fail{PIRGPU_FAILED_PRECONDITION, "database not fully loaded"};
+  check_transparent(c);
   ensure_packed(c);
   c->prof_cur = -1;
   if (c->mfma_on) {
@@ -1367,12 +1446,7 @@ int pirgpu_batch_run_selectors(pirgpu_ctx* c, const uint64_t* device_sv, uint32_
   return guarded(c, [&]() -> int {
     ensure_workspace(c);
     if (!device_sv || count == 0 || count > 4096) return fail(c, PIRGPU_INVALID_ARGUMENT, "invalid batch");
-    if (count > c->batch_cap) {
-      const uint32_t nq = c->dim_sum / c->N + 1;
-      c->d_bquery = c->dalloc<uint64_t>((size_t)count * nq * c->ctw);
-      c->d_breply = c->dalloc<uint64_t>((size_t)count * c->reply_cts * c->ctw);
-      c->batch_cap = count;
-    }
+    ensure_batch_capacity(c, count);
     c->batch_count = std::max(c->batch_count, count);
     batch_run_impl(c, count, device_sv);
     c->batch_count = count;
@@ -1493,11 +1567,14 @@ int pirgpu_last_timings(pirgpu_ctx* c, float ms[6], uint32_t* runs) {
 }
 
 int pirgpu_keys_blob_matches(pirgpu_ctx* c, const uint8_t* blob, size_t len) {
-  return c && c->keys_blob_valid && c->keys_blob.size() == len && memcmp(c->keys_blob.data(), blob, len) == 0;
+  if (!c) return 0;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  return c->keys_blob_valid && c->keys_blob.size() == len && memcmp(c->keys_blob.data(), blob, len) == 0;
 }
 
 void pirgpu_keys_blob_set(pirgpu_ctx* c, const uint8_t* blob, size_t len) {
   if (!c) return;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
   c->keys_blob.assign(blob, blob + len);
   c->keys_blob_valid = true;
 }

@@ -205,6 +205,10 @@ class PIRServer {
 
   // what SEALDeserialize<GaloisKeys> yields (server.cpp:46-48)
   Status SetGaloisKeys(const GaloisKeys& keys) const {
+    const size_t k = params_->coeff_modulus.size() - 1;
+    const size_t key_words = k * 2 * (k + 1) * params_->poly_modulus_degree;
+    for (auto it = keys.begin(); it != keys.end(); ++it)
+      if (it->second.size() != key_words) return InvalidArgumentError("Galois key has the wrong size");
     int rc = pirgpu_clear_galois_keys(db_->handle());
     for (auto it = keys.begin(); rc == 0 && it != keys.end(); ++it)
       rc = pirgpu_set_galois_key(db_->handle(), it->first, it->second.data());
@@ -213,16 +217,22 @@ class PIRServer {
 
   // server.cpp:67-76
   Status substitute_power_x_inplace(Ciphertext& ct, uint32_t power) const {
+    if (ct.size() != db_->CtWords()) return InvalidArgumentError("ciphertext has the wrong size");
     return detail::FromRc(db_->handle(), pirgpu_substitute_power_x(db_->handle(), ct.data(), power));
   }
   // server.cpp:78-103
   void multiply_inverse_power_of_x(const Ciphertext& encrypted, uint32_t k, Ciphertext& destination) const {
+    if (encrypted.size() != db_->CtWords()) {  // the reference's signature has no status to report through
+      destination.clear();
+      return;
+    }
     destination.resize(encrypted.size());
     pirgpu_multiply_inverse_power_of_x(db_->handle(), encrypted.data(), k, destination.data());
   }
   // server.cpp:105-146
   StatusOr<std::vector<Ciphertext>> oblivious_expansion(const Ciphertext& ct, size_t num_items) const {
     const size_t words = db_->CtWords();
+    if (ct.size() != words) return InvalidArgumentError("ciphertext has the wrong size");
     std::vector<uint64_t> out(std::max<size_t>(num_items, 1) * words);
     int rc = pirgpu_expand(db_->handle(), ct.data(), static_cast<uint32_t>(num_items), out.data());
     if (rc) return detail::FromRc(db_->handle(), rc);
@@ -234,7 +244,10 @@ class PIRServer {
   StatusOr<std::vector<Ciphertext>> oblivious_expansion(const std::vector<Ciphertext>& cts, size_t total_items) const {
     const size_t words = db_->CtWords();
     std::vector<uint64_t> in(cts.size() * words), out(std::max<size_t>(total_items, 1) * words);
-    for (size_t i = 0; i < cts.size(); ++i) std::copy(cts[i].begin(), cts[i].end(), in.begin() + i * words);
+    for (size_t i = 0; i < cts.size(); ++i) {
+      if (cts[i].size() != words) return InvalidArgumentError("ciphertext has the wrong size");
+      std::copy(cts[i].begin(), cts[i].end(), in.begin() + i * words);
+    }
     int rc = pirgpu_expand_multi(db_->handle(), in.data(), static_cast<uint32_t>(cts.size()), total_items, out.data());
     if (rc) return detail::FromRc(db_->handle(), rc);
     std::vector<Ciphertext> result(total_items);

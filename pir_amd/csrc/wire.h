@@ -9,6 +9,13 @@ extern "C" {
 #endif
 void pirgpu_wire_parms_id(uint32_t N, const uint64_t* moduli, size_t n_moduli, uint64_t t, uint64_t out[4]);
 void pirgpu_wire_blake2b(uint8_t* out, size_t outlen, const uint8_t* in, size_t inlen);
+void pirgpu_wire_blake2xb(uint8_t* out, size_t outlen, const uint8_t* in, size_t inlen, const uint8_t* key,
+                          size_t keylen);
+void pirgpu_wire_sample_poly_uniform(const uint8_t* seed, const uint64_t* moduli, uint32_t n_moduli, uint32_t N,
+                                     uint64_t* out);
+struct pirgpu_params;
+int pirgpu_wire_load_kswitch_key(const struct pirgpu_params* params, const uint8_t* blob, size_t len, uint64_t index,
+                                 uint64_t* out);
 // Device-free validation of a serialized pir.Request (same checks as pirgpu_process_request).
 struct pirgpu_params;
 int pirgpu_wire_validate_request(const struct pirgpu_params* params, const uint8_t* request, size_t request_len,
@@ -18,6 +25,10 @@ int pirgpu_wire_validate_request(const struct pirgpu_params* params, const uint8
 struct pirgpu_ctx;
 int pirgpu_keys_blob_matches(struct pirgpu_ctx* ctx, const uint8_t* blob, size_t len);
 void pirgpu_keys_blob_set(struct pirgpu_ctx* ctx, const uint8_t* blob, size_t len);
+// Request-level critical section (recursive with the per-call lock of the ABI entry points): held by
+// pirgpu_process_request for its whole body so that concurrent requests on one context cannot interleave.
+void pirgpu_request_lock(struct pirgpu_ctx* ctx);
+void pirgpu_request_unlock(struct pirgpu_ctx* ctx);
 // Queries in flight as last set with pirgpu_set_concurrency (1 by default).
 uint32_t pirgpu_get_concurrency(struct pirgpu_ctx* ctx);
 #ifdef __cplusplus

@@ -59,26 +59,136 @@ static void b2_compress(uint64_t h[8], const uint8_t block[128], uint64_t t0, bo
   for (int i = 0; i < 8; ++i) h[i] ^= v[i] ^ v[i + 8];
 }
 
+// BLAKE2b with an explicit 64-byte parameter block (RFC 7693 section 2.5 / BLAKE2X) and optional key.
+namespace {
+struct B2State {
+  uint64_t h[8];
+  uint64_t t = 0;
+  uint8_t buf[128];
+  size_t buflen = 0;
+  void init(const uint8_t param[64]) {
+    for (int i = 0; i < 8; ++i) {
+      uint64_t w;
+      memcpy(&w, param + 8 * i, 8);
+      h[i] = kIV[i] ^ w;
+    }
+    t = 0;
+    buflen = 0;
+  }
+  void update(const uint8_t* in, size_t inlen) {
+    while (inlen) {
+      if (buflen == 128) {  // the buffered block is not the last one
+        t += 128;
+        b2_compress(h, buf, t, false);
+        buflen = 0;
+      }
+      const size_t take = inlen < 128 - buflen ? inlen : 128 - buflen;
+      memcpy(buf + buflen, in, take);
+      buflen += take;
+      in += take;
+      inlen -= take;
+    }
+  }
+  void final(uint8_t* out, size_t outlen) {
+    t += buflen;
+    memset(buf + buflen, 0, 128 - buflen);
+    b2_compress(h, buf, t, true);
+    uint8_t full[64];
+    memcpy(full, h, 64);
+    memcpy(out, full, outlen);
+  }
+};
+}  // namespace
+
 // unkeyed BLAKE2b with outlen <= 64
 void blake2b(uint8_t* out, size_t outlen, const uint8_t* in, size_t inlen) {
-  uint64_t h[8];
-  for (int i = 0; i < 8; ++i) h[i] = kIV[i];
-  h[0] ^= 0x01010000ULL ^ (uint64_t)outlen;
-  uint8_t block[128];
-  uint64_t t = 0;
-  while (inlen > 128) {
-    t += 128;
-    b2_compress(h, in, t, false);
-    in += 128;
-    inlen -= 128;
+  uint8_t param[64] = {0};
+  param[0] = (uint8_t)outlen;  // digest_length
+  param[2] = 1;                // fanout
+  param[3] = 1;                // depth
+  B2State st;
+  st.init(param);
+  st.update(in, inlen);
+  st.final(out, outlen);
+}
+
+// BLAKE2Xb (the BLAKE2 team's blake2xb.c, which SEAL 3.5.6 vendors for its BlakePRNG): root hash
+// H0 = BLAKE2b-512(key block || in) with xof_length = outlen in the parameter block, then output block i =
+// BLAKE2b(H0) with node_offset = i, leaf_length = inner_length = 64, fanout = depth = 0, digest = block size.
+void blake2xb(uint8_t* out, size_t outlen, const uint8_t* in, size_t inlen, const uint8_t* key, size_t keylen) {
+  uint8_t param[64] = {0};
+  param[0] = 64;
+  param[1] = (uint8_t)keylen;
+  param[2] = 1;
+  param[3] = 1;
+  const uint32_t xof = (uint32_t)outlen;
+  memcpy(param + 12, &xof, 4);  // xof_length (leaf_length at 4, node_offset at 8)
+  B2State root;
+  root.init(param);
+  if (keylen) {
+    uint8_t block[128] = {0};
+    memcpy(block, key, keylen);
+    root.update(block, 128);
   }
-  memset(block, 0, 128);
-  if (inlen) memcpy(block, in, inlen);
-  t += inlen;
-  b2_compress(h, block, t, true);
-  uint8_t full[64];
-  memcpy(full, h, 64);
-  memcpy(out, full, outlen);
+  root.update(in, inlen);
+  uint8_t h0[64];
+  root.final(h0, 64);
+  param[1] = 0;  // key_length
+  param[2] = 0;  // fanout
+  param[3] = 0;  // depth
+  const uint32_t leaf = 64;
+  memcpy(param + 4, &leaf, 4);
+  param[17] = 64;  // inner_length (node_depth at 16 stays 0)
+  for (uint32_t i = 0; outlen > 0; ++i) {
+    const size_t block = outlen < 64 ? outlen : 64;
+    param[0] = (uint8_t)block;
+    memcpy(param + 8, &i, 4);  // node_offset
+    B2State c;
+    c.init(param);
+    c.update(h0, 64);
+    c.final(out + (size_t)i * 64, block);
+    outlen -= block;
+  }
+}
+
+// SEAL 3.5.6 BlakePRNG (randomgen.h/.cpp): a 4096-byte buffer refilled with
+// blake2xb(buffer, 4096, &counter (u64, starting at 0), 8, seed, 64), counter++ per refill; consumers
+// take bytes in order.  UNVERIFIED against a SEAL build (none in this image) -- see DESIGN.md section 8b.
+SealPrng::SealPrng(const uint8_t seed_bytes[kSeedBytes]) { memcpy(seed, seed_bytes, kSeedBytes); }
+
+void SealPrng::generate(uint8_t* dst, size_t n) {
+  while (n) {
+    if (head == sizeof(buf)) {
+      blake2xb(buf, sizeof(buf), reinterpret_cast<const uint8_t*>(&counter), 8, seed, kSeedBytes);
+      ++counter;
+      head = 0;
+    }
+    const size_t take = n < sizeof(buf) - head ? n : sizeof(buf) - head;
+    memcpy(dst, buf + head, take);
+    head += take;
+    dst += take;
+    n -= take;
+  }
+}
+
+// SEAL 3.5.6 sample_poly_uniform (util/rlwe.cpp): per modulus, per coefficient, rejection-sample
+// rand = (u32 << 31) | (u32 >> 1) (a 63-bit value from two successive 32-bit outputs) below the largest
+// multiple of the modulus, then reduce.  out: [n_moduli][N].
+void sample_poly_uniform(SealPrng& rng, const uint64_t* moduli, uint32_t n_moduli, uint32_t N, uint64_t* out) {
+  const uint64_t max_random = 0x7FFFFFFFFFFFFFFFULL;
+  for (uint32_t j = 0; j < n_moduli; ++j) {
+    const uint64_t q = moduli[j];
+    const uint64_t max_multiple = max_random - max_random % q - 1;
+    for (uint32_t i = 0; i < N; ++i) {
+      uint64_t rand;
+      do {
+        const uint64_t a = rng.u32();
+        const uint64_t b = rng.u32();
+        rand = (a << 31) | (b >> 1);
+      } while (rand >= max_multiple);
+      out[(size_t)j * N + i] = rand % q;
+    }
+  }
 }
 
 // EncryptionParameters::compute_parms_id: BLAKE2b-256 over
@@ -144,13 +254,22 @@ void load_ciphertext(Cursor& c, const Shape& sh, bool key_level, std::vector<uin
   Cursor a{o.p + kHeader, arr_end};
   uint64_t count = a.u64();
   const uint64_t full = 2ull * nres * sh.N;
-  if (count == full / 2)
-    throw Err{PIRGPU_UNIMPLEMENTED,
-              "seed-compressed SEAL object: expanding it needs SEAL's Blake2xb PRNG (not implemented)"};
-  if (count != full) throw Err{PIRGPU_INVALID_ARGUMENT, "ciphertext data is invalid (coefficient count)"};
+  if (count != full && count != full / 2)
+    throw Err{PIRGPU_INVALID_ARGUMENT, "ciphertext data is invalid (coefficient count)"};
   a.need(count * 8);
-  out.resize(count);
+  out.resize(full);
   memcpy(out.data(), a.p, count * 8);
+  if (count == full / 2) {
+    // Seed-compressed object (Serializable<>, what PIRClient::initialize sends for its keys, client.cpp:47-54):
+    // only c0 was saved; the 64-byte seed follows the IntArray and c1 is re-sampled from it
+    // (Ciphertext::load_members -> expand_seed -> sample_poly_uniform over this object's moduli).
+    Cursor sc{arr_end, o.end};
+    sc.need(kSeedBytes);
+    SealPrng rng(sc.p);
+    uint64_t mods[PIRGPU_MAX_PRIMES + 1];
+    for (uint32_t j = 0; j < nres; ++j) mods[j] = sh.q[j];
+    sample_poly_uniform(rng, mods, nres, sh.N, out.data() + full / 2);
+  }
   // is_data_valid_for: every coefficient below its modulus
   for (uint32_t poly = 0; poly < 2; ++poly)
     for (uint32_t j = 0; j < nres; ++j) {
@@ -162,9 +281,10 @@ void load_ciphertext(Cursor& c, const Shape& sh, bool key_level, std::vector<uin
   c.p = obj_end;
 }
 
-std::string save_ciphertext(const Shape& sh, const uint64_t* ct, bool key_level) {
+// seed != nullptr: the Serializable<> form -- only c0 is written, followed by the 64-byte seed c1 was sampled from.
+std::string save_ciphertext(const Shape& sh, const uint64_t* ct, bool key_level, const uint8_t* seed) {
   const uint32_t nres = key_level ? sh.k + 1 : sh.k;
-  const uint64_t count = 2ull * nres * sh.N;
+  const uint64_t count = (seed ? 1ull : 2ull) * nres * sh.N;
   std::string arr;
   put_header(arr, kHeader + 8 + count * 8);
   put_u64(arr, count);
@@ -181,14 +301,15 @@ std::string save_ciphertext(const Shape& sh, const uint64_t* ct, bool key_level)
   memcpy(&sbits, &scale, 8);
   put_u64(body, sbits);
   body.append(arr);
+  if (seed) body.append(reinterpret_cast<const char*>(seed), kSeedBytes);
   std::string out;
   put_header(out, kHeader + body.size());
   out.append(body);
   return out;
 }
 
-std::string save_public_key(const Shape& sh, const uint64_t* pk) {
-  const std::string ct = save_ciphertext(sh, pk, true);
+std::string save_public_key(const Shape& sh, const uint64_t* pk, const uint8_t* seed) {
+  const std::string ct = save_ciphertext(sh, pk, true, seed);
   std::string out;
   put_header(out, kHeader + ct.size());
   out.append(ct);
@@ -223,15 +344,19 @@ void load_kswitch_keys(const Shape& sh, const uint8_t* data, size_t len,
   }
 }
 
-std::string save_kswitch_keys(const Shape& sh, const std::vector<const uint64_t*>& entries) {
+std::string save_kswitch_keys(const Shape& sh, const std::vector<const uint64_t*>& entries,
+                              const std::vector<const uint8_t*>* seeds) {
   const size_t pk_words = (size_t)2 * (sh.k + 1) * sh.N;
   std::string body;
   for (int i = 0; i < 4; ++i) put_u64(body, sh.key_id[i]);
   put_u64(body, entries.size());
-  for (const uint64_t* key : entries) {
+  for (size_t e = 0; e < entries.size(); ++e) {
+    const uint64_t* key = entries[e];
     put_u64(body, key ? sh.k : 0);
     if (!key) continue;
-    for (uint32_t j = 0; j < sh.k; ++j) body.append(save_public_key(sh, key + j * pk_words));
+    const uint8_t* sd = seeds ? (*seeds)[e] : nullptr;  // k seeds of kSeedBytes each, one per decomposition digit
+    for (uint32_t j = 0; j < sh.k; ++j)
+      body.append(save_public_key(sh, key + j * pk_words, sd ? sd + (size_t)j * kSeedBytes : nullptr));
   }
   std::string out;
   put_header(out, kHeader + body.size());

@@ -14,6 +14,26 @@ namespace pirgpu {
 namespace wire {
 
 void blake2b(uint8_t* out, size_t outlen, const uint8_t* in, size_t inlen);
+// BLAKE2Xb extendable-output function (outlen < 2^32), optionally keyed (keylen <= 64).
+void blake2xb(uint8_t* out, size_t outlen, const uint8_t* in, size_t inlen, const uint8_t* key, size_t keylen);
+
+// SEAL 3.5.6's seeded PRNG (BlakePRNG) and uniform polynomial sampler: what re-expands the c1 half of a
+// seed-compressed Serializable<> object on load (reference serialization.h:104-118 -> Ciphertext::load).
+constexpr size_t kSeedBytes = 64;  // random_seed_type = std::array<uint64_t, 8>
+struct SealPrng {
+  uint8_t seed[kSeedBytes];
+  uint64_t counter = 0;
+  uint8_t buf[4096];
+  size_t head = sizeof(buf);
+  explicit SealPrng(const uint8_t seed_bytes[kSeedBytes]);
+  void generate(uint8_t* dst, size_t n);
+  uint32_t u32() {
+    uint32_t v;
+    generate(reinterpret_cast<uint8_t*>(&v), 4);
+    return v;
+  }
+};
+void sample_poly_uniform(SealPrng& rng, const uint64_t* moduli, uint32_t n_moduli, uint32_t N, uint64_t* out);
 void parms_id(uint32_t N, const uint64_t* moduli, size_t n_moduli, uint64_t t, uint64_t out[4]);
 
 // ------------------------------------------------------------------ proto3 primitives
@@ -115,14 +135,17 @@ Shape make_shape(const pirgpu_params& prm);
 void load_ciphertext(Cursor& c, const Shape& sh, bool key_level, std::vector<uint64_t>& out);
 // Ciphertext::save of a size-2 ciphertext: data level (k primes, coefficient form) or, with
 // key_level, the (k+1)-prime NTT-form body of a PublicKey.
-std::string save_ciphertext(const Shape& sh, const uint64_t* ct, bool key_level = false);
+std::string save_ciphertext(const Shape& sh, const uint64_t* ct, bool key_level = false,
+                            const uint8_t* seed = nullptr);
 // PublicKey::save = header + Ciphertext::save(key level).
-std::string save_public_key(const Shape& sh, const uint64_t* pk);
+std::string save_public_key(const Shape& sh, const uint64_t* pk, const uint8_t* seed = nullptr);
 // KSwitchKeys::load (GaloisKeys / RelinKeys): calls sink(index, key [k][2][k+1][N]) per present entry.
 void load_kswitch_keys(const Shape& sh, const uint8_t* data, size_t len,
                        const std::function<void(uint64_t, const uint64_t*)>& sink);
 // KSwitchKeys::save: entries[i] = key [k][2][k+1][N] or nullptr (absent), i < dim1.
-std::string save_kswitch_keys(const Shape& sh, const std::vector<const uint64_t*>& entries);
+// seeds (optional): per entry k * kSeedBytes bytes -> the seed-compressed Serializable<> form (c1 halves omitted).
+std::string save_kswitch_keys(const Shape& sh, const std::vector<const uint64_t*>& entries,
+                              const std::vector<const uint8_t*>* seeds = nullptr);
 
 // LoadCiphertexts (serialization.cpp:32-42) of one pir.Ciphertexts message -> residues [n][2][k][N]; returns n.
 uint32_t load_query(const Shape& sh, const uint8_t* data, size_t len, std::vector<uint64_t>& qbuf);

@@ -117,6 +117,11 @@ class PIRDatabase:
     def size(self) -> int:
         return int(self.lib.pirgpu_db_size(self._h))
 
+    def set_transparent_policy(self, allow: bool) -> None:
+        """False (default): an identically-zero database plaintext makes every query fail with Internal, like SEAL's
+        "result ciphertext is transparent" through database.cpp:313-315; True: return the defined reply."""
+        self._check(self.lib.pirgpu_set_transparent_policy(self._h, 1 if allow else 0))
+
     def finalize(self, release_staging: bool = False) -> None:
         """Pack the operand-layout copy now; optionally free the u64 staging copy (no reloads afterwards)."""
         self._check(self.lib.pirgpu_db_finalize(self._h, 1 if release_staging else 0))
@@ -135,6 +140,8 @@ class PIRDatabase:
     def multiply(self, selection_vector) -> np.ndarray:
         """database.cpp:290-316: selection vector [dim_sum, 2, k, N] (coefficient form) -> reply cts."""
         sv = _u64(selection_vector)
+        if sv.ndim != 4 or sv.shape[1:] != (2, self.k, self.N):
+            raise PirGpuError(3, "selection vector must have shape [n, 2, %d, %d], got %s" % (self.k, self.N, list(sv.shape)))
         n = self.reply_ct_count()
         out = np.empty((n, 2, self.k, self.N), dtype=np.uint64)
         cnt = C.c_uint64(0)
@@ -170,13 +177,23 @@ class PIRServer:
     def _check(self, rc):
         self.db._check(rc)
 
+    def _cts(self, a, ndim: int, what: str) -> np.ndarray:
+        """uint64, contiguous, shape [..., 2, k, N] with `ndim` dimensions -- checked before any pointer reaches C."""
+        a = _u64(a)
+        if a.ndim != ndim or a.shape[-3:] != (2, self.k, self.N):
+            raise PirGpuError(3, "%s must have shape [%s2, %d, %d], got %s"
+                              % (what, "n, " * (ndim - 3), self.k, self.N, list(a.shape)))
+        return a
+
     # -- keys -----------------------------------------------------------------------
     def set_galois_keys(self, galois_keys: Dict[int, np.ndarray]) -> None:
         """Install what SEALDeserialize<GaloisKeys> yields per request (server.cpp:46-48)."""
         self._check(self.lib.pirgpu_clear_galois_keys(self.db.handle))
         for g, key in galois_keys.items():
             key = _u64(key)
-            assert key.shape == (self.k, 2, self.k + 1, self.N), key.shape
+            if key.shape != (self.k, 2, self.k + 1, self.N):
+                raise PirGpuError(3, "Galois key must have shape [%d, 2, %d, %d], got %s"
+                                  % (self.k, self.k + 1, self.N, list(key.shape)))
             self._check(self.lib.pirgpu_set_galois_key(self.db.handle, int(g), _ptr(key)))
 
     # -- query path -------------------------------------------------------------------
@@ -184,7 +201,7 @@ class PIRServer:
         """processQuery (server.cpp:173-195) on residue arrays: query [nq, 2, k, N] -> reply cts."""
         if galois_keys is not None:
             self.set_galois_keys(galois_keys)
-        q = _u64(query)
+        q = self._cts(query, 4, "query")
         n = self.db.reply_ct_count()
         out = np.empty((n, 2, self.k, self.N), dtype=np.uint64)
         cnt = C.c_uint64(0)
@@ -205,7 +222,7 @@ class PIRServer:
 
     # -- device-resident split (bench / pipelining) -----------------------------------
     def stage_query(self, query) -> None:
-        q = _u64(query)
+        q = self._cts(query, 4, "query")
         self._check(self.lib.pirgpu_query_stage(self.db.handle, _ptr(q), q.shape[0]))
 
     def run_staged(self) -> None:
@@ -227,7 +244,7 @@ class PIRServer:
 
     def stage_batch(self, queries) -> None:
         """queries: [count, nq, 2, k, N]"""
-        q = _u64(queries)
+        q = self._cts(queries, 5, "queries")
         self._batch_count = q.shape[0]
         self._check(self.lib.pirgpu_batch_stage(self.db.handle, _ptr(q), q.shape[1], q.shape[0]))
 
@@ -303,13 +320,15 @@ class PIRServer:
     # -- test-visible helpers (server.h:66-131) -----------------------------------------
     def substitute_power_x_inplace(self, ct: np.ndarray, power: int) -> np.ndarray:
         """server.cpp:67-76; returns the substituted ciphertext (ct itself is updated too)."""
-        assert ct.dtype == np.uint64 and ct.flags["C_CONTIGUOUS"]
+        if not (isinstance(ct, np.ndarray) and ct.dtype == np.uint64 and ct.flags["C_CONTIGUOUS"]
+                and ct.shape == (2, self.k, self.N)):
+            raise PirGpuError(3, "ciphertext must be a contiguous uint64 array of shape [2, %d, %d]" % (self.k, self.N))
         self._check(self.lib.pirgpu_substitute_power_x(self.db.handle, _ptr(ct), power))
         return ct
 
     def multiply_inverse_power_of_x(self, ct, k: int) -> np.ndarray:
         """server.cpp:78-103"""
-        ct = _u64(ct)
+        ct = self._cts(ct, 3, "ciphertext")
         out = np.empty_like(ct)
         self._check(self.lib.pirgpu_multiply_inverse_power_of_x(self.db.handle, _ptr(ct), k, _ptr(out)))
         return out
@@ -317,6 +336,7 @@ class PIRServer:
     def oblivious_expansion(self, ct, num_items: int) -> np.ndarray:
         """server.cpp:105-146 (one ciphertext) or :148-171 (a list / 4-D array of ciphertexts)."""
         ct = _u64(ct)
+        ct = self._cts(ct, 3 if ct.ndim == 3 else 4, "ciphertext(s)")
         out = np.empty((max(num_items, 1), 2, self.k, self.N), dtype=np.uint64)
         if ct.ndim == 3:
             self._check(self.lib.pirgpu_expand(self.db.handle, _ptr(ct), num_items, _ptr(out)))

@@ -29,3 +29,15 @@ class PirSetup:
 
     def item(self, i):
         return self.raw[i].tobytes()
+
+
+def oracle_partial_reply(orc, db_ntt, dims, lo, hi, sv_coeff):
+    """Partial reply of the row shard [lo, hi) of dimension 0, computed by the oracle on those rows ONLY (cost
+    proportional to the shard): db_ntt = the shard's plaintexts (row-major, local), sv_coeff = the full selection
+    vector in coefficient form [dim_sum, 2, k, N].  The recursion of database.cpp:170-258 over dimension 0 is a sum
+    over its indices, so restricting it to [lo, hi) with the matching selectors gives that shard's summand."""
+    dims = list(dims)
+    sub_dims = [hi - lo] + dims[1:]
+    sv = np.concatenate([sv_coeff[lo:hi], sv_coeff[dims[0]:]]).copy()
+    rc, part = orc.db_multiply(np.ascontiguousarray(db_ntt), sub_dims, sv)
+    return rc, part

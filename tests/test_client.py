@@ -299,7 +299,18 @@ def test_round_trip_through_oracle_server(dbsize, d, elem, indexes):
     assert body[16:48] == pid
     for g in P.generate_galois_elts(N):
         keys[g] = c.galois_key(g)
-    assert galois[0] == seal_wire.save_galois_keys(keys, N, pid)
+    # default: seed-compressed Serializable<GaloisKeys> like the reference client (client.cpp:47-54) -- the
+    # independent Python loader (hashlib BLAKE2b inside BLAKE2Xb) must re-expand it to exactly these keys
+    assert len(galois[0]) < 0.55 * len(seal_wire.save_galois_keys(keys, N, pid))
+    loaded = seal_wire.load_kswitch_keys(galois[0], enc.coeff_modulus, N)
+    assert sorted(2 * i + 1 for i in loaded) == sorted(keys)
+    for i, key in loaded.items():
+        assert np.array_equal(key, keys[2 * i + 1])
+    # fully expanded objects on request: byte-identical to the Python model's encoding
+    c.set_seeded_keys(False)
+    _, galois_x, _ = split_request(c.CreateRequest(indexes))
+    assert galois_x[0] == seal_wire.save_galois_keys(keys, N, pid)
+    c.set_seeded_keys(True)
 
     replies = []
     for q in queries:

@@ -1,7 +1,7 @@
 """World-size-2 gloo test of the multi-GPU glue on CPU: shard ranges, and that the integer
 all-reduce of per-shard partial replies followed by `x mod q_j` equals the full reply.
-Per-shard partial replies are produced by the CPU oracle (a shard == the database with every
-plaintext outside its row range replaced by zero, which contributes nothing to any sum)."""
+Per-shard partial replies are produced by the CPU oracle run on the shard's rows only (the recursion of
+database.cpp:170-258 over dimension 0 is a sum over its indices)."""
 import os
 import socket
 
@@ -44,14 +44,15 @@ def _worker(rank, world, port, d, dbsize, elem, out_q):
         s = PirSetup(dbsize, elem, d, N=4096, plain_bits=24)      # same seeds on every rank
         p = s.params
         q = s.client.create_query_for(p, dbsize - 2)
-        # this rank's shard: zero every plaintext outside its top-level range
+        # this rank's shard: the plaintexts under its top-level range, multiplied with the matching selectors
+        from pir_fixtures import oracle_partial_reply
         lo, hi = shard_range(p.dimensions[0], rank, world)
         stride = 1
         for x in p.dimensions[1:]:
             stride *= x
-        db = np.zeros_like(s.db_ntt)
-        db[lo * stride:min(hi * stride, p.num_pt)] = s.db_ntt[lo * stride:min(hi * stride, p.num_pt)]
-        rc, part = s.orc.process_query(db, p.dimensions, q, s.galois_keys)
+        rc, sv = s.orc.oblivious_expansion_multi(q, p.dim_sum, s.galois_keys)
+        assert rc == 0
+        rc, part = oracle_partial_reply(s.orc, s.db_ntt[lo * stride:min(hi * stride, p.num_pt)], p.dimensions, lo, hi, sv)
         assert rc == 0
         t = torch.from_numpy(part.view(np.int64).copy())
         dist.all_reduce(t, op=dist.ReduceOp.SUM)                 # what RCCL does on the GPUs

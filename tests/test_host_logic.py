@@ -165,3 +165,98 @@ def test_wire_request_validation_and_fuzz():
     p2 = capi.Params.from_buffer_copy(p)
     p2.plain_modulus = 40961
     assert _validate(lib, p2, req)[0] == 3
+
+
+# ---------------------------------------------------------------- seed-compressed SEAL objects
+
+def _wire_hooks():
+    lib = capi.load()
+    lib.pirgpu_wire_blake2xb.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    lib.pirgpu_wire_blake2xb.restype = None
+    lib.pirgpu_wire_sample_poly_uniform.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32,
+                                                    C.POINTER(C.c_uint64)]
+    lib.pirgpu_wire_sample_poly_uniform.restype = None
+    lib.pirgpu_wire_load_kswitch_key.argtypes = [C.POINTER(capi.Params), C.POINTER(C.c_uint8), C.c_size_t, C.c_uint64,
+                                                 C.POINTER(C.c_uint64)]
+    lib.pirgpu_wire_load_kswitch_key.restype = C.c_int
+    lib.pirgpu_wire_validate_request.argtypes = [C.POINTER(capi.Params), C.POINTER(C.c_uint8), C.c_size_t,
+                                                 C.POINTER(C.c_uint32)]
+    lib.pirgpu_wire_validate_request.restype = C.c_int
+    return lib
+
+
+def test_blake2xb_matches_python_model():
+    """C++ BLAKE2Xb (wire_codec.cpp) == the numpy model in tests/seal_wire.py, whose BLAKE2b core and parameter
+    block handling are checked against hashlib field by field (hashlib itself refuses depth = 0, which BLAKE2X's
+    output blocks use, so it cannot serve as the model directly)."""
+    import seal_wire as W
+    lib = _wire_hooks()
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 64, 127, 128, 129, 300):               # the BLAKE2b core against hashlib, every parameter field
+        d = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        for key in (b"", b"k" * 64, b"abc"):
+            for (ds, fo, de, ls, no, nd, isz) in [(64, 1, 1, 0, 0, 0, 0), (48, 2, 3, 77, 0x123456789, 1, 32),
+                                                  (17, 0, 255, 64, 5, 0, 64)]:
+                want = hashlib.blake2b(d, digest_size=ds, key=key, fanout=fo, depth=de, leaf_size=ls, node_offset=no,
+                                       node_depth=nd, inner_size=isz).digest()
+                par = W.b2_param(ds, len(key), fo, de, ls, no & 0xFFFFFFFF, no >> 32, nd, isz)
+                assert W.blake2b_param(par[None, :], d, key)[:ds] == want
+    for outlen in (1, 63, 64, 65, 128, 1000, 4096):
+        for inlen in (0, 8, 200):
+            for keylen in (0, 32, 64):
+                data = rng.integers(0, 256, inlen, dtype=np.uint8).tobytes()
+                key = rng.integers(0, 256, keylen, dtype=np.uint8).tobytes()
+                out = C.create_string_buffer(outlen)
+                lib.pirgpu_wire_blake2xb(out, outlen, data, inlen, key, keylen)
+                assert out.raw == W.blake2xb(outlen, data, key), (outlen, inlen, keylen)
+
+
+def test_seeded_sampler_matches_python_model():
+    import seal_wire as W
+    lib = _wire_hooks()
+    moduli = oracle.coeff_modulus_create(2048, [27, 27]) + [oracle.BFV_DEFAULT[4096][2]]
+    for seed in (bytes(64), bytes(range(64))):
+        out = np.empty((3, 2048), dtype=np.uint64)
+        lib.pirgpu_wire_sample_poly_uniform(seed, (C.c_uint64 * 3)(*moduli), 3, 2048, out.ctypes.data_as(capi.u64p))
+        want = W.sample_poly_uniform(seed, moduli, 2048)
+        assert np.array_equal(out, want)
+        assert all(int(out[j].max()) < moduli[j] for j in range(3))
+
+
+def test_seeded_galois_keys_load_like_expanded_ones():
+    """A seed-compressed GaloisKeys object written by the PYTHON codec loads through the C++ codec to the same
+    residues as its expanded twin; a seeded request validates; malformed RelinKeys are InvalidArgument
+    (reference server.cpp:53-58) while well-formed ones (seeded or expanded) are accepted."""
+    import seal_wire as W
+    lib = _wire_hooks()
+    z = np.load(os.path.join(ROOT, "tests", "golden", "cfg1_n2048.npz"))
+    N, moduli, t = int(z["N"]), [int(x) for x in z["moduli"]], int(z["t"])
+    _, p = _wire_fixture()
+    key_pid, data_pid = W.parms_id(N, moduli, t), W.parms_id(N, moduli[:-1], t)
+    rng = np.random.default_rng(9)
+    keys, seeds = {}, {}
+    for g in (3, N + 1, N // 2 + 1):
+        key = np.array(z["galois_keys"][0])                     # [k=1, 2, 2, N]: keep c0, replace c1 by a seeded half
+        seeds[g] = [rng.integers(0, 256, 64, dtype=np.uint8).tobytes()]
+        key[0, 1] = W.sample_poly_uniform(seeds[g][0], moduli, N)
+        keys[g] = key
+    seeded = W.save_galois_keys_seeded(keys, seeds, N, key_pid)
+    expanded = W.save_galois_keys(keys, N, key_pid)
+    assert len(seeded) < 0.6 * len(expanded)
+    for blob in (seeded, expanded):
+        buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+        for g, key in keys.items():
+            out = np.empty_like(key)
+            assert lib.pirgpu_wire_load_kswitch_key(C.byref(p), buf, len(blob), (g - 1) // 2,
+                                                    out.ctypes.data_as(capi.u64p)) == 0
+            assert np.array_equal(out, key), g
+        out = np.empty_like(keys[3])
+        assert lib.pirgpu_wire_load_kswitch_key(C.byref(p), buf, len(blob), 2, out.ctypes.data_as(capi.u64p)) == 5
+    relin_ok = W.save_galois_keys_seeded({1: keys[3]}, {1: seeds[3]}, N, key_pid)     # RelinKeys: one entry, index 0
+    req = W.save_request([z["query"]], seeded, data_pid, relin_keys=relin_ok)
+    assert _validate(lib, p, req) == (0, 1)
+    assert _validate(lib, p, W.save_request([z["query"]], seeded, data_pid, relin_keys=relin_ok[:-5]))[0] == 3
+    assert _validate(lib, p, W.save_request([z["query"]], seeded, data_pid, relin_keys=b"\x01\x02\x03"))[0] == 3
+    bad = bytearray(seeded)
+    bad[-70] ^= 0x80          # inside the last c0: coefficient out of range or seed/size damage -> rejected or changed
+    assert _validate(lib, p, W.save_request([z["query"]], seeded[:-1], data_pid))[0] == 3

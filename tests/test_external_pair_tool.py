@@ -17,7 +17,7 @@ import check_external_pair as tool  # noqa: E402
 import seal_wire as W  # noqa: E402
 
 
-def _tuple(dbsize=90, d=2, elem=64, indexes=(3, 88)):
+def _tuple(dbsize=900, d=2, elem=64, indexes=(3, 888)):
     N = 4096
     enc = P.generate_encryption_params(N, 20)
     pp = P.create_pir_parameters(dbsize, elem, d, enc)
@@ -57,7 +57,7 @@ def test_oracle_leg_accepts_and_localises_a_flipped_bit():
     lines = []
     assert tool.run(params_b, db_b, request, bytes(bad), use_gpu=False, log=lines.append) == 1
     assert any("MISMATCH" in ln and "coefficient" in ln for ln in lines), lines
-    assert tool.run(params_b[:-3], db_b, request, response, use_gpu=False, log=lines.append) == 2
+    assert tool.run(params_b[:40], db_b, request, response, use_gpu=False, log=lines.append) == 2
 
 
 @pytest.mark.gpu

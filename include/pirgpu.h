@@ -223,6 +223,11 @@ uint64_t pirgpu_scan_bytes(const pirgpu_ctx* ctx);
  * info[5] = rows, info[6] = columns of the scanned matrix, info[7] = 1 if single queries use the MFMA
  * scan as well (matrices wider than one column chunk scan single queries with the 64-bit kernels). */
 int pirgpu_scan_info(pirgpu_ctx* ctx, uint32_t info[8]);
+/* Arithmetic flavour of the transform kernels of this context: 0 = 64-bit integer Shoup/Harvey butterflies (any
+ * modulus < 2^61), 1 = exact fp64 (all moduli < 2^46), 2 = exact fp64 with per-stage renormalisation (< 2^49).
+ * Chosen from the largest modulus; PIRGPU_NTT_MODE=0|2 in the environment at pirgpu_create forces a more general
+ * flavour (all three produce identical residues -- tests/test_gpu_ntt_modes.py). */
+int pirgpu_ntt_mode(const pirgpu_ctx* ctx);
 
 #ifdef __cplusplus
 }

@@ -75,6 +75,7 @@ SIGNATURES = {
     "pirgpu_db_read_plaintext": (C.c_int, [C.c_void_p, C.c_uint64, u64p]),
     "pirgpu_db_finalize": (C.c_int, [C.c_void_p, C.c_int]),
     "pirgpu_set_transparent_policy": (C.c_int, [C.c_void_p, C.c_int]),
+    "pirgpu_ntt_mode": (C.c_int, [C.c_void_p]),
     "pirgpu_set_galois_key": (C.c_int, [C.c_void_p, C.c_uint32, u64p]),
     "pirgpu_clear_galois_keys": (C.c_int, [C.c_void_p]),
     "pirgpu_process_query": (C.c_int, [C.c_void_p, u64p, C.c_uint32, u64p, C.c_uint64, u64p]),

@@ -602,34 +602,30 @@ struct pirclient {
     return (index % prm.items_per_plaintext) * prm.bytes_per_item;
   }
 
-  void create_query(uint64_t desired_index, uint64_t* out) {  // client.cpp:92-144
+  // PIRClient::createQueryFor (client.cpp:92-144).  The query is the concatenation of one one-hot selection
+  // vector per dimension, cut into ring-degree sized ciphertexts: dimension l's hot slot sits at global position
+  // (d_0 + ... + d_{l-1}) + index_l, i.e. in ciphertext pos / N at coefficient pos % N, and carries the inverse of
+  // the factor the expansion of that ciphertext multiplies in (N for full ciphertexts, next_power_two(dim_sum % N)
+  // for the last one, client.cpp:122-125).
+  void create_query(uint64_t desired_index, uint64_t* out) {
     if (desired_index >= prm.num_items)
       throw Err{PIRGPU_INVALID_ARGUMENT, "invalid index " + std::to_string(desired_index)};
-    std::vector<uint64_t> dims(prm.dimensions, prm.dimensions + prm.num_dimensions);
-    std::vector<uint64_t> indices = calculate_indices(desired_index);
+    const std::vector<uint64_t> indices = calculate_indices(desired_index);
     const uint64_t ds = dim_sum();
-    const uint32_t n = query_ct_count();
-    uint64_t offset = 0;
+    const uint32_t n_cts = query_ct_count();
+    std::vector<std::pair<uint64_t, uint64_t>> hot;  // (global position, scale inverse mod t)
+    uint64_t first_slot = 0;
+    for (uint32_t l = 0; l < prm.num_dimensions; ++l) {
+      const uint64_t pos = first_slot + indices[l];
+      const bool last_ct = pos / N + 1 == n_cts;
+      hot.emplace_back(pos, invert_mod_t(last_ct ? hm::next_power_two(ds % N) : N));
+      first_slot += prm.dimensions[l];
+    }
     std::vector<uint64_t> pt(N);
-    for (uint32_t c = 0; c < n; ++c) {
+    for (uint32_t c = 0; c < n_cts; ++c) {
       std::fill(pt.begin(), pt.end(), 0);
-      while (!indices.empty()) {
-        if (indices[0] + offset >= N) {  // no more slots in this poly
-          indices[0] -= (N - offset);
-          dims[0] -= (N - offset);
-          offset = 0;
-          break;
-        }
-        const uint64_t m = (c + 1 < n) ? N : hm::next_power_two(ds % N);
-        pt[indices[0] + offset] = invert_mod_t(m);
-        offset += dims[0];
-        indices.erase(indices.begin());
-        dims.erase(dims.begin());
-        if (offset >= N) {
-          offset -= N;
-          break;
-        }
-      }
+      for (const auto& h : hot)
+        if (h.first / N == c) pt[h.first % N] = h.second;
       encrypt(pt.data(), N, out + (size_t)c * ct_words());
     }
   }

@@ -827,6 +827,8 @@ uint64_t pirgpu_scan_bytes(const pirgpu_ctx* cc) {
   return c->mfma_on && c->mfma_single ? (uint64_t)c->mg.db_bytes : (c->pt_end - c->pt_begin) * c->k * c->N * 8;
 }
 
+int pirgpu_ntt_mode(const pirgpu_ctx* c) { return c ? c->mode : -1; }
+
 int pirgpu_scan_info(pirgpu_ctx* c, uint32_t info[8]) {
   return guarded(c, [&]() -> int {
     if (!info) return fail(c, PIRGPU_INVALID_ARGUMENT, "null info");

@@ -307,6 +307,10 @@ class PIRServer:
         self._check(self.lib.pirgpu_reduce_fixup_device(self.db.handle, C.c_void_p(device_ptr),
                                                         self.db.reply_ct_count()))
 
+    def ntt_mode(self) -> int:
+        """0 integer / 1 fp64 / 2 wide fp64 butterflies (pirgpu_ntt_mode)."""
+        return int(self.lib.pirgpu_ntt_mode(self.db.handle))
+
     def scan_bytes(self) -> int:
         return int(self.lib.pirgpu_scan_bytes(self.db.handle))
 

@@ -1,0 +1,81 @@
+"""Every kernel family under all three arithmetic flavours of the transforms (PIRGPU_NTT_MODE = 0 integer
+Shoup/Harvey, 1 exact fp64, 2 wide fp64), each compared bit for bit with the CPU oracle: the flavours must be
+indistinguishable in their residues.  Families: batched forward / inverse NTT, key switch (substitute), the
+expansion tree (ks_digit / ks_mac_intt / ks_combine), database encode, scan + upper recursion level + batch path."""
+import numpy as np
+import pytest
+
+import oracle
+import pir_amd
+from gpu_helpers import random_ct, random_key, to_product_params
+from pir_fixtures import PirSetup
+
+pytestmark = pytest.mark.gpu
+
+CHAINS = {
+    "n4096_36bit": (4096, oracle.BFV_DEFAULT[4096], 1),                                       # default flavour 1
+    "n8192_44bit": (8192, oracle.BFV_DEFAULT[8192][:3] + [oracle.BFV_DEFAULT[8192][4]], 1),
+    "n2048_27bit": (2048, oracle.coeff_modulus_create(2048, [27, 27]), 1),
+    "n16384_49bit": (16384, oracle.BFV_DEFAULT[16384][:4] + [oracle.BFV_DEFAULT[16384][8]], 2),  # default flavour 2
+}
+
+
+def _server(s, load_db=True):
+    pp = to_product_params(s.params)
+    db = pir_amd.PIRDatabase.Create(pp)
+    if load_db:
+        db.populate(s.raw)
+    return db, pir_amd.PIRServer(db, pp)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("chain", sorted(CHAINS))
+def test_transform_and_key_switch_flavours(monkeypatch, chain, mode):
+    N, moduli, default = CHAINS[chain]
+    monkeypatch.setenv("PIRGPU_NTT_MODE", str(mode))
+    s = PirSetup(12, 0, 1, N=N, plain_bits=20, moduli=moduli)
+    db, srv = _server(s)
+    # a request for a narrower flavour than the moduli allow keeps the default one
+    assert srv.ntt_mode() == (mode if mode in (0, 2) or mode == default else default)
+    rng = np.random.default_rng(N + mode)
+    cts = random_ct(s.orc, rng, 2)
+    fwd = srv.ntt_forward(cts)
+    assert np.array_equal(fwd, np.stack([s.orc.ct_ntt_fwd(c) for c in cts]))
+    assert np.array_equal(srv.ntt_inverse(fwd), cts)
+    for g in (3, N + 1, N // 4 + 1):
+        key = random_key(s.orc, rng)
+        srv.set_galois_keys({g: key})
+        rc, exp = s.orc.apply_galois_ct(cts[0], g, key)
+        assert rc == 0 and np.array_equal(srv.substitute_power_x_inplace(cts[0].copy(), g), exp)
+    keys = {(N >> j) + 1: random_key(s.orc, rng) for j in range(4)}
+    srv.set_galois_keys(keys)
+    rc, exp = s.orc.oblivious_expansion(cts[1], 11, keys)
+    assert rc == 0 and np.array_equal(srv.oblivious_expansion(cts[1], 11), exp)
+    for i in range(s.params.num_pt):
+        assert np.array_equal(db.read_plaintext(i), s.db_ntt[i])
+    db.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("chain,items,elem", [("n4096_36bit", 2600, 288), ("n8192_44bit", 1500, 1024),
+                                              ("n16384_49bit", 11000, 288)])
+def test_query_path_flavours(monkeypatch, chain, items, elem, mode):
+    """d = 2 with >= 8 rows: MFMA scan, fused upper level (re-encode + lift + NTT + MAC), final inverse NTT, the
+    batched expansion -- replies of single and batched queries equal the oracle's in every flavour."""
+    N, moduli, default = CHAINS[chain]
+    monkeypatch.setenv("PIRGPU_NTT_MODE", str(mode))
+    s = PirSetup(items, elem, 2, N=N, plain_bits=24, moduli=moduli)
+    db, srv = _server(s)
+    assert srv.scan_info()["mfma"]
+    rng = np.random.default_rng(mode)
+    keys = {(N >> j) + 1: random_key(s.orc, rng) for j in range(N.bit_length() - 1)}
+    srv.set_galois_keys(keys)
+    queries = random_ct(s.orc, rng, 3)[:, None]          # [3 queries, 1 ct each, 2, k, N]
+    rc, exp = s.orc.process_query(s.db_ntt, s.params.dimensions, queries[0], keys)
+    assert rc == 0
+    assert np.array_equal(srv.process_query(queries[0]), exp)
+    batch = srv.process_batch(queries, n_workers=3)
+    assert np.array_equal(batch[0], exp)
+    for i in (1, 2):
+        assert np.array_equal(batch[i], srv.process_query(queries[i]))
+    db.close()

@@ -4,29 +4,32 @@
 One "step" = one pass of the hot path (PIRServer::ProcessRequest's query loop, reference
 server.cpp:60-63 -> processQuery :173-195: oblivious expansion -> database scan ->
 recursive re-encode / multiply-accumulate) over one batch of `--batch` independent
-queries (default 16, different synthetic query ciphertexts), with the encoded database,
-the Galois keys and the query ciphertexts already resident in HBM.  Groups of up to 8
+queries (default 64 for the WHOLE job, different synthetic query ciphertexts), with the encoded
+database, the Galois keys and the query ciphertexts already resident in HBM.  Groups of up to 8
 queries are expanded together and share one pass over the database (the digit-sliced
 int8-MFMA scan serves 8 queries per pass); two groups alternate on two lanes so the
 bandwidth-bound scan of one overlaps the compute-bound expansion of the other; every
-query does the full work.  `value` = queries/s over the timed steps; the single-query latency
-(`--batch 1` behaviour, what benchmark.cpp:71-79 times per request) is measured as well
-and reported as `latency_ms_single_query`, and the scan kernel's roofline comes from
+query does the full work.  `value` = queries/s over the timed steps (defaults: 120 steps of 64 queries,
+about 2 s of GPU time); the single-query latency (`--batch 1` behaviour, what benchmark.cpp:71-79 times per
+request) is measured as well and reported as `latency_ms_single_query`, and the scan kernel's roofline comes from
 those single-query runs (one scan launch per query, HIP events on the library's stream).
 Workload = BASELINE.json configs[2]: N=4096, 2 RNS primes, DB = 2^20 x 288 B, d=2 (the
 reference's own benchmark parameters, benchmark.cpp:17-23).
 
-Multi-GPU (launched by torch.distributed.run, one rank per GPU), two modes:
-  --dist-mode queries (what the default `auto` resolves to while the database fits one GPU): queries are independent, so they are the unit that is sharded --
-      every GPU holds the whole packed database (1.27 GB of 288 GB at this workload) and serves
-      its own `--batch` queries per step; no collective on the data path (the barrier and the
-      max-over-ranks timing are the only communication); per-GPU work is fixed as N grows ->
-      "scaling": "weak", value = all ranks' queries / time.
-  --dist-mode rows: the database is row-sharded across ranks (for databases larger than one
-      GPU), every rank expands its share of the batch, the selection vectors are all-gathered,
-      every rank scans its rows and the per-shard reply ciphertexts are summed with one RCCL
-      all-reduce + a mod-q fix-up.  Total work is fixed as N grows -> "scaling": "strong".
-DESIGN.md section 7 explains why `queries` is the default at this database size.
+Multi-GPU (launched by torch.distributed.run, one rank per GPU).  The headline `value` is ALWAYS the
+north-star mode: the database row-sharded across the GPUs ("scaling": "strong" -- the same 64 queries per
+step whatever the GPU count):
+  rows     every rank holds 1/G of the rows, expands batch/G of the step's queries (the expansion does not
+           shard by rows, so it is partitioned by query), packs their column selectors into the scan's
+           operand layout and lays their row selectors out by owner; one RCCL all-gather (packed column
+           selectors) and one all-to-all (each rank receives only its own rows' selectors); every rank scans
+           its shard once per group of 8 queries and runs the upper level on its rows; one reduce-scatter
+           sums the per-shard reply ciphertexts (rank r ends with the replies of the queries it expanded),
+           then x mod q_j.  `--exchange u64` all-gathers whole selection vectors instead (any d).
+  queries  (reference point, reported in the same JSON line as `replicas_reference` when --dist-mode both,
+           the default): every GPU holds the whole database and serves batch/G of the same queries, no
+           data-path collective.
+DESIGN.md section 7 has the byte counts of the exchange and what bounds each mode.
 
 The GPU leg uses synthetic inputs of the right shape (uniform residues); the
 cpu_baseline leg (rank 0, N=1 only) times the CPU oracle -- the restatement of the
@@ -48,6 +51,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PMC_FILE = "r01_pmc_scan_mfma_traffic.json"
+VALU_FILE = "r02_valu_roofline.json"
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -131,28 +135,74 @@ def cpu_baseline(pp, raw, keys, query, gpu_reply, budget_s=25.0):
     }
 
 
+def build_workload(args, pir_amd):
+    """BASELINE.json configs (1-based as in SURVEY.md section 8): parameters of the selected one."""
+    item_bytes = 288
+    if args.config == 2:      # N=4096, 2 primes, DB = 2^16 x 288 B, d=1
+        enc = pir_amd.generate_encryption_params(4096, 24)
+        args.log_items, args.dims = 16, 1
+    elif args.config == 4:    # N=8192, 3 data primes (first 3 of BFVDefault + its last as special), 2^22 x 1 KB, d=2
+        m = pir_amd.BFV_DEFAULT[8192]
+        enc = pir_amd.generate_encryption_params(8192, 24, coeff_modulus=m[:3] + [m[4]])
+        args.log_items, args.dims, item_bytes = 22, 2, 1024
+    elif args.config == 5:    # N=16384, 4 data primes (first 4 of BFVDefault + its last as special), 2^24 x 288 B, d=2
+        m = pir_amd.BFV_DEFAULT[16384]
+        enc = pir_amd.generate_encryption_params(16384, 24, coeff_modulus=m[:4] + [m[8]])
+        args.log_items, args.dims = 24, 2
+    else:                     # the headline workload: benchmark.cpp:17-23 parameters at 2^20 items
+        enc = pir_amd.generate_encryption_params(4096, 24)
+    pp = pir_amd.create_pir_parameters(1 << args.log_items, item_bytes, args.dims, enc)
+    return enc, pp, item_bytes
+
+
+def timed_steps(step, barrier, steps, warmup, dist, use_dist, torch, dev):
+    """The bench contract: W untimed steps, then exactly K steps between barrier + synchronise, MAX over ranks."""
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=120)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="queries per step (per request)")
-    ap.add_argument("--workers", type=int, default=0, help="queries in flight on the GPU (0 = min(batch, 16): two "
+    ap.add_argument("--batch", type=int, default=64, help="queries per step: the WHOLE job's, whatever the GPU count "
+                                                         "(strong scaling); a multiple of 8 x gpus keeps every rank's "
+                                                         "expansion groups full")
+    ap.add_argument("--workers", type=int, default=0, help="queries in flight on one GPU (0 = min(batch, 16): two "
                                                            "groups of 8 share one database pass each and overlap)")
     ap.add_argument("--latency-runs", type=int, default=30, help="single-query runs for latency + roofline")
     ap.add_argument("--log-items", type=int, default=20, help="database = 2^log_items x 288 B")
     ap.add_argument("--dims", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dist-mode", choices=["auto", "queries", "rows"],
-                    default=os.environ.get("PIRGPU_DIST_MODE", "auto"),
-                    help="multi-GPU: 'queries' = every GPU holds the whole database and serves its own batch "
-                         "(independent queries, no data-path collective, weak scaling); 'rows' = the database is "
-                         "row-sharded, replies summed with an RCCL all-reduce (strong scaling; for databases "
-                         "larger than one GPU); 'auto' = queries while the encoded database (both layouts) takes "
-                         "less than half of one GPU's memory, else rows")
+    ap.add_argument("--dist-mode", choices=["both", "rows", "queries"],
+                    default=os.environ.get("PIRGPU_DIST_MODE", "both"),
+                    help="multi-GPU: 'rows' = the database is row-sharded across the GPUs, every rank expands its "
+                         "share of the batch, selectors are exchanged (packed), replies summed over RCCL -- the "
+                         "north-star mode and always the headline `value`; 'queries' = every GPU holds the whole "
+                         "database and serves its own share of the batch (replicas, no data-path collective); "
+                         "'both' (default) = time rows for `value` and replicas as the named extra `replicas_reference`")
+    ap.add_argument("--exchange", choices=["auto", "packed", "u64"], default=os.environ.get("PIRGPU_EXCHANGE", "auto"),
+                    help="rows mode: what is exchanged per query -- packed = column selectors in the scan's operand "
+                         "layout (all-gather) + each rank's own row selectors (all-to-all); u64 = whole NTT-form "
+                         "selection vectors (all-gather); auto = packed when every shard supports it (d = 2, MFMA scan)")
     ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5],
                     help="BASELINE.json config (1-based as in SURVEY.md section 8): 3 = the headline workload; "
                          "2/4/5 are reference points (other ring degrees / database shapes)")
+    ap.add_argument("--keep-staging", action="store_true",
+                    help="keep the u64 staging copy of the database next to the operand-layout copy (default: "
+                         "released for d >= 2, one copy of the database in HBM)")
     args = ap.parse_args()
 
     # stdout carries exactly one JSON line: anything native libraries print there (RCCL's version banner)
@@ -169,17 +219,12 @@ def main():
 
     import torch
     import pir_amd
+    from pir_amd import distributed as D
 
     dist = None
-    # PIRGPU_FORCE_DIST=1 / =queries: run the multi-GPU code path (rows / queries mode) with a single rank
-    force = os.environ.get("PIRGPU_FORCE_DIST", "")
-    use_dist = world > 1 or force in ("1", "rows", "queries")
-    if force in ("1", "rows"):
-        args.dist_mode = "rows"
-    elif force == "queries":
-        args.dist_mode = "queries"
-    dist_mode_requested = args.dist_mode
-    row_sharded = use_dist and args.dist_mode == "rows"   # 'auto' is resolved once the database size is known
+    # PIRGPU_FORCE_DIST=1: run the multi-GPU code path (process group, collectives, fix-up) with a single rank
+    force = os.environ.get("PIRGPU_FORCE_DIST", "") in ("1", "rows", "queries", "both")
+    use_dist = world > 1 or force
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -188,171 +233,204 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
-    # ---- workload: BASELINE.json configs[2] (benchmark.cpp:17-23 parameters)
-    item_bytes = 288
-    if args.config == 2:      # N=4096, 2 primes, DB = 2^16 x 288 B, d=1
-        enc = pir_amd.generate_encryption_params(4096, 24)
-        args.log_items, args.dims = 16, 1
-    elif args.config == 4:    # N=8192, 3 data primes (first 3 of BFVDefault + its last as special), 2^22 x 1 KB, d=2
-        m = pir_amd.BFV_DEFAULT[8192]
-        enc = pir_amd.generate_encryption_params(8192, 24, coeff_modulus=m[:3] + [m[4]])
-        args.log_items, args.dims, item_bytes = 22, 2, 1024
-    elif args.config == 5:    # N=16384, 4 data primes (first 4 of BFVDefault + its last as special), 2^24 x 288 B, d=2
-        m = pir_amd.BFV_DEFAULT[16384]
-        enc = pir_amd.generate_encryption_params(16384, 24, coeff_modulus=m[:4] + [m[8]])
-        args.log_items, args.dims = 24, 2
-    else:
-        enc = pir_amd.generate_encryption_params(4096, 24)
-    pp = pir_amd.create_pir_parameters(1 << args.log_items, item_bytes, args.dims, enc)
-    if args.dist_mode == "auto":
-        # u64 staging copy + operand-layout copy (at most 7/8 of it, plus tile padding)
-        db_bytes = pp.num_pt * (len(enc.coeff_modulus) - 1) * enc.poly_modulus_degree * 8 * 2
-        hbm = torch.cuda.get_device_properties(local_rank).total_memory
-        args.dist_mode = "rows" if db_bytes > hbm // 2 else "queries"
-        row_sharded = use_dist and args.dist_mode == "rows"
-    batch = max(1, args.batch)
-    workers = args.workers if args.workers > 0 else min(batch, 16)
-    # query-sharded runs: same database and keys everywhere, every rank draws its own queries
-    raw, keys, queries = synthetic_inputs(pp, n_queries=batch,
-                                          query_seed=1000 + rank if use_dist and not row_sharded else None)
-    query = queries[0]
-
-    from pir_amd.distributed import (all_reduce_batch_replies, all_reduce_reply, run_batch_query_parallel,
-                                     shard_range)
-    shard = shard_range(pp.dimensions[0], rank, world) if world > 1 and row_sharded else None
-    db = pir_amd.PIRDatabase.Create(pp, device=local_rank, shard=shard)
-    t0 = time.perf_counter()
-    db.populate(raw)
-    t_populate = time.perf_counter() - t0
-    srv = pir_amd.PIRServer(db, pp) if shard else pir_amd.PIRServer.Create(db, pp)
-    srv.set_galois_keys(keys)
-
-    reply_cts = db.reply_ct_count()
-    k, N = srv.k, srv.N
     dev = "cuda:%d" % local_rank
-    red1 = redb = sv_all = None
-    # multi-GPU: query-parallel expansion + all-gather of the selection vectors when the batch
-    # divides evenly over the ranks; otherwise every rank expands every query (replicated)
-    query_parallel = row_sharded and batch % world == 0 and os.environ.get("PIRGPU_REPLICATED_EXPANSION") != "1"
-    if row_sharded:
-        red1 = torch.empty((reply_cts, 2, k, N), dtype=torch.int64, device=dev)
-        redb = torch.empty((batch, reply_cts, 2, k, N), dtype=torch.int64, device=dev)
-        if query_parallel:
-            sv_all = torch.empty((batch, pp.dim_sum, 2, k, N), dtype=torch.int64, device=dev)
 
-    def barrier():
-        srv.sync()                      # the library's own streams (not torch's current stream)
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
+    enc, pp, item_bytes = build_workload(args, pir_amd)
+    k, N = len(enc.coeff_modulus) - 1, enc.poly_modulus_degree
+    batch = max(1, args.batch)
+    if use_dist and batch % world:
+        batch += world - batch % world
+    per_rank = batch // world if use_dist else batch
+    workers = args.workers if args.workers > 0 else min(max(per_rank, 8) if use_dist else batch, 16)
+    run_rows = (not use_dist) or args.dist_mode in ("both", "rows")
+    run_replicas = use_dist and world > 1 and args.dist_mode in ("both", "queries")
+    # same database, keys and queries on every rank (fixed seeds): query i of the batch is the same everywhere
+    raw, keys, queries = synthetic_inputs(pp, n_queries=batch)
+    query = queries[0]
+    if use_dist:
+        D.check_sum_fits(max(enc.coeff_modulus[:-1]), world)
+
+    def make_server(shard):
+        db = pir_amd.PIRDatabase.Create(pp, device=local_rank, shard=shard)
+        t0 = time.perf_counter()
+        db.populate(raw)
+        if args.dims > 1 and not args.keep_staging:
+            db.finalize(release_staging=True)      # one copy of the database: the scan's operand layout
+        t_pop = time.perf_counter() - t0
+        srv = pir_amd.PIRServer(db, pp) if shard else pir_amd.PIRServer.Create(db, pp)
+        srv.set_galois_keys(keys)
+        return db, srv, t_pop
+
+    def barrier_for(srv):
+        def barrier():
+            srv.sync()                      # the library's own streams (not torch's current stream)
             torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+                torch.cuda.synchronize()
+        return barrier
+
+    out_extra = {}
+    comm = D.Comm(dist, world) if use_dist else None
+
+    # =========================== rows mode (single GPU: the plain path) -> headline ===========================
+    shard = D.shard_range(pp.dimensions[0], rank, world) if world > 1 else None
+    db, srv, t_populate = make_server(shard)
+    reply_cts = db.reply_ct_count()
+    barrier = barrier_for(srv)
+    exchange = "none"
+    bufs = sv_all = redb = red1 = None
+    if use_dist:
+        red1 = torch.empty((reply_cts, 2, k, N), dtype=torch.int64, device=dev)
+        packed_ok = args.exchange != "u64" and D.packed_exchange_supported(srv, dist, world, comm, torch, dev)
+        if args.exchange == "packed" and not packed_ok:
+            raise SystemExit("--exchange packed needs d = 2 and an int8-MFMA-scanned shard (>= 8 rows) on every rank")
+        exchange = "packed" if packed_ok else "u64"
 
     # ---- (1) single-query latency + scan-kernel roofline (one scan launch per query)
     srv.stage_query(query)
     for _ in range(3):
         srv.run_staged()
-        if row_sharded:
-            all_reduce_reply(srv, red1, dist)
+        if use_dist:
+            D.all_reduce_reply(srv, red1, dist, comm)
     srv.set_profiling(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.latency_runs):
         srv.run_staged()
-        if row_sharded:
-            all_reduce_reply(srv, red1, dist)
+        if use_dist:
+            D.all_reduce_reply(srv, red1, dist, comm)
     barrier()
     latency_ms = (time.perf_counter() - t0) / args.latency_runs * 1e3
     timings = srv.last_timings()
     srv.set_profiling(False)
     single_reply = srv.fetch_reply() if world == 1 else None
 
-    # ---- (2) throughput: `batch` queries per step, `workers` in flight
+    # ---- (2) throughput: `batch` queries per step (the whole job's), `workers` in flight per GPU
     srv.set_concurrency(workers)
     srv.stage_batch(queries)
+    if use_dist and exchange == "packed":
+        bufs = D.PackedBuffers(srv, batch, rank, world, torch, dev)
+    elif use_dist:
+        sv_all = torch.empty((batch, pp.dim_sum, 2, k, N), dtype=torch.int64, device=dev)
+        redb = torch.empty((batch, reply_cts, 2, k, N), dtype=torch.int64, device=dev)
 
-    def step():
-        if query_parallel:
-            run_batch_query_parallel(srv, sv_all, redb, dist, rank, world)
-        else:
+    def step_rows():
+        if not use_dist:
             srv.run_batch()
-            if row_sharded:
-                all_reduce_batch_replies(srv, redb, dist)
+        elif exchange == "packed":
+            D.run_batch_rows_packed(srv, bufs, dist, rank, world, comm)
+        else:
+            D.run_batch_query_parallel(srv, sv_all, redb, dist, rank, world, comm)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed_steps(step_rows, barrier, args.steps, args.warmup, dist, use_dist, torch, dev)
+    qps = args.steps * batch / elapsed
+    forced_check = None
+    if use_dist and world == 1:   # forced single-rank run: the reduced replies must equal the plain ones
+        got = (bufs.replies if exchange == "packed" else redb).cpu().numpy().view(np.uint64)
+        srv.stage_batch(queries)
+        srv.run_batch()
+        forced_check = bool(np.array_equal(got, srv.fetch_batch()))
+        print("forced-dist check: replies through the collective path equal plain replies: %s" % forced_check, file=sys.stderr)
+    scan_bytes = srv.scan_bytes()
+    info = srv.scan_info()
+    batch_replies = srv.fetch_batch() if world == 1 and not use_dist else None
+
+    # =========================== replicas (reference point, multi-GPU only) ===========================
+    if run_replicas:
+        if shard is not None:
+            db.close()
+            db, srv, _ = make_server(None)
+            barrier = barrier_for(srv)
+        # every GPU holds the whole database and serves its own share of the same global batch
+        srv.set_concurrency(min(max(per_rank, 1), 16))
+        lo, hi = D.owned_queries(batch, rank, world)
+        srv.stage_batch(queries[lo:hi])
+        el2 = timed_steps(srv.run_batch, barrier, args.steps, args.warmup, dist, use_dist, torch, dev)
+        out_extra["replicas_reference"] = {
+            "value": args.steps * batch / el2, "unit": "queries/s", "ms_per_step": el2 / args.steps * 1e3,
+            "scaling": "strong", "queries_per_step": batch, "queries_per_step_per_gpu": per_rank,
+            "note": "every GPU holds the whole database and serves batch/gpus queries of the same global batch; no "
+                    "data-path collective (barrier + max-over-ranks timing only). Reference point, not the headline."}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        # query-sharded: every rank served its own `batch` queries per step
-        total_batch = batch * world if use_dist and not row_sharded else batch
-        qps = args.steps * total_batch / elapsed
-        scan_bytes = srv.scan_bytes()                   # bytes one database pass must read
-        info = srv.scan_info()
-        u64_bytes = pp.num_pt * (len(enc.coeff_modulus) - 1) * enc.poly_modulus_degree * 8
+        u64_bytes = pp.num_pt * k * N * 8          # B_q = num_pt * k * N * 8
         scan_ms = timings["scan_ms"]
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         traffic = None
-        try:   # HBM bytes per scan launch from the committed PMC passes (profiles/), same workload only
+        try:   # HBM bytes per scan launch: a RECORDED constant from the committed PMC passes, same workload only
             pm = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
             if args.config == 3 and args.log_items == 20 and args.dims == 2 and world == 1 and info["single_query_mfma"]:
                 traffic = pm["traffic_bytes_per_launch"]
         except Exception:
             pass
+        compute = None
+        try:   # VALU-issue roofline of the transform kernels (recorded: tools/valu_roofline.py over PMC passes)
+            compute = json.load(open(os.path.join(ROOT, "profiles", VALU_FILE)))
+        except Exception:
+            pass
+        if world == 1:
+            parallelism = "single GPU" + (" (collective code path forced with one rank)" if use_dist else "")
+        else:
+            parallelism = ("database row-sharded over %d GPUs; every rank expands %d of the %d queries of a step; "
+                           % (world, per_rank, batch)) + \
+                          ("all-gather of packed column selectors + all-to-all of row selectors, reduce-scatter of replies (RCCL)"
+                           if exchange == "packed" else "all-gather of u64 selection vectors, all-reduce of replies (RCCL)")
         out = {
             "metric": "PIR queries/sec (ms/query in ms_per_step), N=%d DB=2^%d x %dB d=%d"
-                      % (enc.poly_modulus_degree, args.log_items, item_bytes, args.dims),
+                      % (N, args.log_items, item_bytes, args.dims),
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong" if row_sharded or world == 1 else "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": "N=%d, %d RNS data primes (%s bit | special %d bit), t=24 bit, DB=2^%d x %dB, "
-                                   "d=%d, dims=%s, num_pt=%d, %d queries/step, %d in flight (BASELINE.json configs[%d])"
-                                   % (enc.poly_modulus_degree, len(enc.coeff_modulus) - 1,
-                                      ",".join(str(q.bit_length()) for q in enc.coeff_modulus[:-1]),
+                                   "d=%d, dims=%s, num_pt=%d, %d queries/step (whole job), %d in flight per GPU "
+                                   "(BASELINE.json configs[%d])"
+                                   % (N, k, ",".join(str(q.bit_length()) for q in enc.coeff_modulus[:-1]),
                                       enc.coeff_modulus[-1].bit_length(), args.log_items, item_bytes, args.dims,
                                       pp.dimensions, pp.num_pt, batch, workers, args.config - 1),
-                       "queries_per_step": total_batch, "queries_per_step_per_gpu": batch, "workers": workers,
-                       "dist_mode": "%s (requested: %s)" % (args.dist_mode, dist_mode_requested),
-                       "parallelism": ("single GPU" if world == 1 else
-                                       ("rows sharded over %d GPU(s), %s, RCCL all-reduce of replies"
-                                        % (world, "query-parallel expansion + RCCL all-gather of selection vectors"
-                                           if query_parallel else "replicated expansion")) if row_sharded else
-                                       ("queries sharded over %d GPUs: every GPU holds the whole database and "
-                                        "serves its own %d queries per step, no data-path collective" % (world, batch)))},
+                       "queries_per_step": batch, "queries_per_step_per_gpu": per_rank, "workers": workers,
+                       "dist_mode": "rows" if world > 1 or use_dist else "single",
+                       "exchange": exchange, "parallelism": parallelism,
+                       "database_copies_in_hbm": "operand layout only (u64 staging released)"
+                       if args.dims > 1 and not args.keep_staging else "u64 staging" + (" + operand layout" if info["mfma"] else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, profiles/" + PMC_FILE,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "frac_definition": "bytes the kernel must read (packed operand layout) / HIP-event duration / 8 TB/s",
+                         "traffic": traffic,
+                         "traffic_source": "RECORDED constant, not measured in this run: rocprofv3 --pmc FETCH_SIZE/"
+                                           "WRITE_SIZE passes of round 1 on this workload, profiles/" + PMC_FILE,
                          "kernel": ("scan_mfma_kernel<%d digits, %d k-steps> (int8 MFMA digit products, 1 query; "
                                     "the same pass serves up to 8)" % (info["digits"], info["ksteps"])) if info["single_query_mfma"]
                          else ("scan_mq_kernel<4 rows/wave, 1 query>" if args.dims > 1
                                else "scan_kernel + reduce_splits (column split)"),
                          "kernel_ms": scan_ms, "algorithmic_bytes": scan_bytes,
+                         "algorithmic_bytes_definition": "packed operand-layout bytes of this GPU's shard = what one "
+                                                         "launch must read (DESIGN.md section 5)",
                          "launches_averaged": timings["runs"],
-                         # SURVEY 8(d) prices the scan in u64 residues (num_pt*k*N*8 per query) whatever the
-                         # stored layout: reported for comparison only -- these are NOT bytes the kernel moves
+                         # SURVEY 8(d) prices the scan in u64 residues (num_pt*k*N*8 per query) whatever the stored
+                         # layout; both figures side by side, named
+                         "frac_survey_8d_u64": (u64_bytes / max(world, 1)) / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if scan_ms > 0 else 0.0,
                          "survey_8d_u64_equivalent": {
                              "B_q": u64_bytes,
-                             "single_query_launch_GBps": u64_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0,
-                             "batched_B_q_times_qps_GBps": u64_bytes * qps / max(world, 1) / 1e9,
-                             "note": "equivalent rates; can exceed the HBM peak because the packed layout is "
-                                     "smaller than u64 and one pass serves up to 8 queries"}},
+                             "single_query_launch_GBps": (u64_bytes / max(world, 1)) / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0,
+                             "batched_B_q_times_qps_per_gpu_GBps": u64_bytes * qps / max(world, 1) / 1e9,
+                             "batched_frac_of_one_read_per_query_bound": u64_bytes * qps / max(world, 1) / 1e9 / HBM_PEAK_GBS,
+                             "note": "u64-equivalent rates (SURVEY 8(d) formula); they can exceed the packed-bytes "
+                                     "figure because the operand layout stores L <= 7 bytes per residue and one "
+                                     "pass serves up to 8 queries"}},
+            "roofline_compute": compute,
             "latency_ms_single_query": round(latency_ms, 4),
             "single_query_qps": round(1e3 / latency_ms, 1),
             "phases_ms_single_query": {kk: round(v, 4) for kk, v in timings.items() if kk.endswith("_ms")},
             "db_populate_s": round(t_populate, 2),
         }
-        if world == 1 and args.config == 3:
+        out.update(out_extra)
+        if forced_check is not None:
+            out["forced_dist_replies_equal_plain"] = forced_check
+        if use_dist and bufs is not None:
+            out["exchange_bytes_received_per_query_per_gpu"] = bufs.exchange_bytes_per_query(world)
+        if world == 1 and not use_dist and args.config == 3:
             # wire-level ProcessRequest (what benchmark.cpp:71-79 times): serialized pir.Request in host
             # memory -> serialized pir.Response, incl. parsing, H2D of keys + query, D2H, serialisation
             try:
@@ -363,28 +441,25 @@ def main():
                 req = W.save_request([query], gk, W.parms_id(N, mods[:-1], enc.plain_modulus))
                 srv.set_concurrency(1)
                 wt = []
-                for _ in range(6):
+                for _ in range(25):
                     t0 = time.perf_counter()
                     resp = srv.ProcessRequest(req)
                     wt.append((time.perf_counter() - t0) * 1e3)
                 same = bool(np.array_equal(W.load_response(resp)[0], single_reply))
                 out["wire_process_request_ms"] = {"first_request_with_key_upload": round(wt[0], 3),
-                                                  "repeat_client_keys_cached": round(float(np.median(wt[1:])), 3),
+                                                  "repeat_client_keys_cached_median_of_24": round(float(np.median(wt[1:])), 3),
+                                                  "repeat_min": round(float(np.min(wt[1:])), 3),
                                                   "request_bytes": len(req), "response_bytes": len(resp),
                                                   "response_equals_residue_path": same}
             except Exception as e:   # measurement extra only
                 out["wire_process_request_ms"] = {"error": repr(e)}
-        if world == 1 and not args.no_cpu_baseline:
-            batch_replies = srv.fetch_batch()
+        if world == 1 and not use_dist and not args.no_cpu_baseline:
             out["batch_reply0_equals_single_query_reply"] = bool(np.array_equal(batch_replies[0], single_reply))
             out["cpu_baseline"] = cpu_baseline(pp, raw, keys, query, single_reply)
             out["speedup_vs_cpu_baseline"] = qps / out["cpu_baseline"]["value"]
         print(json.dumps(out), file=result_out)
         result_out.flush()
     if use_dist:
-        if world == 1 and rank == 0 and row_sharded:   # forced single-rank run: the reduced replies must equal the plain ones
-            ok = bool(np.array_equal(redb.cpu().numpy().view(np.uint64), srv.fetch_batch()))
-            print("forced-dist check: all-reduced batch replies equal plain replies: %s" % ok, file=sys.stderr)
         dist.barrier()
         dist.destroy_process_group()
 

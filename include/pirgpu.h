@@ -159,6 +159,24 @@ int pirgpu_batch_fetch(pirgpu_ctx* ctx, uint64_t* replies, uint64_t reply_capaci
  * the batch reply buffer like pirgpu_batch_run's. */
 int pirgpu_batch_expand(pirgpu_ctx* ctx, uint32_t first, uint32_t count, uint64_t* device_dst);
 int pirgpu_batch_run_selectors(pirgpu_ctx* ctx, const uint64_t* device_sv, uint32_t count);
+/* Row-sharded multi-GPU runs with the PACKED selector exchange (d = 2 and the int8-MFMA scan on every rank;
+ * DESIGN.md section 7).  What every rank needs from a query is (a) all its column selectors, in the scan's
+ * B-operand layout (digit-packed signed bytes, one buffer per group of <= 8 queries), and (b) only its own rows'
+ * dimension-0 selectors (NTT form, u64).  packed_selector_bytes: size of one group buffer (identical on every rank;
+ * 0 if the packed exchange does not apply to this context).  batch_expand_packed: oblivious expansion + selector NTT
+ * of the staged queries [first, first+count) in groups of 8 (group g = queries first+8g ..); writes group g's packed
+ * column selectors to device_packed + g * packed_selector_bytes and, for every destination rank s holding rows
+ * [row_cuts[s], row_cuts[s+1]), the block [count][rows of s][2][k][N] of row selectors, blocks back to back in
+ * device_rows (= the send buffer of an all-to-all with split sizes count * rows_s * 2kN words).
+ * batch_run_packed: PIRDatabase::multiply on this shard for n_ranks * per_rank queries whose packed groups arrive as
+ * [source rank][group] (the all-gather of every rank's device_packed) and whose row selectors for THIS shard's rows
+ * arrive as [query][my rows][2][k][N] (the all-to-all's receive buffer); replies go to the batch reply buffer,
+ * query i = source rank i / per_rank, its query i % per_rank.  Needs pirgpu_set_concurrency(>= 8). */
+uint64_t pirgpu_packed_selector_bytes(pirgpu_ctx* ctx);
+int pirgpu_batch_expand_packed(pirgpu_ctx* ctx, uint32_t first, uint32_t count, uint8_t* device_packed,
+                               uint64_t* device_rows, const uint32_t* row_cuts, uint32_t n_ranks);
+int pirgpu_batch_run_packed(pirgpu_ctx* ctx, const uint8_t* device_packed, uint32_t n_ranks, uint32_t per_rank,
+                            const uint64_t* device_rows);
 /* Waits for the batch and copies its replies into caller-owned DEVICE memory (multi-GPU reduce). */
 int pirgpu_batch_reply_copy_to_device(pirgpu_ctx* ctx, uint64_t* device_dst, uint64_t capacity);
 

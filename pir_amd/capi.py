@@ -76,6 +76,10 @@ SIGNATURES = {
     "pirgpu_db_finalize": (C.c_int, [C.c_void_p, C.c_int]),
     "pirgpu_set_transparent_policy": (C.c_int, [C.c_void_p, C.c_int]),
     "pirgpu_ntt_mode": (C.c_int, [C.c_void_p]),
+    "pirgpu_packed_selector_bytes": (C.c_uint64, [C.c_void_p]),
+    "pirgpu_batch_expand_packed": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                             C.POINTER(C.c_uint32), C.c_uint32]),
+    "pirgpu_batch_run_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "pirgpu_set_galois_key": (C.c_int, [C.c_void_p, C.c_uint32, u64p]),
     "pirgpu_clear_galois_keys": (C.c_int, [C.c_void_p]),
     "pirgpu_process_query": (C.c_int, [C.c_void_p, u64p, C.c_uint32, u64p, C.c_uint64, u64p]),

@@ -58,6 +58,7 @@ struct Worker {
   uint64_t* d_query = nullptr;
   uint32_t staged_nq = 0;
   const uint64_t* sv_cur = nullptr;  // selection vector the multiply reads: sv_ntt, or caller-owned memory
+  const uint64_t* sv_rows = nullptr; // packed multi-GPU exchange: only this shard's dimension-0 selectors, local index
   std::vector<uint64_t*> lvl;  // per level results; lvl[0] = reply
   uint64_t* pt_buf = nullptr;
   uint64_t* scan_part = nullptr;
@@ -499,6 +500,7 @@ uint64_t* expand_on_device(pirgpu_ctx* c, Worker& w, uint32_t n) {
 void expand_query_to_sv(pirgpu_ctx* c, Worker& w, const uint64_t* d_query, uint32_t nq, uint64_t* coeff_out_host) {
   ensure_expansion_buffers(c, w);
   w.sv_cur = nullptr;
+  w.sv_rows = nullptr;
   const uint32_t N = c->N, k = c->k;
   const size_t ctw = c->ctw;
   uint64_t remaining = c->dim_sum;
@@ -543,19 +545,20 @@ void ensure_packed(pirgpu_ctx* c) {
 // One pass of the MFMA scan for up to 8 queries (the workers in `members`, expanded already; the
 // caller has ordered stream `st` after their expansions): pack the selectors, scan, fold column chunks.
 void scan_group_mfma(pirgpu_ctx* c, hipStream_t st, uint8_t*& selp, Worker* const* members, uint32_t n,
-                     Worker* profiled) {
+                     Worker* profiled, const uint8_t* packed = nullptr) {
   const uint32_t kN = c->k * c->N;
   const uint64_t words = (uint64_t)c->scan_rows * c->ctw;
   ensure_packed(c);
-  if (!selp) selp = c->dalloc<uint8_t>(c->mg.sel_bytes);
   MfmaPtrs sv{}, out{};
-  for (uint32_t q = 0; q < n; ++q) {
-    sv.p[q] = scan_selectors(c, *members[q]);
-    out.p[q] = c->mg.nchunks > 1 ? members[q]->scan_part : members[q]->lvl[c->d - 1];
+  for (uint32_t q = 0; q < n; ++q) out.p[q] = c->mg.nchunks > 1 ? members[q]->scan_part : members[q]->lvl[c->d - 1];
+  if (!packed) {  // with `packed` the group's digit-packed column selectors already exist (multi-GPU exchange)
+    if (!selp) selp = c->dalloc<uint8_t>(c->mg.sel_bytes);
+    for (uint32_t q = 0; q < n; ++q) sv.p[q] = scan_selectors(c, *members[q]);
+    HIP_TRY(launch_sel_pack(st, c->dp, c->mg, sv, n, selp, c->scan_cols, kN));
+    packed = selp;
   }
-  HIP_TRY(launch_sel_pack(st, c->dp, c->mg, sv, n, selp, c->scan_cols, kN));
   if (profiled) record(c, *profiled, PH_SCAN);  // selector packing counts as selector preparation, not as the scan
-  HIP_TRY(launch_scan_mfma(st, c->dp, c->mg, c->d_dbp, selp, out, n, c->scan_rows, kN, words));
+  HIP_TRY(launch_scan_mfma(st, c->dp, c->mg, c->d_dbp, packed, out, n, c->scan_rows, kN, words));
   if (c->mg.nchunks > 1)
     for (uint32_t q = 0; q < n; ++q)
       HIP_TRY(launch_reduce_splits(st, c->dp, members[q]->scan_part, c->mg.nchunks, words, members[q]->lvl[c->d - 1]));
@@ -609,7 +612,10 @@ void post_scan_on_device(pirgpu_ctx* c, Worker& w) {
   for (int l = (int)d - 2; l >= 0; --l) {
     const uint64_t nch = ceil_div(shard_pts, c->stride[l + 1]);
     const uint64_t rows = c->lvl_rows[l];
-    const uint32_t sv_first = c->sv_off[l] + (l == 0 ? c->sb : 0);
+    // dimension-0 selectors: the query's whole selection vector at index sv_off[0] + shard_begin + i, or (packed
+    // multi-GPU exchange) a buffer holding just this shard's rows at local index i
+    const bool local_rows = l == 0 && w.sv_rows;
+    const uint32_t sv_first = local_rows ? 0 : c->sv_off[l] + (l == 0 ? c->sb : 0);
     // enough workgroups to fill the chip: ~1024 over (rows * C * chunks * E * k)
     const uint64_t per_chunk = rows * C * c->E * k;
     uint32_t n_chunks = (uint32_t)std::min<uint64_t>(c->dims[l], std::max<uint64_t>(1, ceil_div(c->upper_blocks, per_chunk)));
@@ -618,8 +624,8 @@ void post_scan_on_device(pirgpu_ctx* c, Worker& w) {
     const uint64_t out_polys = rows * C * c->E * 2 * k;
     if (out_polys * n_chunks * N > c->pt_words)
       throw Fail{PIRGPU_INTERNAL, "upper-level scratch undersized"};
-    HIP_TRY(c->ops->upper_fused(w.stream, c->mode, c->dp, k, c->E, w.lvl[l + 1], w.sv_cur ? w.sv_cur : w.sv_ntt,
-                                w.pt_buf,
+    HIP_TRY(c->ops->upper_fused(w.stream, c->mode, c->dp, k, c->E, w.lvl[l + 1],
+                                local_rows ? w.sv_rows : (w.sv_cur ? w.sv_cur : w.sv_ntt), w.pt_buf,
                                 (uint32_t)rows, c->dims[l], (uint32_t)nch, sv_first, (uint32_t)C, chunk_len,
                                 n_chunks));
     if (l == 0) record(c, w, PH_FINAL);
@@ -1179,6 +1185,7 @@ int pirgpu_multiply(pirgpu_ctx* c, const uint64_t* sv, uint64_t sv_count, uint64
     }
     c->prof_cur = -1;
     w.sv_cur = nullptr;
+    w.sv_rows = nullptr;
     multiply_on_device(c, w);
     HIP_TRY(hipMemcpyAsync(reply, w.lvl[0], c->reply_cts * c->ctw * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1287,38 +1294,67 @@ static void expand_group_on_lane(pirgpu_ctx* c, BatchLane& ln, Worker* const* me
     produced += slots;
     remaining -= slots;
   }
-  for (uint32_t q = 0; q < B; ++q) members[q]->sv_cur = nullptr;
+  for (uint32_t q = 0; q < B; ++q) {
+    members[q]->sv_cur = nullptr;
+    members[q]->sv_rows = nullptr;
+  }
 }
 
 // Batch mode with the MFMA scan (see BatchLane): groups of up to mfma_nq queries share one batched
 // expansion and one database pass; consecutive groups alternate between two lanes.
-static void batch_run_mfma(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv) {
+struct PackedInput {            // multi-GPU packed exchange (pirgpu_batch_run_packed)
+  const uint8_t* packed;       // [src rank][group] digit-packed column selectors, mg.sel_bytes each
+  const uint64_t* rows;        // [query][this shard's rows][2][k][N] dimension-0 selectors
+  uint32_t per_rank;           // queries per source rank (groups never span two source ranks)
+};
+
+static void batch_run_mfma(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv, const PackedInput* pk = nullptr) {
   const size_t rwords = (size_t)c->reply_cts * c->ctw, svwords = (size_t)c->dim_sum * c->ctw;
   const uint32_t W = std::max<uint32_t>(1, std::min<uint32_t>(c->n_active, (uint32_t)c->workers.size()));
   const uint32_t G = std::min<uint32_t>(c->mfma_nq, W);
-  ensure_lanes(c, !ext_sv);
-  for (uint32_t base = 0; base < count; base += W) {
-    const uint32_t n = std::min<uint32_t>(W, count - base);
-    for (uint32_t j0 = 0; j0 < n; j0 += G) {
-      const uint32_t B = std::min<uint32_t>(G, n - j0);
+  const uint32_t my_rows = c->se - c->sb;
+  ensure_lanes(c, !ext_sv && !pk);
+  // groups: runs of up to G consecutive queries; with packed input a group is what ONE source rank packed together
+  // (its queries in runs of kMaxMfmaQueries), so the walk restarts at every source-rank boundary
+  uint32_t next_worker = 0;
+  const uint32_t span = pk ? pk->per_rank : count;
+  for (uint32_t rank0 = 0; rank0 < count; rank0 += span) {
+    const uint32_t step = pk ? (uint32_t)kMaxMfmaQueries : G;
+    for (uint32_t j0 = 0; j0 < std::min<uint32_t>(span, count - rank0); j0 += step) {
+      const uint32_t B = std::min<uint32_t>(step, std::min<uint32_t>(span, count - rank0) - j0);
+      if (B > W) throw Fail{PIRGPU_FAILED_PRECONDITION, "packed groups need at least 8 workers (pirgpu_set_concurrency)"};
+      if (next_worker + B > W) next_worker = 0;
       BatchLane& ln = c->lanes[c->groups_run++ % c->lanes.size()];
       Worker* members[kMaxMfmaQueries];
       for (uint32_t q = 0; q < B; ++q) {
-        members[q] = &c->workers[j0 + q];
+        members[q] = &c->workers[next_worker + q];
         HIP_TRY(hipStreamWaitEvent(ln.stream, members[q]->ev_done, 0));  // its buffers are free again
       }
-      if (ext_sv) {
-        for (uint32_t q = 0; q < B; ++q) members[q]->sv_cur = ext_sv + (size_t)(base + j0 + q) * svwords;
+      next_worker += B;
+      const uint32_t first = rank0 + j0;  // global index of the group's first query
+      const uint8_t* packed = nullptr;
+      if (pk) {
+        const uint32_t groups_per_rank = (pk->per_rank + kMaxMfmaQueries - 1) / kMaxMfmaQueries;
+        packed = pk->packed + ((size_t)(rank0 / pk->per_rank) * groups_per_rank + j0 / kMaxMfmaQueries) * c->mg.sel_bytes;
+        for (uint32_t q = 0; q < B; ++q) {
+          members[q]->sv_cur = nullptr;
+          members[q]->sv_rows = pk->rows + (size_t)(first + q) * my_rows * c->ctw;
+        }
+      } else if (ext_sv) {
+        for (uint32_t q = 0; q < B; ++q) {
+          members[q]->sv_cur = ext_sv + (size_t)(first + q) * svwords;
+          members[q]->sv_rows = nullptr;
+        }
       } else {
-        expand_group_on_lane(c, ln, members, B, base + j0);
+        expand_group_on_lane(c, ln, members, B, first);
       }
-      scan_group_mfma(c, ln.stream, ln.selp, members, B, nullptr);
+      scan_group_mfma(c, ln.stream, ln.selp, members, B, nullptr, packed);
       HIP_TRY(hipEventRecord(ln.ev_scanned, ln.stream));
       for (uint32_t q = 0; q < B; ++q) {
         Worker& w = *members[q];
         HIP_TRY(hipStreamWaitEvent(w.stream, ln.ev_scanned, 0));
         post_scan_on_device(c, w);
-        HIP_TRY(hipMemcpyAsync(c->d_breply + (size_t)(base + j0 + q) * rwords, w.lvl[0], rwords * 8,
+        HIP_TRY(hipMemcpyAsync(c->d_breply + (size_t)(first + q) * rwords, w.lvl[0], rwords * 8,
                                hipMemcpyDeviceToDevice, w.stream));
         HIP_TRY(hipEventRecord(w.ev_done, w.stream));
         w.reply_valid = true;
@@ -1456,13 +1492,103 @@ int pirgpu_batch_run_selectors(pirgpu_ctx* c, const uint64_t* device_sv, uint32_
   });
 }
 
+// ---- packed selector exchange for row-sharded multi-GPU runs ----
+
+uint64_t pirgpu_packed_selector_bytes(pirgpu_ctx* c) {
+  uint64_t bytes = 0;
+  (void)guarded(c, [&]() -> int {
+    ensure_workspace(c);
+    // d = 2 only (dimension 0 = rows, dimension 1 = the scanned columns) and the shard scanned by the MFMA kernel
+    if (c->d == 2 && c->mfma_on) bytes = c->mg.sel_bytes;
+    return PIRGPU_OK;
+  });
+  return bytes;
+}
+
+int pirgpu_batch_expand_packed(pirgpu_ctx* c, uint32_t first, uint32_t count, uint8_t* device_packed,
+                               uint64_t* device_rows, const uint32_t* row_cuts, uint32_t n_ranks) {
+  return guarded(c, [&]() -> int {
+    ensure_workspace(c);
+    if (c->d != 2 || !c->mfma_on)
+      return fail(c, PIRGPU_FAILED_PRECONDITION, "packed selector exchange needs d = 2 and the int8-MFMA scan");
+    if (!c->batch_count || (uint64_t)first + count > c->batch_count)
+      return fail(c, PIRGPU_INVALID_ARGUMENT, "query range outside the staged batch");
+    if (!device_packed || !device_rows || !row_cuts || n_ranks == 0 || row_cuts[0] != 0 || row_cuts[n_ranks] != c->dims[0])
+      return fail(c, PIRGPU_INVALID_ARGUMENT, "invalid packed-exchange buffers or row cuts");
+    for (uint32_t s = 0; s < n_ranks; ++s)
+      if (row_cuts[s] > row_cuts[s + 1]) return fail(c, PIRGPU_INVALID_ARGUMENT, "row cuts must be non-decreasing");
+    const uint32_t W = std::max<uint32_t>(1, std::min<uint32_t>(c->n_active, (uint32_t)c->workers.size()));
+    if (W < std::min<uint32_t>(count, kMaxMfmaQueries))
+      return fail(c, PIRGPU_FAILED_PRECONDITION, "packed groups need min(count, 8) workers (pirgpu_set_concurrency)");
+    ensure_lanes(c, true);
+    c->prof_cur = -1;
+    const size_t ctw = c->ctw;
+    const uint32_t kN = c->k * c->N;
+    uint32_t next_worker = 0, g = 0;
+    for (uint32_t j0 = 0; j0 < count; j0 += kMaxMfmaQueries, ++g) {
+      const uint32_t B = std::min<uint32_t>(kMaxMfmaQueries, count - j0);
+      if (next_worker + B > W) next_worker = 0;
+      BatchLane& ln = c->lanes[c->groups_run++ % c->lanes.size()];
+      Worker* members[kMaxMfmaQueries];
+      for (uint32_t q = 0; q < B; ++q) {
+        members[q] = &c->workers[next_worker + q];
+        HIP_TRY(hipStreamWaitEvent(ln.stream, members[q]->ev_done, 0));
+      }
+      next_worker += B;
+      expand_group_on_lane(c, ln, members, B, first + j0);
+      // column selectors (dimension 1) of the whole group -> one B-operand buffer
+      MfmaPtrs sv{};
+      for (uint32_t q = 0; q < B; ++q) sv.p[q] = members[q]->sv_ntt + (size_t)c->sv_off[1] * ctw;
+      HIP_TRY(launch_sel_pack(ln.stream, c->dp, c->mg, sv, B, device_packed + (size_t)g * c->mg.sel_bytes, c->scan_cols, kN));
+      // row selectors (dimension 0): block of destination rank s = [query][rows of s][2][k][N]
+      for (uint32_t s2 = 0; s2 < n_ranks; ++s2) {
+        const uint32_t r0 = row_cuts[s2], nr = row_cuts[s2 + 1] - r0;
+        if (!nr) continue;
+        for (uint32_t q = 0; q < B; ++q)
+          HIP_TRY(hipMemcpyAsync(device_rows + ((size_t)count * r0 + (size_t)(j0 + q) * nr) * ctw,
+                                 members[q]->sv_ntt + (size_t)(c->sv_off[0] + r0) * ctw, (size_t)nr * ctw * 8,
+                                 hipMemcpyDeviceToDevice, ln.stream));
+      }
+      for (uint32_t q = 0; q < B; ++q) {  // the members' selection vectors are free once this lane got here
+        HIP_TRY(hipEventRecord(members[q]->ev_done, ln.stream));
+      }
+    }
+    for (BatchLane& ln : c->lanes) HIP_TRY(hipStreamSynchronize(ln.stream));
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_batch_run_packed(pirgpu_ctx* c, const uint8_t* device_packed, uint32_t n_ranks, uint32_t per_rank,
+                            const uint64_t* device_rows) {
+  return guarded(c, [&]() -> int {
+    ensure_workspace(c);
+    if (c->d != 2 || !c->mfma_on)
+      return fail(c, PIRGPU_FAILED_PRECONDITION, "packed selector exchange needs d = 2 and the int8-MFMA scan");
+    const uint64_t count = (uint64_t)n_ranks * per_rank;
+    if (!device_packed || !device_rows || count == 0 || count > 4096) return fail(c, PIRGPU_INVALID_ARGUMENT, "invalid batch");
+    if (c->n_loaded != c->pt_end - c->pt_begin) return fail(c, PIRGPU_FAILED_PRECONDITION, "database not fully loaded");
+    check_transparent(c);
+    ensure_packed(c);
+    ensure_batch_capacity(c, (uint32_t)count);
+    c->prof_cur = -1;
+    PackedInput pk{device_packed, device_rows, per_rank};
+    batch_run_mfma(c, (uint32_t)count, nullptr, &pk);
+    c->batch_count = (uint32_t)count;
+    c->batch_valid = true;
+    return PIRGPU_OK;
+  });
+}
+
 int pirgpu_batch_reply_copy_to_device(pirgpu_ctx* c, uint64_t* dst, uint64_t cap) {
   return guarded(c, [&]() -> int {
     if (!c->batch_valid) return fail(c, PIRGPU_FAILED_PRECONDITION, "no batch has been run");
     const uint64_t total = (uint64_t)c->batch_count * c->reply_cts;
     if (!dst || cap < total) return fail(c, PIRGPU_INVALID_ARGUMENT, "reply buffer too small");
     for (Worker& w : c->workers) HIP_TRY(hipStreamSynchronize(w.stream));
-    HIP_TRY(hipMemcpy(dst, c->d_breply, total * c->ctw * 8, hipMemcpyDeviceToDevice));
+    // a device-to-device hipMemcpy on the null stream may return before the copy has run, and the context's
+    // streams are non-blocking (not ordered with the null stream): copy on the context's stream and wait
+    HIP_TRY(hipMemcpyAsync(dst, c->d_breply, total * c->ctw * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return PIRGPU_OK;
   });
 }

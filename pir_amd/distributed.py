@@ -1,9 +1,16 @@
-"""Multi-GPU glue (one process per GPU, torch.distributed over RCCL): row sharding of the
-database and the sum of per-shard partial replies.  Not in the reference (single-threaded,
-single-process); see DESIGN.md section 7."""
+"""Multi-GPU glue (one process per GPU, torch.distributed over RCCL): row sharding of the database, the
+exchange of what every shard needs from a query, and the sum of the per-shard partial replies.  Not in the
+reference (single-threaded, single-process); see DESIGN.md section 7.
+
+The server object is duck-typed (pir_amd.PIRServer; the CPU tests drive the same code with an oracle-backed
+stand-in), the collectives go through `Comm`, which runs them on the tensors' own device (RCCL) or -- for the
+world-size-2 `gloo` tests -- stages them through host memory.
+"""
 from __future__ import annotations
 
-from typing import Tuple
+from typing import List, Optional, Tuple
+
+GROUP = 8          # queries per packed group = queries sharing one database pass (kMaxMfmaQueries)
 
 
 def shard_range(n_top: int, rank: int, world: int) -> Tuple[int, int]:
@@ -13,30 +20,17 @@ def shard_range(n_top: int, rank: int, world: int) -> Tuple[int, int]:
     return (n_top * rank) // world, (n_top * (rank + 1)) // world
 
 
-def all_reduce_reply(server, reply_tensor, dist) -> None:
-    """Sum the ranks' partial replies in place and reduce mod q_j.
-
-    reply_tensor: int64 CUDA tensor [reply_cts, 2, k, N] owned by the caller.  Partial replies
-    are canonical residues (< q_j < 2^61), so the integer sum over <= 8 ranks cannot overflow.
-    """
-    import torch
-    if not reply_tensor.is_cuda:
-        raise RuntimeError("all_reduce_reply needs a CUDA tensor (RCCL); there is no CPU path")
-    server.reply_copy_to_device(reply_tensor.data_ptr())     # waits for this rank's kernels
-    dist.all_reduce(reply_tensor, op=dist.ReduceOp.SUM)      # RCCL over xGMI
-    torch.cuda.current_stream().synchronize()
-    server.reduce_fixup_device(reply_tensor.data_ptr())      # x mod q_j on the GPU
+def row_cuts(n_top: int, world: int) -> List[int]:
+    """shard_range of every rank as one non-decreasing list of world + 1 cuts."""
+    return [(n_top * r) // world for r in range(world + 1)]
 
 
-def all_reduce_batch_replies(server, reply_tensor, dist) -> None:
-    """Batch-mode counterpart of all_reduce_reply: reply_tensor int64 CUDA [count, reply_cts, 2, k, N]."""
-    import torch
-    if not reply_tensor.is_cuda:
-        raise RuntimeError("all_reduce_batch_replies needs a CUDA tensor (RCCL); there is no CPU path")
-    server.batch_reply_copy_to_device(reply_tensor.data_ptr())   # waits for every worker stream
-    dist.all_reduce(reply_tensor, op=dist.ReduceOp.SUM)
-    torch.cuda.current_stream().synchronize()
-    server.reduce_fixup_device_n(reply_tensor.data_ptr(), reply_tensor.shape[0] * reply_tensor.shape[1])
+def check_sum_fits(q_max: int, world: int) -> None:
+    """Partial replies are canonical residues < q_j; their integer sum over the ranks must not wrap 64 bits
+    (int64 tensors wrap like uint64, so the bound is 2^64)."""
+    if world * (q_max - 1) >= 1 << 64:
+        raise ValueError("world size %d too large for %d-bit moduli: the 64-bit sum of partial replies would wrap"
+                         % (world, q_max.bit_length()))
 
 
 def owned_queries(count: int, rank: int, world: int):
@@ -47,24 +41,177 @@ def owned_queries(count: int, rank: int, world: int):
     return rank * per, (rank + 1) * per
 
 
-def run_batch_query_parallel(server, sv_all, replies, dist, rank: int, world: int) -> None:
-    """One step over a staged batch on `world` GPUs holding row shards of the database:
+class Comm:
+    """The four collectives of a step.  backend 'nccl' (RCCL): on the tensors' device, on torch's current stream,
+    followed by a stream synchronise (the library runs on its own HIP streams).  Any other backend (gloo in the
+    tests): tensors are staged through host memory, so the same glue runs with two processes on one GPU or on CPU."""
 
-      1. every rank expands only its own block of the batch's queries (oblivious expansion is the
-         part of the path that does not shard by rows) straight into its slice of `sv_all`;
-      2. one RCCL all-gather makes every query's NTT-form selection vector available everywhere;
+    def __init__(self, dist, world: int):
+        self.dist, self.world = dist, world
+        self.device_native = world > 1 and dist.get_backend() == "nccl"
+
+    def _sync(self, t):
+        if t.is_cuda:
+            import torch
+            torch.cuda.current_stream(t.device).synchronize()
+
+    def all_gather_inplace(self, full, rank: int):
+        """full: [world, ...]; every rank has filled full[rank]."""
+        if self.world == 1:
+            return
+        d = self.dist
+        if self.device_native:
+            d.all_gather_into_tensor(full.view(-1), full[rank].reshape(-1))
+            self._sync(full)
+            return
+        mine = full[rank].cpu().contiguous()
+        parts = [mine.new_empty(mine.shape) for _ in range(self.world)]
+        d.all_gather(parts, mine)
+        for r, p in enumerate(parts):
+            full[r].copy_(p)
+        self._sync(full)
+
+    def all_to_all(self, recv, send, recv_splits, send_splits):
+        """1-D tensors; split sizes in elements."""
+        if self.world == 1:
+            recv.copy_(send)
+            self._sync(recv)
+            return
+        d = self.dist
+        if self.device_native:
+            d.all_to_all_single(recv, send, list(recv_splits), list(send_splits))
+            self._sync(recv)
+            return
+        s, r = send.cpu(), recv.new_empty(recv.shape, device="cpu")
+        d.all_to_all_single(r, s, list(recv_splits), list(send_splits))
+        recv.copy_(r)
+        self._sync(recv)
+
+    def reduce_scatter_sum(self, out, full, rank: int):
+        """full: [world * n] int64 partial sums, out: [n] = sum over ranks of full[rank*n:(rank+1)*n]."""
+        if self.world == 1:
+            out.copy_(full.view(-1)[: out.numel()].view(out.shape))
+            self._sync(out)
+            return
+        d = self.dist
+        if self.device_native:
+            d.reduce_scatter_tensor(out.view(-1), full.view(-1), op=d.ReduceOp.SUM)
+            self._sync(out)
+            return
+        c = full.cpu()
+        d.all_reduce(c, op=d.ReduceOp.SUM)          # gloo has no reduce-scatter: reduce everything, keep the slice
+        n = out.numel()
+        out.copy_(c.view(-1)[rank * n:(rank + 1) * n].view(out.shape))
+        self._sync(out)
+
+    def all_reduce_sum(self, t):
+        if self.world == 1:
+            return
+        d = self.dist
+        if self.device_native:
+            d.all_reduce(t, op=d.ReduceOp.SUM)
+            self._sync(t)
+            return
+        c = t.cpu()
+        d.all_reduce(c, op=d.ReduceOp.SUM)
+        t.copy_(c)
+        self._sync(t)
+
+
+def all_reduce_reply(server, reply_tensor, dist, comm: Optional[Comm] = None) -> None:
+    """Sum the ranks' partial replies of the last single query in place and reduce mod q_j.
+    reply_tensor: int64 tensor [reply_cts, 2, k, N] owned by the caller (on the server's device)."""
+    comm = comm or Comm(dist, dist.get_world_size())
+    server.reply_copy_to_device(reply_tensor.data_ptr())     # waits for this rank's kernels
+    comm.all_reduce_sum(reply_tensor)                         # RCCL over xGMI
+    server.reduce_fixup_device(reply_tensor.data_ptr())       # x mod q_j on the GPU
+
+
+def all_reduce_batch_replies(server, reply_tensor, dist, comm: Optional[Comm] = None) -> None:
+    """Batch-mode counterpart of all_reduce_reply: reply_tensor int64 [count, reply_cts, 2, k, N]."""
+    comm = comm or Comm(dist, dist.get_world_size())
+    server.batch_reply_copy_to_device(reply_tensor.data_ptr())   # waits for every worker stream
+    comm.all_reduce_sum(reply_tensor)
+    server.reduce_fixup_device_n(reply_tensor.data_ptr(), reply_tensor.shape[0] * reply_tensor.shape[1])
+
+
+def run_batch_query_parallel(server, sv_all, replies, dist, rank: int, world: int, comm: Optional[Comm] = None) -> None:
+    """One step over a staged batch on `world` GPUs holding row shards, exchanging whole u64 selection vectors
+    (any d, any scan kernel; 2 k N 8 dim_sum bytes per query to every rank):
+
+      1. every rank expands only its own block of the batch's queries straight into its slice of `sv_all`;
+      2. one all-gather makes every query's NTT-form selection vector available everywhere;
       3. every rank multiplies all queries against its row shard (shared database passes);
-      4. the partial replies are summed with one RCCL all-reduce and reduced mod q_j.
+      4. the partial replies are summed with one all-reduce and reduced mod q_j.
 
-    sv_all:  int64 CUDA tensor [count, dim_sum, 2, k, N]   (all-gather buffer)
-    replies: int64 CUDA tensor [count, reply_cts, 2, k, N] (all-reduce buffer)
+    sv_all:  int64 tensor [count, dim_sum, 2, k, N]   (all-gather buffer)
+    replies: int64 tensor [count, reply_cts, 2, k, N] (all-reduce buffer; every rank ends with every reply)
     """
-    import torch
+    comm = comm or Comm(dist, world)
     count = sv_all.shape[0]
     lo, hi = owned_queries(count, rank, world)
     server.batch_expand(lo, hi - lo, sv_all[lo].data_ptr())          # synchronous
-    if world > 1:
-        dist.all_gather_into_tensor(sv_all.view(-1), sv_all[lo:hi].reshape(-1))
-        torch.cuda.current_stream().synchronize()
+    comm.all_gather_inplace(sv_all.view(world, -1), rank)
     server.batch_run_selectors(sv_all.data_ptr(), count)
-    all_reduce_batch_replies(server, replies, dist)
+    all_reduce_batch_replies(server, replies, dist, comm)
+
+
+class PackedBuffers:
+    """Device buffers of run_batch_rows_packed for one (server, batch size, world)."""
+
+    def __init__(self, server, batch: int, rank: int, world: int, torch, device):
+        if batch % world:
+            raise ValueError("batch size must be a multiple of the world size")
+        self.per = batch // world
+        self.groups = (self.per + GROUP - 1) // GROUP
+        self.cuts = row_cuts(server.params.dimensions[0], world)
+        self.sel_bytes = server.packed_selector_bytes()
+        k, N = server.k, server.N
+        self.ctw = 2 * k * N
+        self.my_rows = self.cuts[rank + 1] - self.cuts[rank]
+        n0 = server.params.dimensions[0]
+        reply_cts = server.db.reply_ct_count()
+        self.packed = torch.empty((world, self.groups, max(self.sel_bytes, 1)), dtype=torch.uint8, device=device)
+        self.rows_send = torch.empty((self.per * n0 * self.ctw,), dtype=torch.int64, device=device)
+        self.rows_recv = torch.empty((max(batch * self.my_rows, 1) * self.ctw,), dtype=torch.int64, device=device)
+        self.partial = torch.empty((batch, reply_cts, 2, k, N), dtype=torch.int64, device=device)
+        self.replies = torch.empty((self.per, reply_cts, 2, k, N), dtype=torch.int64, device=device)
+        self.send_splits = [self.per * (self.cuts[s + 1] - self.cuts[s]) * self.ctw for s in range(world)]
+        self.recv_splits = [self.per * self.my_rows * self.ctw] * world
+
+    def exchange_bytes_per_query(self, world: int) -> float:
+        """Bytes a rank receives per query of the batch (packed column selectors from the other ranks + its rows)."""
+        return (world - 1) / world * (self.sel_bytes * self.groups / self.per + self.my_rows * self.ctw * 8)
+
+
+def packed_exchange_supported(server, dist, world: int, comm: Optional[Comm] = None, torch=None, device=None) -> bool:
+    """True when every rank's shard can take the packed exchange (d = 2, int8-MFMA scan active on the shard)."""
+    mine = 1 if server.packed_selector_bytes() > 0 else 0
+    if world == 1:
+        return bool(mine)
+    t = torch.tensor([mine], dtype=torch.int64, device=device)
+    (comm or Comm(dist, world)).all_reduce_sum(t)
+    return int(t.item()) == world
+
+
+def run_batch_rows_packed(server, bufs: PackedBuffers, dist, rank: int, world: int, comm: Optional[Comm] = None) -> None:
+    """One step over a staged batch on `world` GPUs holding row shards, with the PACKED exchange (d = 2):
+
+      1. every rank expands its own `per` queries (groups of 8 expanded together), packs their column selectors
+         into the scan's B-operand layout (L signed bytes per residue) and lays their row selectors out by owner;
+      2. all-gather of the packed column selectors; all-to-all of the row selectors (a rank receives only its rows);
+      3. every rank scans its row shard once per group of 8 queries and runs the upper level on its rows;
+      4. reduce-scatter of the partial replies: rank r ends with the finished replies of the queries it expanded
+         (reply i answers query i, reference server.cpp:60-63), then x mod q_j.
+
+    Per query a rank receives (world-1)/world * (14.4 MB + 2.6 MB/world) at cfg 3 instead of 42 MB of u64 selectors.
+    """
+    comm = comm or Comm(dist, world)
+    lo, hi = owned_queries(bufs.per * world, rank, world)
+    server.batch_expand_packed(lo, bufs.per, bufs.packed[rank].data_ptr(), bufs.rows_send.data_ptr(), bufs.cuts)
+    comm.all_gather_inplace(bufs.packed, rank)
+    comm.all_to_all(bufs.rows_recv, bufs.rows_send, bufs.recv_splits, bufs.send_splits)
+    server.batch_run_packed(bufs.packed.data_ptr(), world, bufs.per, bufs.rows_recv.data_ptr())
+    server.batch_reply_copy_to_device(bufs.partial.data_ptr())
+    comm.reduce_scatter_sum(bufs.replies, bufs.partial, rank)
+    server.reduce_fixup_device_n(bufs.replies.data_ptr(), bufs.replies.shape[0] * bufs.replies.shape[1])

@@ -270,6 +270,25 @@ class PIRServer:
     def dim_sum(self) -> int:
         return self.params.dim_sum
 
+    # -- packed selector exchange (row-sharded multi-GPU, d = 2) --------------------------
+    def packed_selector_bytes(self) -> int:
+        return int(self.lib.pirgpu_packed_selector_bytes(self.db.handle))
+
+    def batch_expand_packed(self, first: int, count: int, packed_ptr: int, rows_ptr: int, row_cuts) -> None:
+        cuts = (C.c_uint32 * len(row_cuts))(*row_cuts)
+        self._check(self.lib.pirgpu_batch_expand_packed(self.db.handle, first, count, C.c_void_p(packed_ptr),
+                                                        C.c_void_p(rows_ptr), cuts, len(row_cuts) - 1))
+
+    def batch_run_packed(self, packed_ptr: int, n_ranks: int, per_rank: int, rows_ptr: int) -> None:
+        self._batch_count = n_ranks * per_rank
+        self._check(self.lib.pirgpu_batch_run_packed(self.db.handle, C.c_void_p(packed_ptr), n_ranks, per_rank,
+                                                     C.c_void_p(rows_ptr)))
+
+    def shard_rows(self):
+        """[begin, end) of dimension 0 held by this server's database."""
+        p = self.db._cparams
+        return (int(p.shard_begin), int(p.shard_end) if (p.shard_begin or p.shard_end) else self.params.dimensions[0])
+
     def batch_reply_copy_to_device(self, device_ptr: int) -> None:
         self._check(self.lib.pirgpu_batch_reply_copy_to_device(self.db.handle, C.c_void_p(device_ptr),
                                                                self._batch_count * self.db.reply_ct_count()))

@@ -1,7 +1,12 @@
-"""World-size-2 gloo test of the multi-GPU glue on CPU: shard ranges, and that the integer
-all-reduce of per-shard partial replies followed by `x mod q_j` equals the full reply.
-Per-shard partial replies are produced by the CPU oracle run on the shard's rows only (the recursion of
-database.cpp:170-258 over dimension 0 is a sum over its indices)."""
+"""World-size-2 gloo tests of the multi-GPU glue on CPU.
+
+`pir_amd.distributed` is the product code under test: shard ranges, the packed exchange step
+(run_batch_rows_packed: all-gather of packed column selectors, all-to-all of row selectors, reduce-scatter of the
+partial replies, mod-q fix-up) and the whole-selection-vector step (run_batch_query_parallel: all-gather + all-reduce).
+Two processes run them over gloo with a stand-in for the GPU server that is backed by the CPU oracle (it implements
+the same duck-typed methods on host tensors; its "packed" format is simply the raw column selectors -- the glue only
+moves bytes), and every rank checks the replies it ends up with against the oracle's full-database replies."""
+import ctypes as C
 import os
 import socket
 
@@ -11,6 +16,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from pir_amd import distributed as D
 from pir_amd.distributed import shard_range
 
 
@@ -23,8 +29,14 @@ def test_shard_range_partitions_rows():
                 assert a[1] == b[0]
             sizes = [b - a for a, b in cuts]
             assert max(sizes) - min(sizes) <= 1
+            assert D.row_cuts(n, world) == [c[0] for c in cuts] + [n]
     with pytest.raises(ValueError):
         shard_range(10, 2, 2)
+    with pytest.raises(ValueError):
+        D.owned_queries(5, 0, 2)
+    D.check_sum_fits((1 << 61) - 1, 8)
+    with pytest.raises(ValueError):
+        D.check_sum_fits((1 << 61) - 1, 9)
 
 
 def _free_port():
@@ -33,7 +45,96 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, d, dbsize, elem, out_q):
+def _view(ptr, n, dtype=np.uint64):
+    ct = {np.uint64: C.c_uint64, np.uint8: C.c_uint8}[dtype]
+    return np.ctypeslib.as_array((ct * n).from_address(ptr))
+
+
+class _Db:
+    def __init__(self, n):
+        self._n = n
+
+    def reply_ct_count(self):
+        return self._n
+
+
+class OracleShardServer:
+    """The methods pir_amd.distributed calls on a server, on host memory, computed by the CPU oracle."""
+
+    def __init__(self, setup, rank, world):
+        self.s, self.params = setup, setup.params
+        self.orc = setup.orc
+        self.k, self.N = self.orc.k, self.orc.N
+        self.ctw = 2 * self.k * self.N
+        self.dims = list(self.params.dimensions)
+        self.lo, self.hi = shard_range(self.dims[0], rank, world)
+        stride = int(np.prod(self.dims[1:])) if len(self.dims) > 1 else 1
+        self.shard_db = setup.db_ntt[self.lo * stride:min(self.hi * stride, self.params.num_pt)]
+        self.db = _Db(self.orc.reply_ct_count(len(self.dims)))
+        self.queries, self.partials = None, None
+
+    # -- staging / expansion -------------------------------------------------------------------------------
+    def stage_batch(self, queries):
+        self.queries = queries
+
+    def _sv(self, i):
+        rc, sv = self.orc.oblivious_expansion_multi(self.queries[i], self.params.dim_sum, self.s.galois_keys)
+        assert rc == 0
+        return sv
+
+    def packed_selector_bytes(self):
+        return D.GROUP * self.dims[1] * self.ctw * 8 if len(self.dims) == 2 and self.hi > self.lo else 0
+
+    def batch_expand_packed(self, first, count, packed_ptr, rows_ptr, cuts):
+        n0, n1 = self.dims
+        groups = (count + D.GROUP - 1) // D.GROUP
+        packed = _view(packed_ptr, groups * D.GROUP * n1 * self.ctw).reshape(groups, D.GROUP, n1, self.ctw)
+        rows = _view(rows_ptr, count * n0 * self.ctw)
+        for i in range(count):
+            sv = self._sv(first + i).reshape(n0 + n1, self.ctw)
+            packed[i // D.GROUP, i % D.GROUP] = sv[n0:]
+            for s in range(len(cuts) - 1):
+                r0, nr = cuts[s], cuts[s + 1] - cuts[s]
+                off = (count * r0 + i * nr) * self.ctw
+                rows[off:off + nr * self.ctw] = sv[r0:r0 + nr].reshape(-1)
+
+    def batch_expand(self, first, count, dst_ptr):
+        out = _view(dst_ptr, count * self.params.dim_sum * self.ctw).reshape(count, -1)
+        for i in range(count):
+            out[i] = self._sv(first + i).reshape(-1)
+
+    # -- multiply on the shard -------------------------------------------------------------------------------
+    def _partial(self, rows_sel, rest_sel):
+        sub_dims = [self.hi - self.lo] + self.dims[1:]
+        sv = np.concatenate([rows_sel, rest_sel]).reshape(-1, 2, self.k, self.N).copy()
+        rc, part = self.orc.db_multiply(np.ascontiguousarray(self.shard_db), sub_dims, sv)
+        assert rc == 0
+        return part
+
+    def batch_run_packed(self, packed_ptr, n_ranks, per_rank, rows_ptr):
+        n1, my = self.dims[1], self.hi - self.lo
+        groups = (per_rank + D.GROUP - 1) // D.GROUP
+        packed = _view(packed_ptr, n_ranks * groups * D.GROUP * n1 * self.ctw).reshape(n_ranks, groups, D.GROUP, n1, self.ctw)
+        rows = _view(rows_ptr, n_ranks * per_rank * my * self.ctw).reshape(n_ranks * per_rank, my, self.ctw)
+        self.partials = [self._partial(rows[r * per_rank + i], packed[r, i // D.GROUP, i % D.GROUP])
+                         for r in range(n_ranks) for i in range(per_rank)]
+
+    def batch_run_selectors(self, sv_ptr, count):
+        ds = self.params.dim_sum
+        sv = _view(sv_ptr, count * ds * self.ctw).reshape(count, ds, self.ctw)
+        self.partials = [self._partial(sv[i, self.lo:self.hi], sv[i, self.dims[0]:]) for i in range(count)]
+
+    def batch_reply_copy_to_device(self, dst_ptr):
+        out = _view(dst_ptr, len(self.partials) * self.db.reply_ct_count() * self.ctw)
+        out[:] = np.stack(self.partials).reshape(-1)
+
+    def reduce_fixup_device_n(self, ptr, n_cts):
+        a = _view(ptr, n_cts * self.ctw).reshape(n_cts, 2, self.k, self.N)
+        for j, qj in enumerate(self.orc.moduli[: self.k]):
+            a[:, :, j, :] %= np.uint64(qj)
+
+
+def _worker(rank, world, port, d, dbsize, elem, batch, out_q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -43,40 +144,46 @@ def _worker(rank, world, port, d, dbsize, elem, out_q):
         from pir_fixtures import PirSetup
         s = PirSetup(dbsize, elem, d, N=4096, plain_bits=24)      # same seeds on every rank
         p = s.params
-        q = s.client.create_query_for(p, dbsize - 2)
-        # this rank's shard: the plaintexts under its top-level range, multiplied with the matching selectors
-        from pir_fixtures import oracle_partial_reply
-        lo, hi = shard_range(p.dimensions[0], rank, world)
-        stride = 1
-        for x in p.dimensions[1:]:
-            stride *= x
-        rc, sv = s.orc.oblivious_expansion_multi(q, p.dim_sum, s.galois_keys)
-        assert rc == 0
-        rc, part = oracle_partial_reply(s.orc, s.db_ntt[lo * stride:min(hi * stride, p.num_pt)], p.dimensions, lo, hi, sv)
-        assert rc == 0
-        t = torch.from_numpy(part.view(np.int64).copy())
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)                 # what RCCL does on the GPUs
-        summed = t.numpy().view(np.uint64).copy()
-        for j, qj in enumerate(s.orc.moduli[: s.orc.k]):         # the mod-q fix-up kernel's job
-            summed[:, :, j, :] %= np.uint64(qj)
-        if rank == 0:
-            rc, full = s.orc.process_query(s.db_ntt, p.dimensions, q, s.galois_keys)
-            ok = bool(np.array_equal(summed, full)) and \
-                s.client.process_response(p, dbsize - 2, summed) == s.item(dbsize - 2)
-            out_q.put(ok)
+        indexes = [(dbsize - 2 - 37 * i) % dbsize for i in range(batch)]
+        queries = [s.client.create_query_for(p, i) for i in indexes]
+        srv = OracleShardServer(s, rank, world)
+        srv.stage_batch(queries)
+        comm = D.Comm(dist, world)
+        assert not comm.device_native
+        D.check_sum_fits(max(s.orc.moduli[: s.orc.k]), world)
+        ok = True
+        lo, hi = D.owned_queries(batch, rank, world)
+        full = [s.orc.process_query(s.db_ntt, p.dimensions, queries[i], s.galois_keys)[1] for i in range(batch)]
+        if d == 2:
+            assert D.packed_exchange_supported(srv, dist, world, comm, torch, "cpu")
+            bufs = D.PackedBuffers(srv, batch, rank, world, torch, "cpu")
+            D.run_batch_rows_packed(srv, bufs, dist, rank, world, comm)
+            mine = bufs.replies.numpy().view(np.uint64)
+            for i in range(lo, hi):                                # rank r ends with the replies of ITS queries
+                ok &= bool(np.array_equal(mine[i - lo], full[i]))
+                ok &= s.client.process_response(p, indexes[i], mine[i - lo]) == s.item(indexes[i])
+        # the whole-selection-vector exchange (any d): every rank ends with every reply
+        sv_all = torch.empty((batch, p.dim_sum, 2, s.orc.k, 4096), dtype=torch.int64)
+        replies = torch.empty((batch, srv.db.reply_ct_count(), 2, s.orc.k, 4096), dtype=torch.int64)
+        D.run_batch_query_parallel(srv, sv_all, replies, dist, rank, world, comm)
+        allr = replies.numpy().view(np.uint64)
+        for i in range(batch):
+            ok &= bool(np.array_equal(allr[i], full[i]))
+        out_q.put((rank, ok))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("d,dbsize,elem", [(2, 300, 288), (1, 120, 288)])
-def test_partial_reply_all_reduce_gloo(d, dbsize, elem):
+@pytest.mark.parametrize("d,dbsize,elem,batch", [(2, 300, 288, 4), (1, 120, 288, 2)])
+def test_row_sharded_step_over_gloo(d, dbsize, elem, batch):
     ctx = mp.get_context("spawn")
     out_q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, d, dbsize, elem, out_q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, d, dbsize, elem, batch, out_q)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(180)
+        p.join(300)
         assert p.exitcode == 0
-    assert out_q.get(timeout=5) is True
+    got = dict(out_q.get(timeout=5) for _ in range(2))
+    assert got == {0: True, 1: True}

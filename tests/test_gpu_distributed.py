@@ -1,0 +1,101 @@
+"""The row-sharded multi-GPU step with the REAL server (libpirgpu) under torch.distributed, world size 2.
+
+The test box has one GPU: both ranks create their shard context on cuda:0 and the collectives run over gloo through
+host memory (pir_amd.distributed.Comm stages device tensors when the backend is not RCCL) -- every line of the
+step except the RCCL calls themselves is the code `bench.py --gpus N` runs.  Packed exchange (all-gather of packed
+column selectors, all-to-all of row selectors, reduce-scatter) and whole-selection-vector exchange, both against
+the oracle's full-database replies, plus the world-size-1 degenerate case in-process."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _step(rank, world, dist, items, batch, out):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import pir_amd
+    from pir_amd import distributed as D
+    from gpu_helpers import to_product_params
+    from pir_fixtures import PirSetup
+    s = PirSetup(items, 288, 2, N=4096, plain_bits=24)
+    p = s.params
+    pp = to_product_params(p)
+    shard = D.shard_range(p.dimensions[0], rank, world) if world > 1 else None
+    db = pir_amd.PIRDatabase.Create(pp, s.raw, shard=shard)
+    srv = pir_amd.PIRServer(db, pp)
+    srv.set_galois_keys(s.galois_keys)
+    srv.set_concurrency(8)
+    indexes = [(items - 1 - 131 * i) % items for i in range(batch)]
+    queries = np.stack([s.client.create_query_for(p, i) for i in indexes])
+    srv.stage_batch(queries)
+    comm = D.Comm(dist, world)
+    dev = "cuda:0"
+    full = [s.orc.process_query(s.db_ntt, p.dimensions, q, s.galois_keys)[1] for q in queries]
+    ok = True
+    assert D.packed_exchange_supported(srv, dist, world, comm, torch, dev), srv.scan_info()
+    bufs = D.PackedBuffers(srv, batch, rank, world, torch, dev)
+    for _ in range(2):                                            # twice: buffers and workers are reused
+        D.run_batch_rows_packed(srv, bufs, dist, rank, world, comm)
+        lo, hi = D.owned_queries(batch, rank, world)
+        mine = bufs.replies.cpu().numpy().view(np.uint64)
+        for i in range(lo, hi):
+            same = bool(np.array_equal(mine[i - lo], full[i]))
+            if not same:
+                print("rank %d: packed step, query %d differs" % (rank, i), flush=True)
+            ok &= same
+    sv_all = torch.empty((batch, p.dim_sum, 2, srv.k, srv.N), dtype=torch.int64, device=dev)
+    replies = torch.empty((batch, db.reply_ct_count(), 2, srv.k, srv.N), dtype=torch.int64, device=dev)
+    D.run_batch_query_parallel(srv, sv_all, replies, dist, rank, world, comm)
+    allr = replies.cpu().numpy().view(np.uint64)
+    for i in range(batch):
+        same = bool(np.array_equal(allr[i], full[i]))
+        if not same:
+            print("rank %d: selection-vector step, query %d differs" % (rank, i), flush=True)
+        ok &= same
+    out.append(ok)
+    db.close()
+
+
+def _worker(rank, world, port, items, batch, out_q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out = []
+        _step(rank, world, dist, items, batch, out)
+        out_q.put((rank, out[0]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("items,batch", [(10800, 4), (10800, 18)])   # 270 plaintexts = 17 x 16: shards of 8 and 9 rows
+def test_row_sharded_step_two_ranks_one_gpu(items, batch):
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, items, batch, out_q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    assert dict(out_q.get(timeout=5) for _ in range(2)) == {0: True, 1: True}
+
+
+def test_row_sharded_step_world_size_one():
+    out = []
+    _step(0, 1, None, 10800, 3, out)
+    assert out == [True]

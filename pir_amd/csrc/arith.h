@@ -103,4 +103,23 @@ __device__ __forceinline__ uint64_t f64_to_u64(double r) {
   return ((uint64_t)hi << 32) | lo;
 }
 
+// ---- 40-bit packed storage of signed representatives (fp64 flavours, every modulus < 2^39) ----
+//
+// A key-switch intermediate x (an exact integer, |x| <= q) is kept in HBM as the unsigned integer u = x + q
+// < 2^40: 4 low bytes + 1 high byte (5 N bytes per polynomial instead of 8 N).  Adding the magic constant
+// 2^52 + q to the double puts u into the low mantissa bits, so packing is ONE v_add_f64 (the low word and the
+// low byte of the high word are stored as they are) and unpacking is one v_or + one v_add_f64 -- against ~10
+// conversion instructions per element for a canonical u64 round trip.
+__device__ __forceinline__ double f64_pack_magic(double q) { return 4503599627370496.0 + q; }  // 2^52 + q
+
+__device__ __forceinline__ void f64_pack40(double x, double magic, uint32_t& lo, uint32_t& hi) {
+  const uint64_t b = (uint64_t)__double_as_longlong(x + magic);
+  lo = (uint32_t)b;
+  hi = (uint32_t)(b >> 32);  // stored with a byte store: only bits 32..39 of u
+}
+
+__device__ __forceinline__ double f64_unpack40(uint32_t lo, uint32_t hi_byte, double magic) {
+  return __longlong_as_double((long long)(((uint64_t)(0x43300000u | hi_byte) << 32) | lo)) - magic;
+}
+
 }  // namespace pirgpu

@@ -250,6 +250,8 @@ void build_tables(pirgpu_ctx* c) {
   hp.ntt_mode = c->mode;
   const uint64_t p = c->prm.special_prime, t = c->prm.plain_modulus;
   hp.p_half = p >> 1;
+  hp.p_f = (double)p;
+  hp.p_half_f = (double)(p >> 1);
   hp.t = t;
   hp.plain_thr = (t + 1) >> 1;
   for (uint32_t j = 0; j < k; ++j) {
@@ -257,6 +259,7 @@ void build_tables(pirgpu_ctx* c) {
     hp.p_half_mod[j] = (p >> 1) % q;
     hp.p_inv[j] = hm::invmod_prime(p % q, q);
     hp.p_inv_s[j] = hm::shoup(hp.p_inv[j], q);
+    hp.p_inv_f[j] = hp.p_inv[j] > q / 2 ? -(double)(q - hp.p_inv[j]) : (double)hp.p_inv[j];
     hp.lift_inc[j] = q - (t % q);
   }
   // CiphertextReencoder::Encode order (reference ct_reencoder.cpp:49-69)
@@ -385,7 +388,8 @@ void ensure_workspace(pirgpu_ctx* c) {
     //   PIRGPU_SCAN_MFMA=0 keeps the 64-bit multiply-accumulate kernels for d >= 2 as well
     //   PIRGPU_SCAN_MFMA_NQ queries per database pass of the MFMA scan in batch mode (1..8)
     c->pack40 = env_u32("PIRGPU_PACK40", 1) != 0;
-    for (uint32_t j = 0; j <= k; ++j) c->pack40 = c->pack40 && (c->hp.mod[j].q >> 40) == 0;
+    // 5-byte storage of the key-switch intermediates: the fp64 flavours store x + q (|x| <= q), so q < 2^39
+    for (uint32_t j = 0; j <= k; ++j) c->pack40 = c->pack40 && (c->hp.mod[j].q >> 39) == 0;
     c->mg = mfma_geometry(c->hp, c->scan_rows, c->scan_cols);
     c->mfma_on = env_u32("PIRGPU_SCAN_MFMA", 1) != 0 && d >= 2 && c->mg.L != 0 && c->scan_rows >= 8 && shard_pts > 0;
     c->mfma_nq = std::max<uint32_t>(1, std::min<uint32_t>(env_u32("PIRGPU_SCAN_MFMA_NQ", kMaxMfmaQueries),
@@ -482,8 +486,8 @@ uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* 
     HIP_TRY(c->ops->ks_mac_intt(st, c->mode, c->dp, k, dig, key, nodes, prod, c->pack40));
     // outputs n*B.. of the last level are never read (only the first n results per query are used)
     const uint32_t hi_limit = j + 1 == logm ? n * B : UINT32_MAX;
-    HIP_TRY(launch_ks_combine(st, c->dp, N, k, cur, prod, galois_inverse(g, N), nodes, 1u << j, true, hi_limit, c->pack40,
-                              nxt));
+    HIP_TRY(launch_ks_combine(st, c->dp, c->mode, N, k, cur, prod, galois_inverse(g, N), nodes, 1u << j, true, hi_limit,
+                              c->pack40, nxt));
     std::swap(cur, nxt);
   }
   return cur;
@@ -497,7 +501,7 @@ uint64_t* expand_on_device(pirgpu_ctx* c, Worker& w, uint32_t n) {
 // expansion of all staged query ciphertexts into sv_ntt (NTT form) -- reference
 // server.cpp:148-171 followed by the lazy transform_to_ntt_inplace of
 // database.cpp:190,222 applied to every selector.
-void expand_query_to_sv(pirgpu_ctx* c, Worker& w, const uint64_t* d_query, uint32_t nq, uint64_t* coeff_out_host) {
+void expand_query_to_sv(pirgpu_ctx* c, Worker& w, const uint64_t* d_query, uint32_t nq) {
   ensure_expansion_buffers(c, w);
   w.sv_cur = nullptr;
   w.sv_rows = nullptr;
@@ -508,14 +512,10 @@ void expand_query_to_sv(pirgpu_ctx* c, Worker& w, const uint64_t* d_query, uint3
   for (uint32_t q = 0; q < nq; ++q) {
     uint32_t n = (uint32_t)std::min<uint64_t>(remaining, N);
     if (n > 0) {
-      HIP_TRY(hipMemcpyAsync(w.res_a, d_query + (size_t)q * ctw, ctw * 8, hipMemcpyDeviceToDevice, w.stream));
+      // the query ciphertext (canonical u64) becomes the root of the expansion tree (the tree's element type)
+      HIP_TRY(launch_tree_convert(w.stream, c->dp, c->mode, d_query + (size_t)q * ctw, w.res_a, ctw, true));
       uint64_t* res = expand_on_device(c, w, n);
-      if (coeff_out_host) {
-        HIP_TRY(hipMemcpyAsync(coeff_out_host + produced * ctw, res, (size_t)n * ctw * 8, hipMemcpyDeviceToHost,
-                               w.stream));
-      } else {
-        HIP_TRY(c->ops->ct_ntt_fwd_oop(w.stream, c->mode, c->dp, k, res, w.sv_ntt + produced * ctw, n));
-      }
+      HIP_TRY(c->ops->ct_ntt_fwd_oop(w.stream, c->mode, c->dp, k, res, w.sv_ntt + produced * ctw, n, true));
     }
     produced += n;
     remaining -= n;
@@ -652,7 +652,7 @@ void run_staged(pirgpu_ctx* c, Worker& w, bool profile) {
   record(c, w, PH_EXPAND);
   // expansion and selection-vector NTT are interleaved per query ciphertext; the
   // PH_SVNTT mark is taken after the last expansion level of the last ciphertext.
-  expand_query_to_sv(c, w, w.d_query, w.staged_nq, nullptr);
+  expand_query_to_sv(c, w, w.d_query, w.staged_nq);
   record(c, w, PH_SVNTT);
   record(c, w, PH_SCAN);
   multiply_on_device(c, w);
@@ -1099,10 +1099,13 @@ int pirgpu_expand(pirgpu_ctx* c, const uint64_t* ct, uint32_t num_items, uint64_
     const uint64_t m_max = std::min<uint64_t>(c->N, hm::next_power_two(std::max<uint32_t>(c->dim_sum, 1)));
     if (hm::next_power_two(num_items) > m_max)
       return fail(c, PIRGPU_INVALID_ARGUMENT, "num_items exceeds this context's expansion workspace");
-    HIP_TRY(hipMemcpyAsync(w.res_a, ct, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(w.res_b, ct, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_tree_convert(c->stream, c->dp, c->mode, w.res_b, w.res_a, c->ctw, true));
     uint64_t* res = expand_on_device(c, w, num_items);
-    if (num_items)
+    if (num_items) {  // tree element type -> canonical residues (in place), then out
+      HIP_TRY(launch_tree_convert(c->stream, c->dp, c->mode, res, res, (uint64_t)num_items * c->ctw, false));
       HIP_TRY(hipMemcpyAsync(out, res, (size_t)num_items * c->ctw * 8, hipMemcpyDeviceToHost, c->stream));
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PIRGPU_OK;
   });
@@ -1122,8 +1125,10 @@ int pirgpu_expand_multi(pirgpu_ctx* c, const uint64_t* cts, uint32_t num_cts, ui
       uint32_t n = (uint32_t)std::min<uint64_t>(remaining, c->N);
       if (hm::next_power_two(n) > m_max)
         return fail(c, PIRGPU_INVALID_ARGUMENT, "total_items exceeds this context's expansion workspace");
-      HIP_TRY(hipMemcpyAsync(w.res_a, cts + (size_t)q * c->ctw, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(hipMemcpyAsync(w.res_b, cts + (size_t)q * c->ctw, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(launch_tree_convert(c->stream, c->dp, c->mode, w.res_b, w.res_a, c->ctw, true));
       uint64_t* res = expand_on_device(c, w, n);
+      HIP_TRY(launch_tree_convert(c->stream, c->dp, c->mode, res, res, (uint64_t)n * c->ctw, false));
       HIP_TRY(hipMemcpyAsync(out + produced * c->ctw, res, (size_t)n * c->ctw * 8, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(hipStreamSynchronize(c->stream));
       produced += n;
@@ -1141,11 +1146,13 @@ int pirgpu_substitute_power_x(pirgpu_ctx* c, uint64_t* ct, uint32_t power) {
     if (!(power & 1) || power >= 2 * c->N)  // SEAL: "Galois element is not valid" -> InternalError
       return fail(c, PIRGPU_INTERNAL, "Galois element is not valid");
     const uint64_t* key = find_key(c, power);
-    HIP_TRY(hipMemcpyAsync(w.res_a, ct, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(w.res_b, ct, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_tree_convert(c->stream, c->dp, c->mode, w.res_b, w.res_a, c->ctw, true));
     HIP_TRY(c->ops->ks_digit(c->stream, c->mode, c->dp, c->k, w.res_a, power, 1, w.dig, c->pack40));
     HIP_TRY(c->ops->ks_mac_intt(c->stream, c->mode, c->dp, c->k, w.dig, key, 1, w.prod, c->pack40));
-    HIP_TRY(launch_ks_combine(c->stream, c->dp, c->N, c->k, w.res_a, w.prod, galois_inverse(power, c->N), 1, 0,
+    HIP_TRY(launch_ks_combine(c->stream, c->dp, c->mode, c->N, c->k, w.res_a, w.prod, galois_inverse(power, c->N), 1, 0,
                               false, /*hi_limit: unused without the expand step*/ 0, c->pack40, w.res_b));
+    HIP_TRY(launch_tree_convert(c->stream, c->dp, c->mode, w.res_b, w.res_b, c->ctw, false));
     HIP_TRY(hipMemcpyAsync(ct, w.res_b, c->ctw * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PIRGPU_OK;
@@ -1180,7 +1187,7 @@ int pirgpu_multiply(pirgpu_ctx* c, const uint64_t* sv, uint64_t sv_count, uint64
     for (uint64_t s = 0; s < sv_count; s += m_max) {
       const uint64_t n = std::min<uint64_t>(m_max, sv_count - s);
       HIP_TRY(hipMemcpyAsync(w.res_a, sv + s * c->ctw, n * c->ctw * 8, hipMemcpyHostToDevice, c->stream));
-      HIP_TRY(c->ops->ct_ntt_fwd_oop(c->stream, c->mode, c->dp, c->k, w.res_a, w.sv_ntt + s * c->ctw, n));
+      HIP_TRY(c->ops->ct_ntt_fwd_oop(c->stream, c->mode, c->dp, c->k, w.res_a, w.sv_ntt + s * c->ctw, n, false));
       HIP_TRY(hipStreamSynchronize(c->stream));
     }
     c->prof_cur = -1;
@@ -1285,8 +1292,10 @@ static void expand_group_on_lane(pirgpu_ctx* c, BatchLane& ln, Worker* const* me
   uint64_t remaining = c->dim_sum, produced = 0;
   for (uint32_t qc = 0; qc < nq && remaining; ++qc) {
     const uint32_t slots = (uint32_t)std::min<uint64_t>(remaining, N);
-    HIP_TRY(hipMemcpy2DAsync(ln.res_a, ctw * 8, c->d_bquery + (size_t)first * qwords + (size_t)qc * ctw, qwords * 8,
+    // the B query ciphertexts side by side (staged in res_b) become the roots of the B interleaved trees
+    HIP_TRY(hipMemcpy2DAsync(ln.res_b, ctw * 8, c->d_bquery + (size_t)first * qwords + (size_t)qc * ctw, qwords * 8,
                              ctw * 8, B, hipMemcpyDeviceToDevice, ln.stream));
+    HIP_TRY(launch_tree_convert(ln.stream, c->dp, c->mode, ln.res_b, ln.res_a, (uint64_t)B * ctw, true));
     uint64_t* res = expand_core(c, ln.stream, ln.res_a, ln.res_b, ln.dig, ln.prod, slots, B);
     MfmaPtrs dst{};
     for (uint32_t q = 0; q < B; ++q) dst.p[q] = members[q]->sv_ntt + produced * ctw;
@@ -1471,7 +1480,7 @@ int pirgpu_batch_expand(pirgpu_ctx* c, uint32_t first, uint32_t count, uint64_t*
       HIP_TRY(hipMemcpyAsync(w.d_query, c->d_bquery + (size_t)(first + i) * qwords, qwords * 8,
                              hipMemcpyDeviceToDevice, w.stream));
       w.staged_nq = nq;
-      expand_query_to_sv(c, w, w.d_query, nq, nullptr);
+      expand_query_to_sv(c, w, w.d_query, nq);
       HIP_TRY(hipMemcpyAsync(device_dst + (size_t)i * svwords, w.sv_ntt, svwords * 8, hipMemcpyDeviceToDevice,
                              w.stream));
     }

@@ -52,6 +52,9 @@ struct DevParams {
   uint64_t p_half_mod[kMaxPrimes];  // floor(p/2) mod q_j
   uint64_t p_inv[kMaxPrimes];       // p^-1 mod q_j
   uint64_t p_inv_s[kMaxPrimes];     // Shoup quotient of p_inv
+  // the same for the fp64 flavours: p, (p-1)/2 and the centred p^-1 mod q_j as doubles
+  double p_f, p_half_f;
+  double p_inv_f[kMaxPrimes];
   // plain lift
   uint64_t t, plain_thr;
   uint64_t lift_inc[kMaxPrimes];    // q_j - (t mod q_j)

@@ -19,8 +19,9 @@ struct NttOps {
   hipError_t (*configure)(int mode);
   hipError_t (*ntt_batch)(hipStream_t st, int mode, const DevParams* P, uint64_t* data, uint64_t n_polys,
                           uint32_t mod_period, uint32_t mod_base, bool inverse);
+  // src_is_tree: the source holds the expansion tree's element type (doubles in the fp64 flavours)
   hipError_t (*ct_ntt_fwd_oop)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* src,
-                               uint64_t* dst, uint64_t n_cts);
+                               uint64_t* dst, uint64_t n_cts, bool src_is_tree);
   // same transform for B interleaved queries (source ciphertext i*B + q -> dst.p[q] + i): batched expansion
   hipError_t (*ct_ntt_fwd_split)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* src,
                                  const MfmaPtrs& dst, uint32_t B, uint64_t n_cts_total);
@@ -41,9 +42,11 @@ const NttOps* ntt_ops_for(uint32_t N);  // nullptr for unsupported degrees
 
 hipError_t launch_ntt_reorder(hipStream_t st, uint32_t N, const uint64_t* in, uint64_t* out, uint64_t n_polys,
                               bool to_device, bool as_f64);
-hipError_t launch_ks_combine(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* res_in,
-                             const uint64_t* prod, uint32_t galois_inv, uint32_t nodes, uint32_t shift_pow,
-                             bool expand_step, uint32_t hi_limit, bool pack40, uint64_t* res_out);
+hipError_t launch_ks_combine(hipStream_t st, const DevParams* P, int mode, uint32_t N, uint32_t k,
+                             const uint64_t* res_in, const uint64_t* prod, uint32_t galois_inv, uint32_t nodes,
+                             uint32_t shift_pow, bool expand_step, uint32_t hi_limit, bool pack40, uint64_t* res_out);
+hipError_t launch_tree_convert(hipStream_t st, const DevParams* P, int mode, const uint64_t* in, uint64_t* out,
+                               uint64_t words, bool to_tree);
 hipError_t launch_monomial_shift(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* in,
                                  uint32_t shift, uint64_t count, uint64_t* out);
 hipError_t launch_scan(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* db,

@@ -126,6 +126,94 @@ __global__ void ks_combine_kernel(const DevParams* __restrict__ P, const uint64_
   }
 }
 
+// The same step for the fp64 flavours.  The expansion tree is held as doubles (exact integers, signed
+// representatives |x| <= (1/2 + eps) q_j), the key-switch products arrive as signed representatives as well
+// (offset 40-bit packed, arith.h f64_pack40, or plain doubles), and everything is fp64 arithmetic: ~100 VALU
+// instructions per element against ~325 for the 64-bit integer version.  Divide-and-round by the special prime
+// (SURVEY App. A.4): with r = (s + floor(p/2)) mod p, r - floor(p/2) is the CENTRED representative c of the
+// special-prime residue s, so delta_j = c mod q_j; c must be exactly centred (a signed representative may be
+// off-centre by eps p, which would change delta by p mod q_j), the data residue may be any representative.
+template <bool P40>
+__global__ void ks_combine_f64_kernel(const DevParams* __restrict__ P, const double* __restrict__ res_in,
+                                      const uint64_t* __restrict__ prod, uint32_t galois_inv, uint32_t nodes,
+                                      uint32_t shift_pow, int expand_step, uint32_t hi_limit,
+                                      double* __restrict__ res_out) {
+  const uint32_t N = P->N, k = P->k, km = k + 1;
+  const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t total = (uint64_t)nodes * k * N;
+  if (gid >= total) return;
+  const uint32_t i = (uint32_t)(gid & (N - 1));
+  const uint32_t j = (uint32_t)((gid >> P->logN) % k);
+  const uint32_t node = (uint32_t)(gid / ((uint64_t)k * N));
+  const F64Mod mj{P->tab[j].qd, P->tab[j].qinvd};
+  const double pf = P->p_f, half = P->p_half_f, pinv = P->p_inv_f[j];
+  const uint32_t raw = (i * galois_inv) & (2 * N - 1);  // gather index for sigma_g(c0)[i]
+  const uint32_t src_i = raw & (N - 1);
+  const bool neg = raw >= N;
+  double g[2];
+#pragma unroll
+  for (int comp = 0; comp < 2; ++comp) {
+    double sp, dj;  // special-prime and data-prime residues of the key-switch product (signed representatives)
+    if constexpr (P40) {
+      const uint8_t* pr = reinterpret_cast<const uint8_t*>(prod) + ((size_t)node * 2 + comp) * km * 5 * N;
+      const uint8_t* ps = pr + (size_t)k * 5 * N;
+      const uint8_t* pj = pr + (size_t)j * 5 * N;
+      sp = f64_unpack40(reinterpret_cast<const uint32_t*>(ps)[i], ps[4 * (size_t)N + i], f64_pack_magic(pf));
+      dj = f64_unpack40(reinterpret_cast<const uint32_t*>(pj)[i], pj[4 * (size_t)N + i], f64_pack_magic(mj.q));
+    } else {
+      const double* pr = reinterpret_cast<const double*>(prod) + ((size_t)node * 2 + comp) * km * N;
+      sp = pr[(size_t)k * N + i];
+      dj = pr[(size_t)j * N + i];
+    }
+    sp = sp > half ? sp - pf : sp;   // exact centring: c in [-(p-1)/2, (p-1)/2]
+    sp = sp < -half ? sp + pf : sp;
+    const double delta = f64_norm(sp, mj);
+    g[comp] = f64_mulmod(dj - delta, pinv, mj);
+  }
+  const double* a_ct = res_in + (size_t)node * 2 * k * N;
+  const double c0 = a_ct[(size_t)j * N + src_i];
+  g[0] += neg ? -c0 : c0;
+  if (!expand_step) {
+    double* o = res_out + (size_t)node * 2 * k * N;
+    o[(size_t)j * N + i] = f64_norm(g[0], mj);
+    o[((size_t)k + j) * N + i] = g[1];
+    return;
+  }
+  const uint32_t sraw = i + (2 * N - shift_pow);  // x^(-2^j): negacyclic shift by 2N - shift_pow
+  const uint32_t sidx = sraw & (N - 1);
+  const bool sneg = (sraw & N) != 0;
+  double* lo = res_out + (size_t)node * 2 * k * N;
+  double* hi = res_out + ((size_t)node + nodes) * 2 * k * N;
+  const bool want_hi = node + nodes < hi_limit;
+#pragma unroll
+  for (int comp = 0; comp < 2; ++comp) {
+    const size_t off = ((size_t)comp * k + j) * N;
+    const double a = a_ct[off + i];
+    lo[off + i] = f64_norm(a + g[comp], mj);
+    if (!want_hi) continue;
+    const double d = f64_norm(a - g[comp], mj);
+    hi[off + sidx] = sneg ? -d : d;
+  }
+}
+
+// Expansion tree <-> canonical u64 ciphertexts for the fp64 flavours (query import, test-hook export).
+__global__ void tree_import_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ in,
+                                   double* __restrict__ out, uint64_t words) {
+  const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= words) return;
+  const uint32_t j = (uint32_t)((gid >> P->logN) % P->k);
+  out[gid] = f64_norm(f64_from_u64(in[gid]), F64Mod{P->tab[j].qd, P->tab[j].qinvd});
+}
+
+__global__ void tree_export_kernel(const DevParams* __restrict__ P, const double* __restrict__ in,
+                                   uint64_t* __restrict__ out, uint64_t words) {
+  const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= words) return;
+  const uint32_t j = (uint32_t)((gid >> P->logN) % P->k);
+  const F64Mod m{P->tab[j].qd, P->tab[j].qinvd};
+  out[gid] = f64_to_u64(f64_canon(f64_norm(in[gid], m), m));
+}
+
 // multiply_inverse_power_of_x on whole ciphertexts (reference server.cpp:78-103).
 __global__ void monomial_shift_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ in,
                                       uint32_t shift, uint64_t count, uint64_t* __restrict__ out) {
@@ -627,16 +715,42 @@ hipError_t launch_ntt_reorder(hipStream_t st, uint32_t N, const uint64_t* in, ui
   return hipSuccess;
 }
 
-hipError_t launch_ks_combine(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* res_in,
-                             const uint64_t* prod, uint32_t galois_inv, uint32_t nodes, uint32_t shift_pow,
-                             bool expand_step, uint32_t hi_limit, bool pack40, uint64_t* res_out) {
-  uint64_t total = (uint64_t)nodes * k * N;
-  if (pack40)
-    hipLaunchKernelGGL(ks_combine_kernel<true>, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, P, res_in,
-                       prod, galois_inv, nodes, shift_pow, expand_step ? 1 : 0, hi_limit, res_out);
+hipError_t launch_ks_combine(hipStream_t st, const DevParams* P, int mode, uint32_t N, uint32_t k,
+                             const uint64_t* res_in, const uint64_t* prod, uint32_t galois_inv, uint32_t nodes,
+                             uint32_t shift_pow, bool expand_step, uint32_t hi_limit, bool pack40, uint64_t* res_out) {
+  const uint64_t total = (uint64_t)nodes * k * N;
+  const dim3 grid((uint32_t)((total + 255) / 256)), block(256);
+  if (mode != kNttInt) {  // fp64 flavours: tree and products are doubles / offset-packed signed representatives
+    const double* in = reinterpret_cast<const double*>(res_in);
+    double* out = reinterpret_cast<double*>(res_out);
+    if (pack40)
+      hipLaunchKernelGGL(ks_combine_f64_kernel<true>, grid, block, 0, st, P, in, prod, galois_inv, nodes, shift_pow,
+                         expand_step ? 1 : 0, hi_limit, out);
+    else
+      hipLaunchKernelGGL(ks_combine_f64_kernel<false>, grid, block, 0, st, P, in, prod, galois_inv, nodes, shift_pow,
+                         expand_step ? 1 : 0, hi_limit, out);
+  } else if (pack40) {
+    hipLaunchKernelGGL(ks_combine_kernel<true>, grid, block, 0, st, P, res_in, prod, galois_inv, nodes, shift_pow,
+                       expand_step ? 1 : 0, hi_limit, res_out);
+  } else {
+    hipLaunchKernelGGL(ks_combine_kernel<false>, grid, block, 0, st, P, res_in, prod, galois_inv, nodes, shift_pow,
+                       expand_step ? 1 : 0, hi_limit, res_out);
+  }
+  PIRGPU_LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+// canonical u64 ciphertext words <-> the expansion tree's element type (doubles in the fp64 flavours; a plain
+// copy for the integer flavour)
+hipError_t launch_tree_convert(hipStream_t st, const DevParams* P, int mode, const uint64_t* in, uint64_t* out,
+                               uint64_t words, bool to_tree) {
+  if (!words) return hipSuccess;
+  if (mode == kNttInt) return hipMemcpyAsync(out, in, words * 8, hipMemcpyDeviceToDevice, st);
+  const dim3 grid((uint32_t)((words + 255) / 256)), block(256);
+  if (to_tree)
+    hipLaunchKernelGGL(tree_import_kernel, grid, block, 0, st, P, in, reinterpret_cast<double*>(out), words);
   else
-    hipLaunchKernelGGL(ks_combine_kernel<false>, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, P, res_in,
-                       prod, galois_inv, nodes, shift_pow, expand_step ? 1 : 0, hi_limit, res_out);
+    hipLaunchKernelGGL(tree_export_kernel, grid, block, 0, st, P, reinterpret_cast<const double*>(in), out, words);
   PIRGPU_LAUNCH_CHECK();
   return hipSuccess;
 }

@@ -84,6 +84,7 @@ struct Arith<kNttInt> {
     return v >= m.q ? v - m.q : v;
   }
   static __device__ __forceinline__ T canon_inv(T v, const Mod& m) { return v >= m.q ? v - m.q : v; }
+  static __device__ __forceinline__ T signed_fwd(T v, const Mod& m) { return canon_fwd(v, m); }
   static __device__ __forceinline__ T pass_norm(T v, const Mod&) { return v; }
 };
 
@@ -126,6 +127,7 @@ struct ArithF64 {
     b = f64_mulmod(d, iw1n, m);
   }
   static __device__ __forceinline__ T canon_fwd(T v, const Mod& m) { return f64_canon(f64_norm(v, m), m); }
+  static __device__ __forceinline__ T signed_fwd(T v, const Mod& m) { return f64_norm(v, m); }
   static __device__ __forceinline__ T canon_inv(T v, const Mod& m) { return f64_canon(v, m); }
 };
 
@@ -213,7 +215,8 @@ __device__ __forceinline__ void fwd_chain(typename A::T (&x)[16], typename A::T*
 // Out: x[e] = SEAL NTT position 16*tid + e == device-order slot e*NT + tid, canonical
 // representative (A::out gives the residue).  The caller guarantees nobody still reads
 // `s` (barrier) when this is entered.
-template <int MODE, int LOGN, bool PF = true>
+// CANON = false (fp64 flavours only): leave signed representatives |x| <= (1/2 + eps) q instead of canonical ones.
+template <int MODE, int LOGN, bool PF = true, bool CANON = true>
 __device__ __forceinline__ void ntt_forward(typename Arith<MODE>::T (&x)[16], void* lds, const DevParams* P, int mi,
                                             uint32_t tid) {
   using A = Arith<MODE>;
@@ -224,7 +227,10 @@ __device__ __forceinline__ void ntt_forward(typename Arith<MODE>::T (&x)[16], vo
   load_twiddles<A, LOGN, LOGN - 4, 3, 0>(W0, tw, 0u);
   fwd_chain<A, LOGN, LOGN - 4, 3, PF>(x, s, tw, m, tid, W0);
 #pragma unroll
-  for (int e = 0; e < 16; ++e) x[e] = A::canon_fwd(x[e], m);
+  for (int e = 0; e < 16; ++e) {
+    if constexpr (CANON) x[e] = A::canon_fwd(x[e], m);
+    else x[e] = A::signed_fwd(x[e], m);
+  }
 }
 
 // Gentleman-Sande stages for relative bits RLO..3 (low to high) with preloaded twiddles; with
@@ -284,7 +290,7 @@ __device__ __forceinline__ void inv_chain(typename A::T (&x)[16], typename A::T*
 // Inverse NTT.  In: x[e] = NTT position 16*tid + e (any representative the flavour
 // accepts: < 2q for integers, |v| <= 4q for fp64).  Out: x[e] = coefficient e*NT + tid,
 // canonical, scaled by N^-1.
-template <int MODE, int LOGN, bool PF = true>
+template <int MODE, int LOGN, bool PF = true, bool CANON = true>
 __device__ __forceinline__ void ntt_inverse(typename Arith<MODE>::T (&x)[16], void* lds, const DevParams* P, int mi,
                                             uint32_t tid) {
   static_assert(LOGN >= 8, "at least two passes expected");
@@ -296,8 +302,10 @@ __device__ __forceinline__ void ntt_inverse(typename Arith<MODE>::T (&x)[16], vo
   typename A::TW W0[15];
   load_twiddles<A, LOGN, 0, 3, 0>(W0, itw, tid);
   inv_chain<A, LOGN, 0, 0, PF>(x, s, itw, ninv, iw1n, m, tid, W0);
+  if constexpr (CANON) {
 #pragma unroll
-  for (int e = 0; e < 16; ++e) x[e] = A::canon_inv(x[e], m);
+    for (int e = 0; e < 16; ++e) x[e] = A::canon_inv(x[e], m);
+  }  // else: the last stage's products already are signed representatives
 }
 
 }  // namespace pirgpu

@@ -56,6 +56,17 @@ __device__ __forceinline__ void store40(uint8_t* poly, uint32_t i, uint64_t v) {
   poly[4 * N + i] = (uint8_t)(v >> 32);
 }
 
+// fp64 flavours: signed representative <-> offset 40-bit storage (arith.h f64_pack40)
+__device__ __forceinline__ double load40f(const uint8_t* poly, uint32_t i, double magic) {
+  return f64_unpack40(reinterpret_cast<const uint32_t*>(poly)[i], poly[4 * N + i], magic);
+}
+__device__ __forceinline__ void store40f(uint8_t* poly, uint32_t i, double x, double magic) {
+  uint32_t lo, hi;
+  f64_pack40(x, magic, lo, hi);
+  reinterpret_cast<uint32_t*>(poly)[i] = lo;
+  poly[4 * N + i] = (uint8_t)hi;
+}
+
 // One workgroup per polynomial; modulus index = mod_base + (poly % mod_period).
 // Forward: natural coefficients -> device NTT order; inverse: the reverse.  In place.
 template <int MODE, bool INVERSE>
@@ -79,8 +90,9 @@ ntt_batch_kernel(const DevParams* __restrict__ P, uint64_t* __restrict__ data, u
 }
 
 // Out-of-place forward NTT of ciphertexts: src[ct][2][k][N] (coefficient form)
-// -> dst[ct][2][k][N] (device NTT order); selection vector -> NTT form.
-template <int MODE>
+// -> dst[ct][2][k][N] (device NTT order); selection vector -> NTT form.  SRC_TREE: the source is the
+// expansion tree (element type A::T: doubles holding signed representatives in the fp64 flavours).
+template <int MODE, bool SRC_TREE>
 __global__ void __launch_bounds__(NT)
 ct_ntt_fwd_oop_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ src, uint64_t* __restrict__ dst) {
   using A = Arith<MODE>;
@@ -91,7 +103,10 @@ ct_ntt_fwd_oop_kernel(const DevParams* __restrict__ P, const uint64_t* __restric
   uint64_t* out = dst + (size_t)blockIdx.x * N;
   typename A::T x[16];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) x[e] = A::in(in[e * NT + tid], m);
+  for (int e = 0; e < 16; ++e) {
+    if constexpr (SRC_TREE) x[e] = reinterpret_cast<const typename A::T*>(in)[e * NT + tid];
+    else x[e] = A::in(in[e * NT + tid], m);
+  }
   ntt_forward<MODE, LOGN, kPF>(x, smem_raw, P, mi, tid);
 #pragma unroll
   for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
@@ -109,11 +124,11 @@ ct_ntt_fwd_split_kernel(const DevParams* __restrict__ P, const uint64_t* __restr
   const typename A::Mod m = A::mod(P, mi);
   const uint32_t ct = blockIdx.x / k2, rem = blockIdx.x % k2;
   const uint32_t slot = ct / B, q = ct % B;
-  const uint64_t* in = src + (size_t)blockIdx.x * N;
+  const typename A::T* in = reinterpret_cast<const typename A::T*>(src) + (size_t)blockIdx.x * N;  // the expansion tree
   uint64_t* out = (uint64_t*)dst.p[q] + ((size_t)slot * k2 + rem) * N;
   typename A::T x[16];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) x[e] = A::in(in[e * NT + tid], m);
+  for (int e = 0; e < 16; ++e) x[e] = in[e * NT + tid];
   ntt_forward<MODE, LOGN, kPF>(x, smem_raw, P, mi, tid);
 #pragma unroll
   for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
@@ -201,30 +216,63 @@ ks_digit_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ re
   const typename A::Mod m = A::mod(P, I);
   const uint64_t qJ = P->mod[J].q;
   const uint64_t* src = res_in + (((size_t)node * 2 + 1) * k + J) * N;  // poly 1, residue J
-  // sigma_g in coefficient form (SEAL GaloisTool::apply_galois), then reduce mod m_I
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const uint32_t i = e * NT + tid;
-    const uint32_t raw = i * galois_elt;
-    uint64_t v = src[i];
-    if ((raw >> LOGN) & 1) v = neg_mod(v, qJ);
-    s[lds_idx(raw & (N - 1))] = reduce64(v, mI);
-  }
-  __syncthreads();
   typename A::T x[16];
+  if constexpr (MODE == kNttInt) {
+    // sigma_g in coefficient form (SEAL GaloisTool::apply_galois), then reduce mod m_I
 #pragma unroll
-  for (int e = 0; e < 16; ++e) x[e] = A::in(s[lds_idx(e * NT + tid)], m);
-  __syncthreads();  // the transform reuses the same LDS words with its own element type
-  ntt_forward<MODE, LOGN, kPF>(x, smem_raw, P, I, tid);
-  const size_t poly = ((size_t)node * (k + 1) + I) * k + J;
-  if constexpr (P40) {
-    uint8_t* out = reinterpret_cast<uint8_t*>(dig) + poly * kPoly40;
+    for (int e = 0; e < 16; ++e) {
+      const uint32_t i = e * NT + tid;
+      const uint32_t raw = i * galois_elt;
+      uint64_t v = src[i];
+      if ((raw >> LOGN) & 1) v = neg_mod(v, qJ);
+      s[lds_idx(raw & (N - 1))] = reduce64(v, mI);
+    }
+    __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 16; ++e) store40(out, e * NT + tid, A::out(x[e], m));
+    for (int e = 0; e < 16; ++e) x[e] = A::in(s[lds_idx(e * NT + tid)], m);
   } else {
-    typename A::T* out = reinterpret_cast<typename A::T*>(dig) + poly * N;
+    // fp64 flavours: the tree holds doubles (signed representatives, |v| <= (1/2 + eps) q_J); sigma_g's sign
+    // is the double's sign bit.  The RNS digit is the CANONICAL residue in [0, q_J) read as an integer and
+    // reduced mod m_I (D_j mod m_i), so the representative is made canonical before it
+    // changes modulus; as a butterfly input mod m_I it is then fine as it stands in the plain fp64 flavour
+    // (every modulus < 2^46: inputs up to 2^52 are exact), the wide flavour normalises it.
+    double* sd = reinterpret_cast<double*>(smem_raw);
+    const double* srcd = reinterpret_cast<const double*>(src);
+    const bool norm_in = MODE == kNttF64Wide && I != J;
+    const double qJd = P->tab[J].qd;
+    const uint32_t raw0 = tid * galois_elt, rstep = (uint32_t)NT * galois_elt;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) out[e * NT + tid] = x[e];
+    for (int e = 0; e < 16; ++e) {
+      const uint32_t raw = raw0 + (uint32_t)e * rstep;
+      const uint64_t sign = (uint64_t)((raw << (31 - LOGN)) & 0x80000000u) << 32;
+      double v = __longlong_as_double((long long)((uint64_t)__double_as_longlong(srcd[e * NT + tid]) ^ sign));
+      v = v < 0.0 ? v + qJd : v;  // -0.0 stays 0
+      if (norm_in) v = f64_norm(v, m);
+      sd[lds_idx(raw & (N - 1))] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x[e] = sd[lds_idx(e * NT + tid)];
+  }
+  __syncthreads();  // the transform reuses the same LDS words with its own element type
+  const size_t poly = ((size_t)node * (k + 1) + I) * k + J;
+  if constexpr (P40 && MODE != kNttInt) {
+    ntt_forward<MODE, LOGN, kPF, /*CANON=*/false>(x, smem_raw, P, I, tid);  // signed representatives, |x| <= q/2
+    uint8_t* out = reinterpret_cast<uint8_t*>(dig) + poly * kPoly40;
+    const double magic = f64_pack_magic(m.q);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) store40f(out, e * NT + tid, x[e], magic);
+  } else {
+    ntt_forward<MODE, LOGN, kPF>(x, smem_raw, P, I, tid);
+    if constexpr (P40) {
+      uint8_t* out = reinterpret_cast<uint8_t*>(dig) + poly * kPoly40;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) store40(out, e * NT + tid, A::out(x[e], m));
+    } else {
+      typename A::T* out = reinterpret_cast<typename A::T*>(dig) + poly * N;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) out[e * NT + tid] = x[e];
+    }
   }
 }
 
@@ -257,8 +305,11 @@ ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
   const uint8_t* d40 = reinterpret_cast<const uint8_t*>(dig_raw) + poly0 * kPoly40;
   const T* key = reinterpret_cast<const T*>(key_raw);
   // digit J, element i, in the flavour's register type
+  [[maybe_unused]] double magic = 0.0;
+  if constexpr (MODE != kNttInt) magic = f64_pack_magic(m.q);
   auto digit = [&](uint32_t J, uint32_t i) -> T {
-    if constexpr (P40) return A::in(load40(d40 + (size_t)J * kPoly40, i), m);
+    if constexpr (P40 && MODE != kNttInt) return load40f(d40 + (size_t)J * kPoly40, i, magic);
+    else if constexpr (P40) return A::in(load40(d40 + (size_t)J * kPoly40, i), m);
     else return d0[(size_t)J * N + i];
   };
   T x[16];
@@ -284,8 +335,22 @@ ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
 #pragma unroll
     for (int e = 0; e < 16; ++e) x[e] = f64_norm(x[e], m);
   }
-  ntt_inverse<MODE, LOGN, kPF>(x, smem_raw, P, I, tid);
   const size_t opoly = ((size_t)node * 2 + comp) * km + I;
+  if constexpr (P40 && MODE != kNttInt) {
+    ntt_inverse<MODE, LOGN, kPF, /*CANON=*/false>(x, smem_raw, P, I, tid);  // signed representatives, |x| <= q/2
+    uint8_t* out = reinterpret_cast<uint8_t*>(prod) + opoly * kPoly40;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) store40f(out, e * NT + tid, x[e], magic);
+    return;
+  }
+  if constexpr (MODE != kNttInt) {  // plain doubles (moduli >= 2^39): signed representatives as they are
+    ntt_inverse<MODE, LOGN, kPF, /*CANON=*/false>(x, smem_raw, P, I, tid);
+    T* out = reinterpret_cast<T*>(prod) + opoly * N;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) out[e * NT + tid] = x[e];
+    return;
+  }
+  ntt_inverse<MODE, LOGN, kPF>(x, smem_raw, P, I, tid);
   if constexpr (P40) {
     uint8_t* out = reinterpret_cast<uint8_t*>(prod) + opoly * kPoly40;
 #pragma unroll
@@ -417,7 +482,8 @@ static hipError_t configure_mode() {
   if ((e = hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e
   PIRGPU_SET((ntt_batch_kernel<MODE, false>));
   PIRGPU_SET((ntt_batch_kernel<MODE, true>));
-  PIRGPU_SET(ct_ntt_fwd_oop_kernel<MODE>);
+  PIRGPU_SET((ct_ntt_fwd_oop_kernel<MODE, false>));
+  PIRGPU_SET((ct_ntt_fwd_oop_kernel<MODE, true>));
   PIRGPU_SET(ct_ntt_fwd_split_kernel<MODE>);
   PIRGPU_SET(db_encode_kernel<MODE>);
   PIRGPU_SET((ks_digit_kernel<MODE, false>));
@@ -447,9 +513,13 @@ static hipError_t op_ntt_batch(hipStream_t st, int mode, const DevParams* P, uin
 }
 
 static hipError_t op_ct_ntt_fwd_oop(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* src,
-                                    uint64_t* dst, uint64_t n_cts) {
-  PIRGPU_BY_MODE(mode, hipLaunchKernelGGL(ct_ntt_fwd_oop_kernel<MODE>, dim3((uint32_t)(n_cts * 2 * k)), dim3(NT),
-                                          kLdsBytes, st, P, src, dst));
+                                    uint64_t* dst, uint64_t n_cts, bool src_is_tree) {
+  const dim3 grid((uint32_t)(n_cts * 2 * k));
+  if (src_is_tree) {
+    PIRGPU_BY_MODE(mode, hipLaunchKernelGGL((ct_ntt_fwd_oop_kernel<MODE, true>), grid, dim3(NT), kLdsBytes, st, P, src, dst));
+  } else {
+    PIRGPU_BY_MODE(mode, hipLaunchKernelGGL((ct_ntt_fwd_oop_kernel<MODE, false>), grid, dim3(NT), kLdsBytes, st, P, src, dst));
+  }
   return hipGetLastError();
 }
 

@@ -77,6 +77,21 @@ struct BatchLane {
   uint64_t *res_a = nullptr, *res_b = nullptr, *prod = nullptr, *dig = nullptr;
   uint8_t* selp = nullptr;
   hipEvent_t ev_scanned = nullptr;
+  // the multiply of a whole group runs on the lane's stream in these query-major buffers: one launch per kernel
+  // for the (up to) 8 queries instead of one stream + one launch per query
+  std::vector<uint64_t*> lvl;        // [level][query][lvl_cts[level]][2][k][N]
+  uint64_t* pt_buf = nullptr;        // [query][pt_words]
+  uint64_t* scan_part = nullptr;     // [query][column chunk][scan_rows][2][k][N] (matrices wider than one chunk)
+};
+
+// Where one multiply (scan results -> reply) runs: a worker's buffers (one query) or a lane's (a group).
+struct Stage {
+  hipStream_t stream;
+  uint64_t* const* lvl;   // per level, query-major
+  uint64_t* pt_buf;       // query-major, pt_words each
+  uint32_t n;             // queries
+  MfmaPtrs sel;           // per query: the selection vector (whole, NTT form) or, with local_rows, only this shard's
+  bool local_rows;        // dimension-0 selectors at local index (packed multi-GPU exchange)
 };
 
 struct pirgpu_ctx {
@@ -121,6 +136,9 @@ struct pirgpu_ctx {
   uint32_t batch_cap = 0, batch_count = 0, n_active = 1;
   bool batch_valid = false;
   uint32_t upper_blocks = 512;   // target workgroup count of upper_fused_kernel (PIRGPU_UPPER_BLOCKS)
+  uint32_t upper_blocks_batch = 128;  // the same per query in batch mode, where other queries fill the chip too: fewer
+                                      // chunks = fewer partial sums to write and fold (PIRGPU_UPPER_BLOCKS_BATCH)
+  bool in_batch = false;         // set while the batch pipeline enqueues work
   uint32_t scan_nsplit = 1, scan_cps = 0, scan_rows = 0, scan_cols = 0;
   uint32_t scan_rpt = 4, scan_block = 256;  // rows per thread / workgroup size of the scan kernel
   bool scan_limb = false;                   // 28-bit limb accumulators (all data moduli < 2^50)
@@ -134,6 +152,7 @@ struct pirgpu_ctx {
   MfmaGeom mg{};
   uint32_t mfma_nq = kMaxMfmaQueries;       // queries per database pass in batch mode
   bool mfma_single = true;                  // single queries use it too (off for matrices wider than one chunk)
+  bool fuse_last_level = true;              // last expansion level fused with the selector NTT (PIRGPU_FUSE_LAST=0: off)
   bool pack40 = false;                      // key-switch digits stored in 5 bytes (all moduli < 2^40; PIRGPU_PACK40)
   uint8_t* d_dbp = nullptr;
   bool packed_valid = false;
@@ -289,6 +308,14 @@ void build_tables(pirgpu_ctx* c) {
 
 uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
+// waits for everything the batch pipeline has enqueued: lane streams (grouped expansion + multiply) and worker streams
+void sync_batch_streams(pirgpu_ctx* c) {
+  for (BatchLane& ln : c->lanes)
+    if (ln.stream) HIP_TRY(hipStreamSynchronize(ln.stream));
+  for (Worker& w : c->workers)
+    if (w.stream) HIP_TRY(hipStreamSynchronize(w.stream));
+}
+
 bool all_zero_bytes(const uint8_t* p, size_t n) {
   for (size_t i = 0; i < n; ++i)
     if (p[i]) return false;
@@ -326,6 +353,8 @@ void ensure_workspace(pirgpu_ctx* c) {
   // per-level node counts inside this shard and result buffers
   const uint64_t shard_pts = c->pt_end - c->pt_begin;
   if (const char* v = getenv("PIRGPU_UPPER_BLOCKS")) c->upper_blocks = std::max(1, atoi(v));
+  if (const char* v = getenv("PIRGPU_UPPER_BLOCKS_BATCH")) c->upper_blocks_batch = std::max(1, atoi(v));
+  c->upper_blocks_batch = std::min(c->upper_blocks_batch, c->upper_blocks);  // the scratch is sized for upper_blocks
   c->lvl_rows.assign(d, 0);
   c->lvl_cts.assign(d, 0);
   uint64_t pt_words = 0;
@@ -387,6 +416,7 @@ void ensure_workspace(pirgpu_ctx* c) {
     c->scan_nsplit = (uint32_t)ceil_div(std::max<uint32_t>(c->scan_cols, 1), c->scan_cps);
     //   PIRGPU_SCAN_MFMA=0 keeps the 64-bit multiply-accumulate kernels for d >= 2 as well
     //   PIRGPU_SCAN_MFMA_NQ queries per database pass of the MFMA scan in batch mode (1..8)
+    c->fuse_last_level = env_u32("PIRGPU_FUSE_LAST", 1) != 0;
     c->pack40 = env_u32("PIRGPU_PACK40", 1) != 0;
     // 5-byte storage of the key-switch intermediates: the fp64 flavours store x + q (|x| <= q), so q < 2^39
     for (uint32_t j = 0; j <= k; ++j) c->pack40 = c->pack40 && (c->hp.mod[j].q >> 39) == 0;
@@ -472,11 +502,15 @@ void begin_profiled_run(pirgpu_ctx* c) {
 // next_power_two(n) results.
 // B queries at once: ciphertext index = node * B + query, so every level is the same three launches
 // over B times the nodes (the per-level Galois element and monomial shift are uniform).
+// sel_dst (optional, fp64 flavours): per query, where selector 0 of this ciphertext's expansion goes (NTT form).  The
+// last level then runs fused with the selectors' forward transform (ks_last_level_kernel) and nullptr is returned:
+// there is no coefficient-form result to transform any more.
 uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* res_b, uint64_t* dig, uint64_t* prod,
-                      uint32_t n, uint32_t B) {
+                      uint32_t n, uint32_t B, const MfmaPtrs* sel_dst = nullptr) {
   const uint32_t N = c->N, k = c->k;
   if (n > N) throw Fail{PIRGPU_INVALID_ARGUMENT, "Cannot expand more items from a CT than poly modulus degree"};
   const uint32_t logm = hm::ceil_log2(n);
+  const bool fuse_last = sel_dst && c->mode != kNttInt && c->fuse_last_level;
   uint64_t *cur = res_a, *nxt = res_b;
   for (uint32_t j = 0; j < logm; ++j) {
     const uint32_t g = (N >> j) + 1;
@@ -484,6 +518,10 @@ uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* 
     const uint32_t nodes = (1u << j) * B;
     HIP_TRY(c->ops->ks_digit(st, c->mode, c->dp, k, cur, g, nodes, dig, c->pack40));
     HIP_TRY(c->ops->ks_mac_intt(st, c->mode, c->dp, k, dig, key, nodes, prod, c->pack40));
+    if (fuse_last && j + 1 == logm) {
+      HIP_TRY(c->ops->ks_last_level(st, c->mode, c->dp, k, cur, prod, g, 1u << j, n, B, *sel_dst, nodes, c->pack40));
+      return nullptr;
+    }
     // outputs n*B.. of the last level are never read (only the first n results per query are used)
     const uint32_t hi_limit = j + 1 == logm ? n * B : UINT32_MAX;
     HIP_TRY(launch_ks_combine(st, c->dp, c->mode, N, k, cur, prod, galois_inverse(g, N), nodes, 1u << j, true, hi_limit,
@@ -514,8 +552,10 @@ void expand_query_to_sv(pirgpu_ctx* c, Worker& w, const uint64_t* d_query, uint3
     if (n > 0) {
       // the query ciphertext (canonical u64) becomes the root of the expansion tree (the tree's element type)
       HIP_TRY(launch_tree_convert(w.stream, c->dp, c->mode, d_query + (size_t)q * ctw, w.res_a, ctw, true));
-      uint64_t* res = expand_on_device(c, w, n);
-      HIP_TRY(c->ops->ct_ntt_fwd_oop(w.stream, c->mode, c->dp, k, res, w.sv_ntt + produced * ctw, n, true));
+      MfmaPtrs dst{};
+      dst.p[0] = w.sv_ntt + produced * ctw;
+      uint64_t* res = expand_core(c, w.stream, w.res_a, w.res_b, w.dig, w.prod, n, 1, &dst);
+      if (res) HIP_TRY(c->ops->ct_ntt_fwd_oop(w.stream, c->mode, c->dp, k, res, w.sv_ntt + produced * ctw, n, true));
     }
     produced += n;
     remaining -= n;
@@ -542,26 +582,26 @@ void ensure_packed(pirgpu_ctx* c) {
   c->packed_valid = true;
 }
 
-// One pass of the MFMA scan for up to 8 queries (the workers in `members`, expanded already; the
-// caller has ordered stream `st` after their expansions): pack the selectors, scan, fold column chunks.
-void scan_group_mfma(pirgpu_ctx* c, hipStream_t st, uint8_t*& selp, Worker* const* members, uint32_t n,
-                     Worker* profiled, const uint8_t* packed = nullptr) {
+// One pass of the MFMA scan for up to 8 queries (the caller has ordered stream `st` after their expansions): pack
+// the column selectors (unless they arrive packed), scan, fold column chunks.  Row sums of query q go to
+// out + q * scan_rows ciphertexts; `part` (query-major as well) holds the per-chunk sums of matrices wider than one chunk.
+void scan_group_mfma(pirgpu_ctx* c, hipStream_t st, uint8_t*& selp, const MfmaPtrs& col_sel, uint32_t n, uint64_t* out_base,
+                     uint64_t* part, Worker* profiled, const uint8_t* packed = nullptr) {
   const uint32_t kN = c->k * c->N;
   const uint64_t words = (uint64_t)c->scan_rows * c->ctw;
   ensure_packed(c);
-  MfmaPtrs sv{}, out{};
-  for (uint32_t q = 0; q < n; ++q) out.p[q] = c->mg.nchunks > 1 ? members[q]->scan_part : members[q]->lvl[c->d - 1];
+  MfmaPtrs out{};
+  for (uint32_t q = 0; q < n; ++q)
+    out.p[q] = c->mg.nchunks > 1 ? part + (size_t)q * c->mg.nchunks * words : out_base + (size_t)q * words;
   if (!packed) {  // with `packed` the group's digit-packed column selectors already exist (multi-GPU exchange)
     if (!selp) selp = c->dalloc<uint8_t>(c->mg.sel_bytes);
-    for (uint32_t q = 0; q < n; ++q) sv.p[q] = scan_selectors(c, *members[q]);
-    HIP_TRY(launch_sel_pack(st, c->dp, c->mg, sv, n, selp, c->scan_cols, kN));
+    HIP_TRY(launch_sel_pack(st, c->dp, c->mg, col_sel, n, selp, c->scan_cols, kN));
     packed = selp;
   }
   if (profiled) record(c, *profiled, PH_SCAN);  // selector packing counts as selector preparation, not as the scan
   HIP_TRY(launch_scan_mfma(st, c->dp, c->mg, c->d_dbp, packed, out, n, c->scan_rows, kN, words));
   if (c->mg.nchunks > 1)
-    for (uint32_t q = 0; q < n; ++q)
-      HIP_TRY(launch_reduce_splits(st, c->dp, members[q]->scan_part, c->mg.nchunks, words, members[q]->lvl[c->d - 1]));
+    HIP_TRY(launch_reduce_splits(st, c->dp, part, c->mg.nchunks, words, out_base, n, (uint64_t)c->mg.nchunks * words, words));
 }
 
 // Base case of PIRDatabase::multiply (reference database.cpp:185-194,238-247): one fused
@@ -574,8 +614,9 @@ void scan_on_device(pirgpu_ctx* c, Worker& w) {
   check_transparent(c);
   if (c->pt_end == c->pt_begin) return;
   if (c->mfma_on && c->mfma_single) {
-    Worker* one = &w;
-    scan_group_mfma(c, w.stream, w.selp, &one, 1, &w);
+    MfmaPtrs col{};
+    col.p[0] = scan_selectors(c, w);
+    scan_group_mfma(c, w.stream, w.selp, col, 1, w.lvl[d - 1], w.scan_part, &w);
     return;
   }
   const uint64_t* sv_base = scan_selectors(c, w);
@@ -595,17 +636,17 @@ void scan_on_device(pirgpu_ctx* c, Worker& w) {
 
 // Everything after the scan: inverse NTT of the row sums and the upper recursion levels
 // (reference database.cpp:196-254).  Leaves the reply in lvl[0].
-void post_scan_on_device(pirgpu_ctx* c, Worker& w) {
+void post_scan_stage(pirgpu_ctx* c, const Stage& sg, Worker* profiled) {
   const uint32_t N = c->N, k = c->k, d = c->d;
   const size_t ctw = c->ctw;
   const uint64_t shard_pts = c->pt_end - c->pt_begin;
+  hipStream_t st = sg.stream;
   if (shard_pts == 0) {
-    HIP_TRY(hipMemsetAsync(w.lvl[0], 0, c->reply_cts * ctw * 8, w.stream));
+    HIP_TRY(hipMemsetAsync(sg.lvl[0], 0, (size_t)sg.n * c->reply_cts * ctw * 8, st));
     return;
   }
-  uint64_t* base_out = w.lvl[d - 1];
-  record(c, w, PH_UPPER);  // end of scan phase
-  HIP_TRY(c->ops->ntt_batch(w.stream, c->mode, c->dp, base_out, (uint64_t)c->scan_rows * 2 * k, k, 0, true));
+  if (profiled) record(c, *profiled, PH_UPPER);  // end of scan phase
+  HIP_TRY(c->ops->ntt_batch(st, c->mode, c->dp, sg.lvl[d - 1], (uint64_t)sg.n * c->scan_rows * 2 * k, k, 0, true));
   // upper levels: fused re-encode + lift + NTT + multiply-accumulate over chunks of children,
   // then one kernel folds the chunk sums and applies the inverse NTT
   uint64_t C = 1;  // ciphertexts per child
@@ -614,27 +655,37 @@ void post_scan_on_device(pirgpu_ctx* c, Worker& w) {
     const uint64_t rows = c->lvl_rows[l];
     // dimension-0 selectors: the query's whole selection vector at index sv_off[0] + shard_begin + i, or (packed
     // multi-GPU exchange) a buffer holding just this shard's rows at local index i
-    const bool local_rows = l == 0 && w.sv_rows;
+    const bool local_rows = l == 0 && sg.local_rows;
     const uint32_t sv_first = local_rows ? 0 : c->sv_off[l] + (l == 0 ? c->sb : 0);
-    // enough workgroups to fill the chip: ~1024 over (rows * C * chunks * E * k)
+    // enough workgroups to fill the chip: ~1024 over (queries * rows * C * chunks * E * k)
     const uint64_t per_chunk = rows * C * c->E * k;
-    uint32_t n_chunks = (uint32_t)std::min<uint64_t>(c->dims[l], std::max<uint64_t>(1, ceil_div(c->upper_blocks, per_chunk)));
+    const uint32_t target = sg.n > 1 || c->in_batch ? c->upper_blocks_batch : c->upper_blocks;
+    uint32_t n_chunks = (uint32_t)std::min<uint64_t>(c->dims[l], std::max<uint64_t>(1, ceil_div(target, per_chunk)));
     const uint32_t chunk_len = (uint32_t)ceil_div(c->dims[l], n_chunks);
     n_chunks = (uint32_t)ceil_div(c->dims[l], chunk_len);
     const uint64_t out_polys = rows * C * c->E * 2 * k;
     if (out_polys * n_chunks * N > c->pt_words)
       throw Fail{PIRGPU_INTERNAL, "upper-level scratch undersized"};
-    HIP_TRY(c->ops->upper_fused(w.stream, c->mode, c->dp, k, c->E, w.lvl[l + 1],
-                                local_rows ? w.sv_rows : (w.sv_cur ? w.sv_cur : w.sv_ntt), w.pt_buf,
-                                (uint32_t)rows, c->dims[l], (uint32_t)nch, sv_first, (uint32_t)C, chunk_len,
-                                n_chunks));
-    if (l == 0) record(c, w, PH_FINAL);
+    if (local_rows && l != 0) throw Fail{PIRGPU_INTERNAL, "local row selectors are a d = 2 feature"};
+    HIP_TRY(c->ops->upper_fused(st, c->mode, c->dp, k, c->E, sg.lvl[l + 1], sg.sel, sg.pt_buf, (uint32_t)rows,
+                                c->dims[l], (uint32_t)nch, sv_first, (uint32_t)C, chunk_len, n_chunks, sg.n,
+                                c->lvl_cts[l + 1] * ctw, c->pt_words));
+    if (l == 0 && profiled) record(c, *profiled, PH_FINAL);
     // fold the chunk sums (wide, elementwise) and return to coefficient form (database.cpp:250-254)
-    HIP_TRY(launch_reduce_splits(w.stream, c->dp, w.pt_buf, n_chunks, out_polys * N, w.lvl[l]));
-    HIP_TRY(c->ops->ntt_batch(w.stream, c->mode, c->dp, w.lvl[l], out_polys, k, 0, true));
+    HIP_TRY(launch_reduce_splits(st, c->dp, sg.pt_buf, n_chunks, out_polys * N, sg.lvl[l], sg.n, c->pt_words,
+                                 c->lvl_cts[l] * ctw));
+    HIP_TRY(c->ops->ntt_batch(st, c->mode, c->dp, sg.lvl[l], (uint64_t)sg.n * out_polys, k, 0, true));
     C *= c->E;
   }
-  if (d == 1) record(c, w, PH_FINAL);
+  if (d == 1 && profiled) record(c, *profiled, PH_FINAL);
+}
+
+// Everything after the scan for one worker's query: inverse NTT of the row sums and the upper recursion levels
+// (reference database.cpp:196-254).  Leaves the reply in lvl[0].
+void post_scan_on_device(pirgpu_ctx* c, Worker& w) {
+  Stage sg{w.stream, w.lvl.data(), w.pt_buf, 1, MfmaPtrs{}, w.sv_rows != nullptr};
+  sg.sel.p[0] = w.sv_rows ? w.sv_rows : (w.sv_cur ? w.sv_cur : w.sv_ntt);
+  post_scan_stage(c, sg, &w);
 }
 
 void multiply_on_device(pirgpu_ctx* c, Worker& w) {
@@ -936,8 +987,7 @@ int pirgpu_db_finalize(pirgpu_ctx* c, int release_staging) {
     if (c->n_loaded != c->pt_end - c->pt_begin) return fail(c, PIRGPU_FAILED_PRECONDITION, "database not fully loaded");
     ensure_packed(c);
     if (release_staging && c->mfma_on && c->d_db) {
-      for (Worker& w : c->workers)
-        if (w.stream) HIP_TRY(hipStreamSynchronize(w.stream));
+      sync_batch_streams(c);
       HIP_TRY(hipStreamSynchronize(c->stream));
       auto it = std::find(c->allocs.begin(), c->allocs.end(), (void*)c->d_db);
       if (it != c->allocs.end()) c->allocs.erase(it);
@@ -1011,8 +1061,7 @@ int pirgpu_clear_galois_keys(pirgpu_ctx* c) {
   return guarded(c, [&]() -> int {
     c->keys_blob_valid = false;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    for (Worker& w : c->workers)
-      if (w.stream) HIP_TRY(hipStreamSynchronize(w.stream));
+    sync_batch_streams(c);
     for (auto& kv : c->keys) HIP_TRY(hipFree(kv.second));
     c->keys.clear();
     return PIRGPU_OK;
@@ -1281,6 +1330,15 @@ static void ensure_lanes(pirgpu_ctx* c, bool with_expansion_buffers) {
       ln.dig = c->dalloc<uint64_t>((size_t)kMaxMfmaQueries * half * (k + 1) * k * N);
     }
   }
+  if (c->mfma_on && c->lanes[0].lvl.empty()) {  // the group's multiply runs in lane-owned, query-major buffers
+    for (BatchLane& ln : c->lanes) {
+      ln.lvl.assign(c->d, nullptr);
+      for (uint32_t l = 0; l < c->d; ++l) ln.lvl[l] = c->dalloc<uint64_t>((size_t)kMaxMfmaQueries * c->lvl_cts[l] * c->ctw);
+      if (c->pt_words) ln.pt_buf = c->dalloc<uint64_t>((size_t)kMaxMfmaQueries * c->pt_words);
+      if (c->mg.nchunks > 1)
+        ln.scan_part = c->dalloc<uint64_t>((size_t)kMaxMfmaQueries * c->mg.nchunks * std::max<uint32_t>(c->scan_rows, 1) * c->ctw);
+    }
+  }
 }
 
 // Batched oblivious expansion of the staged queries first .. first+B-1 on lane `ln`, B queries interleaved
@@ -1296,10 +1354,10 @@ static void expand_group_on_lane(pirgpu_ctx* c, BatchLane& ln, Worker* const* me
     HIP_TRY(hipMemcpy2DAsync(ln.res_b, ctw * 8, c->d_bquery + (size_t)first * qwords + (size_t)qc * ctw, qwords * 8,
                              ctw * 8, B, hipMemcpyDeviceToDevice, ln.stream));
     HIP_TRY(launch_tree_convert(ln.stream, c->dp, c->mode, ln.res_b, ln.res_a, (uint64_t)B * ctw, true));
-    uint64_t* res = expand_core(c, ln.stream, ln.res_a, ln.res_b, ln.dig, ln.prod, slots, B);
     MfmaPtrs dst{};
     for (uint32_t q = 0; q < B; ++q) dst.p[q] = members[q]->sv_ntt + produced * ctw;
-    HIP_TRY(c->ops->ct_ntt_fwd_split(ln.stream, c->mode, c->dp, k, res, dst, B, (uint64_t)slots * B));
+    uint64_t* res = expand_core(c, ln.stream, ln.res_a, ln.res_b, ln.dig, ln.prod, slots, B, &dst);
+    if (res) HIP_TRY(c->ops->ct_ntt_fwd_split(ln.stream, c->mode, c->dp, k, res, dst, B, (uint64_t)slots * B));
     produced += slots;
     remaining -= slots;
   }
@@ -1317,56 +1375,59 @@ struct PackedInput {            // multi-GPU packed exchange (pirgpu_batch_run_p
   uint32_t per_rank;           // queries per source rank (groups never span two source ranks)
 };
 
+// Members (selection-vector buffers) of the group that runs on lane `li`: lane-bound, so that stream order on the
+// lane covers their reuse; with fewer than 2 x G workers every group uses lane 0.
+static uint32_t lanes_in_use(pirgpu_ctx* c, uint32_t G) {
+  const uint32_t W = std::max<uint32_t>(1, std::min<uint32_t>(c->n_active, (uint32_t)c->workers.size()));
+  return W >= 2 * G ? 2 : 1;
+}
+
 static void batch_run_mfma(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv, const PackedInput* pk = nullptr) {
   const size_t rwords = (size_t)c->reply_cts * c->ctw, svwords = (size_t)c->dim_sum * c->ctw;
   const uint32_t W = std::max<uint32_t>(1, std::min<uint32_t>(c->n_active, (uint32_t)c->workers.size()));
   const uint32_t G = std::min<uint32_t>(c->mfma_nq, W);
   const uint32_t my_rows = c->se - c->sb;
   ensure_lanes(c, !ext_sv && !pk);
+  const uint32_t nl = lanes_in_use(c, G);
   // groups: runs of up to G consecutive queries; with packed input a group is what ONE source rank packed together
   // (its queries in runs of kMaxMfmaQueries), so the walk restarts at every source-rank boundary
-  uint32_t next_worker = 0;
   const uint32_t span = pk ? pk->per_rank : count;
   for (uint32_t rank0 = 0; rank0 < count; rank0 += span) {
     const uint32_t step = pk ? (uint32_t)kMaxMfmaQueries : G;
-    for (uint32_t j0 = 0; j0 < std::min<uint32_t>(span, count - rank0); j0 += step) {
-      const uint32_t B = std::min<uint32_t>(step, std::min<uint32_t>(span, count - rank0) - j0);
+    const uint32_t in_span = std::min<uint32_t>(span, count - rank0);
+    for (uint32_t j0 = 0; j0 < in_span; j0 += step) {
+      const uint32_t B = std::min<uint32_t>(step, in_span - j0);
       if (B > W) throw Fail{PIRGPU_FAILED_PRECONDITION, "packed groups need at least 8 workers (pirgpu_set_concurrency)"};
-      if (next_worker + B > W) next_worker = 0;
-      BatchLane& ln = c->lanes[c->groups_run++ % c->lanes.size()];
+      const uint32_t li = (uint32_t)(c->groups_run++ % nl);
+      BatchLane& ln = c->lanes[li];
       Worker* members[kMaxMfmaQueries];
       for (uint32_t q = 0; q < B; ++q) {
-        members[q] = &c->workers[next_worker + q];
-        HIP_TRY(hipStreamWaitEvent(ln.stream, members[q]->ev_done, 0));  // its buffers are free again
+        members[q] = &c->workers[(li * G + q) % W];
+        HIP_TRY(hipStreamWaitEvent(ln.stream, members[q]->ev_done, 0));  // whoever used its buffers last is done
       }
-      next_worker += B;
       const uint32_t first = rank0 + j0;  // global index of the group's first query
       const uint8_t* packed = nullptr;
+      Stage sg{ln.stream, ln.lvl.data(), ln.pt_buf, B, MfmaPtrs{}, pk != nullptr};
+      MfmaPtrs col{};
       if (pk) {
         const uint32_t groups_per_rank = (pk->per_rank + kMaxMfmaQueries - 1) / kMaxMfmaQueries;
         packed = pk->packed + ((size_t)(rank0 / pk->per_rank) * groups_per_rank + j0 / kMaxMfmaQueries) * c->mg.sel_bytes;
-        for (uint32_t q = 0; q < B; ++q) {
-          members[q]->sv_cur = nullptr;
-          members[q]->sv_rows = pk->rows + (size_t)(first + q) * my_rows * c->ctw;
-        }
-      } else if (ext_sv) {
-        for (uint32_t q = 0; q < B; ++q) {
-          members[q]->sv_cur = ext_sv + (size_t)(first + q) * svwords;
-          members[q]->sv_rows = nullptr;
-        }
+        for (uint32_t q = 0; q < B; ++q) sg.sel.p[q] = pk->rows + (size_t)(first + q) * my_rows * c->ctw;
       } else {
-        expand_group_on_lane(c, ln, members, B, first);
+        if (!ext_sv) expand_group_on_lane(c, ln, members, B, first);
+        for (uint32_t q = 0; q < B; ++q) {
+          const uint64_t* sv = ext_sv ? ext_sv + (size_t)(first + q) * svwords : members[q]->sv_ntt;
+          sg.sel.p[q] = sv;
+          col.p[q] = sv + (size_t)c->sv_off[c->d - 1] * c->ctw;
+        }
       }
-      scan_group_mfma(c, ln.stream, ln.selp, members, B, nullptr, packed);
-      HIP_TRY(hipEventRecord(ln.ev_scanned, ln.stream));
+      scan_group_mfma(c, ln.stream, ln.selp, col, B, ln.lvl[c->d - 1], ln.scan_part, nullptr, packed);
+      post_scan_stage(c, sg, nullptr);
+      HIP_TRY(hipMemcpyAsync(c->d_breply + (size_t)first * rwords, ln.lvl[0], (size_t)B * rwords * 8,
+                             hipMemcpyDeviceToDevice, ln.stream));
       for (uint32_t q = 0; q < B; ++q) {
-        Worker& w = *members[q];
-        HIP_TRY(hipStreamWaitEvent(w.stream, ln.ev_scanned, 0));
-        post_scan_on_device(c, w);
-        HIP_TRY(hipMemcpyAsync(c->d_breply + (size_t)(first + q) * rwords, w.lvl[0], rwords * 8,
-                               hipMemcpyDeviceToDevice, w.stream));
-        HIP_TRY(hipEventRecord(w.ev_done, w.stream));
-        w.reply_valid = true;
+        HIP_TRY(hipEventRecord(members[q]->ev_done, ln.stream));
+        members[q]->reply_valid = false;  // the group's replies live in the lane / batch buffers, not in the worker
       }
     }
   }
@@ -1377,7 +1438,16 @@ static void batch_run_mfma(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
 // also shares the database pass (batch_run_mfma), otherwise groups of up to 4 workers share one pass of
 // scan_mq_kernel (d = 1 / few rows), hand-offs between streams through events.  With ext_sv the expansion
 // is skipped and query i reads its NTT-form selection vector at ext_sv + i*dim_sum.
+static void batch_run_impl_body(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv);
 static void batch_run_impl(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv) {
+  struct Flag {
+    bool& f;
+    explicit Flag(bool& x) : f(x) { f = true; }
+    ~Flag() { f = false; }
+  } flag(c->in_batch);
+  batch_run_impl_body(c, count, ext_sv);
+}
+static void batch_run_impl_body(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv) {
   const size_t rwords = (size_t)c->reply_cts * c->ctw;
   const size_t svwords = (size_t)c->dim_sum * c->ctw;
   const uint32_t W = std::max<uint32_t>(1, std::min<uint32_t>(c->n_active, (uint32_t)c->workers.size()));
@@ -1514,13 +1584,13 @@ uint64_t pirgpu_packed_selector_bytes(pirgpu_ctx* c) {
   return bytes;
 }
 
-int pirgpu_batch_expand_packed(pirgpu_ctx* c, uint32_t first, uint32_t count, uint8_t* device_packed,
+int pirgpu_batch_expand_packed(pirgpu_ctx* c, uint32_t first_query, uint32_t count, uint8_t* device_packed,
                                uint64_t* device_rows, const uint32_t* row_cuts, uint32_t n_ranks) {
   return guarded(c, [&]() -> int {
     ensure_workspace(c);
     if (c->d != 2 || !c->mfma_on)
       return fail(c, PIRGPU_FAILED_PRECONDITION, "packed selector exchange needs d = 2 and the int8-MFMA scan");
-    if (!c->batch_count || (uint64_t)first + count > c->batch_count)
+    if (!c->batch_count || (uint64_t)first_query + count > c->batch_count)
       return fail(c, PIRGPU_INVALID_ARGUMENT, "query range outside the staged batch");
     if (!device_packed || !device_rows || !row_cuts || n_ranks == 0 || row_cuts[0] != 0 || row_cuts[n_ranks] != c->dims[0])
       return fail(c, PIRGPU_INVALID_ARGUMENT, "invalid packed-exchange buffers or row cuts");
@@ -1533,17 +1603,18 @@ int pirgpu_batch_expand_packed(pirgpu_ctx* c, uint32_t first, uint32_t count, ui
     c->prof_cur = -1;
     const size_t ctw = c->ctw;
     const uint32_t kN = c->k * c->N;
-    uint32_t next_worker = 0, g = 0;
+    const uint32_t first = first_query;
+    const uint32_t G = std::min<uint32_t>(kMaxMfmaQueries, W), nl = lanes_in_use(c, G);
+    uint32_t g = 0;
     for (uint32_t j0 = 0; j0 < count; j0 += kMaxMfmaQueries, ++g) {
       const uint32_t B = std::min<uint32_t>(kMaxMfmaQueries, count - j0);
-      if (next_worker + B > W) next_worker = 0;
-      BatchLane& ln = c->lanes[c->groups_run++ % c->lanes.size()];
+      const uint32_t li = (uint32_t)(c->groups_run++ % nl);
+      BatchLane& ln = c->lanes[li];
       Worker* members[kMaxMfmaQueries];
       for (uint32_t q = 0; q < B; ++q) {
-        members[q] = &c->workers[next_worker + q];
+        members[q] = &c->workers[(li * G + q) % W];
         HIP_TRY(hipStreamWaitEvent(ln.stream, members[q]->ev_done, 0));
       }
-      next_worker += B;
       expand_group_on_lane(c, ln, members, B, first + j0);
       // column selectors (dimension 1) of the whole group -> one B-operand buffer
       MfmaPtrs sv{};
@@ -1581,7 +1652,14 @@ int pirgpu_batch_run_packed(pirgpu_ctx* c, const uint8_t* device_packed, uint32_
     ensure_batch_capacity(c, (uint32_t)count);
     c->prof_cur = -1;
     PackedInput pk{device_packed, device_rows, per_rank};
-    batch_run_mfma(c, (uint32_t)count, nullptr, &pk);
+    c->in_batch = true;
+    try {
+      batch_run_mfma(c, (uint32_t)count, nullptr, &pk);
+    } catch (...) {
+      c->in_batch = false;
+      throw;
+    }
+    c->in_batch = false;
     c->batch_count = (uint32_t)count;
     c->batch_valid = true;
     return PIRGPU_OK;
@@ -1593,7 +1671,7 @@ int pirgpu_batch_reply_copy_to_device(pirgpu_ctx* c, uint64_t* dst, uint64_t cap
     if (!c->batch_valid) return fail(c, PIRGPU_FAILED_PRECONDITION, "no batch has been run");
     const uint64_t total = (uint64_t)c->batch_count * c->reply_cts;
     if (!dst || cap < total) return fail(c, PIRGPU_INVALID_ARGUMENT, "reply buffer too small");
-    for (Worker& w : c->workers) HIP_TRY(hipStreamSynchronize(w.stream));
+    sync_batch_streams(c);
     // a device-to-device hipMemcpy on the null stream may return before the copy has run, and the context's
     // streams are non-blocking (not ordered with the null stream): copy on the context's stream and wait
     HIP_TRY(hipMemcpyAsync(dst, c->d_breply, total * c->ctw * 8, hipMemcpyDeviceToDevice, c->stream));
@@ -1607,7 +1685,7 @@ int pirgpu_batch_fetch(pirgpu_ctx* c, uint64_t* replies, uint64_t cap, uint64_t*
     if (!c->batch_valid) return fail(c, PIRGPU_FAILED_PRECONDITION, "no batch has been run");
     const uint64_t total = (uint64_t)c->batch_count * c->reply_cts;
     if (!replies || cap < total) return fail(c, PIRGPU_INVALID_ARGUMENT, "reply buffer too small");
-    for (Worker& w : c->workers) HIP_TRY(hipStreamSynchronize(w.stream));
+    sync_batch_streams(c);
     HIP_TRY(hipMemcpy(replies, c->d_breply, total * c->ctw * 8, hipMemcpyDeviceToHost));
     if (count) *count = total;
     return PIRGPU_OK;

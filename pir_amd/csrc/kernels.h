@@ -32,10 +32,17 @@ struct NttOps {
                          uint32_t galois_elt, uint32_t nodes, uint64_t* dig, bool pack40);
   hipError_t (*ks_mac_intt)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* dig,
                             const uint64_t* key, uint32_t nodes, uint64_t* prod, bool pack40);
+  // n_queries queries in one launch: query q reads src + q * src_qstride, selectors svq.p[q], writes part + q * part_qstride
   hipError_t (*upper_fused)(hipStream_t st, int mode, const DevParams* P, uint32_t k, uint32_t enc_count,
-                            const uint64_t* src, const uint64_t* sv, uint64_t* part, uint32_t n_rows,
+                            const uint64_t* src, const MfmaPtrs& svq, uint64_t* part, uint32_t n_rows,
                             uint32_t n_dim, uint32_t n_children_total, uint32_t sv_first, uint32_t C,
-                            uint32_t chunk_len, uint32_t n_chunks);
+                            uint32_t chunk_len, uint32_t n_chunks, uint32_t n_queries, uint64_t src_qstride,
+                            uint64_t part_qstride);
+  // last expansion level fused with the selectors' forward NTT (fp64 flavours): tree_cts tree ciphertexts
+  // (index = slot * B + query) -> selectors slot and slot + shift_pow of query q at dst.p[q], if < n_items
+  hipError_t (*ks_last_level)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* tree,
+                              const uint64_t* prod, uint32_t galois_elt, uint32_t shift_pow, uint32_t n_items,
+                              uint32_t B, const MfmaPtrs& dst, uint32_t tree_cts, bool pack40);
 };
 
 const NttOps* ntt_ops_for(uint32_t N);  // nullptr for unsupported degrees
@@ -56,8 +63,10 @@ hipError_t launch_scan(hipStream_t st, const DevParams* P, uint32_t N, uint32_t 
 hipError_t launch_scan_mq(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* db,
                           const uint64_t* const* sv, uint64_t* const* out, uint32_t nq, uint32_t rows,
                           uint32_t cols, uint32_t rows_per_wave, bool limb);
+// n_queries > 1: query q folds part + q * part_qstride into out + q * out_qstride (one launch for a group)
 hipError_t launch_reduce_splits(hipStream_t st, const DevParams* P, const uint64_t* part, uint32_t nsplit,
-                                uint64_t words, uint64_t* out);
+                                uint64_t words, uint64_t* out, uint32_t n_queries = 1, uint64_t part_qstride = 0,
+                                uint64_t out_qstride = 0);
 
 
 // ---- digit-sliced int8-MFMA scan (scan_mfma.hip) ----

@@ -664,10 +664,13 @@ scan_mq_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ db,
 
 // out[x] = sum_s part[s][x] mod q_j over ciphertext words (split reduce and
 // multi-GPU fix-up share this kernel: nsplit == 1 is a pure x mod q_j).
-__global__ void reduce_splits_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ part,
-                                     uint32_t nsplit, uint64_t words, uint64_t* __restrict__ out) {
+__global__ void reduce_splits_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ part_all,
+                                     uint32_t nsplit, uint64_t words, uint64_t* __restrict__ out_all,
+                                     uint64_t part_qstride, uint64_t out_qstride) {
   const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= words) return;
+  const uint64_t* part = part_all + (size_t)blockIdx.y * part_qstride;   // blockIdx.y = query of the group
+  uint64_t* out = out_all + (size_t)blockIdx.y * out_qstride;
   const uint32_t j = (uint32_t)((gid >> P->logN) % P->k);
   const ModConst m = P->mod[j];
   uint64_t acc = 0;
@@ -834,10 +837,11 @@ hipError_t launch_scan_mq(hipStream_t st, const DevParams* P, uint32_t N, uint32
 }
 
 hipError_t launch_reduce_splits(hipStream_t st, const DevParams* P, const uint64_t* part, uint32_t nsplit,
-                                uint64_t words, uint64_t* out) {
-  if (!words) return hipSuccess;
-  hipLaunchKernelGGL(reduce_splits_kernel, dim3((uint32_t)((words + 255) / 256)), dim3(256), 0, st, P, part, nsplit,
-                     words, out);
+                                uint64_t words, uint64_t* out, uint32_t n_queries, uint64_t part_qstride,
+                                uint64_t out_qstride) {
+  if (!words || !n_queries) return hipSuccess;
+  hipLaunchKernelGGL(reduce_splits_kernel, dim3((uint32_t)((words + 255) / 256), n_queries), dim3(256), 0, st, P, part,
+                     nsplit, words, out, part_qstride, out_qstride);
   PIRGPU_LAUNCH_CHECK();
   return hipSuccess;
 }

@@ -362,6 +362,99 @@ ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
   }
 }
 
+// Last level of the expansion tree fused with the selectors' forward NTT (fp64 flavours).  One workgroup per
+// (tree ciphertext, component, data modulus): divide-and-round of the key-switch product, + sigma_g(c0), the tree
+// butterfly lo = a + g, hi = x^(-2^j) (a - g) -- exactly ks_combine_f64_kernel's arithmetic -- but the two output
+// polynomials stay in registers / LDS and go straight through the forward transform into the queries' selection
+// vectors: the last level's ciphertexts are never written to HBM in coefficient form and never read back
+// (reference server.cpp:137-141 followed by database.cpp:190,222).  Tree ciphertext index = slot * B + query;
+// lo is selector `slot`, hi selector `slot + shift_pow`; selectors >= n_items are not produced (server.cpp:144).
+// 3 waves per SIMD (<= 168 VGPRs: g, the polynomial in flight and the transform's own registers fit without the
+// twiddle prefetch); a 1024-thread workgroup (N = 16384) is 4 waves per SIMD by itself
+template <int MODE, bool P40>
+__global__ void __launch_bounds__(NT, LOGN < 14 ? 3 : 4)
+ks_last_level_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ tree_raw,
+                     const uint64_t* __restrict__ prod, uint32_t galois_elt, uint32_t shift_pow, uint32_t n_items,
+                     uint32_t B, MfmaPtrs dst) {
+  using A = Arith<MODE>;
+  static_assert(MODE != kNttInt, "fp64 flavours only");
+  double* sd = reinterpret_cast<double*>(smem_raw);
+  const uint32_t tid = threadIdx.x, k = P->k, km = k + 1;
+  const uint32_t j = blockIdx.x % k, comp = (blockIdx.x / k) & 1, ct = blockIdx.x / (2 * k);
+  const uint32_t slot = ct / B, q = ct % B;
+  if (slot >= n_items) return;
+  const typename A::Mod m = A::mod(P, j);
+  const double pf = P->p_f, half = P->p_half_f, pinv = P->p_inv_f[j];
+  const double* tree = reinterpret_cast<const double*>(tree_raw) + (size_t)ct * 2 * k * N;
+  // g = round(S / p) mod q_j, signed representative (ks_combine_f64_kernel)
+  double g[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const uint32_t i = e * NT + tid;
+    double sp, dj;
+    if constexpr (P40) {
+      const uint8_t* pr = reinterpret_cast<const uint8_t*>(prod) + ((size_t)ct * 2 + comp) * km * kPoly40;
+      sp = load40f(pr + (size_t)k * kPoly40, i, f64_pack_magic(pf));
+      dj = load40f(pr + (size_t)j * kPoly40, i, f64_pack_magic(m.q));
+    } else {
+      const double* pr = reinterpret_cast<const double*>(prod) + ((size_t)ct * 2 + comp) * km * N;
+      sp = pr[(size_t)k * N + i];
+      dj = pr[(size_t)j * N + i];
+    }
+    sp = sp > half ? sp - pf : sp;
+    sp = sp < -half ? sp + pf : sp;
+    g[e] = f64_mulmod(dj - f64_norm(sp, m), pinv, m);
+  }
+  if (comp == 0) {  // + sigma_g(c0): scatter c0 through LDS (GaloisTool::apply_galois index map), read back in order
+    const double* c0 = tree + (size_t)j * N;
+    const uint32_t raw0 = tid * galois_elt, rstep = (uint32_t)NT * galois_elt;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const uint32_t raw = raw0 + (uint32_t)e * rstep;
+      const uint64_t sign = (uint64_t)((raw << (31 - LOGN)) & 0x80000000u) << 32;
+      sd[lds_idx(raw & (N - 1))] =
+          __longlong_as_double((long long)((uint64_t)__double_as_longlong(c0[e * NT + tid]) ^ sign));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) g[e] += sd[lds_idx(e * NT + tid)];
+    __syncthreads();
+  }
+  const double* a = tree + ((size_t)comp * k + j) * N;
+  const uint32_t k2 = 2 * k;
+  typename A::T x[16];
+  // lo = a + g -> selector `slot`
+#pragma unroll
+  for (int e = 0; e < 16; ++e) x[e] = f64_norm(a[e * NT + tid] + g[e], m);
+  ntt_forward<MODE, LOGN, false>(x, smem_raw, P, j, tid);
+  {
+    uint64_t* out = (uint64_t*)dst.p[q] + ((size_t)slot * k2 + comp * k + j) * N;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
+  }
+  const uint32_t hi_slot = slot + shift_pow;
+  if (hi_slot >= n_items) return;  // uniform per workgroup
+  // hi = x^(-2^j) (a - g): negacyclic rotation by 2N - 2^j through LDS -> selector `slot + 2^j`
+  __syncthreads();  // the transform above is done with the LDS words
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const uint32_t i = e * NT + tid;
+    const double d = f64_norm(a[i] - g[e], m);
+    const uint32_t sraw = i + (2 * N - shift_pow);
+    sd[lds_idx(sraw & (N - 1))] = (sraw & N) ? -d : d;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 16; ++e) x[e] = sd[lds_idx(e * NT + tid)];
+  __syncthreads();
+  ntt_forward<MODE, LOGN, false>(x, smem_raw, P, j, tid);
+  {
+    uint64_t* out = (uint64_t*)dst.p[q] + ((size_t)hi_slot * k2 + comp * k + j) * N;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
+  }
+}
+
 // Upper recursion level, fused: for output slot (row r, source ciphertext cc, Encode chunk
 // e_idx, target residue jt) and a chunk of the row's children,
 //   part[chunk][r][cc*E+e_idx][p][jt] = sum_{ii in chunk} sv[sv_first+ii][p][jt] (.)
@@ -372,16 +465,23 @@ ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
 // selector.  grid = (n_rows*C*n_chunks, E, k); partial sums are folded by reduce_splits_kernel, then ntt_batch_kernel (inverse).
 template <int MODE>
 __global__ void __launch_bounds__(NT)
-upper_fused_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ src,
-                   const uint64_t* __restrict__ sv, uint64_t* __restrict__ part, uint32_t n_rows, uint32_t n_dim,
+upper_fused_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ src_all, MfmaPtrs svq,
+                   uint64_t* __restrict__ part_all, uint32_t n_rows, uint32_t n_dim,
                    uint32_t n_children_total, uint32_t sv_first, uint32_t C, uint32_t chunk_len,
-                   uint32_t n_chunks) {
+                   uint32_t n_chunks, uint64_t src_qstride, uint64_t part_qstride) {
   using A = Arith<MODE>;
   using T = typename A::T;
   const uint32_t tid = threadIdx.x, k = P->k, E = P->enc_count;
-  const uint32_t chunk = blockIdx.x % n_chunks;
-  const uint32_t cc = (blockIdx.x / n_chunks) % C;
-  const uint32_t r = blockIdx.x / (n_chunks * C);
+  // blockIdx.x = ((query * n_rows + r) * C + cc) * n_chunks + chunk: the queries of a group share one launch,
+  // each with its own child ciphertexts (src_all + q * src_qstride), selectors (svq.p[q]) and partial sums
+  const uint32_t per_query = n_rows * C * n_chunks;
+  const uint32_t qi = blockIdx.x / per_query, bx = blockIdx.x % per_query;
+  const uint64_t* src = src_all + (size_t)qi * src_qstride;
+  const uint64_t* sv = reinterpret_cast<const uint64_t*>(svq.p[qi]);
+  uint64_t* part = part_all + (size_t)qi * part_qstride;
+  const uint32_t chunk = bx % n_chunks;
+  const uint32_t cc = (bx / n_chunks) % C;
+  const uint32_t r = bx / (n_chunks * C);
   const uint32_t e_idx = blockIdx.y, jt = blockIdx.z;
   const ModConst mc = P->mod[jt];
   const typename A::Mod m = A::mod(P, jt);
@@ -405,19 +505,45 @@ upper_fused_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
     acc1[e] = 0;
     if constexpr (MODE == kNttInt) wide0[e] = wide1[e] = 0;
   }
+  // fp64 flavours, usual parameters (chunks of <= 31 bits, t < q_jt): the chunk fits a u32, converts with one
+  // v_cvt, and the plain lift is "subtract t above the threshold" on a signed representative -- no 64-bit
+  // integer reduction anywhere on the input side
+  const bool fast_lift = MODE != kNttInt && P->enc_bits <= 31 && P->t < mc.q;
+  const double td = (double)P->t;
+  const uint32_t thr32 = (uint32_t)thr, mask32 = (uint32_t)mask;
   uint32_t since = 0;
   for (uint32_t ii = ii0; ii < ii1; ++ii) {
     const uint64_t* in = src + ((((size_t)(child0 + ii) * C + cc) * 2 + sp) * k + sj) * N;
     T x[16];
+    if constexpr (MODE != kNttInt) {
+      if (fast_lift) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      uint64_t v = (in[e * NT + tid] >> sh) & mask;
-      uint64_t rr = reduce64(v, mc);
-      if (v >= thr) rr = add_mod(rr, inc, mc.q);
-      x[e] = A::in(rr, m);
+        for (int e = 0; e < 16; ++e) {
+          const uint32_t v = (uint32_t)(in[e * NT + tid] >> sh) & mask32;
+          const double d = (double)v;
+          x[e] = v >= thr32 ? d - td : d;  // m >= (t+1)/2 -> m + q - t == m - t (mod q): SURVEY App. A.5
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          uint64_t v = (in[e * NT + tid] >> sh) & mask;
+          uint64_t rr = reduce64(v, mc);
+          if (v >= thr) rr = add_mod(rr, inc, mc.q);
+          x[e] = A::in(rr, m);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        uint64_t v = (in[e * NT + tid] >> sh) & mask;
+        uint64_t rr = reduce64(v, mc);
+        if (v >= thr) rr = add_mod(rr, inc, mc.q);
+        x[e] = A::in(rr, m);
+      }
     }
     __syncthreads();  // previous iteration's transform may still be reading LDS
-    ntt_forward<MODE, LOGN, false>(x, smem_raw, P, jt, tid);  // no twiddle prefetch: accumulators need the registers
+    // no twiddle prefetch: the accumulators need the registers; signed representatives suffice for the products
+    ntt_forward<MODE, LOGN, false, /*CANON=*/MODE == kNttInt>(x, smem_raw, P, jt, tid);
     const uint64_t* s0 = sv + (((size_t)(sv_first + ii) * 2 + 0) * k + jt) * N;
     const uint64_t* s1 = sv + (((size_t)(sv_first + ii) * 2 + 1) * k + jt) * N;
     if constexpr (MODE == kNttInt) {
@@ -491,6 +617,10 @@ static hipError_t configure_mode() {
   PIRGPU_SET((ks_mac_intt_kernel<MODE, false>));
   PIRGPU_SET((ks_mac_intt_kernel<MODE, true>));
   PIRGPU_SET(upper_fused_kernel<MODE>);
+  if constexpr (MODE != kNttInt) {
+    PIRGPU_SET((ks_last_level_kernel<MODE, false>));
+    PIRGPU_SET((ks_last_level_kernel<MODE, true>));
+  }
 #undef PIRGPU_SET
   return hipSuccess;
 }
@@ -564,13 +694,40 @@ static hipError_t op_ks_mac_intt(hipStream_t st, int mode, const DevParams* P, u
   return hipGetLastError();
 }
 
+// fp64 flavours only (the caller keeps the unfused ks_combine + forward NTT for the integer flavour)
+static hipError_t op_ks_last_level(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* tree,
+                                   const uint64_t* prod, uint32_t galois_elt, uint32_t shift_pow, uint32_t n_items,
+                                   uint32_t B, const MfmaPtrs& dst, uint32_t tree_cts, bool pack40) {
+  const dim3 grid(tree_cts * 2 * k);
+  if (mode == kNttF64) {
+    if (pack40)
+      hipLaunchKernelGGL((ks_last_level_kernel<kNttF64, true>), grid, dim3(NT), kLdsBytes, st, P, tree, prod, galois_elt,
+                         shift_pow, n_items, B, dst);
+    else
+      hipLaunchKernelGGL((ks_last_level_kernel<kNttF64, false>), grid, dim3(NT), kLdsBytes, st, P, tree, prod, galois_elt,
+                         shift_pow, n_items, B, dst);
+  } else if (mode == kNttF64Wide) {
+    if (pack40)
+      hipLaunchKernelGGL((ks_last_level_kernel<kNttF64Wide, true>), grid, dim3(NT), kLdsBytes, st, P, tree, prod,
+                         galois_elt, shift_pow, n_items, B, dst);
+    else
+      hipLaunchKernelGGL((ks_last_level_kernel<kNttF64Wide, false>), grid, dim3(NT), kLdsBytes, st, P, tree, prod,
+                         galois_elt, shift_pow, n_items, B, dst);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 static hipError_t op_upper_fused(hipStream_t st, int mode, const DevParams* P, uint32_t k, uint32_t enc_count,
-                                 const uint64_t* src, const uint64_t* sv, uint64_t* part, uint32_t n_rows,
+                                 const uint64_t* src, const MfmaPtrs& svq, uint64_t* part, uint32_t n_rows,
                                  uint32_t n_dim, uint32_t n_children_total, uint32_t sv_first, uint32_t C,
-                                 uint32_t chunk_len, uint32_t n_chunks) {
-  PIRGPU_BY_MODE(mode, hipLaunchKernelGGL(upper_fused_kernel<MODE>, dim3(n_rows * C * n_chunks, enc_count, k),
-                                          dim3(NT), kLdsBytes, st, P, src, sv, part, n_rows, n_dim,
-                                          n_children_total, sv_first, C, chunk_len, n_chunks));
+                                 uint32_t chunk_len, uint32_t n_chunks, uint32_t n_queries, uint64_t src_qstride,
+                                 uint64_t part_qstride) {
+  PIRGPU_BY_MODE(mode, hipLaunchKernelGGL(upper_fused_kernel<MODE>, dim3(n_queries * n_rows * C * n_chunks, enc_count, k),
+                                          dim3(NT), kLdsBytes, st, P, src, svq, part, n_rows, n_dim,
+                                          n_children_total, sv_first, C, chunk_len, n_chunks, src_qstride,
+                                          part_qstride));
   return hipGetLastError();
 }
 
@@ -580,7 +737,7 @@ static hipError_t op_upper_fused(hipStream_t st, int mode, const DevParams* P, u
 const NttOps* PIRGPU_OPS_NAME() {
   using namespace PIRGPU_DEG_NS;
   static const NttOps ops = {op_configure, op_ntt_batch,   op_ct_ntt_fwd_oop, op_ct_ntt_fwd_split, op_db_encode,
-                             op_ks_digit,  op_ks_mac_intt, op_upper_fused};
+                             op_ks_digit,  op_ks_mac_intt, op_upper_fused,     op_ks_last_level};
   return &ops;
 }
 

@@ -75,6 +75,7 @@ __device__ __forceinline__ uint64_t mul_mod(uint64_t a, uint64_t b, const ModCon
 
 struct F64Mod {
   double q, qinv;
+  bool lazy_inv = false;  // log2(q) + log2(N) <= 52: an inverse transform needs no intermediate renormalisation
 };
 
 __device__ __forceinline__ double f64_mulmod(double y, double w, const F64Mod& m) {

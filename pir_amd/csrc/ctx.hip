@@ -267,6 +267,8 @@ void build_tables(pirgpu_ctx* c) {
     if (want == kNttInt || (want == kNttF64Wide && c->mode != kNttInt) || want == c->mode) c->mode = want;
   }
   hp.ntt_mode = c->mode;
+  hp.f64_lazy_inv = (64 - (uint32_t)__builtin_clzll(qmax)) + c->logN <= 52 ? 1u : 0u;
+  if (const char* v = getenv("PIRGPU_F64_LAZY_INV")) hp.f64_lazy_inv = atoi(v) ? hp.f64_lazy_inv : 0u;
   const uint64_t p = c->prm.special_prime, t = c->prm.plain_modulus;
   hp.p_half = p >> 1;
   hp.p_f = (double)p;

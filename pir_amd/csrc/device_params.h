@@ -65,6 +65,9 @@ struct DevParams {
   // how many 128-bit products of two residues may be summed before reduction
   uint32_t lazy_limit;
   int32_t ntt_mode;  // NttMode
+  // fp64 flavours: 1 when (bits of the largest modulus) + log2 N <= 52 -- the sums of a whole inverse transform
+  // (they at most double per stage) then stay below 2^52 without the per-pass renormalisation
+  uint32_t f64_lazy_inv;
 };
 
 }  // namespace pirgpu

@@ -94,7 +94,7 @@ struct ArithF64 {
   using TW = double;
   using Mod = F64Mod;
   static __device__ __forceinline__ Mod mod(const DevParams* P, int mi) {
-    return Mod{P->tab[mi].qd, P->tab[mi].qinvd};
+    return Mod{P->tab[mi].qd, P->tab[mi].qinvd, MODE == kNttF64 && P->f64_lazy_inv != 0};
   }
   using TWPtr = const PIRGPU_GLOBAL TW*;
   static __device__ __forceinline__ TW load_tw(TWPtr p, uint32_t i) { return p[i]; }
@@ -120,7 +120,9 @@ struct ArithF64 {
     a = kNormPerPass ? u : f64_norm(u, m);
     b = f64_mulmod(d, w, m);
   }
-  static __device__ __forceinline__ T pass_norm(T v, const Mod& m) { return kNormPerPass ? f64_norm(v, m) : v; }
+  static __device__ __forceinline__ T pass_norm(T v, const Mod& m) {
+    return kNormPerPass && !m.lazy_inv ? f64_norm(v, m) : v;  // lazy_inv is uniform: a scalar branch per pass
+  }
   static __device__ __forceinline__ void inv_last(T& a, T& b, const TW& ninv, const TW& iw1n, const Mod& m) {
     const T u = a + b, d = a - b;
     a = f64_mulmod(u, ninv, m);
@@ -138,21 +140,45 @@ struct Arith<kNttF64Wide> : ArithF64<kNttF64Wide> {};
 
 // ------------------------------------------------------------------ passes
 
-template <int LB, typename T>
-__device__ __forceinline__ void lds_store16(T* s, const T (&x)[16], uint32_t tid) {
+// Padded LDS position of the 16 residues a thread owns in a pass with window LB: lds_idx(base | (e << LB)) is
+// lds_base16<LB>(tid) + lds_off16<LB>(e) with a compile-time second term, so the 16 accesses of a pass are one
+// address computation plus immediate offsets (written as `idx + (idx >> 4)` per element the compiler spends
+// four VALU instructions on every access).
+//   LB >= 4: (idx >> 4) = (base >> 4) | (e << (LB - 4)), the two terms occupy disjoint bits;
+//   LB <  4: (idx >> 4) = (outer << LB) | (e >> (4 - LB)), since (e << LB) | inner < 2^(LB + 4).
+template <int LB>
+__device__ __forceinline__ uint32_t lds_base16(uint32_t tid) {
   const uint32_t inner = tid & ((1u << LB) - 1u), outer = tid >> LB;
   const uint32_t base = (outer << (LB + 4)) | inner;
+  if constexpr (LB >= 4) return base + (base >> 4);
+  else return base + (outer << LB);
+}
+template <int LB>
+__device__ __forceinline__ constexpr uint32_t lds_off16(int e) {
+  if constexpr (LB >= 4) return (uint32_t)e * ((1u << LB) + (1u << (LB - 4)));
+  else return ((uint32_t)e << LB) + ((uint32_t)e >> (4 - LB));
+}
+
+template <int LB, typename T>
+__device__ __forceinline__ void lds_store16(T* s, const T (&x)[16], uint32_t tid) {
+  T* p = s + lds_base16<LB>(tid);
 #pragma unroll
-  for (int e = 0; e < 16; ++e) s[lds_idx(base | ((uint32_t)e << LB))] = x[e];
+  for (int e = 0; e < 16; ++e) p[lds_off16<LB>(e)] = x[e];
 }
 
 template <int LB, typename T>
 __device__ __forceinline__ void lds_load16(const T* s, T (&x)[16], uint32_t tid) {
-  const uint32_t inner = tid & ((1u << LB) - 1u), outer = tid >> LB;
-  const uint32_t base = (outer << (LB + 4)) | inner;
+  const T* p = s + lds_base16<LB>(tid);
 #pragma unroll
-  for (int e = 0; e < 16; ++e) x[e] = s[lds_idx(base | ((uint32_t)e << LB))];
+  for (int e = 0; e < 16; ++e) x[e] = p[lds_off16<LB>(e)];
 }
+
+// Padded LDS position of element e * NT + tid (the layout a thread's 16 residues have in global memory), NT a
+// multiple of 16: tid + (tid >> 4) + e * (NT + NT / 16).
+template <int NT_>
+__device__ __forceinline__ uint32_t lds_lin_base(uint32_t tid) { return tid + (tid >> 4); }
+template <int NT_>
+__device__ __forceinline__ constexpr uint32_t lds_lin_off(int e) { return (uint32_t)e * (NT_ + NT_ / 16); }
 
 // The 15 twiddles of one 4-stage pass, in the order the stages consume them: relative bit rb
 // (3..0) owns slots (8 >> rb) - 1 ... ; loaded one pass AHEAD of their use so that their L2

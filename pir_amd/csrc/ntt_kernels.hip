@@ -229,7 +229,7 @@ ks_digit_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ re
     }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 16; ++e) x[e] = A::in(s[lds_idx(e * NT + tid)], m);
+    for (int e = 0; e < 16; ++e) x[e] = A::in(s[lds_lin_base<NT>(tid) + lds_lin_off<NT>(e)], m);
   } else {
     // fp64 flavours: the tree holds doubles (signed representatives, |v| <= (1/2 + eps) q_J); sigma_g's sign
     // is the double's sign bit.  The RNS digit is the CANONICAL residue in [0, q_J) read as an integer and
@@ -252,7 +252,7 @@ ks_digit_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ re
     }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 16; ++e) x[e] = sd[lds_idx(e * NT + tid)];
+    for (int e = 0; e < 16; ++e) x[e] = sd[lds_lin_base<NT>(tid) + lds_lin_off<NT>(e)];
   }
   __syncthreads();  // the transform reuses the same LDS words with its own element type
   const size_t poly = ((size_t)node * (k + 1) + I) * k + J;
@@ -417,7 +417,7 @@ ks_last_level_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict
     }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 16; ++e) g[e] += sd[lds_idx(e * NT + tid)];
+    for (int e = 0; e < 16; ++e) g[e] += sd[lds_lin_base<NT>(tid) + lds_lin_off<NT>(e)];
     __syncthreads();
   }
   const double* a = tree + ((size_t)comp * k + j) * N;
@@ -445,7 +445,7 @@ ks_last_level_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict
   }
   __syncthreads();
 #pragma unroll
-  for (int e = 0; e < 16; ++e) x[e] = sd[lds_idx(e * NT + tid)];
+  for (int e = 0; e < 16; ++e) x[e] = sd[lds_lin_base<NT>(tid) + lds_lin_off<NT>(e)];
   __syncthreads();
   ntt_forward<MODE, LOGN, false>(x, smem_raw, P, j, tid);
   {

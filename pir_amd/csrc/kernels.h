@@ -7,6 +7,7 @@
 
 namespace pirgpu {
 
+constexpr int kMaxScanChunks = 16;    // column chunks of one MFMA scan pass (wider matrices use the 64-bit kernels)
 constexpr int kMaxMfmaQueries = 8;   // (query, comp) pairs fill the 16 columns of one MFMA tile
 
 struct MfmaPtrs {                    // one pointer per query of a group (by-value kernel argument)
@@ -75,6 +76,7 @@ struct MfmaGeom {
   uint32_t RT;       // row tiles (16 rows)
   uint32_t KG;       // column groups (16 columns)
   uint32_t KS;       // k-steps (64 columns) per chunk, selectors of one chunk live in registers
+  uint32_t GC;       // column groups per chunk = ceil(KG / nchunks) <= 4 KS
   uint32_t nchunks;  // column chunks (grid.y); > 1 leaves partial sums to reduce_splits_kernel
   size_t db_bytes, sel_bytes;
 };

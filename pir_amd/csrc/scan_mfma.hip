@@ -18,7 +18,8 @@
 // the u64 layout (incl. padding to 16 x 16 tiles) and serves up to 8 queries.
 //
 // Layouts (bytes):
-//   database   [j][rt = r / 16][kg = c / 16][a][r % 16][c % 16]
+//   database   [j][chunk][rt = r / 16][kg within the chunk][a][r % 16][c % 16]   (kg = c / 16; a chunk = the 4 * KS
+//              column groups one launch row keeps selectors for; one chunk -> [j][rt][kg][a][..] as before)
 //   selectors  [j][kg][b][x = 2 * query + comp][c % 16]
 // A workgroup is 8 waves = 8 consecutive slots j (one per wave); results are staged through LDS so
 // that each (row, x) is written as one 64-byte run of 8 slots.
@@ -36,6 +37,16 @@ namespace pirgpu {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef unsigned __int128 u128;
 
+// Byte offset of tile (slot j, row tile rt, column group kg, digit a) in the packed database.  Column chunks are
+// the outer dimension inside a slot, so the part of a slot's slab one workgroup row streams is contiguous
+// (a matrix wider than one chunk used to be read as 14-18 KB pieces with gaps: 3.8-4.2 TB/s instead of ~5.8).
+__host__ __device__ __forceinline__ size_t db_tile_offset(uint32_t j, uint32_t rt, uint32_t kg, uint32_t a, uint32_t L,
+                                                          uint32_t RT, uint32_t KG, uint32_t GC) {
+  const uint32_t ch = kg / GC, kg0 = ch * GC;
+  const uint32_t gc = KG - kg0 < GC ? KG - kg0 : GC;   // groups of this chunk
+  return (((size_t)j * RT * KG + (size_t)RT * kg0 + (size_t)rt * gc + (kg - kg0)) * L + a) * 256;
+}
+
 // centred residue -> L balanced base-256 digits
 template <int L>
 __device__ __forceinline__ void to_digits(uint64_t x, uint64_t q, int8_t (&d)[L]) {
@@ -51,7 +62,7 @@ __device__ __forceinline__ void to_digits(uint64_t x, uint64_t q, int8_t (&d)[L]
 template <int L>
 __global__ void __launch_bounds__(256)
 db_pack_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ db, uint8_t* __restrict__ dbp,
-               uint32_t rows, uint32_t cols, uint32_t kN, uint32_t RT, uint32_t KG) {
+               uint32_t rows, uint32_t cols, uint32_t kN, uint32_t RT, uint32_t KG, uint32_t GC) {
   const uint32_t j = blockIdx.x * 16 + (threadIdx.x & 15);
   const uint32_t r16 = threadIdx.x >> 4;
   const uint32_t rt = blockIdx.y, kg = blockIdx.z;
@@ -72,7 +83,7 @@ db_pack_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ db,
   for (int a = 0; a < L; ++a) {
     v4i v;
     __builtin_memcpy(&v, o[a], 16);
-    *reinterpret_cast<v4i*>(dbp + ((((size_t)j * RT + rt) * KG + kg) * L + a) * 256 + r16 * 16) = v;
+    *reinterpret_cast<v4i*>(dbp + db_tile_offset(j, rt, kg, a, L, RT, KG, GC) + r16 * 16) = v;
   }
 }
 
@@ -111,11 +122,11 @@ sel_pack_kernel(const DevParams* __restrict__ P, MfmaPtrs sv, uint32_t nq, uint8
 template <int L>
 __global__ void __launch_bounds__(256)
 db_unpack_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ dbp, uint64_t* __restrict__ out,
-                 uint32_t r, uint32_t c, uint32_t kN, uint32_t RT, uint32_t KG) {
+                 uint32_t r, uint32_t c, uint32_t kN, uint32_t RT, uint32_t KG, uint32_t GC) {
   const uint32_t j = blockIdx.x * 256 + threadIdx.x;
   if (j >= kN) return;
   const uint64_t q = P->mod[j >> P->logN].q;
-  const uint8_t* p = dbp + (((size_t)j * RT + (r >> 4)) * KG + (c >> 4)) * L * 256 + (r & 15) * 16 + (c & 15);
+  const uint8_t* p = dbp + db_tile_offset(j, r >> 4, c >> 4, 0, L, RT, KG, GC) + (r & 15) * 16 + (c & 15);
   int64_t v = 0;
 #pragma unroll
   for (int a = L - 1; a >= 0; --a) v = v * 256 + (int8_t)p[(size_t)a * 256];
@@ -126,68 +137,81 @@ __device__ __forceinline__ v4i load_tile(const uint8_t* p) {
   return __builtin_nontemporal_load(reinterpret_cast<const v4i*>(p));
 }
 
-// grid = (workgroups, nchunks); block = 512 (wave w <-> slot j0 + w).  A workgroup is persistent: it walks
-// the slot blocks blk = blockIdx.x, blockIdx.x + gridDim.x, ... and, while it folds and stores the last row
-// tile of one block, the selector tiles and the first database tiles of its next block are already in
-// flight (one workgroup per CU at this register count, so nothing else would hide that latency).
-// Chunk ch covers column groups [ch * 4 * KS, (ch + 1) * 4 * KS) and writes to out.p[q] + ch * chunk_stride
-// (partial sums when nchunks > 1).
+// Workgroups per column chunk: first[c] .. first[c+1] run chunk c (equal shares of equal chunks).
+struct ChunkPlan {
+  uint16_t first[kMaxScanChunks + 1];
+  uint32_t nchunks;
+};
+
+// grid = sum of the plan's workgroups; block = 512 (wave w <-> slot j0 + w).  A workgroup is persistent: it walks
+// the slot blocks blk = i, i + n_c, ... (i = its index among the n_c workgroups of its chunk) and, while it folds
+// and stores the last row tile of one block, the selector tiles and the first database tiles of its next block are
+// already in flight (one workgroup per CU at this register count, so nothing else would hide that latency).
+// Chunk ch covers column groups [ch * GC, (ch + 1) * GC) with GC = ceil(KG / nchunks) <= 4 KS -- equal chunks, so
+// that equal shares of the chip finish together (7 k-steps split 3/3/1 left a third of the CUs idle for two thirds
+// of the pass) -- and writes to out.p[q] + ch * chunk_stride (partial sums when nchunks > 1).
 template <int L, int KS>
 __global__ void __launch_bounds__(512)
 scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ dbp, const uint8_t* __restrict__ selp,
                  MfmaPtrs out, uint32_t nq, uint32_t rows, uint32_t RT, uint32_t KG, uint32_t kN,
-                 uint64_t chunk_stride) {
+                 uint64_t chunk_stride, ChunkPlan plan, uint32_t GC) {
   constexpr int NS = 2 * L - 1;        // digit diagonals
   constexpr int NG = (NS + 4) / 5;     // groups of five diagonals (40 bits)
   __shared__ uint64_t stage[2][16][16][8];
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int g = l >> 4, i16 = l & 15;
   const uint32_t nblocks = kN >> 3;
-  const uint32_t kg0 = blockIdx.y * 4 * KS;
+  uint32_t ch = 0;
+  while (ch + 1 < plan.nchunks && blockIdx.x >= plan.first[ch + 1]) ++ch;
+  const uint32_t wg_in_chunk = blockIdx.x - plan.first[ch], wgs_in_chunk = plan.first[ch + 1] - plan.first[ch];
+  const uint32_t kg0 = ch * GC;                                   // GC <= 4 KS column groups per chunk
+  const uint32_t gc = KG - kg0 < GC ? KG - kg0 : GC;              // column groups of this chunk
   const uint32_t nx = 2 * nq;
-  const size_t slab = (size_t)RT * KG * L * 256;   // database bytes of one slot
+  const size_t slab = (size_t)RT * KG * L * 256;                  // database bytes of one slot
+  const size_t chunk_base = (size_t)RT * kg0 * L * 256 + i16 * 16;  // this chunk inside a slot (+ the lane's 16 bytes)
+  const size_t rt_stride = (size_t)gc * L * 256;
 
   v4i B[KS][L], A[KS][L];
   auto load_B = [&](uint32_t j) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const uint32_t kg = kg0 + ks * 4 + g;
+      const uint32_t gl = ks * 4 + g, kg = kg0 + gl;
 #pragma unroll
       for (int b = 0; b < L; ++b) {
         B[ks][b] = v4i{0, 0, 0, 0};   // columns beyond the group's queries stay zero and are neither packed nor read
-        if (kg < KG && (uint32_t)i16 < nx)
+        if (gl < gc && (uint32_t)i16 < nx)
           B[ks][b] = *reinterpret_cast<const v4i*>(selp + (((size_t)j * KG + kg) * L + b) * 256 + i16 * 16);
       }
     }
   };
 
-  uint32_t blk = blockIdx.x;
+  uint32_t blk = wg_in_chunk;
   if (blk >= nblocks) return;
   load_B(blk * 8 + w);
   {
-    const uint8_t* abase = dbp + (size_t)(blk * 8 + w) * slab + i16 * 16;
+    const uint8_t* abase = dbp + (size_t)(blk * 8 + w) * slab + chunk_base;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const uint32_t kg = kg0 + ks * 4 + g;
+      const uint32_t gl = ks * 4 + g;   // column group inside the chunk
 #pragma unroll
       for (int a = 0; a < L; ++a) {
         A[ks][a] = v4i{0, 0, 0, 0};
-        if (kg < KG) A[ks][a] = load_tile(abase + ((size_t)kg * L + a) * 256);
+        if (gl < gc) A[ks][a] = load_tile(abase + ((size_t)gl * L + a) * 256);
       }
     }
   }
 
   uint32_t parity = 0;
-  for (; blk < nblocks; blk += gridDim.x) {
+  for (; blk < nblocks; blk += wgs_in_chunk) {
     const uint32_t j0 = blk * 8;
     const uint32_t j = j0 + w;
     const ModConst m = P->mod[j >> P->logN];
     // multiple of q that makes every 40-bit group positive: 2^57 <= bias < 2^58, |group| < 2^56.1
     const uint64_t bias = m.q << (58 - (64 - __builtin_clzll(m.q)));
-    const uint8_t* abase = dbp + (size_t)j * slab + i16 * 16;
-    const uint32_t nblk = blk + gridDim.x;
+    const uint8_t* abase = dbp + (size_t)j * slab + chunk_base;
+    const uint32_t nblk = blk + wgs_in_chunk;
     const bool has_next = nblk < nblocks;
-    const uint8_t* nbase = dbp + (size_t)(nblk * 8 + w) * slab + i16 * 16;
+    const uint8_t* nbase = dbp + (size_t)(nblk * 8 + w) * slab + chunk_base;
 
     for (uint32_t rt = 0; rt < RT; ++rt) {
       v4i T[NS];
@@ -196,7 +220,7 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
       const bool last = rt + 1 == RT;   // wave-uniform
       // ring of KS k-steps of A tiles: slot ks is refilled right after use with the same step of the next
       // row tile (or of the next block's first row tile)
-      const uint8_t* next_tile = last ? nbase : abase + (size_t)(rt + 1) * KG * L * 256;
+      const uint8_t* next_tile = last ? nbase : abase + (size_t)(rt + 1) * rt_stride;
       const bool refill = !last || has_next;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -208,10 +232,10 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
             const int b = (a + off) % L;
             T[a + b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks][a], B[ks][b], T[a + b], 0, 0, 0);
           }
-        const uint32_t kg = kg0 + ks * 4 + g;
-        if (refill && kg < KG) {
+        const uint32_t gl = ks * 4 + g;
+        if (refill && gl < gc) {
 #pragma unroll
-          for (int a = 0; a < L; ++a) A[ks][a] = load_tile(next_tile + ((size_t)kg * L + a) * 256);
+          for (int a = 0; a < L; ++a) A[ks][a] = load_tile(next_tile + ((size_t)gl * L + a) * 256);
         }
       }
       if (last && has_next) load_B(nblk * 8 + w);   // all MFMAs of this block are issued: B is free
@@ -241,8 +265,7 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
         const uint32_t r = rt * 16 + r16;
         if (x < (int)nx && r < rows) {
           const v4i v = *reinterpret_cast<const v4i*>(&stage[buf][r16][x][part * 2]);
-          uint64_t* dst = (uint64_t*)out.p[x >> 1] + blockIdx.y * chunk_stride + ((size_t)r * 2 + (x & 1)) * kN + j0 +
-                          part * 2;
+          uint64_t* dst = (uint64_t*)out.p[x >> 1] + ch * chunk_stride + ((size_t)r * 2 + (x & 1)) * kN + j0 + part * 2;
           *reinterpret_cast<v4i*>(dst) = v;
         }
       }
@@ -268,6 +291,9 @@ MfmaGeom mfma_geometry(const DevParams& hp, uint32_t rows, uint32_t cols) {
   const uint32_t steps = (gm.KG + 3) / 4;
   gm.KS = std::min(max_ks, steps);
   gm.nchunks = (steps + gm.KS - 1) / gm.KS;
+  if (gm.nchunks > (uint32_t)kMaxScanChunks) { gm.L = 0; return gm; }   // wider than 16 x 4 KS x 16 columns: 64-bit kernels
+  gm.GC = (gm.KG + gm.nchunks - 1) / gm.nchunks;   // equal chunks (<= 4 KS groups each)
+  gm.KS = (gm.GC + 3) / 4;
   const size_t kN = (size_t)hp.k * hp.N;
   gm.db_bytes = kN * gm.RT * gm.KG * gm.L * 256;
   gm.sel_bytes = kN * gm.KG * gm.L * 256;
@@ -278,9 +304,9 @@ hipError_t launch_db_pack(hipStream_t st, const DevParams* P, const MfmaGeom& gm
                           uint32_t rows, uint32_t cols, uint32_t kN) {
   const dim3 grid(kN / 16, gm.RT, gm.KG);
   switch (gm.L) {
-    case 5: hipLaunchKernelGGL(db_pack_kernel<5>, grid, dim3(256), 0, st, P, db, dbp, rows, cols, kN, gm.RT, gm.KG); break;
-    case 6: hipLaunchKernelGGL(db_pack_kernel<6>, grid, dim3(256), 0, st, P, db, dbp, rows, cols, kN, gm.RT, gm.KG); break;
-    case 7: hipLaunchKernelGGL(db_pack_kernel<7>, grid, dim3(256), 0, st, P, db, dbp, rows, cols, kN, gm.RT, gm.KG); break;
+    case 5: hipLaunchKernelGGL(db_pack_kernel<5>, grid, dim3(256), 0, st, P, db, dbp, rows, cols, kN, gm.RT, gm.KG, gm.GC); break;
+    case 6: hipLaunchKernelGGL(db_pack_kernel<6>, grid, dim3(256), 0, st, P, db, dbp, rows, cols, kN, gm.RT, gm.KG, gm.GC); break;
+    case 7: hipLaunchKernelGGL(db_pack_kernel<7>, grid, dim3(256), 0, st, P, db, dbp, rows, cols, kN, gm.RT, gm.KG, gm.GC); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -290,9 +316,9 @@ hipError_t launch_db_unpack(hipStream_t st, const DevParams* P, const MfmaGeom& 
                             uint32_t row, uint32_t col, uint32_t kN) {
   const dim3 grid((kN + 255) / 256);
   switch (gm.L) {
-    case 5: hipLaunchKernelGGL(db_unpack_kernel<5>, grid, dim3(256), 0, st, P, dbp, out, row, col, kN, gm.RT, gm.KG); break;
-    case 6: hipLaunchKernelGGL(db_unpack_kernel<6>, grid, dim3(256), 0, st, P, dbp, out, row, col, kN, gm.RT, gm.KG); break;
-    case 7: hipLaunchKernelGGL(db_unpack_kernel<7>, grid, dim3(256), 0, st, P, dbp, out, row, col, kN, gm.RT, gm.KG); break;
+    case 5: hipLaunchKernelGGL(db_unpack_kernel<5>, grid, dim3(256), 0, st, P, dbp, out, row, col, kN, gm.RT, gm.KG, gm.GC); break;
+    case 6: hipLaunchKernelGGL(db_unpack_kernel<6>, grid, dim3(256), 0, st, P, dbp, out, row, col, kN, gm.RT, gm.KG, gm.GC); break;
+    case 7: hipLaunchKernelGGL(db_unpack_kernel<7>, grid, dim3(256), 0, st, P, dbp, out, row, col, kN, gm.RT, gm.KG, gm.GC); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -323,9 +349,13 @@ static void launch_scan_mfma_variant(hipStream_t st, const DevParams* P, const M
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256u;
     return (uint32_t)prop.multiProcessorCount;
   }();
-  const uint32_t gx = std::min<uint32_t>(kN / 8, std::max<uint32_t>(1, wgs / std::min<uint32_t>(gm.nchunks, wgs)));
-  hipLaunchKernelGGL((scan_mfma_kernel<L, KS>), dim3(gx, gm.nchunks), dim3(512), 0, st, P, dbp, selp, out, nq, rows,
-                     gm.RT, gm.KG, kN, chunk_stride);
+  // equal shares of the chip for the (equal) column chunks
+  ChunkPlan plan{};
+  plan.nchunks = gm.nchunks;
+  const uint32_t share = std::min<uint32_t>(kN / 8, std::max<uint32_t>(1, wgs / std::min<uint32_t>(gm.nchunks, wgs)));
+  for (uint32_t c = 0; c <= gm.nchunks; ++c) plan.first[c] = (uint16_t)(c * share);
+  hipLaunchKernelGGL((scan_mfma_kernel<L, KS>), dim3(gm.nchunks * share), dim3(512), 0, st, P, dbp, selp, out, nq, rows,
+                     gm.RT, gm.KG, kN, chunk_stride, plan, gm.GC);
 }
 
 hipError_t launch_scan_mfma(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp,

@@ -53,7 +53,7 @@ GEOMETRIES = [
     # N=4096, 36-bit primes -> 5 digits
     ("L5 17x70 (2 k-steps, ragged tiles)", dict(dbsize=0, elem=2048, dims=[17, 70], N=4096, plain_bits=24), 5, 1, 2),
     ("L5 33x9 (1 k-step)", dict(dbsize=0, elem=2048, dims=[33, 9], N=4096, plain_bits=24), 5, 1, 1),
-    ("L5 9x200 (2 column chunks)", dict(dbsize=3, elem=2048, dims=[9, 200], N=4096, plain_bits=24), 5, 2, 3),
+    ("L5 9x200 (2 column chunks)", dict(dbsize=3, elem=2048, dims=[9, 200], N=4096, plain_bits=24), 5, 2, 2),   # 13 column groups -> 2 equal chunks of 7 and 6 groups = 2 k-steps each
     ("L5 d=3 4x4x40 (rows = 16)", dict(dbsize=1, elem=2048, dims=[4, 4, 40], N=4096, plain_bits=20), 5, 1, 1),
 ]
 

@@ -241,7 +241,8 @@ def main():
     if use_dist and batch % world:
         batch += world - batch % world
     per_rank = batch // world if use_dist else batch
-    workers = args.workers if args.workers > 0 else min(max(per_rank, 8) if use_dist else batch, 16)
+    # two groups of 8 alternate on two lanes: 16 working sets, whatever the number of queries this rank expands
+    workers = args.workers if args.workers > 0 else (16 if use_dist else min(batch, 16))
     run_rows = (not use_dist) or args.dist_mode in ("both", "rows")
     run_replicas = use_dist and world > 1 and args.dist_mode in ("both", "queries")
     # same database, keys and queries on every rank (fixed seeds): query i of the batch is the same everywhere

@@ -173,7 +173,7 @@ class PackedBuffers:
         reply_cts = server.db.reply_ct_count()
         self.packed = torch.empty((world, self.groups, max(self.sel_bytes, 1)), dtype=torch.uint8, device=device)
         self.rows_send = torch.empty((self.per * n0 * self.ctw,), dtype=torch.int64, device=device)
-        self.rows_recv = torch.empty((max(batch * self.my_rows, 1) * self.ctw,), dtype=torch.int64, device=device)
+        self.rows_recv = torch.empty((batch * self.my_rows * self.ctw,), dtype=torch.int64, device=device)
         self.partial = torch.empty((batch, reply_cts, 2, k, N), dtype=torch.int64, device=device)
         self.replies = torch.empty((self.per, reply_cts, 2, k, N), dtype=torch.int64, device=device)
         self.send_splits = [self.per * (self.cuts[s + 1] - self.cuts[s]) * self.ctw for s in range(world)]

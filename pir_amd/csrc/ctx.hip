@@ -62,6 +62,8 @@ struct Worker {
   std::vector<uint64_t*> lvl;  // per level results; lvl[0] = reply
   uint64_t* pt_buf = nullptr;
   uint64_t* scan_part = nullptr;
+  uint64_t* up_scratch = nullptr;    // split upper level (large rings): transformed plaintexts of one block of children
+  size_t up_scratch_words = 0;
   uint8_t* selp = nullptr;           // digit-packed selectors of the group this worker leads (MFMA scan)
   bool reply_valid = false;
   hipEvent_t ev_expanded = nullptr, ev_scanned = nullptr;  // batch mode: cross-stream hand-offs
@@ -82,6 +84,8 @@ struct BatchLane {
   std::vector<uint64_t*> lvl;        // [level][query][lvl_cts[level]][2][k][N]
   uint64_t* pt_buf = nullptr;        // [query][pt_words]
   uint64_t* scan_part = nullptr;     // [query][column chunk][scan_rows][2][k][N] (matrices wider than one chunk)
+  uint64_t* up_scratch = nullptr;    // split upper level (large rings)
+  size_t up_scratch_words = 0;
 };
 
 // Where one multiply (scan results -> reply) runs: a worker's buffers (one query) or a lane's (a group).
@@ -92,6 +96,8 @@ struct Stage {
   uint32_t n;             // queries
   MfmaPtrs sel;           // per query: the selection vector (whole, NTT form) or, with local_rows, only this shard's
   bool local_rows;        // dimension-0 selectors at local index (packed multi-GPU exchange)
+  uint64_t** up_scratch = nullptr;   // owner's scratch for the split upper level, grown on demand
+  size_t* up_scratch_words = nullptr;
 };
 
 struct pirgpu_ctx {
@@ -152,6 +158,9 @@ struct pirgpu_ctx {
   MfmaGeom mg{};
   uint32_t mfma_nq = kMaxMfmaQueries;       // queries per database pass in batch mode
   bool mfma_single = true;                  // single queries use it too (off for matrices wider than one chunk)
+  bool split_upper = false;                 // upper level as transform-to-scratch + elementwise MAC (N >= 16384 in the fp64
+                                            // flavours, where the fused kernel spills; PIRGPU_SPLIT_UPPER=0/1 overrides)
+  uint64_t split_upper_words = (3ull << 30) / 8;  // scratch budget per lane / worker (PIRGPU_SPLIT_UPPER_MB)
   bool fuse_last_level = true;              // last expansion level fused with the selector NTT (PIRGPU_FUSE_LAST=0: off)
   bool pack40 = false;                      // key-switch digits stored in 5 bytes (all moduli < 2^40; PIRGPU_PACK40)
   uint8_t* d_dbp = nullptr;
@@ -419,6 +428,8 @@ void ensure_workspace(pirgpu_ctx* c) {
     //   PIRGPU_SCAN_MFMA=0 keeps the 64-bit multiply-accumulate kernels for d >= 2 as well
     //   PIRGPU_SCAN_MFMA_NQ queries per database pass of the MFMA scan in batch mode (1..8)
     c->fuse_last_level = env_u32("PIRGPU_FUSE_LAST", 1) != 0;
+    c->split_upper = env_u32("PIRGPU_SPLIT_UPPER", c->logN >= 14 ? 1 : 0) != 0 && c->mode != kNttInt;
+    c->split_upper_words = (uint64_t)env_u32("PIRGPU_SPLIT_UPPER_MB", 3072) * (1ull << 20) / 8;
     c->pack40 = env_u32("PIRGPU_PACK40", 1) != 0;
     // 5-byte storage of the key-switch intermediates: the fp64 flavours store x + q (|x| <= q), so q < 2^39
     for (uint32_t j = 0; j <= k; ++j) c->pack40 = c->pack40 && (c->hp.mod[j].q >> 39) == 0;
@@ -669,13 +680,39 @@ void post_scan_stage(pirgpu_ctx* c, const Stage& sg, Worker* profiled) {
     if (out_polys * n_chunks * N > c->pt_words)
       throw Fail{PIRGPU_INTERNAL, "upper-level scratch undersized"};
     if (local_rows && l != 0) throw Fail{PIRGPU_INTERNAL, "local row selectors are a d = 2 feature"};
-    HIP_TRY(c->ops->upper_fused(st, c->mode, c->dp, k, c->E, sg.lvl[l + 1], sg.sel, sg.pt_buf, (uint32_t)rows,
-                                c->dims[l], (uint32_t)nch, sv_first, (uint32_t)C, chunk_len, n_chunks, sg.n,
-                                c->lvl_cts[l + 1] * ctw, c->pt_words));
-    if (l == 0 && profiled) record(c, *profiled, PH_FINAL);
-    // fold the chunk sums (wide, elementwise) and return to coefficient form (database.cpp:250-254)
-    HIP_TRY(launch_reduce_splits(st, c->dp, sg.pt_buf, n_chunks, out_polys * N, sg.lvl[l], sg.n, c->pt_words,
+    if (c->split_upper && sg.up_scratch) {
+      // large rings: transform the re-encoded plaintexts of a block of children into scratch, multiply-accumulate
+      // them elementwise, next block (upper_ntt_kernel / upper_mac_kernel)
+      const uint64_t unit = (uint64_t)sg.n * rows * C * c->E * k * N;   // scratch words per child of the block
+      uint32_t blk = (uint32_t)std::min<uint64_t>(c->dims[l], std::max<uint64_t>(1, c->split_upper_words / unit));
+      if (*sg.up_scratch_words < unit * blk) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (*sg.up_scratch) {
+          auto it = std::find(c->allocs.begin(), c->allocs.end(), (void*)*sg.up_scratch);
+          if (it != c->allocs.end()) c->allocs.erase(it);
+          HIP_TRY(hipFree(*sg.up_scratch));
+          *sg.up_scratch = nullptr;
+        }
+        *sg.up_scratch = c->dalloc<uint64_t>(unit * blk);
+        *sg.up_scratch_words = unit * blk;
+      }
+      for (uint32_t b0 = 0; b0 < c->dims[l]; b0 += blk) {
+        HIP_TRY(c->ops->upper_ntt(st, c->mode, c->dp, k, c->E, sg.lvl[l + 1], *sg.up_scratch, (uint32_t)rows, c->dims[l],
+                                  (uint32_t)nch, (uint32_t)C, b0, blk, sg.n, c->lvl_cts[l + 1] * ctw));
+        HIP_TRY(launch_upper_mac(st, c->dp, *sg.up_scratch, sg.sel, sg.pt_buf, sg.lvl[l], sg.n, (uint32_t)rows, (uint32_t)C,
+                                 c->E, k, N, sv_first, b0, blk, c->dims[l], b0 == 0, b0 + blk >= c->dims[l], c->pt_words,
                                  c->lvl_cts[l] * ctw));
+      }
+      if (l == 0 && profiled) record(c, *profiled, PH_FINAL);
+    } else {
+      HIP_TRY(c->ops->upper_fused(st, c->mode, c->dp, k, c->E, sg.lvl[l + 1], sg.sel, sg.pt_buf, (uint32_t)rows,
+                                  c->dims[l], (uint32_t)nch, sv_first, (uint32_t)C, chunk_len, n_chunks, sg.n,
+                                  c->lvl_cts[l + 1] * ctw, c->pt_words));
+      if (l == 0 && profiled) record(c, *profiled, PH_FINAL);
+      // fold the chunk sums (wide, elementwise) and return to coefficient form (database.cpp:250-254)
+      HIP_TRY(launch_reduce_splits(st, c->dp, sg.pt_buf, n_chunks, out_polys * N, sg.lvl[l], sg.n, c->pt_words,
+                                   c->lvl_cts[l] * ctw));
+    }
     HIP_TRY(c->ops->ntt_batch(st, c->mode, c->dp, sg.lvl[l], (uint64_t)sg.n * out_polys, k, 0, true));
     C *= c->E;
   }
@@ -685,7 +722,7 @@ void post_scan_stage(pirgpu_ctx* c, const Stage& sg, Worker* profiled) {
 // Everything after the scan for one worker's query: inverse NTT of the row sums and the upper recursion levels
 // (reference database.cpp:196-254).  Leaves the reply in lvl[0].
 void post_scan_on_device(pirgpu_ctx* c, Worker& w) {
-  Stage sg{w.stream, w.lvl.data(), w.pt_buf, 1, MfmaPtrs{}, w.sv_rows != nullptr};
+  Stage sg{w.stream, w.lvl.data(), w.pt_buf, 1, MfmaPtrs{}, w.sv_rows != nullptr, &w.up_scratch, &w.up_scratch_words};
   sg.sel.p[0] = w.sv_rows ? w.sv_rows : (w.sv_cur ? w.sv_cur : w.sv_ntt);
   post_scan_stage(c, sg, &w);
 }
@@ -1409,7 +1446,7 @@ static void batch_run_mfma(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
       }
       const uint32_t first = rank0 + j0;  // global index of the group's first query
       const uint8_t* packed = nullptr;
-      Stage sg{ln.stream, ln.lvl.data(), ln.pt_buf, B, MfmaPtrs{}, pk != nullptr};
+      Stage sg{ln.stream, ln.lvl.data(), ln.pt_buf, B, MfmaPtrs{}, pk != nullptr, &ln.up_scratch, &ln.up_scratch_words};
       MfmaPtrs col{};
       if (pk) {
         const uint32_t groups_per_rank = (pk->per_rank + kMaxMfmaQueries - 1) / kMaxMfmaQueries;

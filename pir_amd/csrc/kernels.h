@@ -44,6 +44,12 @@ struct NttOps {
   hipError_t (*ks_last_level)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* tree,
                               const uint64_t* prod, uint32_t galois_elt, uint32_t shift_pow, uint32_t n_items,
                               uint32_t B, const MfmaPtrs& dst, uint32_t tree_cts, bool pack40);
+  // split upper level, part 1 (fp64 flavours, large rings): re-encode + lift + forward NTT of the children
+  // [b0, b0 + blk) of every row into scratch [query][row][cc][child in block][chunk][target modulus][N] doubles
+  hipError_t (*upper_ntt)(hipStream_t st, int mode, const DevParams* P, uint32_t k, uint32_t enc_count,
+                          const uint64_t* src, uint64_t* scratch, uint32_t n_rows, uint32_t n_dim,
+                          uint32_t n_children_total, uint32_t C, uint32_t b0, uint32_t blk, uint32_t n_queries,
+                          uint64_t src_qstride);
 };
 
 const NttOps* ntt_ops_for(uint32_t N);  // nullptr for unsupported degrees
@@ -69,6 +75,14 @@ hipError_t launch_reduce_splits(hipStream_t st, const DevParams* P, const uint64
                                 uint64_t words, uint64_t* out, uint32_t n_queries = 1, uint64_t part_qstride = 0,
                                 uint64_t out_qstride = 0);
 
+
+// split upper level, part 2: acc[query][slot][comp][jt][i] (+)= sum over the block's children of
+// scratch (.) selector, elementwise; `first` starts the sums, `last` writes canonical u64 residues to `out`
+// (reduce_splits' output layout) instead of keeping signed doubles in `acc`
+hipError_t launch_upper_mac(hipStream_t st, const DevParams* P, const uint64_t* scratch, const MfmaPtrs& svq,
+                            uint64_t* acc, uint64_t* out, uint32_t n_queries, uint32_t n_rows, uint32_t C,
+                            uint32_t enc_count, uint32_t k, uint32_t N, uint32_t sv_first, uint32_t b0, uint32_t blk,
+                            uint32_t n_dim, bool first, bool last, uint64_t acc_qstride, uint64_t out_qstride);
 
 // ---- digit-sliced int8-MFMA scan (scan_mfma.hip) ----
 struct MfmaGeom {

@@ -214,6 +214,57 @@ __global__ void tree_export_kernel(const DevParams* __restrict__ P, const double
   out[gid] = f64_to_u64(f64_canon(f64_norm(in[gid], m), m));
 }
 
+// Split upper level, part 2 (see upper_ntt_kernel): products of the transformed plaintexts of one block of children
+// with both selector polynomials, summed over the block.  One thread per (query, row, cc, chunk e, target modulus,
+// slot i); both components share the plaintext load.  Sums are signed representatives kept as doubles in `acc`
+// between blocks; the last block writes canonical residues (u64) where reduce_splits_kernel would have.
+__global__ void upper_mac_kernel(const DevParams* __restrict__ P, const double* __restrict__ scratch, MfmaPtrs svq,
+                                 double* __restrict__ acc_all, uint64_t* __restrict__ out_all, uint32_t n_rows, uint32_t C,
+                                 uint32_t E, uint32_t sv_first, uint32_t b0, uint32_t blk, uint32_t n_dim, int first,
+                                 int last, uint64_t acc_qstride, uint64_t out_qstride) {
+  const uint32_t N = P->N, k = P->k;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;   // slot
+  const uint32_t jt = blockIdx.y % k, e_idx = blockIdx.y / k;
+  const uint32_t cc = blockIdx.z % C, r = (blockIdx.z / C) % n_rows, qi = blockIdx.z / (C * n_rows);
+  if (i >= N) return;
+  const F64Mod m{P->tab[jt].qd, P->tab[jt].qinvd};
+  const uint64_t* sv = reinterpret_cast<const uint64_t*>(svq.p[qi]);
+  const double* x = scratch + ((((size_t)qi * n_rows + r) * C + cc) * blk * E + e_idx) * k * N + (size_t)jt * N + i;
+  const size_t child_stride = (size_t)E * k * N;
+  double a0 = 0.0, a1 = 0.0;
+  uint32_t since = 0;
+  for (uint32_t iib = 0; iib < blk; ++iib) {
+    const uint32_t ii = b0 + iib;
+    if (ii >= n_dim) break;
+    const double v = x[(size_t)iib * child_stride];
+    const uint64_t* s0 = sv + (((size_t)(sv_first + ii) * 2 + 0) * k + jt) * N + i;
+    a0 += f64_mulmod(v, f64_from_u64(s0[0]), m);
+    a1 += f64_mulmod(v, f64_from_u64(s0[(size_t)k * N]), m);
+    if (++since == 8) {
+      since = 0;
+      a0 = f64_norm(a0, m);
+      a1 = f64_norm(a1, m);
+    }
+  }
+  const size_t slot = (((size_t)r * C + cc) * E + e_idx);
+  const size_t o0 = ((slot * 2 + 0) * k + jt) * N + i, o1 = ((slot * 2 + 1) * k + jt) * N + i;
+  double* acc = acc_all + (size_t)qi * acc_qstride;
+  if (!first) {
+    a0 += acc[o0];
+    a1 += acc[o1];
+  }
+  a0 = f64_norm(a0, m);
+  a1 = f64_norm(a1, m);
+  if (last) {
+    uint64_t* out = out_all + (size_t)qi * out_qstride;
+    out[o0] = f64_to_u64(f64_canon(a0, m));
+    out[o1] = f64_to_u64(f64_canon(a1, m));
+  } else {
+    acc[o0] = a0;
+    acc[o1] = a1;
+  }
+}
+
 // multiply_inverse_power_of_x on whole ciphertexts (reference server.cpp:78-103).
 __global__ void monomial_shift_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ in,
                                       uint32_t shift, uint64_t count, uint64_t* __restrict__ out) {
@@ -754,6 +805,18 @@ hipError_t launch_tree_convert(hipStream_t st, const DevParams* P, int mode, con
     hipLaunchKernelGGL(tree_import_kernel, grid, block, 0, st, P, in, reinterpret_cast<double*>(out), words);
   else
     hipLaunchKernelGGL(tree_export_kernel, grid, block, 0, st, P, reinterpret_cast<const double*>(in), out, words);
+  PIRGPU_LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_upper_mac(hipStream_t st, const DevParams* P, const uint64_t* scratch, const MfmaPtrs& svq,
+                            uint64_t* acc, uint64_t* out, uint32_t n_queries, uint32_t n_rows, uint32_t C,
+                            uint32_t enc_count, uint32_t k, uint32_t N, uint32_t sv_first, uint32_t b0, uint32_t blk,
+                            uint32_t n_dim, bool first, bool last, uint64_t acc_qstride, uint64_t out_qstride) {
+  const dim3 grid((N + 255) / 256, enc_count * k, n_queries * n_rows * C);
+  hipLaunchKernelGGL(upper_mac_kernel, grid, dim3(256), 0, st, P, reinterpret_cast<const double*>(scratch), svq,
+                     reinterpret_cast<double*>(acc), out, n_rows, C, enc_count, sv_first, b0, blk, n_dim, first ? 1 : 0,
+                     last ? 1 : 0, acc_qstride, out_qstride);
   PIRGPU_LAUNCH_CHECK();
   return hipSuccess;
 }

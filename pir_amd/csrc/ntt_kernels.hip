@@ -591,6 +591,68 @@ upper_fused_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
   }
 }
 
+// Upper recursion level for ring degrees whose fused kernel cannot keep two accumulator sets in registers
+// (N = 16384: 1024-thread workgroups, 128 VGPRs -> upper_fused_kernel spills 128 registers), part 1 of 2: re-encode
+// chunk e_idx of one child ciphertext, plain lift, forward NTT for target modulus jt, and STORE the transformed
+// plaintext (doubles, signed representatives) instead of multiplying it at once; upper_mac_kernel (kernels.hip)
+// then forms the products with the selectors elementwise.  Costs a round trip of the transformed plaintexts through
+// HBM (bounded by processing the children in blocks) and saves the spills: fp64 flavours only.
+// grid = (queries * n_rows * C * blk, E, k); child ii = b0 + (blockIdx.x % blk) of row r.
+template <int MODE>
+__global__ void __launch_bounds__(NT)
+upper_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ src_all, double* __restrict__ scratch,
+                 uint32_t n_rows, uint32_t n_dim, uint32_t n_children_total, uint32_t C, uint32_t b0, uint32_t blk,
+                 uint64_t src_qstride) {
+  using A = Arith<MODE>;
+  static_assert(MODE != kNttInt, "fp64 flavours only");
+  const uint32_t tid = threadIdx.x, k = P->k, E = P->enc_count;
+  const uint32_t iib = blockIdx.x % blk;
+  const uint32_t cc = (blockIdx.x / blk) % C;
+  const uint32_t r = (blockIdx.x / (blk * C)) % n_rows;
+  const uint32_t qi = blockIdx.x / (blk * C * n_rows);
+  const uint32_t e_idx = blockIdx.y, jt = blockIdx.z;
+  const uint32_t ii = b0 + iib;
+  const uint32_t child0 = r * n_dim;
+  uint32_t nchild = n_children_total > child0 ? n_children_total - child0 : 0;
+  if (nchild > n_dim) nchild = n_dim;
+  double* out = scratch + (((((size_t)qi * n_rows + r) * C + cc) * blk + iib) * E + e_idx) * k * N + (size_t)jt * N;
+  typename A::T x[16];
+  if (ii >= nchild) {  // beyond the database: contributes nothing (uniform per workgroup)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) out[e * NT + tid] = 0.0;
+    return;
+  }
+  const ModConst mc = P->mod[jt];
+  const typename A::Mod m = A::mod(P, jt);
+  const uint32_t sp = P->enc_poly[e_idx], sj = P->enc_res[e_idx], sh = P->enc_shift[e_idx];
+  const uint64_t mask = (1ull << P->enc_bits) - 1;
+  const uint64_t thr = P->plain_thr;
+  const uint64_t inc = P->lift_inc[jt] >= mc.q ? P->lift_inc[jt] - mc.q : P->lift_inc[jt];
+  const bool fast_lift = P->enc_bits <= 31 && P->t < mc.q;
+  const double td = (double)P->t;
+  const uint32_t thr32 = (uint32_t)thr, mask32 = (uint32_t)mask;
+  const uint64_t* in = src_all + (size_t)qi * src_qstride + ((((size_t)(child0 + ii) * C + cc) * 2 + sp) * k + sj) * N;
+  if (fast_lift) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const uint32_t v = (uint32_t)(in[e * NT + tid] >> sh) & mask32;
+      const double d = (double)v;
+      x[e] = v >= thr32 ? d - td : d;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      uint64_t v = (in[e * NT + tid] >> sh) & mask;
+      uint64_t rr = reduce64(v, mc);
+      if (v >= thr) rr = add_mod(rr, inc, mc.q);
+      x[e] = A::in(rr, m);
+    }
+  }
+  ntt_forward<MODE, LOGN, kPF, /*CANON=*/false>(x, smem_raw, P, jt, tid);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) out[e * NT + tid] = x[e];
+}
+
 // ------------------------------------------------------------------ host side
 
 #define PIRGPU_BY_MODE(mode, EXPR)                                \
@@ -618,6 +680,7 @@ static hipError_t configure_mode() {
   PIRGPU_SET((ks_mac_intt_kernel<MODE, true>));
   PIRGPU_SET(upper_fused_kernel<MODE>);
   if constexpr (MODE != kNttInt) {
+    PIRGPU_SET(upper_ntt_kernel<MODE>);
     PIRGPU_SET((ks_last_level_kernel<MODE, false>));
     PIRGPU_SET((ks_last_level_kernel<MODE, true>));
   }
@@ -719,6 +782,23 @@ static hipError_t op_ks_last_level(hipStream_t st, int mode, const DevParams* P,
   return hipGetLastError();
 }
 
+static hipError_t op_upper_ntt(hipStream_t st, int mode, const DevParams* P, uint32_t k, uint32_t enc_count,
+                               const uint64_t* src, uint64_t* scratch, uint32_t n_rows, uint32_t n_dim,
+                               uint32_t n_children_total, uint32_t C, uint32_t b0, uint32_t blk, uint32_t n_queries,
+                               uint64_t src_qstride) {
+  const dim3 grid(n_queries * n_rows * C * blk, enc_count, k);
+  double* out = reinterpret_cast<double*>(scratch);
+  if (mode == kNttF64)
+    hipLaunchKernelGGL(upper_ntt_kernel<kNttF64>, grid, dim3(NT), kLdsBytes, st, P, src, out, n_rows, n_dim,
+                       n_children_total, C, b0, blk, src_qstride);
+  else if (mode == kNttF64Wide)
+    hipLaunchKernelGGL(upper_ntt_kernel<kNttF64Wide>, grid, dim3(NT), kLdsBytes, st, P, src, out, n_rows, n_dim,
+                       n_children_total, C, b0, blk, src_qstride);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
 static hipError_t op_upper_fused(hipStream_t st, int mode, const DevParams* P, uint32_t k, uint32_t enc_count,
                                  const uint64_t* src, const MfmaPtrs& svq, uint64_t* part, uint32_t n_rows,
                                  uint32_t n_dim, uint32_t n_children_total, uint32_t sv_first, uint32_t C,
@@ -737,7 +817,8 @@ static hipError_t op_upper_fused(hipStream_t st, int mode, const DevParams* P, u
 const NttOps* PIRGPU_OPS_NAME() {
   using namespace PIRGPU_DEG_NS;
   static const NttOps ops = {op_configure, op_ntt_batch,   op_ct_ntt_fwd_oop, op_ct_ntt_fwd_split, op_db_encode,
-                             op_ks_digit,  op_ks_mac_intt, op_upper_fused,     op_ks_last_level};
+                             op_ks_digit,  op_ks_mac_intt, op_upper_fused,     op_ks_last_level,
+                             op_upper_ntt};
   return &ops;
 }
 

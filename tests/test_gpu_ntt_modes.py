@@ -79,3 +79,25 @@ def test_query_path_flavours(monkeypatch, chain, items, elem, mode):
     for i in (1, 2):
         assert np.array_equal(batch[i], srv.process_query(queries[i]))
     db.close()
+
+
+@pytest.mark.parametrize("d,items,elem,mb", [(2, 2600, 288, 1), (2, 2600, 288, 64), (3, 700, 288, 1)])
+def test_split_upper_level_matches_fused(monkeypatch, d, items, elem, mb):
+    """The upper recursion level as transform-to-scratch + elementwise multiply-accumulate (the N = 16384 default,
+    where the fused kernel cannot hold its accumulators) forced on at N = 4096, with a scratch budget small enough
+    for several blocks of children: single and batched replies equal the oracle's, for d = 2 and d = 3."""
+    monkeypatch.setenv("PIRGPU_SPLIT_UPPER", "1")
+    monkeypatch.setenv("PIRGPU_SPLIT_UPPER_MB", str(mb))
+    s = PirSetup(items, elem, d, N=4096, plain_bits=24)
+    db, srv = _server(s)
+    rng = np.random.default_rng(d)
+    keys = {(4096 >> j) + 1: random_key(s.orc, rng) for j in range(12)}
+    srv.set_galois_keys(keys)
+    queries = random_ct(s.orc, rng, 3)[:, None]
+    exp = [s.orc.process_query(s.db_ntt, s.params.dimensions, q, keys)[1] for q in queries]
+    for i in range(3):
+        assert np.array_equal(srv.process_query(queries[i]), exp[i]), i
+    batch = srv.process_batch(queries, n_workers=3)
+    for i in range(3):
+        assert np.array_equal(batch[i], exp[i]), i
+    db.close()

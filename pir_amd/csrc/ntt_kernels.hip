@@ -363,16 +363,16 @@ ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
 }
 
 // Last level of the expansion tree fused with the selectors' forward NTT (fp64 flavours).  One workgroup per
-// (tree ciphertext, component, data modulus): divide-and-round of the key-switch product, + sigma_g(c0), the tree
-// butterfly lo = a + g, hi = x^(-2^j) (a - g) -- exactly ks_combine_f64_kernel's arithmetic -- but the two output
-// polynomials stay in registers / LDS and go straight through the forward transform into the queries' selection
-// vectors: the last level's ciphertexts are never written to HBM in coefficient form and never read back
-// (reference server.cpp:137-141 followed by database.cpp:190,222).  Tree ciphertext index = slot * B + query;
-// lo is selector `slot`, hi selector `slot + shift_pow`; selectors >= n_items are not produced (server.cpp:144).
-// 3 waves per SIMD (<= 168 VGPRs: g, the polynomial in flight and the transform's own registers fit without the
-// twiddle prefetch); a 1024-thread workgroup (N = 16384) is 4 waves per SIMD by itself
+// (tree ciphertext, component, data modulus, half): divide-and-round of the key-switch product, + sigma_g(c0), the
+// tree butterfly lo = a + g (half 0) or hi = x^(-2^j) (a - g) (half 1) -- exactly ks_combine_f64_kernel's arithmetic
+// -- but the output polynomial stays in registers / LDS and goes straight through the forward transform into the
+// queries' selection vectors: the last level's ciphertexts are never written to HBM in coefficient form and never
+// read back (reference server.cpp:137-141 followed by database.cpp:190,222).  Tree ciphertext index = slot * B +
+// query; lo is selector `slot`, hi selector `slot + shift_pow`; selectors >= n_items are not produced
+// (server.cpp:144).  The two halves recompute g (30 instructions per element) rather than keeping it across a
+// transform: one transform per workgroup, no value live across it, 4 waves per SIMD.
 template <int MODE, bool P40>
-__global__ void __launch_bounds__(NT, LOGN < 14 ? 3 : 4)
+__global__ void __launch_bounds__(NT)
 ks_last_level_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ tree_raw,
                      const uint64_t* __restrict__ prod, uint32_t galois_elt, uint32_t shift_pow, uint32_t n_items,
                      uint32_t B, MfmaPtrs dst) {
@@ -380,9 +380,11 @@ ks_last_level_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict
   static_assert(MODE != kNttInt, "fp64 flavours only");
   double* sd = reinterpret_cast<double*>(smem_raw);
   const uint32_t tid = threadIdx.x, k = P->k, km = k + 1;
-  const uint32_t j = blockIdx.x % k, comp = (blockIdx.x / k) & 1, ct = blockIdx.x / (2 * k);
+  const uint32_t half_id = blockIdx.x & 1, bx = blockIdx.x >> 1;   // the two halves of a polynomial run back to back
+  const uint32_t j = bx % k, comp = (bx / k) & 1, ct = bx / (2 * k);
   const uint32_t slot = ct / B, q = ct % B;
-  if (slot >= n_items) return;
+  const uint32_t out_slot = half_id ? slot + shift_pow : slot;
+  if (out_slot >= n_items) return;  // uniform per workgroup
   const typename A::Mod m = A::mod(P, j);
   const double pf = P->p_f, half = P->p_half_f, pinv = P->p_inv_f[j];
   const double* tree = reinterpret_cast<const double*>(tree_raw) + (size_t)ct * 2 * k * N;
@@ -421,38 +423,27 @@ ks_last_level_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict
     __syncthreads();
   }
   const double* a = tree + ((size_t)comp * k + j) * N;
-  const uint32_t k2 = 2 * k;
   typename A::T x[16];
-  // lo = a + g -> selector `slot`
+  if (!half_id) {  // lo = a + g -> selector `slot`
 #pragma unroll
-  for (int e = 0; e < 16; ++e) x[e] = f64_norm(a[e * NT + tid] + g[e], m);
-  ntt_forward<MODE, LOGN, false>(x, smem_raw, P, j, tid);
-  {
-    uint64_t* out = (uint64_t*)dst.p[q] + ((size_t)slot * k2 + comp * k + j) * N;
+    for (int e = 0; e < 16; ++e) x[e] = f64_norm(a[e * NT + tid] + g[e], m);
+  } else {         // hi = x^(-2^j) (a - g): negacyclic rotation by 2N - 2^j through LDS -> selector `slot + 2^j`
 #pragma unroll
-    for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
+    for (int e = 0; e < 16; ++e) {
+      const uint32_t i = e * NT + tid;
+      const double d = f64_norm(a[i] - g[e], m);
+      const uint32_t sraw = i + (2 * N - shift_pow);
+      sd[lds_idx(sraw & (N - 1))] = (sraw & N) ? -d : d;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x[e] = sd[lds_lin_base<NT>(tid) + lds_lin_off<NT>(e)];
+    __syncthreads();
   }
-  const uint32_t hi_slot = slot + shift_pow;
-  if (hi_slot >= n_items) return;  // uniform per workgroup
-  // hi = x^(-2^j) (a - g): negacyclic rotation by 2N - 2^j through LDS -> selector `slot + 2^j`
-  __syncthreads();  // the transform above is done with the LDS words
+  ntt_forward<MODE, LOGN, kPF>(x, smem_raw, P, j, tid);
+  uint64_t* out = (uint64_t*)dst.p[q] + ((size_t)out_slot * 2 * k + comp * k + j) * N;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const uint32_t i = e * NT + tid;
-    const double d = f64_norm(a[i] - g[e], m);
-    const uint32_t sraw = i + (2 * N - shift_pow);
-    sd[lds_idx(sraw & (N - 1))] = (sraw & N) ? -d : d;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int e = 0; e < 16; ++e) x[e] = sd[lds_lin_base<NT>(tid) + lds_lin_off<NT>(e)];
-  __syncthreads();
-  ntt_forward<MODE, LOGN, false>(x, smem_raw, P, j, tid);
-  {
-    uint64_t* out = (uint64_t*)dst.p[q] + ((size_t)hi_slot * k2 + comp * k + j) * N;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
-  }
+  for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
 }
 
 // Upper recursion level, fused: for output slot (row r, source ciphertext cc, Encode chunk
@@ -761,7 +752,7 @@ static hipError_t op_ks_mac_intt(hipStream_t st, int mode, const DevParams* P, u
 static hipError_t op_ks_last_level(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* tree,
                                    const uint64_t* prod, uint32_t galois_elt, uint32_t shift_pow, uint32_t n_items,
                                    uint32_t B, const MfmaPtrs& dst, uint32_t tree_cts, bool pack40) {
-  const dim3 grid(tree_cts * 2 * k);
+  const dim3 grid(tree_cts * 2 * k * 2);
   if (mode == kNttF64) {
     if (pack40)
       hipLaunchKernelGGL((ks_last_level_kernel<kNttF64, true>), grid, dim3(NT), kLdsBytes, st, P, tree, prod, galois_elt,

@@ -1354,7 +1354,9 @@ static void ensure_batch_capacity(pirgpu_ctx* c, uint32_t count) {
 static void ensure_lanes(pirgpu_ctx* c, bool with_expansion_buffers) {
   const uint32_t N = c->N, k = c->k;
   if (c->lanes.empty()) {
-    c->lanes.resize(2);
+    uint32_t n_lanes = 2;   // PIRGPU_LANES: groups in flight (each lane = one stream + one set of group buffers)
+    if (const char* v = getenv("PIRGPU_LANES")) n_lanes = (uint32_t)std::min(4, std::max(1, atoi(v)));
+    c->lanes.resize(n_lanes);
     for (BatchLane& ln : c->lanes) {
       HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
       HIP_TRY(hipEventCreateWithFlags(&ln.ev_scanned, hipEventDisableTiming));
@@ -1418,7 +1420,7 @@ struct PackedInput {            // multi-GPU packed exchange (pirgpu_batch_run_p
 // lane covers their reuse; with fewer than 2 x G workers every group uses lane 0.
 static uint32_t lanes_in_use(pirgpu_ctx* c, uint32_t G) {
   const uint32_t W = std::max<uint32_t>(1, std::min<uint32_t>(c->n_active, (uint32_t)c->workers.size()));
-  return W >= 2 * G ? 2 : 1;
+  return std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)c->lanes.size(), W / std::max<uint32_t>(G, 1)));
 }
 
 static void batch_run_mfma(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv, const PackedInput* pk = nullptr) {

@@ -223,7 +223,8 @@ def main():
 
     dist = None
     # PIRGPU_FORCE_DIST=1: run the multi-GPU code path (process group, collectives, fix-up) with a single rank
-    force = os.environ.get("PIRGPU_FORCE_DIST", "") in ("1", "rows", "queries", "both")
+    force_env = os.environ.get("PIRGPU_FORCE_DIST", "")     # "both": also run the replica leg with the single rank
+    force = force_env in ("1", "rows", "queries", "both")
     use_dist = world > 1 or force
     if use_dist:
         import torch.distributed as dist
@@ -244,7 +245,7 @@ def main():
     # two groups of 8 alternate on two lanes: 16 working sets, whatever the number of queries this rank expands
     workers = args.workers if args.workers > 0 else (16 if use_dist else min(batch, 16))
     run_rows = (not use_dist) or args.dist_mode in ("both", "rows")
-    run_replicas = use_dist and world > 1 and args.dist_mode in ("both", "queries")
+    run_replicas = use_dist and (world > 1 or force_env == "both") and args.dist_mode in ("both", "queries")
     # same database, keys and queries on every rank (fixed seeds): query i of the batch is the same everywhere
     raw, keys, queries = synthetic_inputs(pp, n_queries=batch)
     query = queries[0]

@@ -161,6 +161,10 @@ struct pirgpu_ctx {
   bool split_upper = false;                 // upper level as transform-to-scratch + elementwise MAC (N >= 16384 in the fp64
                                             // flavours, where the fused kernel spills; PIRGPU_SPLIT_UPPER=0/1 overrides)
   uint64_t split_upper_words = (3ull << 30) / 8;  // scratch budget per lane / worker (PIRGPU_SPLIT_UPPER_MB)
+  uint32_t fuse_mac_nodes = 128;            // ... from this many tree ciphertexts per level on (narrower levels are latency-
+                                            // bound: two dependent transform kernels cost more than mac + light combine)
+  bool fuse_mac_combine = true;             // levels below the last: combine step in the data residues' MAC + inverse-NTT
+                                            // kernel (PIRGPU_FUSE_MAC_COMBINE=0: separate ks_combine pass)
   bool fuse_last_level = true;              // last expansion level fused with the selector NTT (PIRGPU_FUSE_LAST=0: off)
   bool pack40 = false;                      // key-switch digits stored in 5 bytes (all moduli < 2^40; PIRGPU_PACK40)
   uint8_t* d_dbp = nullptr;
@@ -428,6 +432,8 @@ void ensure_workspace(pirgpu_ctx* c) {
     //   PIRGPU_SCAN_MFMA=0 keeps the 64-bit multiply-accumulate kernels for d >= 2 as well
     //   PIRGPU_SCAN_MFMA_NQ queries per database pass of the MFMA scan in batch mode (1..8)
     c->fuse_last_level = env_u32("PIRGPU_FUSE_LAST", 1) != 0;
+    c->fuse_mac_combine = env_u32("PIRGPU_FUSE_MAC_COMBINE", 1) != 0;
+    c->fuse_mac_nodes = env_u32("PIRGPU_FUSE_MAC_NODES", 128);
     c->split_upper = env_u32("PIRGPU_SPLIT_UPPER", c->logN >= 14 ? 1 : 0) != 0 && c->mode != kNttInt;
     c->split_upper_words = (uint64_t)env_u32("PIRGPU_SPLIT_UPPER_MB", 3072) * (1ull << 20) / 8;
     c->pack40 = env_u32("PIRGPU_PACK40", 1) != 0;
@@ -530,7 +536,15 @@ uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* 
     const uint64_t* key = find_key(c, g);
     const uint32_t nodes = (1u << j) * B;
     HIP_TRY(c->ops->ks_digit(st, c->mode, c->dp, k, cur, g, nodes, dig, c->pack40));
-    HIP_TRY(c->ops->ks_mac_intt(st, c->mode, c->dp, k, dig, key, nodes, prod, c->pack40));
+    if (c->mode != kNttInt && c->fuse_mac_combine && nodes >= c->fuse_mac_nodes && !(fuse_last && j + 1 == logm)) {
+      // special-prime product first (the only one that goes through HBM), then the data residues with the combine
+      // step in their epilogue: no data products in HBM, no separate combine pass
+      HIP_TRY(c->ops->ks_mac_intt(st, c->mode, c->dp, k, dig, key, nodes, prod, c->pack40, k, 1));
+      HIP_TRY(c->ops->ks_mac_combine(st, c->mode, c->dp, k, dig, key, prod, cur, g, nodes, 1u << j, nxt, c->pack40));
+      std::swap(cur, nxt);
+      continue;
+    }
+    HIP_TRY(c->ops->ks_mac_intt(st, c->mode, c->dp, k, dig, key, nodes, prod, c->pack40, 0, k + 1));
     if (fuse_last && j + 1 == logm) {
       HIP_TRY(c->ops->ks_last_level(st, c->mode, c->dp, k, cur, prod, g, 1u << j, n, B, *sel_dst, nodes, c->pack40));
       return nullptr;
@@ -1237,7 +1251,7 @@ int pirgpu_substitute_power_x(pirgpu_ctx* c, uint64_t* ct, uint32_t power) {
     HIP_TRY(hipMemcpyAsync(w.res_b, ct, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(launch_tree_convert(c->stream, c->dp, c->mode, w.res_b, w.res_a, c->ctw, true));
     HIP_TRY(c->ops->ks_digit(c->stream, c->mode, c->dp, c->k, w.res_a, power, 1, w.dig, c->pack40));
-    HIP_TRY(c->ops->ks_mac_intt(c->stream, c->mode, c->dp, c->k, w.dig, key, 1, w.prod, c->pack40));
+    HIP_TRY(c->ops->ks_mac_intt(c->stream, c->mode, c->dp, c->k, w.dig, key, 1, w.prod, c->pack40, 0, c->k + 1));
     HIP_TRY(launch_ks_combine(c->stream, c->dp, c->mode, c->N, c->k, w.res_a, w.prod, galois_inverse(power, c->N), 1, 0,
                               false, /*hi_limit: unused without the expand step*/ 0, c->pack40, w.res_b));
     HIP_TRY(launch_tree_convert(c->stream, c->dp, c->mode, w.res_b, w.res_b, c->ctw, false));

@@ -31,8 +31,10 @@ struct NttOps {
                           uint64_t n_pt, uint64_t* db);
   hipError_t (*ks_digit)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* res_in,
                          uint32_t galois_elt, uint32_t nodes, uint64_t* dig, bool pack40);
+  // key-level moduli I_base .. I_base + I_count - 1 (all: 0, k + 1; the special prime alone: k, 1)
   hipError_t (*ks_mac_intt)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* dig,
-                            const uint64_t* key, uint32_t nodes, uint64_t* prod, bool pack40);
+                            const uint64_t* key, uint32_t nodes, uint64_t* prod, bool pack40, uint32_t I_base,
+                            uint32_t I_count);
   // n_queries queries in one launch: query q reads src + q * src_qstride, selectors svq.p[q], writes part + q * part_qstride
   hipError_t (*upper_fused)(hipStream_t st, int mode, const DevParams* P, uint32_t k, uint32_t enc_count,
                             const uint64_t* src, const MfmaPtrs& svq, uint64_t* part, uint32_t n_rows,
@@ -50,6 +52,11 @@ struct NttOps {
                           const uint64_t* src, uint64_t* scratch, uint32_t n_rows, uint32_t n_dim,
                           uint32_t n_children_total, uint32_t C, uint32_t b0, uint32_t blk, uint32_t n_queries,
                           uint64_t src_qstride);
+  // data residues of one level below the last: MAC + inverse transform + combine with the special-prime product
+  // (already in `prod`) + tree butterfly, tree_in -> tree_out (fp64 flavours)
+  hipError_t (*ks_mac_combine)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* dig,
+                               const uint64_t* key, const uint64_t* prod, const uint64_t* tree_in, uint32_t galois_elt,
+                               uint32_t nodes, uint32_t shift_pow, uint64_t* tree_out, bool pack40);
 };
 
 const NttOps* ntt_ops_for(uint32_t N);  // nullptr for unsupported degrees

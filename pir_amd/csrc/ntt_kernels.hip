@@ -276,28 +276,17 @@ ks_digit_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ re
   }
 }
 
-// Part 1b: S[c][I] = sum_J dig[n][I][J] (.) K[J][c][I], then INTT_I -> prod[n][c][I]
-// (coefficient order, canonical u64).  The key is in device NTT order (and in the
-// flavour's register type), so the dyadic products are formed directly in the register
-// layout the inverse transform starts from.  grid = (nodes, k+1, 2).
+// Part 1b: S[c][I] = sum_J dig[n][I][J] (.) K[J][c][I], then INTT_I.  The key is in device NTT order (and in the
+// flavour's register type), so the dyadic products are formed directly in the register layout the inverse transform
+// starts from.  Leaves x[e] = coefficient e * NT + tid: canonical for the integer flavour, a signed representative
+// |x| <= (1/2 + eps) m_I for the fp64 flavours.
 template <int MODE, bool P40>
-__global__ void __launch_bounds__(NT)
-ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ dig_raw,
-                   const uint64_t* __restrict__ key_raw, uint64_t* __restrict__ prod) {
+__device__ __forceinline__ void ks_mac_core(const DevParams* __restrict__ P, const uint64_t* __restrict__ dig_raw,
+                                            const uint64_t* __restrict__ key_raw, uint32_t node, uint32_t I,
+                                            uint32_t comp, uint32_t tid, typename Arith<MODE>::T (&x)[16]) {
   using A = Arith<MODE>;
   using T = typename A::T;
-  const uint32_t tid = threadIdx.x;
   const uint32_t k = P->k, km = k + 1;
-  uint32_t node = blockIdx.x, I = blockIdx.y, comp = blockIdx.z;
-  if (gridDim.y == 1) {
-    // wide levels, 1-D grid: both components of one (node, I) run back to back on the same XCD, so the
-    // second one finds the digits in L2 instead of re-reading them from HBM
-    const uint32_t xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
-    comp = t & 1;
-    const uint32_t u = t >> 1;
-    I = u % km;
-    node = (u / km) * 8 + xcd;
-  }
   const ModConst mI = P->mod[I];
   const typename A::Mod m = A::mod(P, I);
   const size_t poly0 = ((size_t)node * km + I) * k;
@@ -312,7 +301,6 @@ ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
     else if constexpr (P40) return A::in(load40(d40 + (size_t)J * kPoly40, i), m);
     else return d0[(size_t)J * N + i];
   };
-  T x[16];
   if constexpr (MODE == kNttInt) {
     u128 acc[16];
 #pragma unroll
@@ -324,6 +312,7 @@ ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) x[e] = reduce128((uint64_t)acc[e], (uint64_t)(acc[e] >> 64), mI);
+    ntt_inverse<MODE, LOGN, kPF>(x, smem_raw, P, I, tid);
   } else {
 #pragma unroll
     for (int e = 0; e < 16; ++e) x[e] = 0.0;
@@ -334,24 +323,48 @@ ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) x[e] = f64_norm(x[e], m);
+    ntt_inverse<MODE, LOGN, kPF, /*CANON=*/false>(x, smem_raw, P, I, tid);
   }
+}
+
+// Stores prod[n][c][I] (coefficient order): 5-byte packing (offset form for the fp64 flavours), doubles, or u64.
+// grid = (nodes, I_count, 2) or the XCD-aware 1-D equivalent; I = I_base + the grid's modulus index -- the expansion
+// runs it for the special prime alone (I_base = k, I_count = 1) below the last level, where the data residues go
+// through ks_mac_combine_kernel instead.
+template <int MODE, bool P40>
+__global__ void __launch_bounds__(NT)
+ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ dig_raw,
+                   const uint64_t* __restrict__ key_raw, uint64_t* __restrict__ prod, uint32_t I_base,
+                   uint32_t I_count) {
+  using A = Arith<MODE>;
+  using T = typename A::T;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t k = P->k, km = k + 1;
+  uint32_t node = blockIdx.x, I = blockIdx.y, comp = blockIdx.z;
+  if (gridDim.y == 1 && gridDim.z == 1) {
+    // wide levels, 1-D grid: both components of one (node, I) run back to back on the same XCD, so the
+    // second one finds the digits in L2 instead of re-reading them from HBM
+    const uint32_t xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
+    comp = t & 1;
+    const uint32_t u = t >> 1;
+    I = u % I_count;
+    node = (u / I_count) * 8 + xcd;
+  }
+  I += I_base;
+  const typename A::Mod m = A::mod(P, I);
+  T x[16];
+  ks_mac_core<MODE, P40>(P, dig_raw, key_raw, node, I, comp, tid, x);
   const size_t opoly = ((size_t)node * 2 + comp) * km + I;
   if constexpr (P40 && MODE != kNttInt) {
-    ntt_inverse<MODE, LOGN, kPF, /*CANON=*/false>(x, smem_raw, P, I, tid);  // signed representatives, |x| <= q/2
     uint8_t* out = reinterpret_cast<uint8_t*>(prod) + opoly * kPoly40;
+    const double magic = f64_pack_magic(m.q);
 #pragma unroll
     for (int e = 0; e < 16; ++e) store40f(out, e * NT + tid, x[e], magic);
-    return;
-  }
-  if constexpr (MODE != kNttInt) {  // plain doubles (moduli >= 2^39): signed representatives as they are
-    ntt_inverse<MODE, LOGN, kPF, /*CANON=*/false>(x, smem_raw, P, I, tid);
+  } else if constexpr (MODE != kNttInt) {  // plain doubles (moduli >= 2^39): signed representatives as they are
     T* out = reinterpret_cast<T*>(prod) + opoly * N;
 #pragma unroll
     for (int e = 0; e < 16; ++e) out[e * NT + tid] = x[e];
-    return;
-  }
-  ntt_inverse<MODE, LOGN, kPF>(x, smem_raw, P, I, tid);
-  if constexpr (P40) {
+  } else if constexpr (P40) {
     uint8_t* out = reinterpret_cast<uint8_t*>(prod) + opoly * kPoly40;
 #pragma unroll
     for (int e = 0; e < 16; ++e) store40(out, e * NT + tid, A::out(x[e], m));
@@ -359,6 +372,82 @@ ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
     uint64_t* out = prod + opoly * N;
 #pragma unroll
     for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
+  }
+}
+
+// Parts 1b + 2 for the DATA residues of one expansion level below the last (fp64 flavours): the workgroup of
+// (tree ciphertext, data modulus j, component) forms S[c][j], runs its inverse transform and -- instead of storing
+// the product -- applies ks_combine_f64_kernel's arithmetic while the polynomial is in registers: divide-and-round
+// with the special-prime residue (computed before by ks_mac_intt_kernel with I_base = k and read back, the only
+// product that still goes through HBM), + sigma_g(c0) through an LDS scatter, tree butterfly, and writes lo / hi.
+// One transform per workgroup and nothing live across it (the fused variants with several transforms per workgroup
+// lost to their register pressure); saves the data products' round trip and the separate
+// HBM-bound combine pass.  grid = (nodes, k, 2) or the XCD-aware 1-D equivalent.
+template <int MODE, bool P40>
+__global__ void __launch_bounds__(NT)
+ks_mac_combine_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ dig_raw,
+                      const uint64_t* __restrict__ key_raw, const uint64_t* __restrict__ prod,
+                      const uint64_t* __restrict__ tree_in_raw, uint32_t galois_elt, uint32_t nodes, uint32_t shift_pow,
+                      uint64_t* __restrict__ tree_out_raw) {
+  using A = Arith<MODE>;
+  static_assert(MODE != kNttInt, "fp64 flavours only");
+  double* sd = reinterpret_cast<double*>(smem_raw);
+  const uint32_t tid = threadIdx.x, k = P->k, km = k + 1;
+  uint32_t node = blockIdx.x, j = blockIdx.y, comp = blockIdx.z;
+  if (gridDim.y == 1 && gridDim.z == 1) {
+    const uint32_t xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
+    comp = t & 1;
+    const uint32_t u = t >> 1;
+    j = u % k;
+    node = (u / k) * 8 + xcd;
+  }
+  const typename A::Mod m = A::mod(P, j);
+  double g[16];
+  ks_mac_core<MODE, P40>(P, dig_raw, key_raw, node, j, comp, tid, g);
+  {
+    const double pf = P->p_f, half = P->p_half_f, pinv = P->p_inv_f[j];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const uint32_t i = e * NT + tid;
+      double sp;
+      if constexpr (P40) {
+        sp = load40f(reinterpret_cast<const uint8_t*>(prod) + (((size_t)node * 2 + comp) * km + k) * kPoly40, i,
+                     f64_pack_magic(pf));
+      } else {
+        sp = reinterpret_cast<const double*>(prod)[(((size_t)node * 2 + comp) * km + k) * N + i];
+      }
+      sp = sp > half ? sp - pf : sp;   // exact centring (ks_combine_f64_kernel)
+      sp = sp < -half ? sp + pf : sp;
+      g[e] = f64_mulmod(g[e] - f64_norm(sp, m), pinv, m);
+    }
+  }
+  const double* tree_in = reinterpret_cast<const double*>(tree_in_raw) + (size_t)node * 2 * k * N;
+  if (comp == 0) {  // + sigma_g(c0)
+    const double* c0 = tree_in + (size_t)j * N;
+    const uint32_t raw0 = tid * galois_elt, rstep = (uint32_t)NT * galois_elt;
+    __syncthreads();  // the inverse transform is done with the LDS words
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const uint32_t raw = raw0 + (uint32_t)e * rstep;
+      const uint64_t sign = (uint64_t)((raw << (31 - LOGN)) & 0x80000000u) << 32;
+      sd[lds_idx(raw & (N - 1))] =
+          __longlong_as_double((long long)((uint64_t)__double_as_longlong(c0[e * NT + tid]) ^ sign));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) g[e] += sd[lds_lin_base<NT>(tid) + lds_lin_off<NT>(e)];
+  }
+  const size_t off = ((size_t)comp * k + j) * N;
+  double* tree_lo = reinterpret_cast<double*>(tree_out_raw) + (size_t)node * 2 * k * N + off;
+  double* tree_hi = reinterpret_cast<double*>(tree_out_raw) + ((size_t)node + nodes) * 2 * k * N + off;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const uint32_t i = e * NT + tid;
+    const double a = tree_in[off + i];
+    tree_lo[i] = f64_norm(a + g[e], m);
+    const double d = f64_norm(a - g[e], m);
+    const uint32_t sraw = i + (2 * N - shift_pow);
+    tree_hi[sraw & (N - 1)] = (sraw & N) ? -d : d;
   }
 }
 
@@ -672,6 +761,8 @@ static hipError_t configure_mode() {
   PIRGPU_SET(upper_fused_kernel<MODE>);
   if constexpr (MODE != kNttInt) {
     PIRGPU_SET(upper_ntt_kernel<MODE>);
+    PIRGPU_SET((ks_mac_combine_kernel<MODE, false>));
+    PIRGPU_SET((ks_mac_combine_kernel<MODE, true>));
     PIRGPU_SET((ks_last_level_kernel<MODE, false>));
     PIRGPU_SET((ks_last_level_kernel<MODE, true>));
   }
@@ -736,14 +827,41 @@ static hipError_t op_ks_digit(hipStream_t st, int mode, const DevParams* P, uint
 }
 
 static hipError_t op_ks_mac_intt(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* dig,
-                                 const uint64_t* key, uint32_t nodes, uint64_t* prod, bool pack40) {
-  const dim3 grid = nodes >= kWideLevel && nodes % 8 == 0 ? dim3(nodes * (k + 1) * 2) : dim3(nodes, k + 1, 2);
+                                 const uint64_t* key, uint32_t nodes, uint64_t* prod, bool pack40, uint32_t I_base,
+                                 uint32_t I_count) {
+  const dim3 grid = nodes >= kWideLevel && nodes % 8 == 0 ? dim3(nodes * I_count * 2) : dim3(nodes, I_count, 2);
   if (pack40) {
     PIRGPU_BY_MODE(mode, hipLaunchKernelGGL((ks_mac_intt_kernel<MODE, true>), grid, dim3(NT), kLdsBytes, st, P, dig,
-                                            key, prod));
+                                            key, prod, I_base, I_count));
   } else {
     PIRGPU_BY_MODE(mode, hipLaunchKernelGGL((ks_mac_intt_kernel<MODE, false>), grid, dim3(NT), kLdsBytes, st, P, dig,
-                                            key, prod));
+                                            key, prod, I_base, I_count));
+  }
+  return hipGetLastError();
+}
+
+// data residues of a level below the last, fused with the combine step (fp64 flavours)
+static hipError_t op_ks_mac_combine(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* dig,
+                                    const uint64_t* key, const uint64_t* prod, const uint64_t* tree_in,
+                                    uint32_t galois_elt, uint32_t nodes, uint32_t shift_pow, uint64_t* tree_out,
+                                    bool pack40) {
+  const dim3 grid = nodes >= kWideLevel && nodes % 8 == 0 ? dim3(nodes * k * 2) : dim3(nodes, k, 2);
+  if (mode == kNttF64) {
+    if (pack40)
+      hipLaunchKernelGGL((ks_mac_combine_kernel<kNttF64, true>), grid, dim3(NT), kLdsBytes, st, P, dig, key, prod, tree_in,
+                         galois_elt, nodes, shift_pow, tree_out);
+    else
+      hipLaunchKernelGGL((ks_mac_combine_kernel<kNttF64, false>), grid, dim3(NT), kLdsBytes, st, P, dig, key, prod,
+                         tree_in, galois_elt, nodes, shift_pow, tree_out);
+  } else if (mode == kNttF64Wide) {
+    if (pack40)
+      hipLaunchKernelGGL((ks_mac_combine_kernel<kNttF64Wide, true>), grid, dim3(NT), kLdsBytes, st, P, dig, key, prod,
+                         tree_in, galois_elt, nodes, shift_pow, tree_out);
+    else
+      hipLaunchKernelGGL((ks_mac_combine_kernel<kNttF64Wide, false>), grid, dim3(NT), kLdsBytes, st, P, dig, key, prod,
+                         tree_in, galois_elt, nodes, shift_pow, tree_out);
+  } else {
+    return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
@@ -809,7 +927,7 @@ const NttOps* PIRGPU_OPS_NAME() {
   using namespace PIRGPU_DEG_NS;
   static const NttOps ops = {op_configure, op_ntt_batch,   op_ct_ntt_fwd_oop, op_ct_ntt_fwd_split, op_db_encode,
                              op_ks_digit,  op_ks_mac_intt, op_upper_fused,     op_ks_last_level,
-                             op_upper_ntt};
+                             op_upper_ntt, op_ks_mac_combine};
   return &ops;
 }
 

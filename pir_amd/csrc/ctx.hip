@@ -127,6 +127,7 @@ struct pirgpu_ctx {
   std::vector<uint8_t> loaded;  // per local plaintext
   uint64_t n_loaded = 0;
   std::map<uint32_t, uint64_t*> keys;
+  std::map<uint32_t, uint64_t*> xpow;       // shift -> NTT_j(x^(-shift)), [k][N] doubles (NTT-domain last expansion level)
   bool keys_blob_valid = false;    // wire layer: the installed keys came from exactly this blob
   std::vector<uint8_t> keys_blob;
 
@@ -166,6 +167,7 @@ struct pirgpu_ctx {
   bool fuse_mac_combine = true;             // levels below the last: combine step in the data residues' MAC + inverse-NTT
                                             // kernel (PIRGPU_FUSE_MAC_COMBINE=0: separate ks_combine pass)
   bool fuse_last_level = true;              // last expansion level fused with the selector NTT (PIRGPU_FUSE_LAST=0: off)
+  bool last_level_ntt = true;               // ... and carried out in the NTT domain (PIRGPU_LAST_NTT=0: coefficient form)
   bool pack40 = false;                      // key-switch digits stored in 5 bytes (all moduli < 2^40; PIRGPU_PACK40)
   uint8_t* d_dbp = nullptr;
   bool packed_valid = false;
@@ -433,6 +435,7 @@ void ensure_workspace(pirgpu_ctx* c) {
     //   PIRGPU_SCAN_MFMA_NQ queries per database pass of the MFMA scan in batch mode (1..8)
     c->fuse_last_level = env_u32("PIRGPU_FUSE_LAST", 1) != 0;
     c->fuse_mac_combine = env_u32("PIRGPU_FUSE_MAC_COMBINE", 1) != 0;
+    c->last_level_ntt = env_u32("PIRGPU_LAST_NTT", 1) != 0;
     c->fuse_mac_nodes = env_u32("PIRGPU_FUSE_MAC_NODES", 128);
     c->split_upper = env_u32("PIRGPU_SPLIT_UPPER", c->logN >= 14 ? 1 : 0) != 0 && c->mode != kNttInt;
     c->split_upper_words = (uint64_t)env_u32("PIRGPU_SPLIT_UPPER_MB", 3072) * (1ull << 20) / 8;
@@ -516,6 +519,22 @@ void begin_profiled_run(pirgpu_ctx* c) {
   c->prof_cur = c->prof_runs++;
 }
 
+// NTT_j(x^(-shift)) for the k data moduli as doubles in device order (ks_last_ntt_kernel's X); built once per shift.
+const uint64_t* xpow_table(pirgpu_ctx* c, hipStream_t st, uint32_t shift) {
+  auto it = c->xpow.find(shift);
+  if (it != c->xpow.end()) return it->second;
+  const uint32_t N = c->N, k = c->k;
+  std::vector<uint64_t> h((size_t)k * N, 0);
+  for (uint32_t j = 0; j < k; ++j) h[(size_t)j * N + (N - shift)] = c->hp.mod[j].q - 1;   // x^(-s) = -x^(N-s)
+  uint64_t* buf = c->dalloc<uint64_t>((size_t)k * N);
+  HIP_TRY(hipMemcpy(buf, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+  HIP_TRY(c->ops->ntt_batch(st, c->mode, c->dp, buf, k, k, 0, false));
+  HIP_TRY(launch_tree_convert(st, c->dp, c->mode, buf, buf, (uint64_t)k * N, true));
+  HIP_TRY(hipStreamSynchronize(st));   // other streams use the table without an event
+  c->xpow[shift] = buf;
+  return buf;
+}
+
 // oblivious_expansion(ct, n) on the device (reference server.cpp:105-146).
 // Input ciphertext must already be in res_a[0]; returns the buffer holding the
 // next_power_two(n) results.
@@ -543,6 +562,14 @@ uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* 
       HIP_TRY(c->ops->ks_mac_combine(st, c->mode, c->dp, k, dig, key, prod, cur, g, nodes, 1u << j, nxt, c->pack40));
       std::swap(cur, nxt);
       continue;
+    }
+    if (fuse_last && j + 1 == logm && c->last_level_ntt) {
+      // last level in the NTT domain: only the special-prime product is inverse-transformed
+      const uint64_t* X = xpow_table(c, st, 1u << j);
+      HIP_TRY(c->ops->ks_mac_intt(st, c->mode, c->dp, k, dig, key, nodes, prod, c->pack40, k, 1));
+      HIP_TRY(c->ops->ks_last_ntt(st, c->mode, c->dp, k, cur, dig, key, prod, X, g, galois_inverse(g, N), 1u << j, n, B,
+                                  *sel_dst, nodes, c->pack40));
+      return nullptr;
     }
     HIP_TRY(c->ops->ks_mac_intt(st, c->mode, c->dp, k, dig, key, nodes, prod, c->pack40, 0, k + 1));
     if (fuse_last && j + 1 == logm) {

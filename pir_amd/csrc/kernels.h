@@ -57,6 +57,12 @@ struct NttOps {
   hipError_t (*ks_mac_combine)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* dig,
                                const uint64_t* key, const uint64_t* prod, const uint64_t* tree_in, uint32_t galois_elt,
                                uint32_t nodes, uint32_t shift_pow, uint64_t* tree_out, bool pack40);
+  // last expansion level in the NTT domain (fp64 flavours): `prod` holds the special-prime products (ks_mac_intt with
+  // I_base = k) and receives NTT(a_0); xpow = NTT_j(x^(-shift_pow)), [k][N] doubles; galois_inv = galois_elt^-1 mod 2N
+  hipError_t (*ks_last_ntt)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* tree,
+                            const uint64_t* dig, const uint64_t* key, uint64_t* prod, const uint64_t* xpow,
+                            uint32_t galois_elt, uint32_t galois_inv, uint32_t shift_pow, uint32_t n_items, uint32_t B,
+                            const MfmaPtrs& dst, uint32_t nodes, bool pack40);
 };
 
 const NttOps* ntt_ops_for(uint32_t N);  // nullptr for unsupported degrees

@@ -535,6 +535,164 @@ ks_last_level_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict
   for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
 }
 
+// ---- last expansion level in the NTT domain (fp64 flavours) ----
+//
+// The last level's outputs are only ever used in NTT form, and every step after the key-switch products is linear
+// over Z_q[x]/(x^N+1), so it commutes with the transform:
+//   NTT(lo) = A + G,   NTT(hi) = X (.) (A - G),        A = NTT(a), X = NTT(x^(-2^j)) (a table),
+//   G = (S_j - NTT_j(lift(s))) p^-1 (+ NTT(sigma_g(a_0)) for component 0),
+// with S_j the dyadic key-switch product mod q_j (never inverse-transformed) and s the centred special-prime
+// residue of the product (coefficient form, from ks_mac_intt_kernel with I_base = k).  sigma_g acts on NTT-form data as the permutation
+// pi_g(P) = br(((2 br(P) + 1) g mod 2N - 1) / 2) of the SEAL positions P (position P holds the evaluation at
+// psi^(2 br(P) + 1)), so NTT(sigma_g(a_0)) = A_0 o pi_g, and A_1 is already there: the digit kernel's
+// dig[n][j][j] = NTT_j(sigma_g(a_1) mod q_j) = A_1 o pi_g, hence A_1 = dig[n][j][j] o pi_(g^-1).  Per tree
+// ciphertext that is k forward transforms (A_0, tree_c0_ntt_kernel) + 2 inverse (s) + 2k forward (lift(s)) after the
+// digits, against 2(k+1) inverse + 4k forward for ks_mac_intt_kernel + ks_last_level_kernel: 8 instead of 14 at k = 2.
+// All arithmetic is exact mod q_j, so the selectors are the same canonical residues (reference server.cpp:137-141
+// followed by database.cpp:190,222).
+
+// SEAL position P -> pi_g(P) -> device slot
+__device__ __forceinline__ uint32_t galois_ntt_slot(uint32_t P, uint32_t g) {
+  const uint32_t r = __brev(P) >> (32 - LOGN);
+  const uint32_t ex = ((2 * r + 1) * g) & (2 * N - 1);
+  const uint32_t Pin = __brev(ex >> 1) >> (32 - LOGN);
+  return (Pin & 15u) * NT + (Pin >> 4);
+}
+
+// A_0[n][j] = NTT_j(a_0 mod q_j) of every tree ciphertext n, written into the unused data-residue slots
+// prod[n][0][j] of the product buffer (signed representatives; 5-byte packing or doubles).  grid = nodes * k.
+template <int MODE, bool P40>
+__global__ void __launch_bounds__(NT)
+tree_c0_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ tree_raw, uint64_t* __restrict__ prod) {
+  using A = Arith<MODE>;
+  static_assert(MODE != kNttInt, "fp64 flavours only");
+  const uint32_t tid = threadIdx.x, k = P->k, km = k + 1;
+  const uint32_t j = blockIdx.x % k, node = blockIdx.x / k;
+  const typename A::Mod m = A::mod(P, j);
+  const double* in = reinterpret_cast<const double*>(tree_raw) + ((size_t)node * 2 * k + j) * N;
+  double x[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) x[e] = in[e * NT + tid];
+  ntt_forward<MODE, LOGN, kPF, /*CANON=*/false>(x, smem_raw, P, j, tid);
+  const size_t opoly = (size_t)node * 2 * km + j;
+  if constexpr (P40) {
+    uint8_t* out = reinterpret_cast<uint8_t*>(prod) + opoly * kPoly40;
+    const double magic = f64_pack_magic(m.q);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) store40f(out, e * NT + tid, x[e], magic);
+  } else {
+    double* out = reinterpret_cast<double*>(prod) + opoly * N;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) out[e * NT + tid] = x[e];
+  }
+}
+
+// One workgroup per (tree ciphertext, data modulus j, component): one forward transform (of the lifted special
+// residue), then the dyadic products and the epilogue above; writes selector `slot` and -- if < n_items --
+// selector `slot + shift_pow` of query q (tree ciphertext index = slot * B + query).  xpow = X for the k data
+// moduli, [k][N] doubles in device order.  grid = (nodes, k, 2) or the XCD-aware 1-D equivalent.
+template <int MODE, bool P40>
+__global__ void __launch_bounds__(NT)
+ks_last_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ dig_raw,
+                   const uint64_t* __restrict__ key_raw, const uint64_t* __restrict__ prod,
+                   const double* __restrict__ xpow, uint32_t galois_elt, uint32_t galois_inv, uint32_t shift_pow,
+                   uint32_t n_items, uint32_t B, MfmaPtrs dst) {
+  using A = Arith<MODE>;
+  static_assert(MODE != kNttInt, "fp64 flavours only");
+  double* sd = reinterpret_cast<double*>(smem_raw);
+  const uint32_t tid = threadIdx.x, k = P->k, km = k + 1;
+  uint32_t node = blockIdx.x, j = blockIdx.y, comp = blockIdx.z;
+  if (gridDim.y == 1 && gridDim.z == 1) {
+    const uint32_t xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
+    comp = t & 1;
+    const uint32_t u = t >> 1;
+    j = u % k;
+    node = (u / k) * 8 + xcd;
+  }
+  const typename A::Mod m = A::mod(P, j);
+  const uint32_t slot = node / B, q = node % B;
+  // t = NTT_j(lift(s))
+  double x[16];
+  {
+    const double pf = P->p_f, half = P->p_half_f;
+    const size_t spoly = ((size_t)node * 2 + comp) * km + k;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const uint32_t i = e * NT + tid;
+      double sp;
+      if constexpr (P40) sp = load40f(reinterpret_cast<const uint8_t*>(prod) + spoly * kPoly40, i, f64_pack_magic(pf));
+      else sp = reinterpret_cast<const double*>(prod)[spoly * N + i];
+      sp = sp > half ? sp - pf : sp;   // exact centring (ks_combine_f64_kernel)
+      sp = sp < -half ? sp + pf : sp;
+      x[e] = f64_norm(sp, m);
+    }
+  }
+  ntt_forward<MODE, LOGN, kPF, /*CANON=*/false>(x, smem_raw, P, j, tid);
+  // G = (S_j - t) p^-1
+  const size_t dpoly0 = ((size_t)node * km + j) * k;
+  const double magic = f64_pack_magic(m.q);
+  auto digit = [&](uint32_t J, uint32_t i) -> double {
+    if constexpr (P40) return load40f(reinterpret_cast<const uint8_t*>(dig_raw) + (dpoly0 + J) * kPoly40, i, magic);
+    else return reinterpret_cast<const double*>(dig_raw)[(dpoly0 + J) * N + i];
+  };
+  {
+    double acc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0;
+    const double* key = reinterpret_cast<const double*>(key_raw);
+    for (uint32_t J = 0; J < k; ++J) {
+      const double* kj = key + (((size_t)J * 2 + comp) * km + j) * N;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] += f64_mulmod(digit(J, e * NT + tid), kj[e * NT + tid], m);
+    }
+    const double pinv = P->p_inv_f[j];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x[e] = f64_mulmod(f64_norm(acc[e], m) - x[e], pinv, m);
+  }
+  // A (and, for component 0, A_0 o pi_g) through an LDS permutation
+  double a[16];
+  {
+    double v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const uint32_t i = e * NT + tid;
+      if (comp == 0) {
+        const size_t apoly = (size_t)node * 2 * km + j;
+        if constexpr (P40) v[e] = load40f(reinterpret_cast<const uint8_t*>(prod) + apoly * kPoly40, i, magic);
+        else v[e] = reinterpret_cast<const double*>(prod)[apoly * N + i];
+      } else {
+        v[e] = digit(j, i);
+      }
+    }
+    __syncthreads();  // the transform's last exchange is done with the LDS words
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sd[lds_lin_base<NT>(tid) + lds_lin_off<NT>(e)] = v[e];
+    __syncthreads();
+    const uint32_t gel = comp == 0 ? galois_elt : galois_inv;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const double w = sd[lds_idx(galois_ntt_slot(16 * tid + e, gel))];
+      if (comp == 0) {
+        a[e] = v[e];
+        x[e] += w;
+      } else {
+        a[e] = w;
+      }
+    }
+  }
+  const size_t opoly = (size_t)comp * k + j;
+  uint64_t* lo = (uint64_t*)dst.p[q] + ((size_t)slot * 2 * k + opoly) * N;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) lo[e * NT + tid] = A::out(f64_canon(f64_norm(a[e] + x[e], m), m), m);
+  if (slot + shift_pow < n_items) {
+    uint64_t* hi = (uint64_t*)dst.p[q] + ((size_t)(slot + shift_pow) * 2 * k + opoly) * N;
+    const double* X = xpow + (size_t)j * N;
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      hi[e * NT + tid] = A::out(f64_canon(f64_mulmod(f64_norm(a[e] - x[e], m), X[e * NT + tid], m), m), m);
+  }
+}
+
 // Upper recursion level, fused: for output slot (row r, source ciphertext cc, Encode chunk
 // e_idx, target residue jt) and a chunk of the row's children,
 //   part[chunk][r][cc*E+e_idx][p][jt] = sum_{ii in chunk} sv[sv_first+ii][p][jt] (.)
@@ -765,6 +923,10 @@ static hipError_t configure_mode() {
     PIRGPU_SET((ks_mac_combine_kernel<MODE, true>));
     PIRGPU_SET((ks_last_level_kernel<MODE, false>));
     PIRGPU_SET((ks_last_level_kernel<MODE, true>));
+    PIRGPU_SET((tree_c0_ntt_kernel<MODE, false>));
+    PIRGPU_SET((tree_c0_ntt_kernel<MODE, true>));
+    PIRGPU_SET((ks_last_ntt_kernel<MODE, false>));
+    PIRGPU_SET((ks_last_ntt_kernel<MODE, true>));
   }
 #undef PIRGPU_SET
   return hipSuccess;
@@ -891,6 +1053,33 @@ static hipError_t op_ks_last_level(hipStream_t st, int mode, const DevParams* P,
   return hipGetLastError();
 }
 
+// fp64 flavours: A_0 into the product buffer, then the NTT-domain last level
+static hipError_t op_ks_last_ntt(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* tree,
+                                 const uint64_t* dig, const uint64_t* key, uint64_t* prod, const uint64_t* xpow,
+                                 uint32_t galois_elt, uint32_t galois_inv, uint32_t shift_pow, uint32_t n_items,
+                                 uint32_t B, const MfmaPtrs& dst, uint32_t nodes, bool pack40) {
+  const dim3 g0(nodes * k);
+  const dim3 grid = nodes >= kWideLevel && nodes % 8 == 0 ? dim3(nodes * k * 2) : dim3(nodes, k, 2);
+  const double* X = reinterpret_cast<const double*>(xpow);
+#define PIRGPU_LAST_NTT(M, P40)                                                                                    \
+  do {                                                                                                             \
+    hipLaunchKernelGGL((tree_c0_ntt_kernel<M, P40>), g0, dim3(NT), kLdsBytes, st, P, tree, prod);                  \
+    hipLaunchKernelGGL((ks_last_ntt_kernel<M, P40>), grid, dim3(NT), kLdsBytes, st, P, dig, key, prod, X,          \
+                       galois_elt, galois_inv, shift_pow, n_items, B, dst);                                        \
+  } while (0)
+  if (mode == kNttF64) {
+    if (pack40) PIRGPU_LAST_NTT(kNttF64, true);
+    else PIRGPU_LAST_NTT(kNttF64, false);
+  } else if (mode == kNttF64Wide) {
+    if (pack40) PIRGPU_LAST_NTT(kNttF64Wide, true);
+    else PIRGPU_LAST_NTT(kNttF64Wide, false);
+  } else {
+    return hipErrorInvalidValue;
+  }
+#undef PIRGPU_LAST_NTT
+  return hipGetLastError();
+}
+
 static hipError_t op_upper_ntt(hipStream_t st, int mode, const DevParams* P, uint32_t k, uint32_t enc_count,
                                const uint64_t* src, uint64_t* scratch, uint32_t n_rows, uint32_t n_dim,
                                uint32_t n_children_total, uint32_t C, uint32_t b0, uint32_t blk, uint32_t n_queries,
@@ -927,7 +1116,7 @@ const NttOps* PIRGPU_OPS_NAME() {
   using namespace PIRGPU_DEG_NS;
   static const NttOps ops = {op_configure, op_ntt_batch,   op_ct_ntt_fwd_oop, op_ct_ntt_fwd_split, op_db_encode,
                              op_ks_digit,  op_ks_mac_intt, op_upper_fused,     op_ks_last_level,
-                             op_upper_ntt, op_ks_mac_combine};
+                             op_upper_ntt, op_ks_mac_combine, op_ks_last_ntt};
   return &ops;
 }
 

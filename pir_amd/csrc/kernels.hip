@@ -158,8 +158,10 @@ __global__ void ks_combine_f64_kernel(const DevParams* __restrict__ P, const dou
       const uint8_t* pr = reinterpret_cast<const uint8_t*>(prod) + ((size_t)node * 2 + comp) * km * 5 * N;
       const uint8_t* ps = pr + (size_t)k * 5 * N;
       const uint8_t* pj = pr + (size_t)j * 5 * N;
-      sp = f64_unpack40(reinterpret_cast<const uint32_t*>(ps)[i], ps[4 * (size_t)N + i], f64_pack_magic(pf));
-      dj = f64_unpack40(reinterpret_cast<const uint32_t*>(pj)[i], pj[4 * (size_t)N + i], f64_pack_magic(mj.q));
+      // high bytes thread-major (ntt_kernels.hip store40f): element e * (N/16) + t at 4 N + 16 t + e
+      const size_t hi_at = 4 * (size_t)N + 16 * (size_t)(i & (N / 16 - 1)) + (i >> (P->logN - 4));
+      sp = f64_unpack40(reinterpret_cast<const uint32_t*>(ps)[i], ps[hi_at], f64_pack_magic(pf));
+      dj = f64_unpack40(reinterpret_cast<const uint32_t*>(pj)[i], pj[hi_at], f64_pack_magic(mj.q));
     } else {
       const double* pr = reinterpret_cast<const double*>(prod) + ((size_t)node * 2 + comp) * km * N;
       sp = pr[(size_t)k * N + i];

@@ -56,15 +56,42 @@ __device__ __forceinline__ void store40(uint8_t* poly, uint32_t i, uint64_t v) {
   poly[4 * N + i] = (uint8_t)(v >> 32);
 }
 
-// fp64 flavours: signed representative <-> offset 40-bit storage (arith.h f64_pack40)
-__device__ __forceinline__ double load40f(const uint8_t* poly, uint32_t i, double magic) {
-  return f64_unpack40(reinterpret_cast<const uint32_t*>(poly)[i], poly[4 * N + i], magic);
+// fp64 flavours: signed representative <-> offset 40-bit storage (arith.h f64_pack40).  The kernels below all hold
+// element e * NT + tid in register e of thread tid, so the high bytes are stored THREAD-MAJOR: byte e of thread tid
+// at 4 N + 16 tid + e.  A thread then moves its 16 high bytes with one 16-byte access (a wave: 1 KiB contiguous)
+// instead of 16 single-byte ones -- 17 memory instructions per polynomial instead of 32, and no partial-line
+// byte stores.  (The integer flavour keeps the element-major load40/store40 layout above; buffers are never shared
+// between flavours.)
+struct Hi16 {
+  uint32_t w[4];
+};
+__device__ __forceinline__ Hi16 load40f_hi(const uint8_t* poly, uint32_t tid) {
+  const uint4 v = *reinterpret_cast<const uint4*>(poly + 4 * N + 16 * tid);
+  return Hi16{{v.x, v.y, v.z, v.w}};
 }
-__device__ __forceinline__ void store40f(uint8_t* poly, uint32_t i, double x, double magic) {
-  uint32_t lo, hi;
-  f64_pack40(x, magic, lo, hi);
-  reinterpret_cast<uint32_t*>(poly)[i] = lo;
-  poly[4 * N + i] = (uint8_t)hi;
+// element e * NT + tid
+__device__ __forceinline__ double load40f(const uint8_t* poly, const Hi16& h, int e, uint32_t tid, double magic) {
+  const uint32_t lo = reinterpret_cast<const uint32_t*>(poly)[e * NT + tid];
+  // high word of the double 2^52 + u: 0x43300000 | byte e -- one v_perm_b32 (selector bytes: e & 3 of the word, 0, 0x30, 0x43)
+  const uint32_t hi = __builtin_amdgcn_perm(0x43300000u, h.w[e >> 2], 0x07060c00u | (uint32_t)(e & 3));
+  return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo)) - magic;
+}
+__device__ __forceinline__ void store40f(uint8_t* poly, uint32_t tid, const double (&x)[16], double magic) {
+  uint32_t hb[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    uint32_t lo;
+    f64_pack40(x[e], magic, lo, hb[e]);
+    reinterpret_cast<uint32_t*>(poly)[e * NT + tid] = lo;
+  }
+  uint32_t w[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {   // low bytes of four words -> one word
+    const uint32_t ab = __builtin_amdgcn_perm(hb[4 * g + 1], hb[4 * g], 0x0c0c0400u);
+    const uint32_t cd = __builtin_amdgcn_perm(hb[4 * g + 3], hb[4 * g + 2], 0x0c0c0400u);
+    w[g] = __builtin_amdgcn_perm(cd, ab, 0x05040100u);
+  }
+  *reinterpret_cast<uint4*>(poly + 4 * N + 16 * tid) = uint4{w[0], w[1], w[2], w[3]};
 }
 
 // One workgroup per polynomial; modulus index = mod_base + (poly % mod_period).
@@ -259,9 +286,7 @@ ks_digit_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ re
   if constexpr (P40 && MODE != kNttInt) {
     ntt_forward<MODE, LOGN, kPF, /*CANON=*/false>(x, smem_raw, P, I, tid);  // signed representatives, |x| <= q/2
     uint8_t* out = reinterpret_cast<uint8_t*>(dig) + poly * kPoly40;
-    const double magic = f64_pack_magic(m.q);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) store40f(out, e * NT + tid, x[e], magic);
+    store40f(out, tid, x, f64_pack_magic(m.q));
   } else {
     ntt_forward<MODE, LOGN, kPF>(x, smem_raw, P, I, tid);
     if constexpr (P40) {
@@ -293,15 +318,12 @@ __device__ __forceinline__ void ks_mac_core(const DevParams* __restrict__ P, con
   const T* d0 = reinterpret_cast<const T*>(dig_raw) + poly0 * N;
   const uint8_t* d40 = reinterpret_cast<const uint8_t*>(dig_raw) + poly0 * kPoly40;
   const T* key = reinterpret_cast<const T*>(key_raw);
-  // digit J, element i, in the flavour's register type
-  [[maybe_unused]] double magic = 0.0;
-  if constexpr (MODE != kNttInt) magic = f64_pack_magic(m.q);
-  auto digit = [&](uint32_t J, uint32_t i) -> T {
-    if constexpr (P40 && MODE != kNttInt) return load40f(d40 + (size_t)J * kPoly40, i, magic);
-    else if constexpr (P40) return A::in(load40(d40 + (size_t)J * kPoly40, i), m);
-    else return d0[(size_t)J * N + i];
-  };
   if constexpr (MODE == kNttInt) {
+    // digit J, element i
+    auto digit = [&](uint32_t J, uint32_t i) -> T {
+      if constexpr (P40) return A::in(load40(d40 + (size_t)J * kPoly40, i), m);
+      else return d0[(size_t)J * N + i];
+    };
     u128 acc[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0;
@@ -314,12 +336,20 @@ __device__ __forceinline__ void ks_mac_core(const DevParams* __restrict__ P, con
     for (int e = 0; e < 16; ++e) x[e] = reduce128((uint64_t)acc[e], (uint64_t)(acc[e] >> 64), mI);
     ntt_inverse<MODE, LOGN, kPF>(x, smem_raw, P, I, tid);
   } else {
+    const double magic = f64_pack_magic(m.q);
 #pragma unroll
     for (int e = 0; e < 16; ++e) x[e] = 0.0;
     for (uint32_t J = 0; J < k; ++J) {
       const T* kj = key + (((size_t)J * 2 + comp) * km + I) * N;
+      if constexpr (P40) {
+        const uint8_t* dj = d40 + (size_t)J * kPoly40;
+        const Hi16 h = load40f_hi(dj, tid);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) x[e] += f64_mulmod(digit(J, e * NT + tid), kj[e * NT + tid], m);
+        for (int e = 0; e < 16; ++e) x[e] += f64_mulmod(load40f(dj, h, e, tid, magic), kj[e * NT + tid], m);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) x[e] += f64_mulmod(d0[(size_t)J * N + e * NT + tid], kj[e * NT + tid], m);
+      }
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) x[e] = f64_norm(x[e], m);
@@ -357,9 +387,7 @@ ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
   const size_t opoly = ((size_t)node * 2 + comp) * km + I;
   if constexpr (P40 && MODE != kNttInt) {
     uint8_t* out = reinterpret_cast<uint8_t*>(prod) + opoly * kPoly40;
-    const double magic = f64_pack_magic(m.q);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) store40f(out, e * NT + tid, x[e], magic);
+    store40f(out, tid, x, f64_pack_magic(m.q));
   } else if constexpr (MODE != kNttInt) {  // plain doubles (moduli >= 2^39): signed representatives as they are
     T* out = reinterpret_cast<T*>(prod) + opoly * N;
 #pragma unroll
@@ -406,15 +434,16 @@ ks_mac_combine_kernel(const DevParams* __restrict__ P, const uint64_t* __restric
   ks_mac_core<MODE, P40>(P, dig_raw, key_raw, node, j, comp, tid, g);
   {
     const double pf = P->p_f, half = P->p_half_f, pinv = P->p_inv_f[j];
+    const size_t spoly = ((size_t)node * 2 + comp) * km + k;
+    [[maybe_unused]] Hi16 hs{};
+    if constexpr (P40) hs = load40f_hi(reinterpret_cast<const uint8_t*>(prod) + spoly * kPoly40, tid);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const uint32_t i = e * NT + tid;
       double sp;
       if constexpr (P40) {
-        sp = load40f(reinterpret_cast<const uint8_t*>(prod) + (((size_t)node * 2 + comp) * km + k) * kPoly40, i,
-                     f64_pack_magic(pf));
+        sp = load40f(reinterpret_cast<const uint8_t*>(prod) + spoly * kPoly40, hs, e, tid, f64_pack_magic(pf));
       } else {
-        sp = reinterpret_cast<const double*>(prod)[(((size_t)node * 2 + comp) * km + k) * N + i];
+        sp = reinterpret_cast<const double*>(prod)[spoly * N + e * NT + tid];
       }
       sp = sp > half ? sp - pf : sp;   // exact centring (ks_combine_f64_kernel)
       sp = sp < -half ? sp + pf : sp;
@@ -479,14 +508,20 @@ ks_last_level_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict
   const double* tree = reinterpret_cast<const double*>(tree_raw) + (size_t)ct * 2 * k * N;
   // g = round(S / p) mod q_j, signed representative (ks_combine_f64_kernel)
   double g[16];
+  [[maybe_unused]] Hi16 hs{}, hj{};
+  if constexpr (P40) {
+    const uint8_t* pr = reinterpret_cast<const uint8_t*>(prod) + ((size_t)ct * 2 + comp) * km * kPoly40;
+    hs = load40f_hi(pr + (size_t)k * kPoly40, tid);
+    hj = load40f_hi(pr + (size_t)j * kPoly40, tid);
+  }
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
-    const uint32_t i = e * NT + tid;
+    [[maybe_unused]] const uint32_t i = e * NT + tid;
     double sp, dj;
     if constexpr (P40) {
       const uint8_t* pr = reinterpret_cast<const uint8_t*>(prod) + ((size_t)ct * 2 + comp) * km * kPoly40;
-      sp = load40f(pr + (size_t)k * kPoly40, i, f64_pack_magic(pf));
-      dj = load40f(pr + (size_t)j * kPoly40, i, f64_pack_magic(m.q));
+      sp = load40f(pr + (size_t)k * kPoly40, hs, e, tid, f64_pack_magic(pf));
+      dj = load40f(pr + (size_t)j * kPoly40, hj, e, tid, f64_pack_magic(m.q));
     } else {
       const double* pr = reinterpret_cast<const double*>(prod) + ((size_t)ct * 2 + comp) * km * N;
       sp = pr[(size_t)k * N + i];
@@ -577,9 +612,7 @@ tree_c0_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
   const size_t opoly = (size_t)node * 2 * km + j;
   if constexpr (P40) {
     uint8_t* out = reinterpret_cast<uint8_t*>(prod) + opoly * kPoly40;
-    const double magic = f64_pack_magic(m.q);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) store40f(out, e * NT + tid, x[e], magic);
+    store40f(out, tid, x, f64_pack_magic(m.q));
   } else {
     double* out = reinterpret_cast<double*>(prod) + opoly * N;
 #pragma unroll
@@ -616,12 +649,15 @@ ks_last_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
   {
     const double pf = P->p_f, half = P->p_half_f;
     const size_t spoly = ((size_t)node * 2 + comp) * km + k;
+    [[maybe_unused]] Hi16 hs{};
+    if constexpr (P40) hs = load40f_hi(reinterpret_cast<const uint8_t*>(prod) + spoly * kPoly40, tid);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const uint32_t i = e * NT + tid;
       double sp;
-      if constexpr (P40) sp = load40f(reinterpret_cast<const uint8_t*>(prod) + spoly * kPoly40, i, f64_pack_magic(pf));
-      else sp = reinterpret_cast<const double*>(prod)[spoly * N + i];
+      if constexpr (P40)
+        sp = load40f(reinterpret_cast<const uint8_t*>(prod) + spoly * kPoly40, hs, e, tid, f64_pack_magic(pf));
+      else
+        sp = reinterpret_cast<const double*>(prod)[spoly * N + e * NT + tid];
       sp = sp > half ? sp - pf : sp;   // exact centring (ks_combine_f64_kernel)
       sp = sp < -half ? sp + pf : sp;
       x[e] = f64_norm(sp, m);
@@ -631,9 +667,17 @@ ks_last_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
   // G = (S_j - t) p^-1
   const size_t dpoly0 = ((size_t)node * km + j) * k;
   const double magic = f64_pack_magic(m.q);
-  auto digit = [&](uint32_t J, uint32_t i) -> double {
-    if constexpr (P40) return load40f(reinterpret_cast<const uint8_t*>(dig_raw) + (dpoly0 + J) * kPoly40, i, magic);
-    else return reinterpret_cast<const double*>(dig_raw)[(dpoly0 + J) * N + i];
+  // polynomial `poly` of a 5-byte / double buffer, this thread's 16 elements
+  auto load_poly = [&](const uint64_t* base, size_t poly, double (&out)[16]) {
+    if constexpr (P40) {
+      const uint8_t* pp = reinterpret_cast<const uint8_t*>(base) + poly * kPoly40;
+      const Hi16 h = load40f_hi(pp, tid);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) out[e] = load40f(pp, h, e, tid, magic);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) out[e] = reinterpret_cast<const double*>(base)[poly * N + e * NT + tid];
+    }
   };
   {
     double acc[16];
@@ -642,8 +686,10 @@ ks_last_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
     const double* key = reinterpret_cast<const double*>(key_raw);
     for (uint32_t J = 0; J < k; ++J) {
       const double* kj = key + (((size_t)J * 2 + comp) * km + j) * N;
+      double d[16];
+      load_poly(dig_raw, dpoly0 + J, d);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[e] += f64_mulmod(digit(J, e * NT + tid), kj[e * NT + tid], m);
+      for (int e = 0; e < 16; ++e) acc[e] += f64_mulmod(d[e], kj[e * NT + tid], m);
     }
     const double pinv = P->p_inv_f[j];
 #pragma unroll
@@ -653,17 +699,8 @@ ks_last_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
   double a[16];
   {
     double v[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const uint32_t i = e * NT + tid;
-      if (comp == 0) {
-        const size_t apoly = (size_t)node * 2 * km + j;
-        if constexpr (P40) v[e] = load40f(reinterpret_cast<const uint8_t*>(prod) + apoly * kPoly40, i, magic);
-        else v[e] = reinterpret_cast<const double*>(prod)[apoly * N + i];
-      } else {
-        v[e] = digit(j, i);
-      }
-    }
+    if (comp == 0) load_poly(prod, (size_t)node * 2 * km + j, v);
+    else load_poly(dig_raw, dpoly0 + j, v);
     __syncthreads();  // the transform's last exchange is done with the LDS words
 #pragma unroll
     for (int e = 0; e < 16; ++e) sd[lds_lin_base<NT>(tid) + lds_lin_off<NT>(e)] = v[e];

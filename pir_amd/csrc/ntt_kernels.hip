@@ -668,47 +668,54 @@ ks_last_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
   const size_t dpoly0 = ((size_t)node * km + j) * k;
   const double magic = f64_pack_magic(m.q);
   // polynomial `poly` of a 5-byte / double buffer, this thread's 16 elements
-  auto load_poly = [&](const uint64_t* base, size_t poly, double (&out)[16]) {
+  auto load_poly = [&](const uint64_t* base, size_t poly, double (&out)[16], uint32_t t) {
     if constexpr (P40) {
       const uint8_t* pp = reinterpret_cast<const uint8_t*>(base) + poly * kPoly40;
-      const Hi16 h = load40f_hi(pp, tid);
+      const Hi16 h = load40f_hi(pp, t);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) out[e] = load40f(pp, h, e, tid, magic);
+      for (int e = 0; e < 16; ++e) out[e] = load40f(pp, h, e, t, magic);
     } else {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) out[e] = reinterpret_cast<const double*>(base)[poly * N + e * NT + tid];
+      for (int e = 0; e < 16; ++e) out[e] = reinterpret_cast<const double*>(base)[poly * N + e * NT + t];
     }
   };
   {
-    double acc[16];
+    // the products accumulate onto -t in place: a second accumulator array next to x leaves too few registers for
+    // the digit and key loads of one J to be in flight together (the MAC then costs more than the transform)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.0;
+    for (int e = 0; e < 16; ++e) x[e] = -x[e];
     const double* key = reinterpret_cast<const double*>(key_raw);
     for (uint32_t J = 0; J < k; ++J) {
       const double* kj = key + (((size_t)J * 2 + comp) * km + j) * N;
       double d[16];
-      load_poly(dig_raw, dpoly0 + J, d);
+      load_poly(dig_raw, dpoly0 + J, d, tid);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[e] += f64_mulmod(d[e], kj[e * NT + tid], m);
+      for (int e = 0; e < 16; ++e) x[e] += f64_mulmod(d[e], kj[e * NT + tid], m);
     }
     const double pinv = P->p_inv_f[j];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) x[e] = f64_mulmod(f64_norm(acc[e], m) - x[e], pinv, m);
+    for (int e = 0; e < 16; ++e) x[e] = f64_mulmod(f64_norm(x[e], m), pinv, m);
   }
+  // Everything below is indexed through an opaque copy of the thread index: the compiler otherwise computes the
+  // epilogue's 16 permuted LDS addresses and its global addresses BEFORE the product loop, and with those ~40
+  // registers live it serialises the loop's loads (one s_waitcnt vmcnt(0) per load: the products then cost more
+  // than the transform)
+  uint32_t tid_e = tid;
+  asm volatile("" : "+v"(tid_e));
   // A (and, for component 0, A_0 o pi_g) through an LDS permutation
   double a[16];
   {
     double v[16];
-    if (comp == 0) load_poly(prod, (size_t)node * 2 * km + j, v);
-    else load_poly(dig_raw, dpoly0 + j, v);
+    if (comp == 0) load_poly(prod, (size_t)node * 2 * km + j, v, tid_e);
+    else load_poly(dig_raw, dpoly0 + j, v, tid_e);
     __syncthreads();  // the transform's last exchange is done with the LDS words
 #pragma unroll
-    for (int e = 0; e < 16; ++e) sd[lds_lin_base<NT>(tid) + lds_lin_off<NT>(e)] = v[e];
+    for (int e = 0; e < 16; ++e) sd[lds_lin_base<NT>(tid_e) + lds_lin_off<NT>(e)] = v[e];
     __syncthreads();
     const uint32_t gel = comp == 0 ? galois_elt : galois_inv;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const double w = sd[lds_idx(galois_ntt_slot(16 * tid + e, gel))];
+      const double w = sd[lds_idx(galois_ntt_slot(16 * tid_e + e, gel))];
       if (comp == 0) {
         a[e] = v[e];
         x[e] += w;
@@ -720,13 +727,13 @@ ks_last_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
   const size_t opoly = (size_t)comp * k + j;
   uint64_t* lo = (uint64_t*)dst.p[q] + ((size_t)slot * 2 * k + opoly) * N;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) lo[e * NT + tid] = A::out(f64_canon(f64_norm(a[e] + x[e], m), m), m);
+  for (int e = 0; e < 16; ++e) lo[e * NT + tid_e] = A::out(f64_canon(f64_norm(a[e] + x[e], m), m), m);
   if (slot + shift_pow < n_items) {
     uint64_t* hi = (uint64_t*)dst.p[q] + ((size_t)(slot + shift_pow) * 2 * k + opoly) * N;
     const double* X = xpow + (size_t)j * N;
 #pragma unroll
     for (int e = 0; e < 16; ++e)
-      hi[e * NT + tid] = A::out(f64_canon(f64_mulmod(f64_norm(a[e] - x[e], m), X[e * NT + tid], m), m), m);
+      hi[e * NT + tid_e] = A::out(f64_canon(f64_mulmod(f64_norm(a[e] - x[e], m), X[e * NT + tid_e], m), m), m);
   }
 }
 

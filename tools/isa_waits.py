@@ -1,0 +1,17 @@
+import re,sys
+s=open('/tmp/nk12.s').read().split('\n')
+name=sys.argv[1]
+start=[i for i,l in enumerate(s) if l.startswith(name) and ':' in l][0]
+end=next(i for i in range(start,len(s)) if 's_endpgm' in s[i])
+out=[];cnt=0;ld=0;st=0;lds=0
+for l in s[start:end]:
+    t=l.strip()
+    if t.startswith('global_load') or t.startswith('buffer_load'): ld+=1
+    elif t.startswith('global_store'): st+=1
+    elif t.startswith('ds_'): lds+=1
+    elif t.startswith('s_waitcnt') and 'vmcnt' in t:
+        out.append('L%d S%d D%d V%d W[%s]'%(ld,st,lds,cnt,t.split('s_waitcnt')[1].strip())); ld=0;cnt=0;st=0;lds=0
+    elif t.startswith('s_barrier'): out.append('BAR')
+    elif t.startswith('s_cbranch') or t.startswith('.LBB'): out.append(t[:24])
+    elif t.startswith('v_'): cnt+=1
+print(end-start); print(' | '.join(out))

@@ -1,5 +1,5 @@
 import re,sys
-s=open('/tmp/nk12.s').read().split('\n')
+s=open(sys.argv[2] if len(sys.argv) > 2 else '/tmp/nk12.s').read().split('\n')
 name=sys.argv[1]
 start=[i for i,l in enumerate(s) if l.startswith(name) and ':' in l][0]
 end=next(i for i in range(start,len(s)) if 's_endpgm' in s[i])

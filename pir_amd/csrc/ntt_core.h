@@ -97,7 +97,9 @@ struct ArithF64 {
     return Mod{P->tab[mi].qd, P->tab[mi].qinvd, MODE == kNttF64 && P->f64_lazy_inv != 0};
   }
   using TWPtr = const PIRGPU_GLOBAL TW*;
-  static __device__ __forceinline__ TW load_tw(TWPtr p, uint32_t i) { return p[i]; }
+  // any pointer type: the table in global memory (TWPtr) or a copy of it in LDS (upper_fused_kernel)
+  template <typename PT>
+  static __device__ __forceinline__ TW load_tw(PT p, uint32_t i) { return p[i]; }
   static __device__ __forceinline__ TWPtr tw(const DevParams* P, int mi) { return (TWPtr)P->tab[mi].twf; }
   static __device__ __forceinline__ TWPtr itw(const DevParams* P, int mi) { return (TWPtr)P->tab[mi].itwf; }
   static __device__ __forceinline__ TW ninv(const DevParams* P, int mi) { return P->tab[mi].ninv_f; }
@@ -180,17 +182,83 @@ __device__ __forceinline__ uint32_t lds_lin_base(uint32_t tid) { return tid + (t
 template <int NT_>
 __device__ __forceinline__ constexpr uint32_t lds_lin_off(int e) { return (uint32_t)e * (NT_ + NT_ / 16); }
 
+// A forward twiddle table copied to LDS (upper_fused_kernel: a transform free of vector memory instructions lets
+// loads issued before it complete under it -- vmcnt is in order).  Stored pass by pass, slot-major: the twiddle of
+// (pass window LB, slot w = (8 >> rb) - 1 + g, outer = tid >> LB) sits at
+//   offset(LB) + (w - w0(LB)) * (NT >> LB) + outer,
+// so that the lanes of a wave read consecutive words (or the same word) -- the table's natural order has the last
+// pass's eight stage-0 twiddles of a thread 64 bytes from the next thread's: four-way bank conflicts.
+template <int LOGN>
+struct TwSoA {
+  static constexpr int NT = 1 << (LOGN - 4);
+  static constexpr int next_lb(int LB) { return LB >= 4 ? LB - 4 : 0; }
+  static constexpr int rhi(int LB) {  // highest relative bit of the pass with window LB (fwd_chain's sequence)
+    int lb = LOGN - 4, r = 3;
+    while (lb != LB) {
+      r = lb >= 4 ? 3 : lb - 1;
+      lb = next_lb(lb);
+    }
+    return r;
+  }
+  static constexpr int slots(int r) { return 16 - (8 >> r); }  // sum over rb <= r of (8 >> rb)
+  static constexpr int w0(int LB) { return (8 >> rhi(LB)) - 1; }
+  static constexpr int offset(int LB) {
+    int lb = LOGN - 4, off = 0;
+    while (lb != LB) {
+      off += slots(rhi(lb)) * (NT >> lb);
+      lb = next_lb(lb);
+    }
+    return off;
+  }
+  static constexpr int kWords = offset(0) + slots(rhi(0)) * NT;  // = N - 1
+};
+
+struct LdsTw {
+  const double* p;
+};
+
+// twiddle of (window LB, relative bit rb, g, outer): table index 2^(LOGN-1-(LB+rb)) + (outer << (3 - rb)) + g
+template <typename A, int LOGN, int LB, typename TP>
+__device__ __forceinline__ typename A::TW tw_at(TP tw, int rb, int g, uint32_t outer) {
+  const uint32_t mm = 1u << (LOGN - 1 - (LB + rb));
+  return A::load_tw(tw, mm + (outer << (3 - rb)) + g);
+}
+template <typename A, int LOGN, int LB>
+__device__ __forceinline__ typename A::TW tw_at(LdsTw tw, int rb, int g, uint32_t outer) {
+  using S = TwSoA<LOGN>;
+  return tw.p[S::offset(LB) + ((8 >> rb) - 1 + g - S::w0(LB)) * (S::NT >> LB) + outer];
+}
+
+// Fills the LDS copy (TwSoA<LOGN>::kWords doubles) from the table in global memory; all threads of the workgroup.
+template <int LOGN, int LB, typename SRC>
+__device__ __forceinline__ void lds_twiddles_fill_pass(double* dst, SRC src, uint32_t tid) {
+  using S = TwSoA<LOGN>;
+  constexpr int W = S::NT >> LB;  // distinct outer values
+#pragma unroll
+  for (int rb = S::rhi(LB); rb >= 0; --rb) {
+    const uint32_t mm = 1u << (LOGN - 1 - (LB + rb));
+#pragma unroll
+    for (int g = 0; g < (8 >> rb); ++g) {
+      double* row = dst + S::offset(LB) + ((8 >> rb) - 1 + g - S::w0(LB)) * W;
+      for (uint32_t o = tid; o < (uint32_t)W; o += S::NT) row[o] = src[mm + (o << (3 - rb)) + g];
+    }
+  }
+  if constexpr (LB > 0) lds_twiddles_fill_pass<LOGN, S::next_lb(LB)>(dst, src, tid);
+}
+template <int LOGN, typename SRC>
+__device__ __forceinline__ void lds_twiddles_fill(double* dst, SRC src, uint32_t tid) {
+  lds_twiddles_fill_pass<LOGN, LOGN - 4>(dst, src, tid);
+}
+
 // The 15 twiddles of one 4-stage pass, in the order the stages consume them: relative bit rb
 // (3..0) owns slots (8 >> rb) - 1 ... ; loaded one pass AHEAD of their use so that their L2
 // latency hides under the previous pass's butterflies and LDS exchange.
-template <typename A, int LOGN, int LB, int RHI, int RLO>
-__device__ __forceinline__ void load_twiddles(typename A::TW (&W)[15], typename A::TWPtr tw,
-                                              uint32_t outer) {
+template <typename A, int LOGN, int LB, int RHI, int RLO, typename TP>
+__device__ __forceinline__ void load_twiddles(typename A::TW (&W)[15], TP tw, uint32_t outer) {
 #pragma unroll
   for (int rb = RHI; rb >= RLO; --rb) {
-    const uint32_t mm = 1u << (LOGN - 1 - (LB + rb));
 #pragma unroll
-    for (int g = 0; g < (8 >> rb); ++g) W[(8 >> rb) - 1 + g] = A::load_tw(tw, mm + (outer << (3 - rb)) + g);
+    for (int g = 0; g < (8 >> rb); ++g) W[(8 >> rb) - 1 + g] = tw_at<A, LOGN, LB>(tw, rb, g, outer);
   }
 }
 
@@ -214,9 +282,8 @@ __device__ __forceinline__ void fwd_stages(typename A::T (&x)[16], const typenam
 // Runs the pass whose twiddles are in Wcur on window LB (relative bits RHI..0), then the rest.
 // PF: load the next pass's twiddles before this pass's butterflies (hides their L2 latency, costs
 // 30-60 registers); without PF they are loaded at the start of their own pass.
-template <typename A, int LOGN, int LB, int RHI, bool PF>
-__device__ __forceinline__ void fwd_chain(typename A::T (&x)[16], typename A::T* s,
-                                          typename A::TWPtr tw, const typename A::Mod& m,
+template <typename A, int LOGN, int LB, int RHI, bool PF, typename TP>
+__device__ __forceinline__ void fwd_chain(typename A::T (&x)[16], typename A::T* s, TP tw, const typename A::Mod& m,
                                           uint32_t tid, const typename A::TW (&Wcur)[15]) {
   if constexpr (LB > 0) {
     constexpr int NLB = LB >= 4 ? LB - 4 : 0;
@@ -242,13 +309,13 @@ __device__ __forceinline__ void fwd_chain(typename A::T (&x)[16], typename A::T*
 // representative (A::out gives the residue).  The caller guarantees nobody still reads
 // `s` (barrier) when this is entered.
 // CANON = false (fp64 flavours only): leave signed representatives |x| <= (1/2 + eps) q instead of canonical ones.
-template <int MODE, int LOGN, bool PF = true, bool CANON = true>
-__device__ __forceinline__ void ntt_forward(typename Arith<MODE>::T (&x)[16], void* lds, const DevParams* P, int mi,
-                                            uint32_t tid) {
+// `tw`: the forward twiddle table of modulus mi, in global memory (A::tw) or copied to LDS by the caller.
+template <int MODE, int LOGN, bool PF, bool CANON, typename TP>
+__device__ __forceinline__ void ntt_forward_tw(typename Arith<MODE>::T (&x)[16], void* lds, const DevParams* P, int mi,
+                                               uint32_t tid, TP tw) {
   using A = Arith<MODE>;
   typename A::T* s = reinterpret_cast<typename A::T*>(lds);
   const typename A::Mod m = A::mod(P, mi);
-  const typename A::TWPtr tw = A::tw(P, mi);
   typename A::TW W0[15];
   load_twiddles<A, LOGN, LOGN - 4, 3, 0>(W0, tw, 0u);
   fwd_chain<A, LOGN, LOGN - 4, 3, PF>(x, s, tw, m, tid, W0);
@@ -257,6 +324,12 @@ __device__ __forceinline__ void ntt_forward(typename Arith<MODE>::T (&x)[16], vo
     if constexpr (CANON) x[e] = A::canon_fwd(x[e], m);
     else x[e] = A::signed_fwd(x[e], m);
   }
+}
+
+template <int MODE, int LOGN, bool PF = true, bool CANON = true>
+__device__ __forceinline__ void ntt_forward(typename Arith<MODE>::T (&x)[16], void* lds, const DevParams* P, int mi,
+                                            uint32_t tid) {
+  ntt_forward_tw<MODE, LOGN, PF, CANON>(x, lds, P, mi, tid, Arith<MODE>::tw(P, mi));
 }
 
 // Gentleman-Sande stages for relative bits RLO..3 (low to high) with preloaded twiddles; with

@@ -14,6 +14,7 @@
 //                             multiply_plain + add_inplace (upper levels)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "device_params.h"
 #include "kernels.h"
@@ -40,6 +41,10 @@ constexpr size_t kLdsBytes = (size_t)Plan<LOGN>::LDS_WORDS * 8;
 // twiddle prefetch one pass ahead costs ~30 VGPRs: not affordable under the 128-VGPR cap of the 1024-thread
 // workgroups of N = 16384 (it spills)
 constexpr bool kPF = LOGN < 14;
+// upper_fused_kernel with the twiddle table in LDS (exchange buffer + N doubles of LDS per workgroup, ~245 VGPRs).
+// N = 8192 spills there (four passes, more temporaries: 256 VGPRs + 76 bytes of scratch, cfg 4 363 -> 352 queries/s)
+// and N = 16384 runs the split upper level anyway.
+constexpr bool kUpperLdsTw = LOGN <= 12;
 constexpr uint32_t kWideLevel = 256;  // nodes per launch from which the key-switch kernels use the XCD-aware 1-D grid
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -92,6 +97,22 @@ __device__ __forceinline__ void store40f(uint8_t* poly, uint32_t tid, const doub
     w[g] = __builtin_amdgcn_perm(cd, ab, 0x05040100u);
   }
   *reinterpret_cast<uint4*>(poly + 4 * N + 16 * tid) = uint4{w[0], w[1], w[2], w[3]};
+}
+
+// Buffer-resource access to one polynomial of u64 words: element e * NT + tid is the thread's byte offset 8 tid (one
+// VGPR for all 16 elements) plus a scalar offset 8 e NT -- against a 64-bit address pair per one or two elements with
+// flat loads (their immediate offset reaches 4 KiB, the element stride is 8 NT bytes).  The base must be wave-uniform;
+// readfirstlane makes that provable to the compiler.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t poly_rsrc(const uint64_t* base) {
+  const uint64_t b = (uint64_t)base;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, (uint32_t)N * 8u,
+                                           0x00020000);
+}
+__device__ __forceinline__ uint64_t poly_load_u64(__amdgpu_buffer_rsrc_t r, uint32_t tid, int e) {
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, tid * 8u, (uint32_t)e * (uint32_t)NT * 8u, 0);
+  return ((uint64_t)v.y << 32) | v.x;
 }
 
 // One workgroup per polynomial; modulus index = mod_base + (poly % mod_period).
@@ -745,7 +766,7 @@ ks_last_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
 // add_inplace of database.cpp:218-247 without materialising the re-encoded plaintexts: the
 // transformed plaintext stays in registers and is multiplied into both polynomials of the
 // selector.  grid = (n_rows*C*n_chunks, E, k); partial sums are folded by reduce_splits_kernel, then ntt_batch_kernel (inverse).
-template <int MODE>
+template <int MODE, bool LDS_TW = false>
 __global__ void __launch_bounds__(NT)
 upper_fused_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ src_all, MfmaPtrs svq,
                    uint64_t* __restrict__ part_all, uint32_t n_rows, uint32_t n_dim,
@@ -794,6 +815,69 @@ upper_fused_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
   const double td = (double)P->t;
   const uint32_t thr32 = (uint32_t)thr, mask32 = (uint32_t)mask;
   uint32_t since = 0;
+  if constexpr (LDS_TW) {
+    // Pipelined variant (fp64 flavours, rings whose twiddle table fits LDS next to the exchange buffer).  Getting a
+    // child's 2 x 16 selector words into registers costs ~2 us of exposed HBM latency per child with only two waves per
+    // SIMD to hide it (98 of the kernel's 349 us at cfg 3), and a prefetch across the transform
+    // does not work while the transform loads its twiddles from global memory: vmcnt completes in order, so its first
+    // twiddle wait would wait for the prefetch too.  Here the workgroup copies the modulus' forward twiddle table to
+    // LDS once, the transform contains no vector memory instruction, and the selector words of child ii (and the
+    // source words of child ii + 1) are requested BEFORE the transform of child ii and arrive under it.
+    static_assert(MODE != kNttInt, "fp64 flavours only");
+    double* ltw = reinterpret_cast<double*>(smem_raw + kLdsBytes);
+    lds_twiddles_fill<LOGN>(ltw, A::tw(P, jt), tid);
+    uint64_t in_raw[16];
+    auto load_in = [&](uint32_t ii) {
+      const __amdgpu_buffer_rsrc_t in = poly_rsrc(src + ((((size_t)(child0 + ii) * C + cc) * 2 + sp) * k + sj) * N);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) in_raw[e] = poly_load_u64(in, tid, e);
+    };
+    if (ii0 < ii1) load_in(ii0);
+    for (uint32_t ii = ii0; ii < ii1; ++ii) {
+      const __amdgpu_buffer_rsrc_t s0 = poly_rsrc(sv + (((size_t)(sv_first + ii) * 2 + 0) * k + jt) * N);
+      const __amdgpu_buffer_rsrc_t s1 = poly_rsrc(sv + (((size_t)(sv_first + ii) * 2 + 1) * k + jt) * N);
+      T x[16];
+      if (fast_lift) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const uint32_t v = (uint32_t)(in_raw[e] >> sh) & mask32;
+          const double d = (double)v;
+          x[e] = v >= thr32 ? d - td : d;  // m >= (t+1)/2 -> m + q - t == m - t (mod q): SURVEY App. A.5
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          uint64_t v = (in_raw[e] >> sh) & mask;
+          uint64_t rr = reduce64(v, mc);
+          if (v >= thr) rr = add_mod(rr, inc, mc.q);
+          x[e] = A::in(rr, m);
+        }
+      }
+      uint64_t s0r[16], s1r[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        s0r[e] = poly_load_u64(s0, tid, e);
+        s1r[e] = poly_load_u64(s1, tid, e);
+      }
+      if (ii + 1 < ii1) load_in(ii + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();  // previous iteration's transform may still be reading LDS (and, first time, the table copy)
+      ntt_forward_tw<MODE, LOGN, false, /*CANON=*/false>(x, smem_raw, P, jt, tid, LdsTw{ltw});
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        acc0[e] += f64_mulmod(x[e], f64_from_u64(s0r[e]), m);
+        acc1[e] += f64_mulmod(x[e], f64_from_u64(s1r[e]), m);
+      }
+      if (++since == 8) {
+        since = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          acc0[e] = f64_norm(acc0[e], m);
+          acc1[e] = f64_norm(acc1[e], m);
+        }
+      }
+    }
+  } else
   for (uint32_t ii = ii0; ii < ii1; ++ii) {
     const uint64_t* in = src + ((((size_t)(child0 + ii) * C + cc) * 2 + sp) * k + sj) * N;
     T x[16];
@@ -961,6 +1045,11 @@ static hipError_t configure_mode() {
   PIRGPU_SET((ks_mac_intt_kernel<MODE, false>));
   PIRGPU_SET((ks_mac_intt_kernel<MODE, true>));
   PIRGPU_SET(upper_fused_kernel<MODE>);
+  if constexpr (MODE != kNttInt && kUpperLdsTw) {
+    if ((e = hipFuncSetAttribute((const void*)upper_fused_kernel<MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 bytes + N * 8)))
+      return e;
+  }
   if constexpr (MODE != kNttInt) {
     PIRGPU_SET(upper_ntt_kernel<MODE>);
     PIRGPU_SET((ks_mac_combine_kernel<MODE, false>));
@@ -1146,10 +1235,23 @@ static hipError_t op_upper_fused(hipStream_t st, int mode, const DevParams* P, u
                                  uint32_t n_dim, uint32_t n_children_total, uint32_t sv_first, uint32_t C,
                                  uint32_t chunk_len, uint32_t n_chunks, uint32_t n_queries, uint64_t src_qstride,
                                  uint64_t part_qstride) {
-  PIRGPU_BY_MODE(mode, hipLaunchKernelGGL(upper_fused_kernel<MODE>, dim3(n_queries * n_rows * C * n_chunks, enc_count, k),
-                                          dim3(NT), kLdsBytes, st, P, src, svq, part, n_rows, n_dim,
-                                          n_children_total, sv_first, C, chunk_len, n_chunks, src_qstride,
-                                          part_qstride));
+  const dim3 grid(n_queries * n_rows * C * n_chunks, enc_count, k);
+  if constexpr (kUpperLdsTw) {
+    static const bool lds_tw = !(getenv("PIRGPU_UPPER_LDS_TW") && atoi(getenv("PIRGPU_UPPER_LDS_TW")) == 0);
+    if (lds_tw && mode != kNttInt) {
+      const size_t lds = kLdsBytes + (size_t)N * 8;
+      if (mode == kNttF64)
+        hipLaunchKernelGGL((upper_fused_kernel<kNttF64, true>), grid, dim3(NT), lds, st, P, src, svq, part, n_rows, n_dim,
+                           n_children_total, sv_first, C, chunk_len, n_chunks, src_qstride, part_qstride);
+      else
+        hipLaunchKernelGGL((upper_fused_kernel<kNttF64Wide, true>), grid, dim3(NT), lds, st, P, src, svq, part, n_rows,
+                           n_dim, n_children_total, sv_first, C, chunk_len, n_chunks, src_qstride, part_qstride);
+      return hipGetLastError();
+    }
+  }
+  PIRGPU_BY_MODE(mode, hipLaunchKernelGGL(upper_fused_kernel<MODE>, grid, dim3(NT), kLdsBytes, st, P, src, svq, part,
+                                          n_rows, n_dim, n_children_total, sv_first, C, chunk_len, n_chunks,
+                                          src_qstride, part_qstride));
   return hipGetLastError();
 }
 

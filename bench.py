@@ -410,6 +410,11 @@ def main():
                          "algorithmic_bytes_definition": "packed operand-layout bytes of this GPU's shard = what one "
                                                          "launch must read (DESIGN.md section 5)",
                          "launches_averaged": timings["runs"],
+                         # d = 1: the selection vector (one ciphertext per plaintext = 2x the database in u64) is read
+                         # by the same launch; SURVEY 8(d)'s B_q leaves it out, so `frac` is a lower bound there
+                         **({"d1_selector_bytes": pp.num_pt * 2 * k * N * 8,
+                             "frac_incl_selectors": (scan_bytes + pp.num_pt * 2 * k * N * 8) / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                             if scan_ms > 0 else 0.0} if args.dims == 1 else {}),
                          # SURVEY 8(d) prices the scan in u64 residues (num_pt*k*N*8 per query) whatever the stored
                          # layout; both figures side by side, named
                          "frac_survey_8d_u64": (u64_bytes / max(world, 1)) / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if scan_ms > 0 else 0.0,

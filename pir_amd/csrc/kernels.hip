@@ -727,7 +727,15 @@ __global__ void reduce_splits_kernel(const DevParams* __restrict__ P, const uint
   const uint32_t j = (uint32_t)((gid >> P->logN) % P->k);
   const ModConst m = P->mod[j];
   uint64_t acc = 0;
-  for (uint32_t s = 0; s < nsplit; ++s) acc = add_mod(acc, reduce64(part[(size_t)s * words + gid], m), m.q);
+  uint32_t s = 0;
+  for (; s + 8 <= nsplit; s += 8) {  // eight partial sums in flight at a time (the launch is a few workgroups: latency-bound)
+    uint64_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(s + u) * words + gid];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = add_mod(acc, reduce64(v[u], m), m.q);
+  }
+  for (; s < nsplit; ++s) acc = add_mod(acc, reduce64(part[(size_t)s * words + gid], m), m.q);
   out[gid] = acc;
 }
 

@@ -143,7 +143,7 @@ struct pirgpu_ctx {
   uint32_t batch_cap = 0, batch_count = 0, n_active = 1;
   bool batch_valid = false;
   uint32_t upper_blocks = 512;   // target workgroup count of upper_fused_kernel (PIRGPU_UPPER_BLOCKS)
-  uint32_t upper_blocks_batch = 128;  // the same per query in batch mode, where other queries fill the chip too: fewer
+  uint32_t upper_blocks_batch = 64;   // the same per query in batch mode, where other queries fill the chip too: fewer
                                       // chunks = fewer partial sums to write and fold (PIRGPU_UPPER_BLOCKS_BATCH)
   bool in_batch = false;         // set while the batch pipeline enqueues work
   uint32_t scan_nsplit = 1, scan_cps = 0, scan_rows = 0, scan_cols = 0;

@@ -101,3 +101,25 @@ def test_split_upper_level_matches_fused(monkeypatch, d, items, elem, mb):
     for i in range(3):
         assert np.array_equal(batch[i], exp[i]), i
     db.close()
+
+
+@pytest.mark.parametrize("knob", ["PIRGPU_LAST_NTT", "PIRGPU_FUSE_LAST", "PIRGPU_FUSE_MAC_COMBINE", "PIRGPU_PACK40"])
+def test_expansion_fallback_paths(monkeypatch, knob):
+    """The expansion's optional fusions switched off one at a time (coefficient-domain last level, unfused last level,
+    separate combine pass, digits as doubles): every variant must give the oracle's reply, single and batched."""
+    monkeypatch.setenv(knob, "0")
+    N, moduli, _ = CHAINS["n4096_36bit"]
+    s = PirSetup(5000, 288, 2, N=N, plain_bits=24, moduli=moduli)
+    db, srv = _server(s)
+    rng = np.random.default_rng(11)
+    keys = {(N >> j) + 1: random_key(s.orc, rng) for j in range(N.bit_length() - 1)}
+    srv.set_galois_keys(keys)
+    queries = random_ct(s.orc, rng, 9)[:, None]
+    rc, exp = s.orc.process_query(s.db_ntt, s.params.dimensions, queries[0], keys)
+    assert rc == 0
+    assert np.array_equal(srv.process_query(queries[0]), exp)
+    batch = srv.process_batch(queries, n_workers=9)          # one full group of 8 + a group of 1
+    assert np.array_equal(batch[0], exp)
+    rc, exp8 = s.orc.process_query(s.db_ntt, s.params.dimensions, queries[8], keys)
+    assert rc == 0 and np.array_equal(batch[8], exp8)
+    db.close()

@@ -98,6 +98,7 @@ struct Stage {
   bool local_rows;        // dimension-0 selectors at local index (packed multi-GPU exchange)
   uint64_t** up_scratch = nullptr;   // owner's scratch for the split upper level, grown on demand
   size_t* up_scratch_words = nullptr;
+  bool sel_f64 = false;   // the selectors are exact doubles (a lane's own expansion, pirgpu_ctx::sel_f64)
 };
 
 struct pirgpu_ctx {
@@ -168,6 +169,10 @@ struct pirgpu_ctx {
                                             // kernel (PIRGPU_FUSE_MAC_COMBINE=0: separate ks_combine pass)
   bool fuse_last_level = true;              // last expansion level fused with the selector NTT (PIRGPU_FUSE_LAST=0: off)
   bool last_level_ntt = true;               // ... and carried out in the NTT domain (PIRGPU_LAST_NTT=0: coefficient form)
+  bool want_sel_f64 = true;
+  bool sel_f64 = false;                     // batch lanes keep their selectors as exact doubles between the last expansion
+                                            // level and their two consumers (sel_pack, upper level): no u64 round trip
+                                            // (fp64 flavours, MFMA scan, NTT-domain last level; PIRGPU_SEL_F64=0: off)
   bool pack40 = false;                      // key-switch digits stored in 5 bytes (all moduli < 2^40; PIRGPU_PACK40)
   uint8_t* d_dbp = nullptr;
   bool packed_valid = false;
@@ -436,6 +441,7 @@ void ensure_workspace(pirgpu_ctx* c) {
     c->fuse_last_level = env_u32("PIRGPU_FUSE_LAST", 1) != 0;
     c->fuse_mac_combine = env_u32("PIRGPU_FUSE_MAC_COMBINE", 1) != 0;
     c->last_level_ntt = env_u32("PIRGPU_LAST_NTT", 1) != 0;
+    c->want_sel_f64 = env_u32("PIRGPU_SEL_F64", 1) != 0;
     c->fuse_mac_nodes = env_u32("PIRGPU_FUSE_MAC_NODES", 128);
     c->split_upper = env_u32("PIRGPU_SPLIT_UPPER", c->logN >= 14 ? 1 : 0) != 0 && c->mode != kNttInt;
     c->split_upper_words = (uint64_t)env_u32("PIRGPU_SPLIT_UPPER_MB", 3072) * (1ull << 20) / 8;
@@ -449,6 +455,10 @@ void ensure_workspace(pirgpu_ctx* c) {
     //   PIRGPU_SCAN_MFMA_SINGLE: a single query on a matrix wider than one column chunk pays the partial-sum
     //   round trip for one query only; there the 64-bit kernels on the u64 copy are faster (cfg 4: 5.6 vs 6.4 ms)
     c->mfma_single = env_u32("PIRGPU_SCAN_MFMA_SINGLE", c->mg.nchunks == 1 ? 1 : 0) != 0;
+    // selectors as doubles inside a lane: every query ciphertext must go through ks_last_ntt_kernel (>= 2 items each)
+    const uint64_t rem = c->dim_sum % N;
+    c->sel_f64 = c->want_sel_f64 && c->mfma_on && c->mode != kNttInt && c->fuse_last_level && c->last_level_ntt &&
+                 !c->split_upper && c->dim_sum >= 2 && rem != 1;
   }
   c->ws_ready = true;
   if (c->workers.empty()) c->workers.emplace_back();
@@ -544,11 +554,12 @@ const uint64_t* xpow_table(pirgpu_ctx* c, hipStream_t st, uint32_t shift) {
 // last level then runs fused with the selectors' forward transform (ks_last_level_kernel) and nullptr is returned:
 // there is no coefficient-form result to transform any more.
 uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* res_b, uint64_t* dig, uint64_t* prod,
-                      uint32_t n, uint32_t B, const MfmaPtrs* sel_dst = nullptr) {
+                      uint32_t n, uint32_t B, const MfmaPtrs* sel_dst = nullptr, bool sel_f64 = false) {
   const uint32_t N = c->N, k = c->k;
   if (n > N) throw Fail{PIRGPU_INVALID_ARGUMENT, "Cannot expand more items from a CT than poly modulus degree"};
   const uint32_t logm = hm::ceil_log2(n);
   const bool fuse_last = sel_dst && c->mode != kNttInt && c->fuse_last_level;
+  if (sel_f64 && !(fuse_last && c->last_level_ntt && n >= 2)) throw Fail{PIRGPU_INTERNAL, "double-form selectors need the NTT-domain last level"};
   uint64_t *cur = res_a, *nxt = res_b;
   for (uint32_t j = 0; j < logm; ++j) {
     const uint32_t g = (N >> j) + 1;
@@ -568,7 +579,7 @@ uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* 
       const uint64_t* X = xpow_table(c, st, 1u << j);
       HIP_TRY(c->ops->ks_mac_intt(st, c->mode, c->dp, k, dig, key, nodes, prod, c->pack40, k, 1));
       HIP_TRY(c->ops->ks_last_ntt(st, c->mode, c->dp, k, cur, dig, key, prod, X, g, galois_inverse(g, N), 1u << j, n, B,
-                                  *sel_dst, nodes, c->pack40));
+                                  *sel_dst, nodes, c->pack40, sel_f64));
       return nullptr;
     }
     HIP_TRY(c->ops->ks_mac_intt(st, c->mode, c->dp, k, dig, key, nodes, prod, c->pack40, 0, k + 1));
@@ -640,7 +651,7 @@ void ensure_packed(pirgpu_ctx* c) {
 // the column selectors (unless they arrive packed), scan, fold column chunks.  Row sums of query q go to
 // out + q * scan_rows ciphertexts; `part` (query-major as well) holds the per-chunk sums of matrices wider than one chunk.
 void scan_group_mfma(pirgpu_ctx* c, hipStream_t st, uint8_t*& selp, const MfmaPtrs& col_sel, uint32_t n, uint64_t* out_base,
-                     uint64_t* part, Worker* profiled, const uint8_t* packed = nullptr) {
+                     uint64_t* part, Worker* profiled, const uint8_t* packed = nullptr, bool sel_f64 = false) {
   const uint32_t kN = c->k * c->N;
   const uint64_t words = (uint64_t)c->scan_rows * c->ctw;
   ensure_packed(c);
@@ -649,7 +660,7 @@ void scan_group_mfma(pirgpu_ctx* c, hipStream_t st, uint8_t*& selp, const MfmaPt
     out.p[q] = c->mg.nchunks > 1 ? part + (size_t)q * c->mg.nchunks * words : out_base + (size_t)q * words;
   if (!packed) {  // with `packed` the group's digit-packed column selectors already exist (multi-GPU exchange)
     if (!selp) selp = c->dalloc<uint8_t>(c->mg.sel_bytes);
-    HIP_TRY(launch_sel_pack(st, c->dp, c->mg, col_sel, n, selp, c->scan_cols, kN));
+    HIP_TRY(launch_sel_pack(st, c->dp, c->mg, col_sel, n, selp, c->scan_cols, kN, sel_f64));
     packed = selp;
   }
   if (profiled) record(c, *profiled, PH_SCAN);  // selector packing counts as selector preparation, not as the scan
@@ -748,7 +759,7 @@ void post_scan_stage(pirgpu_ctx* c, const Stage& sg, Worker* profiled) {
     } else {
       HIP_TRY(c->ops->upper_fused(st, c->mode, c->dp, k, c->E, sg.lvl[l + 1], sg.sel, sg.pt_buf, (uint32_t)rows,
                                   c->dims[l], (uint32_t)nch, sv_first, (uint32_t)C, chunk_len, n_chunks, sg.n,
-                                  c->lvl_cts[l + 1] * ctw, c->pt_words));
+                                  c->lvl_cts[l + 1] * ctw, c->pt_words, sg.sel_f64));
       if (l == 0 && profiled) record(c, *profiled, PH_FINAL);
       // fold the chunk sums (wide, elementwise) and return to coefficient form (database.cpp:250-254)
       HIP_TRY(launch_reduce_splits(st, c->dp, sg.pt_buf, n_chunks, out_polys * N, sg.lvl[l], sg.n, c->pt_words,
@@ -1425,7 +1436,8 @@ static void ensure_lanes(pirgpu_ctx* c, bool with_expansion_buffers) {
 
 // Batched oblivious expansion of the staged queries first .. first+B-1 on lane `ln`, B queries interleaved
 // (ciphertext index = node * B + query), into the members' own selection vectors (NTT form).
-static void expand_group_on_lane(pirgpu_ctx* c, BatchLane& ln, Worker* const* members, uint32_t B, uint32_t first) {
+static void expand_group_on_lane(pirgpu_ctx* c, BatchLane& ln, Worker* const* members, uint32_t B, uint32_t first,
+                                 bool sel_f64 = false) {
   const uint32_t N = c->N, k = c->k;
   const uint32_t nq = c->dim_sum / N + 1;
   const size_t ctw = c->ctw, qwords = (size_t)nq * ctw;
@@ -1438,7 +1450,7 @@ static void expand_group_on_lane(pirgpu_ctx* c, BatchLane& ln, Worker* const* me
     HIP_TRY(launch_tree_convert(ln.stream, c->dp, c->mode, ln.res_b, ln.res_a, (uint64_t)B * ctw, true));
     MfmaPtrs dst{};
     for (uint32_t q = 0; q < B; ++q) dst.p[q] = members[q]->sv_ntt + produced * ctw;
-    uint64_t* res = expand_core(c, ln.stream, ln.res_a, ln.res_b, ln.dig, ln.prod, slots, B, &dst);
+    uint64_t* res = expand_core(c, ln.stream, ln.res_a, ln.res_b, ln.dig, ln.prod, slots, B, &dst, sel_f64);
     if (res) HIP_TRY(c->ops->ct_ntt_fwd_split(ln.stream, c->mode, c->dp, k, res, dst, B, (uint64_t)slots * B));
     produced += slots;
     remaining -= slots;
@@ -1496,14 +1508,17 @@ static void batch_run_mfma(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
         packed = pk->packed + ((size_t)(rank0 / pk->per_rank) * groups_per_rank + j0 / kMaxMfmaQueries) * c->mg.sel_bytes;
         for (uint32_t q = 0; q < B; ++q) sg.sel.p[q] = pk->rows + (size_t)(first + q) * my_rows * c->ctw;
       } else {
-        if (!ext_sv) expand_group_on_lane(c, ln, members, B, first);
+        if (!ext_sv) {
+          expand_group_on_lane(c, ln, members, B, first, c->sel_f64);
+          sg.sel_f64 = c->sel_f64;   // written and read on this lane only: exact doubles instead of u64
+        }
         for (uint32_t q = 0; q < B; ++q) {
           const uint64_t* sv = ext_sv ? ext_sv + (size_t)(first + q) * svwords : members[q]->sv_ntt;
           sg.sel.p[q] = sv;
           col.p[q] = sv + (size_t)c->sv_off[c->d - 1] * c->ctw;
         }
       }
-      scan_group_mfma(c, ln.stream, ln.selp, col, B, ln.lvl[c->d - 1], ln.scan_part, nullptr, packed);
+      scan_group_mfma(c, ln.stream, ln.selp, col, B, ln.lvl[c->d - 1], ln.scan_part, nullptr, packed, sg.sel_f64);
       post_scan_stage(c, sg, nullptr);
       HIP_TRY(hipMemcpyAsync(c->d_breply + (size_t)first * rwords, ln.lvl[0], (size_t)B * rwords * 8,
                              hipMemcpyDeviceToDevice, ln.stream));

@@ -35,12 +35,13 @@ struct NttOps {
   hipError_t (*ks_mac_intt)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* dig,
                             const uint64_t* key, uint32_t nodes, uint64_t* prod, bool pack40, uint32_t I_base,
                             uint32_t I_count);
-  // n_queries queries in one launch: query q reads src + q * src_qstride, selectors svq.p[q], writes part + q * part_qstride
+  // n_queries queries in one launch: query q reads src + q * src_qstride, selectors svq.p[q], writes part + q * part_qstride;
+  // sel_f64 (fp64 flavours): the selectors are canonical residues stored as exact doubles (lane-internal form)
   hipError_t (*upper_fused)(hipStream_t st, int mode, const DevParams* P, uint32_t k, uint32_t enc_count,
                             const uint64_t* src, const MfmaPtrs& svq, uint64_t* part, uint32_t n_rows,
                             uint32_t n_dim, uint32_t n_children_total, uint32_t sv_first, uint32_t C,
                             uint32_t chunk_len, uint32_t n_chunks, uint32_t n_queries, uint64_t src_qstride,
-                            uint64_t part_qstride);
+                            uint64_t part_qstride, bool sel_f64);
   // last expansion level fused with the selectors' forward NTT (fp64 flavours): tree_cts tree ciphertexts
   // (index = slot * B + query) -> selectors slot and slot + shift_pow of query q at dst.p[q], if < n_items
   hipError_t (*ks_last_level)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* tree,
@@ -62,7 +63,7 @@ struct NttOps {
   hipError_t (*ks_last_ntt)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* tree,
                             const uint64_t* dig, const uint64_t* key, uint64_t* prod, const uint64_t* xpow,
                             uint32_t galois_elt, uint32_t galois_inv, uint32_t shift_pow, uint32_t n_items, uint32_t B,
-                            const MfmaPtrs& dst, uint32_t nodes, bool pack40);
+                            const MfmaPtrs& dst, uint32_t nodes, bool pack40, bool out_f64);
 };
 
 const NttOps* ntt_ops_for(uint32_t N);  // nullptr for unsupported degrees
@@ -114,7 +115,7 @@ hipError_t launch_db_pack(hipStream_t st, const DevParams* P, const MfmaGeom& gm
 hipError_t launch_db_unpack(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp, uint64_t* out,
                             uint32_t row, uint32_t col, uint32_t kN);
 hipError_t launch_sel_pack(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const MfmaPtrs& sv, uint32_t nq,
-                           uint8_t* selp, uint32_t cols, uint32_t kN);
+                           uint8_t* selp, uint32_t cols, uint32_t kN, bool sel_f64 = false);
 hipError_t launch_scan_mfma(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp,
                             const uint8_t* selp, const MfmaPtrs& out, uint32_t nq, uint32_t rows, uint32_t kN,
                             uint64_t chunk_stride);

@@ -645,7 +645,7 @@ tree_c0_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
 // residue), then the dyadic products and the epilogue above; writes selector `slot` and -- if < n_items --
 // selector `slot + shift_pow` of query q (tree ciphertext index = slot * B + query).  xpow = X for the k data
 // moduli, [k][N] doubles in device order.  grid = (nodes, k, 2) or the XCD-aware 1-D equivalent.
-template <int MODE, bool P40>
+template <int MODE, bool P40, bool OUTF64 = false>
 __global__ void __launch_bounds__(NT)
 ks_last_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ dig_raw,
                    const uint64_t* __restrict__ key_raw, const uint64_t* __restrict__ prod,
@@ -748,13 +748,20 @@ ks_last_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
   const size_t opoly = (size_t)comp * k + j;
   uint64_t* lo = (uint64_t*)dst.p[q] + ((size_t)slot * 2 * k + opoly) * N;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) lo[e * NT + tid_e] = A::out(f64_canon(f64_norm(a[e] + x[e], m), m), m);
+  for (int e = 0; e < 16; ++e) {
+    const double r = f64_canon(f64_norm(a[e] + x[e], m), m);
+    if constexpr (OUTF64) reinterpret_cast<double*>(lo)[e * NT + tid_e] = r;   // lane-internal selectors: exact doubles
+    else lo[e * NT + tid_e] = A::out(r, m);
+  }
   if (slot + shift_pow < n_items) {
     uint64_t* hi = (uint64_t*)dst.p[q] + ((size_t)(slot + shift_pow) * 2 * k + opoly) * N;
     const double* X = xpow + (size_t)j * N;
 #pragma unroll
-    for (int e = 0; e < 16; ++e)
-      hi[e * NT + tid_e] = A::out(f64_canon(f64_mulmod(f64_norm(a[e] - x[e], m), X[e * NT + tid_e], m), m), m);
+    for (int e = 0; e < 16; ++e) {
+      const double r = f64_canon(f64_mulmod(f64_norm(a[e] - x[e], m), X[e * NT + tid_e], m), m);
+      if constexpr (OUTF64) reinterpret_cast<double*>(hi)[e * NT + tid_e] = r;
+      else hi[e * NT + tid_e] = A::out(r, m);
+    }
   }
 }
 
@@ -766,7 +773,7 @@ ks_last_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
 // add_inplace of database.cpp:218-247 without materialising the re-encoded plaintexts: the
 // transformed plaintext stays in registers and is multiplied into both polynomials of the
 // selector.  grid = (n_rows*C*n_chunks, E, k); partial sums are folded by reduce_splits_kernel, then ntt_batch_kernel (inverse).
-template <int MODE, bool LDS_TW = false>
+template <int MODE, bool LDS_TW = false, bool SELF64 = false>
 __global__ void __launch_bounds__(NT)
 upper_fused_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ src_all, MfmaPtrs svq,
                    uint64_t* __restrict__ part_all, uint32_t n_rows, uint32_t n_dim,
@@ -865,8 +872,9 @@ upper_fused_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
       ntt_forward_tw<MODE, LOGN, false, /*CANON=*/false>(x, smem_raw, P, jt, tid, LdsTw{ltw});
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        acc0[e] += f64_mulmod(x[e], f64_from_u64(s0r[e]), m);
-        acc1[e] += f64_mulmod(x[e], f64_from_u64(s1r[e]), m);
+        // SELF64: the group's selectors were written as exact doubles by ks_last_ntt_kernel (no conversion)
+        acc0[e] += f64_mulmod(x[e], SELF64 ? __longlong_as_double((long long)s0r[e]) : f64_from_u64(s0r[e]), m);
+        acc1[e] += f64_mulmod(x[e], SELF64 ? __longlong_as_double((long long)s1r[e]) : f64_from_u64(s1r[e]), m);
       }
       if (++since == 8) {
         since = 0;
@@ -929,8 +937,9 @@ upper_fused_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
     } else {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        acc0[e] += f64_mulmod(x[e], f64_from_u64(s0[e * NT + tid]), m);
-        acc1[e] += f64_mulmod(x[e], f64_from_u64(s1[e * NT + tid]), m);
+        const uint64_t w0 = s0[e * NT + tid], w1 = s1[e * NT + tid];
+        acc0[e] += f64_mulmod(x[e], SELF64 ? __longlong_as_double((long long)w0) : f64_from_u64(w0), m);
+        acc1[e] += f64_mulmod(x[e], SELF64 ? __longlong_as_double((long long)w1) : f64_from_u64(w1), m);
       }
       if (++since == 8) {
         since = 0;
@@ -1049,6 +1058,9 @@ static hipError_t configure_mode() {
     if ((e = hipFuncSetAttribute((const void*)upper_fused_kernel<MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  bytes + N * 8)))
       return e;
+    if ((e = hipFuncSetAttribute((const void*)upper_fused_kernel<MODE, true, true>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes + N * 8)))
+      return e;
   }
   if constexpr (MODE != kNttInt) {
     PIRGPU_SET(upper_ntt_kernel<MODE>);
@@ -1060,6 +1072,9 @@ static hipError_t configure_mode() {
     PIRGPU_SET((tree_c0_ntt_kernel<MODE, true>));
     PIRGPU_SET((ks_last_ntt_kernel<MODE, false>));
     PIRGPU_SET((ks_last_ntt_kernel<MODE, true>));
+    PIRGPU_SET((ks_last_ntt_kernel<MODE, false, true>));
+    PIRGPU_SET((ks_last_ntt_kernel<MODE, true, true>));
+    PIRGPU_SET((upper_fused_kernel<MODE, false, true>));
   }
 #undef PIRGPU_SET
   return hipSuccess;
@@ -1190,15 +1205,19 @@ static hipError_t op_ks_last_level(hipStream_t st, int mode, const DevParams* P,
 static hipError_t op_ks_last_ntt(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* tree,
                                  const uint64_t* dig, const uint64_t* key, uint64_t* prod, const uint64_t* xpow,
                                  uint32_t galois_elt, uint32_t galois_inv, uint32_t shift_pow, uint32_t n_items,
-                                 uint32_t B, const MfmaPtrs& dst, uint32_t nodes, bool pack40) {
+                                 uint32_t B, const MfmaPtrs& dst, uint32_t nodes, bool pack40, bool out_f64) {
   const dim3 g0(nodes * k);
   const dim3 grid = nodes >= kWideLevel && nodes % 8 == 0 ? dim3(nodes * k * 2) : dim3(nodes, k, 2);
   const double* X = reinterpret_cast<const double*>(xpow);
 #define PIRGPU_LAST_NTT(M, P40)                                                                                    \
   do {                                                                                                             \
     hipLaunchKernelGGL((tree_c0_ntt_kernel<M, P40>), g0, dim3(NT), kLdsBytes, st, P, tree, prod);                  \
-    hipLaunchKernelGGL((ks_last_ntt_kernel<M, P40>), grid, dim3(NT), kLdsBytes, st, P, dig, key, prod, X,          \
-                       galois_elt, galois_inv, shift_pow, n_items, B, dst);                                        \
+    if (out_f64)                                                                                                   \
+      hipLaunchKernelGGL((ks_last_ntt_kernel<M, P40, true>), grid, dim3(NT), kLdsBytes, st, P, dig, key, prod, X,  \
+                         galois_elt, galois_inv, shift_pow, n_items, B, dst);                                      \
+    else                                                                                                           \
+      hipLaunchKernelGGL((ks_last_ntt_kernel<M, P40>), grid, dim3(NT), kLdsBytes, st, P, dig, key, prod, X,        \
+                         galois_elt, galois_inv, shift_pow, n_items, B, dst);                                      \
   } while (0)
   if (mode == kNttF64) {
     if (pack40) PIRGPU_LAST_NTT(kNttF64, true);
@@ -1234,24 +1253,28 @@ static hipError_t op_upper_fused(hipStream_t st, int mode, const DevParams* P, u
                                  const uint64_t* src, const MfmaPtrs& svq, uint64_t* part, uint32_t n_rows,
                                  uint32_t n_dim, uint32_t n_children_total, uint32_t sv_first, uint32_t C,
                                  uint32_t chunk_len, uint32_t n_chunks, uint32_t n_queries, uint64_t src_qstride,
-                                 uint64_t part_qstride) {
+                                 uint64_t part_qstride, bool sel_f64) {
   const dim3 grid(n_queries * n_rows * C * n_chunks, enc_count, k);
+#define PIRGPU_UF_ARGS P, src, svq, part, n_rows, n_dim, n_children_total, sv_first, C, chunk_len, n_chunks, src_qstride, part_qstride
+  if (sel_f64 && mode == kNttInt) return hipErrorInvalidValue;
   if constexpr (kUpperLdsTw) {
     static const bool lds_tw = !(getenv("PIRGPU_UPPER_LDS_TW") && atoi(getenv("PIRGPU_UPPER_LDS_TW")) == 0);
     if (lds_tw && mode != kNttInt) {
       const size_t lds = kLdsBytes + (size_t)N * 8;
-      if (mode == kNttF64)
-        hipLaunchKernelGGL((upper_fused_kernel<kNttF64, true>), grid, dim3(NT), lds, st, P, src, svq, part, n_rows, n_dim,
-                           n_children_total, sv_first, C, chunk_len, n_chunks, src_qstride, part_qstride);
-      else
-        hipLaunchKernelGGL((upper_fused_kernel<kNttF64Wide, true>), grid, dim3(NT), lds, st, P, src, svq, part, n_rows,
-                           n_dim, n_children_total, sv_first, C, chunk_len, n_chunks, src_qstride, part_qstride);
+      if (mode == kNttF64 && sel_f64) hipLaunchKernelGGL((upper_fused_kernel<kNttF64, true, true>), grid, dim3(NT), lds, st, PIRGPU_UF_ARGS);
+      else if (mode == kNttF64) hipLaunchKernelGGL((upper_fused_kernel<kNttF64, true>), grid, dim3(NT), lds, st, PIRGPU_UF_ARGS);
+      else if (sel_f64) hipLaunchKernelGGL((upper_fused_kernel<kNttF64Wide, true, true>), grid, dim3(NT), lds, st, PIRGPU_UF_ARGS);
+      else hipLaunchKernelGGL((upper_fused_kernel<kNttF64Wide, true>), grid, dim3(NT), lds, st, PIRGPU_UF_ARGS);
       return hipGetLastError();
     }
   }
-  PIRGPU_BY_MODE(mode, hipLaunchKernelGGL(upper_fused_kernel<MODE>, grid, dim3(NT), kLdsBytes, st, P, src, svq, part,
-                                          n_rows, n_dim, n_children_total, sv_first, C, chunk_len, n_chunks,
-                                          src_qstride, part_qstride));
+  if (sel_f64) {
+    if (mode == kNttF64) hipLaunchKernelGGL((upper_fused_kernel<kNttF64, false, true>), grid, dim3(NT), kLdsBytes, st, PIRGPU_UF_ARGS);
+    else hipLaunchKernelGGL((upper_fused_kernel<kNttF64Wide, false, true>), grid, dim3(NT), kLdsBytes, st, PIRGPU_UF_ARGS);
+    return hipGetLastError();
+  }
+  PIRGPU_BY_MODE(mode, hipLaunchKernelGGL(upper_fused_kernel<MODE>, grid, dim3(NT), kLdsBytes, st, PIRGPU_UF_ARGS));
+#undef PIRGPU_UF_ARGS
   return hipGetLastError();
 }
 

@@ -91,7 +91,7 @@ db_pack_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ db,
 template <int L>
 __global__ void __launch_bounds__(256)
 sel_pack_kernel(const DevParams* __restrict__ P, MfmaPtrs sv, uint32_t nq, uint8_t* __restrict__ selp, uint32_t cols,
-                uint32_t kN, uint32_t KG) {
+                uint32_t kN, uint32_t KG, int sel_f64) {
   const uint32_t j = blockIdx.x * 16 + (threadIdx.x & 15);
   const uint32_t x = threadIdx.x >> 4;
   const uint32_t kg = blockIdx.y;
@@ -105,6 +105,7 @@ sel_pack_kernel(const DevParams* __restrict__ P, MfmaPtrs sv, uint32_t nq, uint8
     const uint32_t c = kg * 16 + t;
     uint64_t v = 0;
     if (c < cols) v = src[((size_t)c * 2 + comp) * kN + j];
+    if (sel_f64) v = f64_to_u64(__longlong_as_double((long long)v));   // lane-internal selectors: exact doubles
     int8_t d[L];
     to_digits<L>(v, q, d);
 #pragma unroll
@@ -325,12 +326,13 @@ hipError_t launch_db_unpack(hipStream_t st, const DevParams* P, const MfmaGeom& 
 }
 
 hipError_t launch_sel_pack(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const MfmaPtrs& sv, uint32_t nq,
-                           uint8_t* selp, uint32_t cols, uint32_t kN) {
+                           uint8_t* selp, uint32_t cols, uint32_t kN, bool sel_f64) {
+  const int f = sel_f64 ? 1 : 0;
   const dim3 grid(kN / 16, gm.KG);
   switch (gm.L) {
-    case 5: hipLaunchKernelGGL(sel_pack_kernel<5>, grid, dim3(256), 0, st, P, sv, nq, selp, cols, kN, gm.KG); break;
-    case 6: hipLaunchKernelGGL(sel_pack_kernel<6>, grid, dim3(256), 0, st, P, sv, nq, selp, cols, kN, gm.KG); break;
-    case 7: hipLaunchKernelGGL(sel_pack_kernel<7>, grid, dim3(256), 0, st, P, sv, nq, selp, cols, kN, gm.KG); break;
+    case 5: hipLaunchKernelGGL(sel_pack_kernel<5>, grid, dim3(256), 0, st, P, sv, nq, selp, cols, kN, gm.KG, f); break;
+    case 6: hipLaunchKernelGGL(sel_pack_kernel<6>, grid, dim3(256), 0, st, P, sv, nq, selp, cols, kN, gm.KG, f); break;
+    case 7: hipLaunchKernelGGL(sel_pack_kernel<7>, grid, dim3(256), 0, st, P, sv, nq, selp, cols, kN, gm.KG, f); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -103,10 +103,11 @@ def test_split_upper_level_matches_fused(monkeypatch, d, items, elem, mb):
     db.close()
 
 
-@pytest.mark.parametrize("knob", ["PIRGPU_LAST_NTT", "PIRGPU_FUSE_LAST", "PIRGPU_FUSE_MAC_COMBINE", "PIRGPU_PACK40"])
+@pytest.mark.parametrize("knob", ["PIRGPU_LAST_NTT", "PIRGPU_FUSE_LAST", "PIRGPU_FUSE_MAC_COMBINE", "PIRGPU_PACK40",
+                                  "PIRGPU_SEL_F64"])
 def test_expansion_fallback_paths(monkeypatch, knob):
     """The expansion's optional fusions switched off one at a time (coefficient-domain last level, unfused last level,
-    separate combine pass, digits as doubles): every variant must give the oracle's reply, single and batched."""
+    separate combine pass, digits as doubles, lane selectors as u64): every variant must give the oracle's reply, single and batched."""
     monkeypatch.setenv(knob, "0")
     N, moduli, _ = CHAINS["n4096_36bit"]
     s = PirSetup(5000, 288, 2, N=N, plain_bits=24, moduli=moduli)

@@ -565,7 +565,9 @@ uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* 
     const uint32_t g = (N >> j) + 1;
     const uint64_t* key = find_key(c, g);
     const uint32_t nodes = (1u << j) * B;
-    HIP_TRY(c->ops->ks_digit(st, c->mode, c->dp, k, cur, g, nodes, dig, c->pack40));
+    const bool last_ntt = fuse_last && j + 1 == logm && c->last_level_ntt;
+    const bool c0_in_digit = last_ntt && ks_digit_takes_c0(nodes);
+    HIP_TRY(c->ops->ks_digit(st, c->mode, c->dp, k, cur, g, nodes, dig, c->pack40, c0_in_digit ? prod : nullptr));
     if (c->mode != kNttInt && c->fuse_mac_combine && nodes >= c->fuse_mac_nodes && !(fuse_last && j + 1 == logm)) {
       // special-prime product first (the only one that goes through HBM), then the data residues with the combine
       // step in their epilogue: no data products in HBM, no separate combine pass
@@ -579,7 +581,7 @@ uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* 
       const uint64_t* X = xpow_table(c, st, 1u << j);
       HIP_TRY(c->ops->ks_mac_intt(st, c->mode, c->dp, k, dig, key, nodes, prod, c->pack40, k, 1));
       HIP_TRY(c->ops->ks_last_ntt(st, c->mode, c->dp, k, cur, dig, key, prod, X, g, galois_inverse(g, N), 1u << j, n, B,
-                                  *sel_dst, nodes, c->pack40, sel_f64));
+                                  *sel_dst, nodes, c->pack40, sel_f64, c0_in_digit));
       return nullptr;
     }
     HIP_TRY(c->ops->ks_mac_intt(st, c->mode, c->dp, k, dig, key, nodes, prod, c->pack40, 0, k + 1));
@@ -1288,7 +1290,7 @@ int pirgpu_substitute_power_x(pirgpu_ctx* c, uint64_t* ct, uint32_t power) {
     const uint64_t* key = find_key(c, power);
     HIP_TRY(hipMemcpyAsync(w.res_b, ct, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(launch_tree_convert(c->stream, c->dp, c->mode, w.res_b, w.res_a, c->ctw, true));
-    HIP_TRY(c->ops->ks_digit(c->stream, c->mode, c->dp, c->k, w.res_a, power, 1, w.dig, c->pack40));
+    HIP_TRY(c->ops->ks_digit(c->stream, c->mode, c->dp, c->k, w.res_a, power, 1, w.dig, c->pack40, nullptr));
     HIP_TRY(c->ops->ks_mac_intt(c->stream, c->mode, c->dp, c->k, w.dig, key, 1, w.prod, c->pack40, 0, c->k + 1));
     HIP_TRY(launch_ks_combine(c->stream, c->dp, c->mode, c->N, c->k, w.res_a, w.prod, galois_inverse(power, c->N), 1, 0,
                               false, /*hi_limit: unused without the expand step*/ 0, c->pack40, w.res_b));

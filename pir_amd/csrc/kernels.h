@@ -10,6 +10,9 @@ namespace pirgpu {
 constexpr int kMaxScanChunks = 16;    // column chunks of one MFMA scan pass (wider matrices use the 64-bit kernels)
 constexpr int kMaxMfmaQueries = 8;   // (query, comp) pairs fill the 16 columns of one MFMA tile
 
+constexpr uint32_t kKsWideLevel = 256;   // nodes per launch from which the key-switch kernels use the XCD-aware 1-D grid
+inline bool ks_digit_takes_c0(uint32_t nodes) { return nodes >= kKsWideLevel && nodes % 8 == 0; }
+
 struct MfmaPtrs {                    // one pointer per query of a group (by-value kernel argument)
   const void* p[kMaxMfmaQueries];
 };
@@ -29,8 +32,10 @@ struct NttOps {
   hipError_t (*db_encode)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* coeffs,
                           const uint8_t* bytes, uint64_t bytes_per_pt, uint64_t total_bytes, uint32_t bits,
                           uint64_t n_pt, uint64_t* db);
+  // c0_out != nullptr (fp64 flavours, ks_digit_takes_c0(nodes)): the launch also writes NTT(c0) of every node into the
+  // product buffer c0_out (NTT-domain last level), sparing ks_last_ntt its own launch for that (c0_done)
   hipError_t (*ks_digit)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* res_in,
-                         uint32_t galois_elt, uint32_t nodes, uint64_t* dig, bool pack40);
+                         uint32_t galois_elt, uint32_t nodes, uint64_t* dig, bool pack40, uint64_t* c0_out);
   // key-level moduli I_base .. I_base + I_count - 1 (all: 0, k + 1; the special prime alone: k, 1)
   hipError_t (*ks_mac_intt)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* dig,
                             const uint64_t* key, uint32_t nodes, uint64_t* prod, bool pack40, uint32_t I_base,
@@ -63,7 +68,7 @@ struct NttOps {
   hipError_t (*ks_last_ntt)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* tree,
                             const uint64_t* dig, const uint64_t* key, uint64_t* prod, const uint64_t* xpow,
                             uint32_t galois_elt, uint32_t galois_inv, uint32_t shift_pow, uint32_t n_items, uint32_t B,
-                            const MfmaPtrs& dst, uint32_t nodes, bool pack40, bool out_f64);
+                            const MfmaPtrs& dst, uint32_t nodes, bool pack40, bool out_f64, bool c0_done);
 };
 
 const NttOps* ntt_ops_for(uint32_t N);  // nullptr for unsupported degrees

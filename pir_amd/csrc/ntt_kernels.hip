@@ -45,7 +45,7 @@ constexpr bool kPF = LOGN < 14;
 // N = 8192 spills there (four passes, more temporaries: 256 VGPRs + 76 bytes of scratch, cfg 4 363 -> 352 queries/s)
 // and N = 16384 runs the split upper level anyway.
 constexpr bool kUpperLdsTw = LOGN <= 12;
-constexpr uint32_t kWideLevel = 256;  // nodes per launch from which the key-switch kernels use the XCD-aware 1-D grid
+constexpr uint32_t kWideLevel = kKsWideLevel;  // nodes per launch from which the key-switch kernels use the XCD-aware 1-D grid
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
@@ -239,17 +239,58 @@ db_encode_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ c
   for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
 }
 
+// A_0[n][j] = NTT_j(a_0 mod q_j) of tree ciphertext n (NTT-domain last expansion level, see ks_last_ntt_kernel),
+// written into the unused data-residue slot prod[n][0][j] of the product buffer (signed representatives; 5-byte
+// packing or doubles).  One workgroup; runs as extra workgroups of the last level's ks_digit_kernel launch (wide
+// levels) or as tree_c0_ntt_kernel.
+template <int MODE, bool P40>
+__device__ __forceinline__ void tree_c0_ntt_body(const DevParams* __restrict__ P, const uint64_t* __restrict__ tree_raw,
+                                                 uint64_t* __restrict__ prod, uint32_t node, uint32_t j, uint32_t tid) {
+  using A = Arith<MODE>;
+  static_assert(MODE != kNttInt, "fp64 flavours only");
+  const uint32_t k = P->k, km = k + 1;
+  const typename A::Mod m = A::mod(P, j);
+  const double* in = reinterpret_cast<const double*>(tree_raw) + ((size_t)node * 2 * k + j) * N;
+  double x[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) x[e] = in[e * NT + tid];
+  ntt_forward<MODE, LOGN, kPF, /*CANON=*/false>(x, smem_raw, P, j, tid);
+  const size_t opoly = (size_t)node * 2 * km + j;
+  if constexpr (P40) {
+    uint8_t* out = reinterpret_cast<uint8_t*>(prod) + opoly * kPoly40;
+    store40f(out, tid, x, f64_pack_magic(m.q));
+  } else {
+    double* out = reinterpret_cast<double*>(prod) + opoly * N;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) out[e * NT + tid] = x[e];
+  }
+}
+
+template <int MODE, bool P40>
+__global__ void __launch_bounds__(NT)
+tree_c0_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ tree_raw, uint64_t* __restrict__ prod) {
+  tree_c0_ntt_body<MODE, P40>(P, tree_raw, prod, blockIdx.x / P->k, blockIdx.x % P->k, threadIdx.x);
+}
+
 // One level of the expansion tree, part 1a: for node n, key-level modulus I and
 // RNS digit J:  dig[n][I][J] = NTT_I(sigma_g(c1)_J mod m_I)  (device NTT order, stored in
 // the flavour's register type).  grid = (nodes, k+1, k).
 template <int MODE, bool P40>
 __global__ void __launch_bounds__(NT)
 ks_digit_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ res_in, uint32_t galois_elt,
-                uint64_t* __restrict__ dig) {
+                uint64_t* __restrict__ dig, uint64_t* __restrict__ c0_out, uint32_t digit_blocks) {
   using A = Arith<MODE>;
   uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
   const uint32_t tid = threadIdx.x;
   const uint32_t k = P->k;
+  if constexpr (MODE != kNttInt) {
+    // last level in the NTT domain: the workgroups behind the digit workgroups transform the c0 polynomials
+    if (blockIdx.x >= digit_blocks) {   // 1-D grids only (c0_out != nullptr)
+      const uint32_t b = blockIdx.x - digit_blocks;
+      tree_c0_ntt_body<MODE, P40>(P, res_in, c0_out, b / k, b % k, tid);
+      return;
+    }
+  }
   uint32_t node = blockIdx.x, I = blockIdx.y, J = blockIdx.z;
   if (gridDim.y == 1) {
     // wide levels, 1-D grid: the k+1 target moduli of one (node, J) source polynomial run back to back on
@@ -613,32 +654,6 @@ __device__ __forceinline__ uint32_t galois_ntt_slot(uint32_t P, uint32_t g) {
   const uint32_t ex = ((2 * r + 1) * g) & (2 * N - 1);
   const uint32_t Pin = __brev(ex >> 1) >> (32 - LOGN);
   return (Pin & 15u) * NT + (Pin >> 4);
-}
-
-// A_0[n][j] = NTT_j(a_0 mod q_j) of every tree ciphertext n, written into the unused data-residue slots
-// prod[n][0][j] of the product buffer (signed representatives; 5-byte packing or doubles).  grid = nodes * k.
-template <int MODE, bool P40>
-__global__ void __launch_bounds__(NT)
-tree_c0_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ tree_raw, uint64_t* __restrict__ prod) {
-  using A = Arith<MODE>;
-  static_assert(MODE != kNttInt, "fp64 flavours only");
-  const uint32_t tid = threadIdx.x, k = P->k, km = k + 1;
-  const uint32_t j = blockIdx.x % k, node = blockIdx.x / k;
-  const typename A::Mod m = A::mod(P, j);
-  const double* in = reinterpret_cast<const double*>(tree_raw) + ((size_t)node * 2 * k + j) * N;
-  double x[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) x[e] = in[e * NT + tid];
-  ntt_forward<MODE, LOGN, kPF, /*CANON=*/false>(x, smem_raw, P, j, tid);
-  const size_t opoly = (size_t)node * 2 * km + j;
-  if constexpr (P40) {
-    uint8_t* out = reinterpret_cast<uint8_t*>(prod) + opoly * kPoly40;
-    store40f(out, tid, x, f64_pack_magic(m.q));
-  } else {
-    double* out = reinterpret_cast<double*>(prod) + opoly * N;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) out[e * NT + tid] = x[e];
-  }
 }
 
 // One workgroup per (tree ciphertext, data modulus j, component): one forward transform (of the lifted special
@@ -1123,15 +1138,20 @@ static hipError_t op_db_encode(hipStream_t st, int mode, const DevParams* P, uin
   return hipGetLastError();
 }
 
+// c0_out (fp64 flavours, wide levels -- kernels.h ks_digit_takes_c0): also transform the nodes' c0 polynomials into
+// the product buffer c0_out (what tree_c0_ntt_kernel does), as extra workgroups of the same launch
 static hipError_t op_ks_digit(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* res_in,
-                              uint32_t galois_elt, uint32_t nodes, uint64_t* dig, bool pack40) {
-  const dim3 grid = nodes >= kWideLevel && nodes % 8 == 0 ? dim3(nodes * (k + 1) * k) : dim3(nodes, k + 1, k);
+                              uint32_t galois_elt, uint32_t nodes, uint64_t* dig, bool pack40, uint64_t* c0_out) {
+  const bool wide = ks_digit_takes_c0(nodes);
+  if (c0_out && (!wide || mode == kNttInt)) return hipErrorInvalidValue;
+  const uint32_t digit_blocks = wide ? nodes * (k + 1) * k : 0xffffffffu;
+  const dim3 grid = wide ? dim3(digit_blocks + (c0_out ? nodes * k : 0)) : dim3(nodes, k + 1, k);
   if (pack40) {
     PIRGPU_BY_MODE(mode, hipLaunchKernelGGL((ks_digit_kernel<MODE, true>), grid, dim3(NT), kLdsBytes, st, P, res_in,
-                                            galois_elt, dig));
+                                            galois_elt, dig, c0_out, digit_blocks));
   } else {
     PIRGPU_BY_MODE(mode, hipLaunchKernelGGL((ks_digit_kernel<MODE, false>), grid, dim3(NT), kLdsBytes, st, P, res_in,
-                                            galois_elt, dig));
+                                            galois_elt, dig, c0_out, digit_blocks));
   }
   return hipGetLastError();
 }
@@ -1205,13 +1225,14 @@ static hipError_t op_ks_last_level(hipStream_t st, int mode, const DevParams* P,
 static hipError_t op_ks_last_ntt(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* tree,
                                  const uint64_t* dig, const uint64_t* key, uint64_t* prod, const uint64_t* xpow,
                                  uint32_t galois_elt, uint32_t galois_inv, uint32_t shift_pow, uint32_t n_items,
-                                 uint32_t B, const MfmaPtrs& dst, uint32_t nodes, bool pack40, bool out_f64) {
+                                 uint32_t B, const MfmaPtrs& dst, uint32_t nodes, bool pack40, bool out_f64,
+                                 bool c0_done) {
   const dim3 g0(nodes * k);
   const dim3 grid = nodes >= kWideLevel && nodes % 8 == 0 ? dim3(nodes * k * 2) : dim3(nodes, k, 2);
   const double* X = reinterpret_cast<const double*>(xpow);
 #define PIRGPU_LAST_NTT(M, P40)                                                                                    \
   do {                                                                                                             \
-    hipLaunchKernelGGL((tree_c0_ntt_kernel<M, P40>), g0, dim3(NT), kLdsBytes, st, P, tree, prod);                  \
+    if (!c0_done) hipLaunchKernelGGL((tree_c0_ntt_kernel<M, P40>), g0, dim3(NT), kLdsBytes, st, P, tree, prod);    \
     if (out_f64)                                                                                                   \
       hipLaunchKernelGGL((ks_last_ntt_kernel<M, P40, true>), grid, dim3(NT), kLdsBytes, st, P, dig, key, prod, X,  \
                          galois_elt, galois_inv, shift_pow, n_items, B, dst);                                      \

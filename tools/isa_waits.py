@@ -1,8 +1,12 @@
+"""Loads-in-flight / wait structure of one kernel's ISA: for every s_waitcnt vmcnt the number of global loads (L),
+stores (S), LDS ops (D) and VALU instructions (V) issued since the previous one, plus barriers and branch labels.
+usage: hipcc --offload-arch=gfx950 -O3 -std=c++17 -x hip [-DPIRGPU_LOGN=12] --cuda-device-only -S file.hip -o file.s
+       python tools/isa_waits.py <mangled kernel name prefix> [file.s]"""
 import re,sys
 s=open(sys.argv[2] if len(sys.argv) > 2 else '/tmp/nk12.s').read().split('\n')
 name=sys.argv[1]
 start=[i for i,l in enumerate(s) if l.startswith(name) and ':' in l][0]
-end=next(i for i in range(start,len(s)) if 's_endpgm' in s[i])
+end=next(i for i in range(start,len(s)) if s[i].startswith('.Lfunc_end'))
 out=[];cnt=0;ld=0;st=0;lds=0
 for l in s[start:end]:
     t=l.strip()

@@ -169,6 +169,7 @@ struct pirgpu_ctx {
                                             // kernel (PIRGPU_FUSE_MAC_COMBINE=0: separate ks_combine pass)
   bool fuse_last_level = true;              // last expansion level fused with the selector NTT (PIRGPU_FUSE_LAST=0: off)
   bool last_level_ntt = true;               // ... and carried out in the NTT domain (PIRGPU_LAST_NTT=0: coefficient form)
+  bool tree40 = true;                       // expansion tree between fused wide levels as 5-byte polynomials (PIRGPU_TREE40=0: doubles)
   bool want_sel_f64 = true;
   bool sel_f64 = false;                     // batch lanes keep their selectors as exact doubles between the last expansion
                                             // level and their two consumers (sel_pack, upper level): no u64 round trip
@@ -442,6 +443,7 @@ void ensure_workspace(pirgpu_ctx* c) {
     c->fuse_mac_combine = env_u32("PIRGPU_FUSE_MAC_COMBINE", 1) != 0;
     c->last_level_ntt = env_u32("PIRGPU_LAST_NTT", 1) != 0;
     c->want_sel_f64 = env_u32("PIRGPU_SEL_F64", 1) != 0;
+    c->tree40 = env_u32("PIRGPU_TREE40", 1) != 0;
     c->fuse_mac_nodes = env_u32("PIRGPU_FUSE_MAC_NODES", 128);
     c->split_upper = env_u32("PIRGPU_SPLIT_UPPER", c->logN >= 14 ? 1 : 0) != 0 && c->mode != kNttInt;
     c->split_upper_words = (uint64_t)env_u32("PIRGPU_SPLIT_UPPER_MB", 3072) * (1ull << 20) / 8;
@@ -561,21 +563,32 @@ uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* 
   const bool fuse_last = sel_dst && c->mode != kNttInt && c->fuse_last_level;
   if (sel_f64 && !(fuse_last && c->last_level_ntt && n >= 2)) throw Fail{PIRGPU_INTERNAL, "double-form selectors need the NTT-domain last level"};
   uint64_t *cur = res_a, *nxt = res_b;
+  bool cur40 = false;   // `cur` holds 5-byte polynomials (between fused levels) instead of doubles
   for (uint32_t j = 0; j < logm; ++j) {
     const uint32_t g = (N >> j) + 1;
     const uint64_t* key = find_key(c, g);
     const uint32_t nodes = (1u << j) * B;
     const bool last_ntt = fuse_last && j + 1 == logm && c->last_level_ntt;
     const bool c0_in_digit = last_ntt && ks_digit_takes_c0(nodes);
-    HIP_TRY(c->ops->ks_digit(st, c->mode, c->dp, k, cur, g, nodes, dig, c->pack40, c0_in_digit ? prod : nullptr));
+    if (cur40 && c0_in_digit != last_ntt) throw Fail{PIRGPU_INTERNAL, "5-byte tree reached a level that cannot read it"};
+    HIP_TRY(c->ops->ks_digit(st, c->mode, c->dp, k, cur, g, nodes, dig, c->pack40, c0_in_digit ? prod : nullptr, cur40));
     if (c->mode != kNttInt && c->fuse_mac_combine && nodes >= c->fuse_mac_nodes && !(fuse_last && j + 1 == logm)) {
       // special-prime product first (the only one that goes through HBM), then the data residues with the combine
-      // step in their epilogue: no data products in HBM, no separate combine pass
+      // step in their epilogue: no data products in HBM, no separate combine pass.  Between two fused levels (and into
+      // the NTT-domain last level) the tree is written as 5-byte polynomials: these launches are HBM-bound
+      const uint32_t next_nodes = nodes * 2;
+      const bool next_last = j + 2 == logm;
+      const bool next_reads40 = next_last ? (fuse_last && c->last_level_ntt && ks_digit_takes_c0(next_nodes))
+                                          : (next_nodes >= c->fuse_mac_nodes);
+      const bool out40 = c->tree40 && c->pack40 && j + 1 < logm && next_reads40 && (1u << j) < N / 16;
       HIP_TRY(c->ops->ks_mac_intt(st, c->mode, c->dp, k, dig, key, nodes, prod, c->pack40, k, 1));
-      HIP_TRY(c->ops->ks_mac_combine(st, c->mode, c->dp, k, dig, key, prod, cur, g, nodes, 1u << j, nxt, c->pack40));
+      HIP_TRY(c->ops->ks_mac_combine(st, c->mode, c->dp, k, dig, key, prod, cur, g, nodes, 1u << j, nxt, c->pack40, cur40,
+                                     out40));
+      cur40 = out40;
       std::swap(cur, nxt);
       continue;
     }
+    if (cur40 && !last_ntt) throw Fail{PIRGPU_INTERNAL, "5-byte tree reached an unfused level"};
     if (fuse_last && j + 1 == logm && c->last_level_ntt) {
       // last level in the NTT domain: only the special-prime product is inverse-transformed
       const uint64_t* X = xpow_table(c, st, 1u << j);
@@ -1290,7 +1303,7 @@ int pirgpu_substitute_power_x(pirgpu_ctx* c, uint64_t* ct, uint32_t power) {
     const uint64_t* key = find_key(c, power);
     HIP_TRY(hipMemcpyAsync(w.res_b, ct, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(launch_tree_convert(c->stream, c->dp, c->mode, w.res_b, w.res_a, c->ctw, true));
-    HIP_TRY(c->ops->ks_digit(c->stream, c->mode, c->dp, c->k, w.res_a, power, 1, w.dig, c->pack40, nullptr));
+    HIP_TRY(c->ops->ks_digit(c->stream, c->mode, c->dp, c->k, w.res_a, power, 1, w.dig, c->pack40, nullptr, false));
     HIP_TRY(c->ops->ks_mac_intt(c->stream, c->mode, c->dp, c->k, w.dig, key, 1, w.prod, c->pack40, 0, c->k + 1));
     HIP_TRY(launch_ks_combine(c->stream, c->dp, c->mode, c->N, c->k, w.res_a, w.prod, galois_inverse(power, c->N), 1, 0,
                               false, /*hi_limit: unused without the expand step*/ 0, c->pack40, w.res_b));

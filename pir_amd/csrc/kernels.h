@@ -34,8 +34,9 @@ struct NttOps {
                           uint64_t n_pt, uint64_t* db);
   // c0_out != nullptr (fp64 flavours, ks_digit_takes_c0(nodes)): the launch also writes NTT(c0) of every node into the
   // product buffer c0_out (NTT-domain last level), sparing ks_last_ntt its own launch for that (c0_done)
+  // tree40: res_in holds the tree in the 5-byte form (wide levels of the fused expansion, ks_mac_combine's tout40)
   hipError_t (*ks_digit)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* res_in,
-                         uint32_t galois_elt, uint32_t nodes, uint64_t* dig, bool pack40, uint64_t* c0_out);
+                         uint32_t galois_elt, uint32_t nodes, uint64_t* dig, bool pack40, uint64_t* c0_out, bool tree40);
   // key-level moduli I_base .. I_base + I_count - 1 (all: 0, k + 1; the special prime alone: k, 1)
   hipError_t (*ks_mac_intt)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* dig,
                             const uint64_t* key, uint32_t nodes, uint64_t* prod, bool pack40, uint32_t I_base,
@@ -59,10 +60,12 @@ struct NttOps {
                           uint32_t n_children_total, uint32_t C, uint32_t b0, uint32_t blk, uint32_t n_queries,
                           uint64_t src_qstride);
   // data residues of one level below the last: MAC + inverse transform + combine with the special-prime product
-  // (already in `prod`) + tree butterfly, tree_in -> tree_out (fp64 flavours)
+  // (already in `prod`) + tree butterfly, tree_in -> tree_out (fp64 flavours); tin40 / tout40: that tree buffer holds
+  // 5-byte polynomials (5 N bytes each, offset form) instead of doubles -- tout40 needs shift_pow < N / 16
   hipError_t (*ks_mac_combine)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* dig,
                                const uint64_t* key, const uint64_t* prod, const uint64_t* tree_in, uint32_t galois_elt,
-                               uint32_t nodes, uint32_t shift_pow, uint64_t* tree_out, bool pack40);
+                               uint32_t nodes, uint32_t shift_pow, uint64_t* tree_out, bool pack40, bool tin40,
+                               bool tout40);
   // last expansion level in the NTT domain (fp64 flavours): `prod` holds the special-prime products (ks_mac_intt with
   // I_base = k) and receives NTT(a_0); xpow = NTT_j(x^(-shift_pow)), [k][N] doubles; galois_inv = galois_elt^-1 mod 2N
   hipError_t (*ks_last_ntt)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* tree,

@@ -99,6 +99,23 @@ __device__ __forceinline__ void store40f(uint8_t* poly, uint32_t tid, const doub
   *reinterpret_cast<uint4*>(poly + 4 * N + 16 * tid) = uint4{w[0], w[1], w[2], w[3]};
 }
 
+// Polynomial `poly` (index in units of polynomials) of an expansion-tree buffer, this thread's 16 elements: doubles, or
+// (T40, wide levels of the fused expansion, every modulus < 2^39) the 5-byte offset form with modulus q.
+template <bool T40>
+__device__ __forceinline__ void tree_load(const uint64_t* tree_raw, size_t poly, uint32_t tid, double q, double (&out)[16]) {
+  if constexpr (T40) {
+    const uint8_t* pp = reinterpret_cast<const uint8_t*>(tree_raw) + poly * kPoly40;
+    const Hi16 h = load40f_hi(pp, tid);
+    const double magic = f64_pack_magic(q);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) out[e] = load40f(pp, h, e, tid, magic);
+  } else {
+    const double* pp = reinterpret_cast<const double*>(tree_raw) + poly * N;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) out[e] = pp[e * NT + tid];
+  }
+}
+
 // Buffer-resource access to one polynomial of u64 words: element e * NT + tid is the thread's byte offset 8 tid (one
 // VGPR for all 16 elements) plus a scalar offset 8 e NT -- against a 64-bit address pair per one or two elements with
 // flat loads (their immediate offset reaches 4 KiB, the element stride is 8 NT bytes).  The base must be wave-uniform;
@@ -243,17 +260,15 @@ db_encode_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ c
 // written into the unused data-residue slot prod[n][0][j] of the product buffer (signed representatives; 5-byte
 // packing or doubles).  One workgroup; runs as extra workgroups of the last level's ks_digit_kernel launch (wide
 // levels) or as tree_c0_ntt_kernel.
-template <int MODE, bool P40>
+template <int MODE, bool P40, bool T40>
 __device__ __forceinline__ void tree_c0_ntt_body(const DevParams* __restrict__ P, const uint64_t* __restrict__ tree_raw,
                                                  uint64_t* __restrict__ prod, uint32_t node, uint32_t j, uint32_t tid) {
   using A = Arith<MODE>;
   static_assert(MODE != kNttInt, "fp64 flavours only");
   const uint32_t k = P->k, km = k + 1;
   const typename A::Mod m = A::mod(P, j);
-  const double* in = reinterpret_cast<const double*>(tree_raw) + ((size_t)node * 2 * k + j) * N;
   double x[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) x[e] = in[e * NT + tid];
+  tree_load<T40>(tree_raw, (size_t)node * 2 * k + j, tid, m.q, x);
   ntt_forward<MODE, LOGN, kPF, /*CANON=*/false>(x, smem_raw, P, j, tid);
   const size_t opoly = (size_t)node * 2 * km + j;
   if constexpr (P40) {
@@ -269,13 +284,13 @@ __device__ __forceinline__ void tree_c0_ntt_body(const DevParams* __restrict__ P
 template <int MODE, bool P40>
 __global__ void __launch_bounds__(NT)
 tree_c0_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ tree_raw, uint64_t* __restrict__ prod) {
-  tree_c0_ntt_body<MODE, P40>(P, tree_raw, prod, blockIdx.x / P->k, blockIdx.x % P->k, threadIdx.x);
+  tree_c0_ntt_body<MODE, P40, false>(P, tree_raw, prod, blockIdx.x / P->k, blockIdx.x % P->k, threadIdx.x);
 }
 
 // One level of the expansion tree, part 1a: for node n, key-level modulus I and
 // RNS digit J:  dig[n][I][J] = NTT_I(sigma_g(c1)_J mod m_I)  (device NTT order, stored in
-// the flavour's register type).  grid = (nodes, k+1, k).
-template <int MODE, bool P40>
+// the flavour's register type).  grid = (nodes, k+1, k).  T40: the tree is in the 5-byte form (tree_load).
+template <int MODE, bool P40, bool T40 = false>
 __global__ void __launch_bounds__(NT)
 ks_digit_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ res_in, uint32_t galois_elt,
                 uint64_t* __restrict__ dig, uint64_t* __restrict__ c0_out, uint32_t digit_blocks) {
@@ -287,7 +302,7 @@ ks_digit_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ re
     // last level in the NTT domain: the workgroups behind the digit workgroups transform the c0 polynomials
     if (blockIdx.x >= digit_blocks) {   // 1-D grids only (c0_out != nullptr)
       const uint32_t b = blockIdx.x - digit_blocks;
-      tree_c0_ntt_body<MODE, P40>(P, res_in, c0_out, b / k, b % k, tid);
+      tree_c0_ntt_body<MODE, P40, T40>(P, res_in, c0_out, b / k, b % k, tid);
       return;
     }
   }
@@ -303,8 +318,8 @@ ks_digit_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ re
   }
   const ModConst mI = P->mod[I];
   const typename A::Mod m = A::mod(P, I);
-  const uint64_t qJ = P->mod[J].q;
-  const uint64_t* src = res_in + (((size_t)node * 2 + 1) * k + J) * N;  // poly 1, residue J
+  [[maybe_unused]] const uint64_t qJ = P->mod[J].q;
+  [[maybe_unused]] const uint64_t* src = res_in + (((size_t)node * 2 + 1) * k + J) * N;  // poly 1, residue J (u64 / doubles)
   typename A::T x[16];
   if constexpr (MODE == kNttInt) {
     // sigma_g in coefficient form (SEAL GaloisTool::apply_galois), then reduce mod m_I
@@ -326,15 +341,16 @@ ks_digit_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ re
     // changes modulus; as a butterfly input mod m_I it is then fine as it stands in the plain fp64 flavour
     // (every modulus < 2^46: inputs up to 2^52 are exact), the wide flavour normalises it.
     double* sd = reinterpret_cast<double*>(smem_raw);
-    const double* srcd = reinterpret_cast<const double*>(src);
     const bool norm_in = MODE == kNttF64Wide && I != J;
     const double qJd = P->tab[J].qd;
     const uint32_t raw0 = tid * galois_elt, rstep = (uint32_t)NT * galois_elt;
+    double c1[16];
+    tree_load<T40>(res_in, ((size_t)node * 2 + 1) * k + J, tid, qJd, c1);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const uint32_t raw = raw0 + (uint32_t)e * rstep;
       const uint64_t sign = (uint64_t)((raw << (31 - LOGN)) & 0x80000000u) << 32;
-      double v = __longlong_as_double((long long)((uint64_t)__double_as_longlong(srcd[e * NT + tid]) ^ sign));
+      double v = __longlong_as_double((long long)((uint64_t)__double_as_longlong(c1[e]) ^ sign));
       v = v < 0.0 ? v + qJd : v;  // -0.0 stays 0
       if (norm_in) v = f64_norm(v, m);
       sd[lds_idx(raw & (N - 1))] = v;
@@ -473,7 +489,7 @@ ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
 // One transform per workgroup and nothing live across it (the fused variants with several transforms per workgroup
 // lost to their register pressure); saves the data products' round trip and the separate
 // HBM-bound combine pass.  grid = (nodes, k, 2) or the XCD-aware 1-D equivalent.
-template <int MODE, bool P40>
+template <int MODE, bool P40, bool TIN40 = false, bool TOUT40 = false>
 __global__ void __launch_bounds__(NT)
 ks_mac_combine_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ dig_raw,
                       const uint64_t* __restrict__ key_raw, const uint64_t* __restrict__ prod,
@@ -512,33 +528,71 @@ ks_mac_combine_kernel(const DevParams* __restrict__ P, const uint64_t* __restric
       g[e] = f64_mulmod(g[e] - f64_norm(sp, m), pinv, m);
     }
   }
-  const double* tree_in = reinterpret_cast<const double*>(tree_in_raw) + (size_t)node * 2 * k * N;
   if (comp == 0) {  // + sigma_g(c0)
-    const double* c0 = tree_in + (size_t)j * N;
     const uint32_t raw0 = tid * galois_elt, rstep = (uint32_t)NT * galois_elt;
+    double c0[16];
+    tree_load<TIN40>(tree_in_raw, (size_t)node * 2 * k + j, tid, m.q, c0);
     __syncthreads();  // the inverse transform is done with the LDS words
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const uint32_t raw = raw0 + (uint32_t)e * rstep;
       const uint64_t sign = (uint64_t)((raw << (31 - LOGN)) & 0x80000000u) << 32;
-      sd[lds_idx(raw & (N - 1))] =
-          __longlong_as_double((long long)((uint64_t)__double_as_longlong(c0[e * NT + tid]) ^ sign));
+      sd[lds_idx(raw & (N - 1))] = __longlong_as_double((long long)((uint64_t)__double_as_longlong(c0[e]) ^ sign));
     }
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < 16; ++e) g[e] += sd[lds_lin_base<NT>(tid) + lds_lin_off<NT>(e)];
   }
-  const size_t off = ((size_t)comp * k + j) * N;
-  double* tree_lo = reinterpret_cast<double*>(tree_out_raw) + (size_t)node * 2 * k * N + off;
-  double* tree_hi = reinterpret_cast<double*>(tree_out_raw) + ((size_t)node + nodes) * 2 * k * N + off;
+  const size_t opoly = (size_t)comp * k + j;
+  double a[16];
+  tree_load<TIN40>(tree_in_raw, (size_t)node * 2 * k + opoly, tid, m.q, a);
+  if constexpr (TOUT40) {
+    // 5-byte tree out (shift_pow < NT, checked by the host): lo keeps its index; hi = x^(-shift) (a - g) moves element
+    // e NT + tid to (e NT + tid - shift) mod N, i.e. to thread tid' = (tid - shift) mod NT, same e -- or, for the
+    // threads tid < shift, e - 1 with element 0 wrapping to 15 negated.  All 16 values of a thread land in ONE
+    // destination thread, so its 16 high bytes are still one 16-byte store (rotated by a byte when borrowing).
+    const double magic = f64_pack_magic(m.q);
+    uint8_t* plo = reinterpret_cast<uint8_t*>(tree_out_raw) + ((size_t)node * 2 * k + opoly) * kPoly40;
+    uint8_t* phi = reinterpret_cast<uint8_t*>(tree_out_raw) + (((size_t)node + nodes) * 2 * k + opoly) * kPoly40;
+    double lo[16];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const uint32_t i = e * NT + tid;
-    const double a = tree_in[off + i];
-    tree_lo[i] = f64_norm(a + g[e], m);
-    const double d = f64_norm(a - g[e], m);
-    const uint32_t sraw = i + (2 * N - shift_pow);
-    tree_hi[sraw & (N - 1)] = (sraw & N) ? -d : d;
+    for (int e = 0; e < 16; ++e) lo[e] = f64_norm(a[e] + g[e], m);
+    store40f(plo, tid, lo, magic);
+    const bool borrow = tid < shift_pow;
+    const uint32_t tid_d = (tid - shift_pow) & (NT - 1);
+    uint32_t hb[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      double d = f64_norm(a[e] - g[e], m);
+      if (e == 0) d = borrow ? -d : d;
+      uint32_t l32;
+      f64_pack40(d, magic, l32, hb[e]);
+      reinterpret_cast<uint32_t*>(phi)[(e * NT + tid - shift_pow) & (N - 1)] = l32;
+    }
+    uint32_t w[4];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const uint32_t ab = __builtin_amdgcn_perm(hb[4 * q4 + 1], hb[4 * q4], 0x0c0c0400u);
+      const uint32_t cd = __builtin_amdgcn_perm(hb[4 * q4 + 3], hb[4 * q4 + 2], 0x0c0c0400u);
+      w[q4] = __builtin_amdgcn_perm(cd, ab, 0x05040100u);
+    }
+    uint32_t o[4];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4)   // borrowing threads: destination byte e' holds source byte e' + 1 (mod 16)
+      o[q4] = borrow ? __builtin_amdgcn_alignbyte(w[(q4 + 1) & 3], w[q4], 1) : w[q4];
+    *reinterpret_cast<uint4*>(phi + 4 * N + 16 * tid_d) = uint4{o[0], o[1], o[2], o[3]};
+  } else {
+    const size_t off = opoly * N;
+    double* tree_lo = reinterpret_cast<double*>(tree_out_raw) + (size_t)node * 2 * k * N + off;
+    double* tree_hi = reinterpret_cast<double*>(tree_out_raw) + ((size_t)node + nodes) * 2 * k * N + off;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const uint32_t i = e * NT + tid;
+      tree_lo[i] = f64_norm(a[e] + g[e], m);
+      const double d = f64_norm(a[e] - g[e], m);
+      const uint32_t sraw = i + (2 * N - shift_pow);
+      tree_hi[sraw & (N - 1)] = (sraw & N) ? -d : d;
+    }
   }
 }
 
@@ -1081,6 +1135,10 @@ static hipError_t configure_mode() {
     PIRGPU_SET(upper_ntt_kernel<MODE>);
     PIRGPU_SET((ks_mac_combine_kernel<MODE, false>));
     PIRGPU_SET((ks_mac_combine_kernel<MODE, true>));
+    PIRGPU_SET((ks_mac_combine_kernel<MODE, true, false, true>));
+    PIRGPU_SET((ks_mac_combine_kernel<MODE, true, true, false>));
+    PIRGPU_SET((ks_mac_combine_kernel<MODE, true, true, true>));
+    PIRGPU_SET((ks_digit_kernel<MODE, true, true>));
     PIRGPU_SET((ks_last_level_kernel<MODE, false>));
     PIRGPU_SET((ks_last_level_kernel<MODE, true>));
     PIRGPU_SET((tree_c0_ntt_kernel<MODE, false>));
@@ -1141,12 +1199,21 @@ static hipError_t op_db_encode(hipStream_t st, int mode, const DevParams* P, uin
 // c0_out (fp64 flavours, wide levels -- kernels.h ks_digit_takes_c0): also transform the nodes' c0 polynomials into
 // the product buffer c0_out (what tree_c0_ntt_kernel does), as extra workgroups of the same launch
 static hipError_t op_ks_digit(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* res_in,
-                              uint32_t galois_elt, uint32_t nodes, uint64_t* dig, bool pack40, uint64_t* c0_out) {
+                              uint32_t galois_elt, uint32_t nodes, uint64_t* dig, bool pack40, uint64_t* c0_out,
+                              bool tree40) {
   const bool wide = ks_digit_takes_c0(nodes);
   if (c0_out && (!wide || mode == kNttInt)) return hipErrorInvalidValue;
+  if (tree40 && (!pack40 || mode == kNttInt)) return hipErrorInvalidValue;
   const uint32_t digit_blocks = wide ? nodes * (k + 1) * k : 0xffffffffu;
   const dim3 grid = wide ? dim3(digit_blocks + (c0_out ? nodes * k : 0)) : dim3(nodes, k + 1, k);
-  if (pack40) {
+  if (tree40) {
+    if (mode == kNttF64)
+      hipLaunchKernelGGL((ks_digit_kernel<kNttF64, true, true>), grid, dim3(NT), kLdsBytes, st, P, res_in, galois_elt, dig,
+                         c0_out, digit_blocks);
+    else
+      hipLaunchKernelGGL((ks_digit_kernel<kNttF64Wide, true, true>), grid, dim3(NT), kLdsBytes, st, P, res_in, galois_elt,
+                         dig, c0_out, digit_blocks);
+  } else if (pack40) {
     PIRGPU_BY_MODE(mode, hipLaunchKernelGGL((ks_digit_kernel<MODE, true>), grid, dim3(NT), kLdsBytes, st, P, res_in,
                                             galois_elt, dig, c0_out, digit_blocks));
   } else {
@@ -1174,25 +1241,26 @@ static hipError_t op_ks_mac_intt(hipStream_t st, int mode, const DevParams* P, u
 static hipError_t op_ks_mac_combine(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* dig,
                                     const uint64_t* key, const uint64_t* prod, const uint64_t* tree_in,
                                     uint32_t galois_elt, uint32_t nodes, uint32_t shift_pow, uint64_t* tree_out,
-                                    bool pack40) {
+                                    bool pack40, bool tin40, bool tout40) {
   const dim3 grid = nodes >= kWideLevel && nodes % 8 == 0 ? dim3(nodes * k * 2) : dim3(nodes, k, 2);
-  if (mode == kNttF64) {
-    if (pack40)
-      hipLaunchKernelGGL((ks_mac_combine_kernel<kNttF64, true>), grid, dim3(NT), kLdsBytes, st, P, dig, key, prod, tree_in,
-                         galois_elt, nodes, shift_pow, tree_out);
-    else
-      hipLaunchKernelGGL((ks_mac_combine_kernel<kNttF64, false>), grid, dim3(NT), kLdsBytes, st, P, dig, key, prod,
-                         tree_in, galois_elt, nodes, shift_pow, tree_out);
-  } else if (mode == kNttF64Wide) {
-    if (pack40)
-      hipLaunchKernelGGL((ks_mac_combine_kernel<kNttF64Wide, true>), grid, dim3(NT), kLdsBytes, st, P, dig, key, prod,
-                         tree_in, galois_elt, nodes, shift_pow, tree_out);
-    else
-      hipLaunchKernelGGL((ks_mac_combine_kernel<kNttF64Wide, false>), grid, dim3(NT), kLdsBytes, st, P, dig, key, prod,
-                         tree_in, galois_elt, nodes, shift_pow, tree_out);
-  } else {
-    return hipErrorInvalidValue;
-  }
+  if (mode != kNttF64 && mode != kNttF64Wide) return hipErrorInvalidValue;
+  if ((tin40 || tout40) && !pack40) return hipErrorInvalidValue;
+  if (tout40 && shift_pow >= (uint32_t)NT) return hipErrorInvalidValue;   // the 5-byte hi store assumes shift < NT
+#define PIRGPU_MC(M, P40, TI, TO)                                                                                   \
+  hipLaunchKernelGGL((ks_mac_combine_kernel<M, P40, TI, TO>), grid, dim3(NT), kLdsBytes, st, P, dig, key, prod,     \
+                     tree_in, galois_elt, nodes, shift_pow, tree_out)
+#define PIRGPU_MC_MODE(M)                                   \
+  do {                                                      \
+    if (!pack40) PIRGPU_MC(M, false, false, false);         \
+    else if (tin40 && tout40) PIRGPU_MC(M, true, true, true);   \
+    else if (tin40) PIRGPU_MC(M, true, true, false);        \
+    else if (tout40) PIRGPU_MC(M, true, false, true);       \
+    else PIRGPU_MC(M, true, false, false);                  \
+  } while (0)
+  if (mode == kNttF64) PIRGPU_MC_MODE(kNttF64);
+  else PIRGPU_MC_MODE(kNttF64Wide);
+#undef PIRGPU_MC_MODE
+#undef PIRGPU_MC
   return hipGetLastError();
 }
 

@@ -104,7 +104,7 @@ def test_split_upper_level_matches_fused(monkeypatch, d, items, elem, mb):
 
 
 @pytest.mark.parametrize("knob", ["PIRGPU_LAST_NTT", "PIRGPU_FUSE_LAST", "PIRGPU_FUSE_MAC_COMBINE", "PIRGPU_PACK40",
-                                  "PIRGPU_SEL_F64"])
+                                  "PIRGPU_SEL_F64", "PIRGPU_TREE40"])
 def test_expansion_fallback_paths(monkeypatch, knob):
     """The expansion's optional fusions switched off one at a time (coefficient-domain last level, unfused last level,
     separate combine pass, digits as doubles, lane selectors as u64): every variant must give the oracle's reply, single and batched."""

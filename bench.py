@@ -9,7 +9,7 @@ database, the Galois keys and the query ciphertexts already resident in HBM.  Gr
 queries are expanded together and share one pass over the database (the digit-sliced
 int8-MFMA scan serves 8 queries per pass); two groups alternate on two lanes so the
 bandwidth-bound scan of one overlaps the compute-bound expansion of the other; every
-query does the full work.  `value` = queries/s over the timed steps (defaults: 150 steps of 64 queries,
+query does the full work.  `value` = queries/s over the timed steps (defaults: 200 steps of 64 queries,
 about 2.3 s of GPU time); the single-query latency (`--batch 1` behaviour, what benchmark.cpp:71-79 times per
 request) is measured as well and reported as `latency_ms_single_query`, and the scan kernel's roofline comes from
 those single-query runs (one scan launch per query, HIP events on the library's stream).
@@ -175,7 +175,7 @@ def timed_steps(step, barrier, steps, warmup, dist, use_dist, torch, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=150)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="queries per step: the WHOLE job's, whatever the GPU count "
                                                          "(strong scaling); a multiple of 8 x gpus keeps every rank's "

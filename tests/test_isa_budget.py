@@ -1,0 +1,90 @@
+"""Build-quality guard for the N = 4096 transform kernels (no GPU needed: hipcc cross-compiles gfx950 here).
+
+Two properties the throughput depends on and that an innocent-looking edit can lose without any test failing
+("ks_last_ntt"):
+
+  * occupancy: the one-transform-per-workgroup kernels must fit 128 VGPRs (4 waves per SIMD) without scratch, the
+    upper-level kernel 256 (2 waves per SIMD) without scratch;
+  * the product loops (k digits x key) must have the ~33 loads of one digit in flight TOGETHER.  With a few more
+    registers live across the loop the compiler falls back to one `s_waitcnt vmcnt(0)` per load -- 33 dependent memory
+    round trips -- which once made the products cost more than the transform.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "pir_amd", "csrc", "ntt_kernels.hip")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def isa(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / "ntt12.s"
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-x", "hip", "-DPIRGPU_LOGN=12",
+                    "--cuda-device-only", "-S", SRC, "-o", str(out)], check=True, capture_output=True, timeout=600)
+    return out.read_text().split("\n")
+
+
+def _function(isa, prefix):
+    start = next(i for i, l in enumerate(isa) if l.startswith(prefix) and l.rstrip().split(";")[0].rstrip().endswith(":"))
+    end = next(i for i in range(start, len(isa)) if isa[i].startswith(".Lfunc_end"))
+    return isa[start:end]
+
+
+def _descriptor(isa, prefix):
+    i = next(i for i, l in enumerate(isa) if ".amdhsa_kernel " + prefix in l)
+    block = "\n".join(isa[i:i + 40])
+    return (int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", block).group(1)),
+            int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", block).group(1)))
+
+
+P = "_ZN6pirgpu5deg12"
+FOUR_WAVE = ["15ks_digit_kernelILi1ELb1ELb0E", "15ks_digit_kernelILi1ELb1ELb1E", "18ks_mac_intt_kernelILi1ELb1E",
+             "21ks_mac_combine_kernelILi1ELb1ELb0ELb0E", "21ks_mac_combine_kernelILi1ELb1ELb1ELb1E",
+             "18ks_last_ntt_kernelILi1ELb1ELb0E", "18ks_last_ntt_kernelILi1ELb1ELb1E", "16ntt_batch_kernelILi1ELb1E",
+             "18tree_c0_ntt_kernelILi1ELb1E"]
+
+
+@pytest.mark.parametrize("kernel", FOUR_WAVE)
+def test_transform_kernels_keep_four_waves_per_simd(isa, kernel):
+    vgprs, scratch = _descriptor(isa, P + kernel)
+    assert scratch == 0, "%s spills %d bytes per lane" % (kernel, scratch)
+    assert vgprs <= 128, "%s needs %d VGPRs: 3 waves per SIMD" % (kernel, vgprs)
+
+
+@pytest.mark.parametrize("kernel", ["18upper_fused_kernelILi1ELb1ELb1E", "18upper_fused_kernelILi1ELb1ELb0E",
+                                    "18upper_fused_kernelILi1ELb0ELb0E"])
+def test_upper_level_kernel_keeps_two_waves_per_simd(isa, kernel):
+    vgprs, scratch = _descriptor(isa, P + kernel)
+    assert scratch == 0 and vgprs <= 256, (kernel, vgprs, scratch)
+
+
+def _loop_load_batches(body):
+    """For every loop (label ... backward branch to it): loads issued before the loop's first vmcnt wait."""
+    labels = {l.split(":")[0].strip(): i for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)}
+    batches = []
+    for i, l in enumerate(body):
+        m = re.search(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            loads = 0
+            for t in body[labels[m.group(1)]:i]:
+                t = t.strip()
+                if t.startswith(("global_load", "buffer_load")):
+                    loads += 1
+                elif t.startswith("s_waitcnt") and "vmcnt" in t:
+                    break
+            batches.append(loads)
+    return batches
+
+
+@pytest.mark.parametrize("kernel", ["18ks_mac_intt_kernelILi1ELb1E", "21ks_mac_combine_kernelILi1ELb1ELb1ELb1E",
+                                    "18ks_last_ntt_kernelILi1ELb1ELb1E", "18ks_last_ntt_kernelILi1ELb1ELb0E"])
+def test_product_loop_issues_its_loads_together(isa, kernel):
+    batches = _loop_load_batches(_function(isa, P + kernel))
+    assert batches and max(batches) >= 30, "%s: loads in flight per loop %s (a digit needs 33 together)" % (kernel, batches)

@@ -146,6 +146,8 @@ struct pirgpu_ctx {
   uint32_t upper_blocks = 512;   // target workgroup count of upper_fused_kernel (PIRGPU_UPPER_BLOCKS)
   uint32_t upper_blocks_batch = 64;   // the same per query in batch mode, where other queries fill the chip too: fewer
                                       // chunks = fewer partial sums to write and fold (PIRGPU_UPPER_BLOCKS_BATCH)
+  uint32_t scan_wgs_batch = 128; // persistent workgroups (= CUs) of the MFMA scan in the batch pipeline; 0 = all CUs
+                                 // (PIRGPU_SCAN_MFMA_WGS_BATCH)
   bool in_batch = false;         // set while the batch pipeline enqueues work
   uint32_t scan_nsplit = 1, scan_cps = 0, scan_rows = 0, scan_cols = 0;
   uint32_t scan_rpt = 4, scan_block = 256;  // rows per thread / workgroup size of the scan kernel
@@ -377,6 +379,7 @@ void ensure_workspace(pirgpu_ctx* c) {
   const uint64_t shard_pts = c->pt_end - c->pt_begin;
   if (const char* v = getenv("PIRGPU_UPPER_BLOCKS")) c->upper_blocks = std::max(1, atoi(v));
   if (const char* v = getenv("PIRGPU_UPPER_BLOCKS_BATCH")) c->upper_blocks_batch = std::max(1, atoi(v));
+  if (const char* v = getenv("PIRGPU_SCAN_MFMA_WGS_BATCH")) c->scan_wgs_batch = (uint32_t)std::max(0, atoi(v));
   c->upper_blocks_batch = std::min(c->upper_blocks_batch, c->upper_blocks);  // the scratch is sized for upper_blocks
   c->lvl_rows.assign(d, 0);
   c->lvl_cts.assign(d, 0);
@@ -679,7 +682,9 @@ void scan_group_mfma(pirgpu_ctx* c, hipStream_t st, uint8_t*& selp, const MfmaPt
     packed = selp;
   }
   if (profiled) record(c, *profiled, PH_SCAN);  // selector packing counts as selector preparation, not as the scan
-  HIP_TRY(launch_scan_mfma(st, c->dp, c->mg, c->d_dbp, packed, out, n, c->scan_rows, kN, words));
+  // batch pipeline: the pass runs on part of the chip and overlaps the other lane's transform kernels
+  const uint32_t wgs = !profiled && c->in_batch ? c->scan_wgs_batch : 0;
+  HIP_TRY(launch_scan_mfma(st, c->dp, c->mg, c->d_dbp, packed, out, n, c->scan_rows, kN, words, wgs));
   if (c->mg.nchunks > 1)
     HIP_TRY(launch_reduce_splits(st, c->dp, part, c->mg.nchunks, words, out_base, n, (uint64_t)c->mg.nchunks * words, words));
 }

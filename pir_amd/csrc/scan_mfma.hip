@@ -341,9 +341,9 @@ hipError_t launch_sel_pack(hipStream_t st, const DevParams* P, const MfmaGeom& g
 template <int L, int KS>
 static void launch_scan_mfma_variant(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp,
                                      const uint8_t* selp, const MfmaPtrs& out, uint32_t nq, uint32_t rows, uint32_t kN,
-                                     uint64_t chunk_stride) {
+                                     uint64_t chunk_stride, uint32_t wgs_req) {
   // persistent workgroups: one per CU and chunk (at most), each walking its share of the kN/8 slot blocks
-  static const uint32_t wgs = [] {
+  static const uint32_t wgs_all = [] {
     const char* v = getenv("PIRGPU_SCAN_MFMA_WGS");
     if (v && *v) return (uint32_t)strtoul(v, nullptr, 10);
     hipDeviceProp_t prop;
@@ -351,6 +351,9 @@ static void launch_scan_mfma_variant(hipStream_t st, const DevParams* P, const M
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256u;
     return (uint32_t)prop.multiProcessorCount;
   }();
+  // wgs_req (batch pipeline): a workgroup takes a CU's whole register file, so a launch on fewer CUs leaves the others
+  // to the VALU-bound kernels of the other lane -- the HBM-bound pass and the transforms then really overlap
+  const uint32_t wgs = wgs_req ? std::min(wgs_req, wgs_all) : wgs_all;
   // equal shares of the chip for the (equal) column chunks
   ChunkPlan plan{};
   plan.nchunks = gm.nchunks;
@@ -362,10 +365,10 @@ static void launch_scan_mfma_variant(hipStream_t st, const DevParams* P, const M
 
 hipError_t launch_scan_mfma(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp,
                             const uint8_t* selp, const MfmaPtrs& out, uint32_t nq, uint32_t rows, uint32_t kN,
-                            uint64_t chunk_stride) {
+                            uint64_t chunk_stride, uint32_t wgs) {
 #define PIRGPU_MFMA_CASE(L_, KS_)                                                                     \
   if (gm.L == L_ && gm.KS == KS_) {                                                                   \
-    launch_scan_mfma_variant<L_, KS_>(st, P, gm, dbp, selp, out, nq, rows, kN, chunk_stride);         \
+    launch_scan_mfma_variant<L_, KS_>(st, P, gm, dbp, selp, out, nq, rows, kN, chunk_stride, wgs);    \
     return hipGetLastError();                                                                         \
   }
   PIRGPU_MFMA_CASE(5, 1) PIRGPU_MFMA_CASE(5, 2) PIRGPU_MFMA_CASE(5, 3)

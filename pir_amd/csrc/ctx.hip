@@ -556,8 +556,11 @@ const uint64_t* xpow_table(pirgpu_ctx* c, hipStream_t st, uint32_t shift) {
 // B queries at once: ciphertext index = node * B + query, so every level is the same three launches
 // over B times the nodes (the per-level Galois element and monomial shift are uniform).
 // sel_dst (optional, fp64 flavours): per query, where selector 0 of this ciphertext's expansion goes (NTT form).  The
-// last level then runs fused with the selectors' forward transform (ks_last_level_kernel) and nullptr is returned:
-// there is no coefficient-form result to transform any more.
+// last level then produces the selectors directly -- in the NTT domain (ks_last_ntt_kernel; the default) or fused with
+// their forward transform (ks_last_level_kernel) -- and nullptr is returned: there is no coefficient-form result to
+// transform any more.  sel_f64: selectors written as exact doubles (a batch lane's own consumers only).
+// Levels: narrow ones digit -> products of all moduli -> combine; wide ones digit -> special-prime product -> data
+// products + combine in one kernel, the tree between two such levels in 5-byte polynomials (cur40).
 uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* res_b, uint64_t* dig, uint64_t* prod,
                       uint32_t n, uint32_t B, const MfmaPtrs* sel_dst = nullptr, bool sel_f64 = false) {
   const uint32_t N = c->N, k = c->k;

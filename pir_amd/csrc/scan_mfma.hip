@@ -251,8 +251,12 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
           int64_t G = 0;
 #pragma unroll
           for (int s = grp * 5; s < grp * 5 + 5 && s < NS; ++s) G += (int64_t)T[s][i] << (8 * (s - grp * 5));
-          const u128 v = ((u128)r << 40) + (uint64_t)(G + (int64_t)bias);
-          r = reduce128((uint64_t)v, (uint64_t)(v >> 64), m);
+          if (grp == NG - 1 && NG > 1) {
+            r = (uint64_t)(G + (int64_t)bias);   // top group: < 2^58, reduced together with the next one (bias = 0 mod q)
+          } else {
+            const u128 v = ((u128)r << 40) + (uint64_t)(G + (int64_t)bias);
+            r = reduce128((uint64_t)v, (uint64_t)(v >> 64), m);
+          }
         }
         stage[buf][g * 4 + i][i16][w] = r;
       }

@@ -686,7 +686,14 @@ void scan_group_mfma(pirgpu_ctx* c, hipStream_t st, uint8_t*& selp, const MfmaPt
   }
   if (profiled) record(c, *profiled, PH_SCAN);  // selector packing counts as selector preparation, not as the scan
   // batch pipeline: the pass runs on part of the chip and overlaps the other lane's transform kernels
-  const uint32_t wgs = !profiled && c->in_batch ? c->scan_wgs_batch : 0;
+  // ... when another lane has work queued (asked at enqueue time; the host runs ahead of the GPU, so a lane that is
+  // busy now still is when this launch starts); a lone group gets the whole chip
+  bool share = false;
+  if (!profiled && c->in_batch && c->scan_wgs_batch)
+    for (const BatchLane& ln : c->lanes)
+      if (ln.stream && ln.stream != st && hipStreamQuery(ln.stream) == hipErrorNotReady) share = true;
+  (void)hipGetLastError();   // hipErrorNotReady is not an error here
+  const uint32_t wgs = share ? c->scan_wgs_batch : 0;
   HIP_TRY(launch_scan_mfma(st, c->dp, c->mg, c->d_dbp, packed, out, n, c->scan_rows, kN, words, wgs));
   if (c->mg.nchunks > 1)
     HIP_TRY(launch_reduce_splits(st, c->dp, part, c->mg.nchunks, words, out_base, n, (uint64_t)c->mg.nchunks * words, words));

@@ -21,14 +21,23 @@ SRC = os.path.join(ROOT, "pir_amd", "csrc", "ntt_kernels.hip")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
-@pytest.fixture(scope="module")
-def isa(tmp_path_factory):
+def _compile(tmp_path_factory, logn):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available")
-    out = tmp_path_factory.mktemp("isa") / "ntt12.s"
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-x", "hip", "-DPIRGPU_LOGN=12",
+    out = tmp_path_factory.mktemp("isa") / ("ntt%d.s" % logn)
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-x", "hip", "-DPIRGPU_LOGN=%d" % logn,
                     "--cuda-device-only", "-S", SRC, "-o", str(out)], check=True, capture_output=True, timeout=600)
     return out.read_text().split("\n")
+
+
+@pytest.fixture(scope="module")
+def isa(tmp_path_factory):
+    return _compile(tmp_path_factory, 12)
+
+
+@pytest.fixture(scope="module")
+def isa13(tmp_path_factory):
+    return _compile(tmp_path_factory, 13)
 
 
 def _function(isa, prefix):
@@ -88,3 +97,18 @@ def _loop_load_batches(body):
 def test_product_loop_issues_its_loads_together(isa, kernel):
     batches = _loop_load_batches(_function(isa, P + kernel))
     assert batches and max(batches) >= 30, "%s: loads in flight per loop %s (a digit needs 33 together)" % (kernel, batches)
+
+
+# N = 8192 (cfg 4: 43/44-bit moduli, digits and tree as doubles)
+P13 = "_ZN6pirgpu5deg13"
+
+
+@pytest.mark.parametrize("kernel", ["18ks_mac_intt_kernelILi1ELb0E", "21ks_mac_combine_kernelILi1ELb0ELb0ELb0E",
+                                    "18ks_last_ntt_kernelILi1ELb0ELb0E", "18ks_last_ntt_kernelILi1ELb0ELb1E",
+                                    "15ks_digit_kernelILi1ELb0ELb0E"])
+def test_n8192_transform_kernels(isa13, kernel):
+    vgprs, scratch = _descriptor(isa13, P13 + kernel)
+    assert scratch == 0 and vgprs <= 128, (kernel, vgprs, scratch)
+    if "digit" not in kernel:
+        batches = _loop_load_batches(_function(isa13, P13 + kernel))
+        assert batches and max(batches) >= 30, (kernel, batches)

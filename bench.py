@@ -204,6 +204,14 @@ def main():
                     help="keep the u64 staging copy of the database next to the operand-layout copy (default: "
                          "released for d >= 2, one copy of the database in HBM)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    # `python bench.py --gpus N` without a launcher environment: start the N ranks ourselves (fresh child processes,
+    # before anything here touches a GPU), relay rank 0's JSON line, fail if any rank fails
+    from pir_amd import launcher
+    if args.gpus > 1 and not launcher.launched_by_a_launcher():
+        sys.exit(launcher.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
 
     # stdout carries exactly one JSON line: anything native libraries print there (RCCL's version banner)
     # is sent to stderr instead
@@ -218,6 +226,9 @@ def main():
         args.gpus = world
 
     import torch
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible -- one process per GPU needs %d devices"
+                         % (rank, local_rank, torch.cuda.device_count(), world))
     import pir_amd
     from pir_amd import distributed as D
 
@@ -382,7 +393,10 @@ def main():
         out = {
             "metric": "PIR queries/sec (ms/query in ms_per_step), N=%d DB=2^%d x %dB d=%d"
                       % (N, args.log_items, item_bytes, args.dims),
-            "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": qps, "unit": "queries/s", "n_gpus": world,
+            # ranks of the RCCL process group the collectives of this run went through (null: no process group)
+            "rccl_ranks": (dist.get_world_size() if dist.get_backend() == "nccl" else 0) if use_dist else None,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": "N=%d, %d RNS data primes (%s bit | special %d bit), t=24 bit, DB=2^%d x %dB, "

@@ -110,6 +110,14 @@ int pirgpu_db_finalize(pirgpu_ctx* ctx, int release_staging);
  * (database.cpp:308-315).  Default (allow == 0): same status.  allow != 0: return the mathematically defined
  * reply instead (what a SEAL built without SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT computes). */
 int pirgpu_set_transparent_policy(pirgpu_ctx* ctx, int allow);
+/* Row-sharded servers (not in the reference): the reference's transparent-ciphertext failure depends on the WHOLE
+ * database, so the ranks exchange their shard's count once after loading (pir_amd.distributed.sync_zero_plaintexts:
+ * one all-reduce) and tell their context how many identically-zero plaintexts the other shards hold; every rank then
+ * takes the same decision.  pirgpu_check_ready returns what the next query would fail with before any kernel or
+ * collective has run: FailedPrecondition (database not fully loaded), Internal (transparent), else 0. */
+uint64_t pirgpu_zero_plaintexts(const pirgpu_ctx* ctx);
+int pirgpu_set_remote_zero_plaintexts(pirgpu_ctx* ctx, uint64_t count);
+int pirgpu_check_ready(pirgpu_ctx* ctx);
 /* Test hook: read back one encoded plaintext [k][N] (NTT form) from HBM. */
 int pirgpu_db_read_plaintext(pirgpu_ctx* ctx, uint64_t pt_index, uint64_t* out);
 

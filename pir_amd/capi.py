@@ -75,6 +75,9 @@ SIGNATURES = {
     "pirgpu_db_read_plaintext": (C.c_int, [C.c_void_p, C.c_uint64, u64p]),
     "pirgpu_db_finalize": (C.c_int, [C.c_void_p, C.c_int]),
     "pirgpu_set_transparent_policy": (C.c_int, [C.c_void_p, C.c_int]),
+    "pirgpu_zero_plaintexts": (C.c_uint64, [C.c_void_p]),
+    "pirgpu_set_remote_zero_plaintexts": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "pirgpu_check_ready": (C.c_int, [C.c_void_p]),
     "pirgpu_ntt_mode": (C.c_int, [C.c_void_p]),
     "pirgpu_packed_selector_bytes": (C.c_uint64, [C.c_void_p]),
     "pirgpu_batch_expand_packed": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,

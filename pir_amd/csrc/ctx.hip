@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -31,6 +32,8 @@ thread_local std::string g_create_error;
 // threads use the same context in between
 thread_local std::string t_last_error;
 thread_local const pirgpu_ctx* t_last_error_ctx = nullptr;
+thread_local uint64_t t_last_error_gen = 0;   // generation id of that context (a new context may reuse the address)
+std::atomic<uint64_t> g_ctx_generation{0};
 
 struct Fail {
   int code;
@@ -141,7 +144,8 @@ struct pirgpu_ctx {
   uint64_t pt_words = 0;
   // batch mode (pirgpu_batch_*): queries and replies of one batch, device resident
   uint64_t *d_bquery = nullptr, *d_breply = nullptr;
-  uint32_t batch_cap = 0, batch_count = 0, n_active = 1;
+  uint32_t batch_cap = 0, batch_count = 0, n_active = 1;   // batch_count: replies the reply buffer holds
+  uint32_t staged_count = 0;   // queries pirgpu_batch_stage left in d_bquery (0 again when the buffers are reallocated)
   bool batch_valid = false;
   uint32_t upper_blocks = 512;   // target workgroup count of upper_fused_kernel (PIRGPU_UPPER_BLOCKS)
   uint32_t upper_blocks_batch = 64;   // the same per query in batch mode, where other queries fill the chip too: fewer
@@ -191,8 +195,10 @@ struct pirgpu_ctx {
   float timings[6]{};
 
   std::string err;
+  uint64_t gen = 0;         // unique per context (thread-local error messages are keyed on it, not on the address)
   std::recursive_mutex mu;  // per ABI call; pirgpu_process_request holds it across its whole body
   uint64_t zero_pts = 0;    // all-zero database plaintexts in this shard (SEAL: "result ciphertext is transparent")
+  uint64_t remote_zero_pts = 0;   // ... in the other shards of a row-sharded database (pirgpu_set_remote_zero_plaintexts)
   bool allow_transparent = false;
 
   template <typename T>
@@ -213,6 +219,7 @@ int fail(pirgpu_ctx* c, int code, const std::string& msg) {
     c->err = msg;
     t_last_error = msg;
     t_last_error_ctx = c;
+    t_last_error_gen = c->gen;
   }
   return code;
 }
@@ -362,7 +369,9 @@ void note_plaintext(pirgpu_ctx* c, uint64_t local, bool zero) {
 // (reference database.cpp:308-315).  pirgpu_set_transparent_policy(ctx, 1) returns the mathematically defined
 // reply instead.
 void check_transparent(pirgpu_ctx* c) {
-  if (c->zero_pts && !c->allow_transparent)
+  // the reference fails every query as soon as ANY plaintext of the whole database is zero: a row shard also counts
+  // the zero plaintexts the other shards reported, so that all ranks of a sharded server take the same decision
+  if ((c->zero_pts || c->remote_zero_pts) && !c->allow_transparent)
     throw Fail{PIRGPU_INTERNAL, "result ciphertext is transparent"};
 }
 
@@ -453,7 +462,8 @@ void ensure_workspace(pirgpu_ctx* c) {
     c->pack40 = env_u32("PIRGPU_PACK40", 1) != 0;
     // 5-byte storage of the key-switch intermediates: the fp64 flavours store x + q (|x| <= q), so q < 2^39
     for (uint32_t j = 0; j <= k; ++j) c->pack40 = c->pack40 && (c->hp.mod[j].q >> 39) == 0;
-    c->mg = mfma_geometry(c->hp, c->scan_rows, c->scan_cols);
+    //   PIRGPU_SCAN_MFMA_WIDE  0 / 1 forces the 8-wave / 4-wave (one wave per SIMD, up to 7 k-steps) scan kernel
+    c->mg = mfma_geometry(c->hp, c->scan_rows, c->scan_cols, getenv("PIRGPU_SCAN_MFMA_WIDE") ? (int)env_u32("PIRGPU_SCAN_MFMA_WIDE", 0) : -1);
     c->mfma_on = env_u32("PIRGPU_SCAN_MFMA", 1) != 0 && d >= 2 && c->mg.L != 0 && c->scan_rows >= 8 && shard_pts > 0;
     c->mfma_nq = std::max<uint32_t>(1, std::min<uint32_t>(env_u32("PIRGPU_SCAN_MFMA_NQ", kMaxMfmaQueries),
                                                           kMaxMfmaQueries));
@@ -820,6 +830,8 @@ void run_staged(pirgpu_ctx* c, Worker& w, bool profile) {
     throw Fail{PIRGPU_INVALID_ARGUMENT,
                "Number of ciphertexts doesn't match number of items for oblivious expansion."};
   c->prof_cur = -1;
+  // a batch group that borrowed this worker's selection vector (its multiply runs on a lane stream) must be done
+  HIP_TRY(hipStreamWaitEvent(w.stream, w.ev_done, 0));
   if (profile) begin_profiled_run(c);
   record(c, w, PH_EXPAND);
   // expansion and selection-vector NTT are interleaved per query ciphertext; the
@@ -847,6 +859,7 @@ int pirgpu_create(const pirgpu_params* p, pirgpu_ctx** out) {
   if (!p || !out) return PIRGPU_INVALID_ARGUMENT;
   *out = nullptr;
   pirgpu_ctx* c = new pirgpu_ctx();
+  c->gen = ++g_ctx_generation;
   auto bail = [&](int code, const std::string& msg) {
     g_create_error = msg;
     pirgpu_destroy(c);
@@ -961,7 +974,8 @@ void pirgpu_destroy(pirgpu_ctx* c) {
 
 const char* pirgpu_last_error(const pirgpu_ctx* c) {
   if (!c) return "null context";
-  if (t_last_error_ctx == c) return t_last_error.c_str();  // this thread's own last failure on this context
+  if (t_last_error_ctx == c && t_last_error_gen == c->gen)
+    return t_last_error.c_str();  // this thread's own last failure on this context
   return c->err.c_str();
 }
 
@@ -977,6 +991,23 @@ void pirgpu_request_unlock(pirgpu_ctx* c) {
 int pirgpu_set_transparent_policy(pirgpu_ctx* c, int allow) {
   return guarded(c, [&]() -> int {
     c->allow_transparent = allow != 0;
+    return PIRGPU_OK;
+  });
+}
+
+uint64_t pirgpu_zero_plaintexts(const pirgpu_ctx* c) { return c ? c->zero_pts : 0; }
+
+int pirgpu_set_remote_zero_plaintexts(pirgpu_ctx* c, uint64_t n) {
+  return guarded(c, [&]() -> int {
+    c->remote_zero_pts = n;
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_check_ready(pirgpu_ctx* c) {
+  return guarded(c, [&]() -> int {
+    if (c->n_loaded != c->pt_end - c->pt_begin) return fail(c, PIRGPU_FAILED_PRECONDITION, "database not fully loaded");
+    check_transparent(c);
     return PIRGPU_OK;
   });
 }
@@ -1196,6 +1227,7 @@ int pirgpu_query_stage(pirgpu_ctx* c, const uint64_t* query, uint32_t nq) {
     if (!query || nq != c->dim_sum / c->N + 1)  // reference server.cpp:154-158
       return fail(c, PIRGPU_INVALID_ARGUMENT,
                   "Number of ciphertexts doesn't match number of items for oblivious expansion.");
+    HIP_TRY(hipStreamWaitEvent(c->stream, w.ev_done, 0));
     HIP_TRY(hipMemcpyAsync(w.d_query, query, (size_t)nq * c->ctw * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     w.staged_nq = nq;
@@ -1399,6 +1431,7 @@ int pirgpu_batch_stage(pirgpu_ctx* c, const uint64_t* queries, uint32_t nq, uint
     HIP_TRY(hipMemcpyAsync(c->d_bquery, queries, (size_t)count * nq * c->ctw * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->batch_count = count;
+    c->staged_count = count;
     c->batch_valid = false;
     return PIRGPU_OK;
   });
@@ -1410,6 +1443,7 @@ int pirgpu_batch_stage(pirgpu_ctx* c, const uint64_t* queries, uint32_t nq, uint
 static void ensure_batch_capacity(pirgpu_ctx* c, uint32_t count) {
   if (count <= c->batch_cap) return;
   const uint32_t nq = c->dim_sum / c->N + 1;
+  const uint32_t old_cap = c->batch_cap;
   if (c->d_bquery || c->d_breply) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (BatchLane& ln : c->lanes)
@@ -1425,8 +1459,9 @@ static void ensure_batch_capacity(pirgpu_ctx* c, uint32_t count) {
     c->d_bquery = c->d_breply = nullptr;
     c->batch_cap = 0;
     c->batch_valid = false;
+    c->staged_count = 0;   // the staged queries went with the old buffer
   }
-  const uint32_t cap = std::max<uint32_t>(count, std::min<uint32_t>(4096, 2 * c->batch_cap));
+  const uint32_t cap = std::max<uint32_t>(count, std::min<uint32_t>(4096, 2 * old_cap));
   c->d_bquery = c->dalloc<uint64_t>((size_t)cap * nq * c->ctw);
   c->d_breply = c->dalloc<uint64_t>((size_t)cap * c->reply_cts * c->ctw);
   c->batch_cap = cap;
@@ -1521,7 +1556,7 @@ static void batch_run_mfma(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
     const uint32_t in_span = std::min<uint32_t>(span, count - rank0);
     for (uint32_t j0 = 0; j0 < in_span; j0 += step) {
       const uint32_t B = std::min<uint32_t>(step, in_span - j0);
-      if (B > W) throw Fail{PIRGPU_FAILED_PRECONDITION, "packed groups need at least 8 workers (pirgpu_set_concurrency)"};
+      if (B > W) throw Fail{PIRGPU_FAILED_PRECONDITION, "packed groups need min(queries per rank, 8) workers (pirgpu_set_concurrency)"};
       const uint32_t li = (uint32_t)(c->groups_run++ % nl);
       BatchLane& ln = c->lanes[li];
       Worker* members[kMaxMfmaQueries];
@@ -1655,8 +1690,9 @@ static void batch_run_impl_body(pirgpu_ctx* c, uint32_t count, const uint64_t* e
 
 int pirgpu_batch_run(pirgpu_ctx* c) {
   return guarded(c, [&]() -> int {
-    if (!c->batch_count) return fail(c, PIRGPU_FAILED_PRECONDITION, "no batch has been staged");
-    batch_run_impl(c, c->batch_count, nullptr);
+    if (!c->staged_count) return fail(c, PIRGPU_FAILED_PRECONDITION, "no batch has been staged");
+    batch_run_impl(c, c->staged_count, nullptr);
+    c->batch_count = c->staged_count;
     return PIRGPU_OK;
   });
 }
@@ -1665,7 +1701,7 @@ int pirgpu_batch_run(pirgpu_ctx* c) {
 
 int pirgpu_batch_expand(pirgpu_ctx* c, uint32_t first, uint32_t count, uint64_t* device_dst) {
   return guarded(c, [&]() -> int {
-    if (!c->batch_count || (uint64_t)first + count > c->batch_count)
+    if (!c->staged_count || (uint64_t)first + count > c->staged_count)
       return fail(c, PIRGPU_INVALID_ARGUMENT, "query range outside the staged batch");
     if (!device_dst && count) return fail(c, PIRGPU_INVALID_ARGUMENT, "null buffer");
     const uint32_t nq = c->dim_sum / c->N + 1;
@@ -1674,6 +1710,7 @@ int pirgpu_batch_expand(pirgpu_ctx* c, uint32_t first, uint32_t count, uint64_t*
     c->prof_cur = -1;
     for (uint32_t i = 0; i < count; ++i) {
       Worker& w = c->workers[i % W];
+      HIP_TRY(hipStreamWaitEvent(w.stream, w.ev_done, 0));   // a lane's group may still be reading its buffers
       HIP_TRY(hipMemcpyAsync(w.d_query, c->d_bquery + (size_t)(first + i) * qwords, qwords * 8,
                              hipMemcpyDeviceToDevice, w.stream));
       w.staged_nq = nq;
@@ -1691,7 +1728,6 @@ int pirgpu_batch_run_selectors(pirgpu_ctx* c, const uint64_t* device_sv, uint32_
     ensure_workspace(c);
     if (!device_sv || count == 0 || count > 4096) return fail(c, PIRGPU_INVALID_ARGUMENT, "invalid batch");
     ensure_batch_capacity(c, count);
-    c->batch_count = std::max(c->batch_count, count);
     batch_run_impl(c, count, device_sv);
     c->batch_count = count;
     return PIRGPU_OK;
@@ -1717,7 +1753,7 @@ int pirgpu_batch_expand_packed(pirgpu_ctx* c, uint32_t first_query, uint32_t cou
     ensure_workspace(c);
     if (c->d != 2 || !c->mfma_on)
       return fail(c, PIRGPU_FAILED_PRECONDITION, "packed selector exchange needs d = 2 and the int8-MFMA scan");
-    if (!c->batch_count || (uint64_t)first_query + count > c->batch_count)
+    if (!c->staged_count || (uint64_t)first_query + count > c->staged_count)
       return fail(c, PIRGPU_INVALID_ARGUMENT, "query range outside the staged batch");
     if (!device_packed || !device_rows || !row_cuts || n_ranks == 0 || row_cuts[0] != 0 || row_cuts[n_ranks] != c->dims[0])
       return fail(c, PIRGPU_INVALID_ARGUMENT, "invalid packed-exchange buffers or row cuts");

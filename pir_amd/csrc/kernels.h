@@ -114,10 +114,12 @@ struct MfmaGeom {
   uint32_t KS;       // k-steps (64 columns) per chunk, selectors of one chunk live in registers
   uint32_t GC;       // column groups per chunk = ceil(KG / nchunks) <= 4 KS
   uint32_t nchunks;  // column chunks (grid.y); > 1 leaves partial sums to reduce_splits_kernel
+  uint32_t NW;       // waves (= slots) per workgroup: 8 (two waves per SIMD, KS <= 3) or 4 (one per SIMD, KS <= 7)
   size_t db_bytes, sel_bytes;
 };
 
-MfmaGeom mfma_geometry(const DevParams& hp, uint32_t rows, uint32_t cols);
+// wide_override: -1 = choose by width, 0 / 1 = force the 8-wave / 4-wave kernel
+MfmaGeom mfma_geometry(const DevParams& hp, uint32_t rows, uint32_t cols, int wide_override = -1);
 hipError_t launch_db_pack(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint64_t* db, uint8_t* dbp,
                           uint32_t rows, uint32_t cols, uint32_t kN);
 hipError_t launch_db_unpack(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp, uint64_t* out,

@@ -140,28 +140,34 @@ __device__ __forceinline__ v4i load_tile(const uint8_t* p) {
 
 // Workgroups per column chunk: first[c] .. first[c+1] run chunk c (equal shares of equal chunks).
 struct ChunkPlan {
-  uint16_t first[kMaxScanChunks + 1];
+  uint32_t first[kMaxScanChunks + 1];
   uint32_t nchunks;
 };
 
-// grid = sum of the plan's workgroups; block = 512 (wave w <-> slot j0 + w).  A workgroup is persistent: it walks
+// grid = sum of the plan's workgroups; block = NW waves (wave w <-> slot j0 + w).  NW = 8: two waves per SIMD, 256
+// registers each -- selectors of up to 3 k-steps; NW = 4 ("wide"): one wave per SIMD with the whole 512-entry register
+// file (VGPRs + AGPRs: MFMA operands may live in either), selectors of up to 7 k-steps = 28 column groups in registers,
+// so the matrices of cfg 4 / 5 (27 / 21 column groups) are scanned in ONE chunk with all but the last k-step full.  A workgroup is persistent: it walks
 // the slot blocks blk = i, i + n_c, ... (i = its index among the n_c workgroups of its chunk) and, while it folds
 // and stores the last row tile of one block, the selector tiles and the first database tiles of its next block are
 // already in flight (one workgroup per CU at this register count, so nothing else would hide that latency).
 // Chunk ch covers column groups [ch * GC, (ch + 1) * GC) with GC = ceil(KG / nchunks) <= 4 KS -- equal chunks, so
 // that equal shares of the chip finish together (7 k-steps split 3/3/1 left a third of the CUs idle for two thirds
 // of the pass) -- and writes to out.p[q] + ch * chunk_stride (partial sums when nchunks > 1).
-template <int L, int KS>
-__global__ void __launch_bounds__(512)
+template <int L, int KS, int NW>
+__global__ void __launch_bounds__(NW * 64)
 scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ dbp, const uint8_t* __restrict__ selp,
                  MfmaPtrs out, uint32_t nq, uint32_t rows, uint32_t RT, uint32_t KG, uint32_t kN,
                  uint64_t chunk_stride, ChunkPlan plan, uint32_t GC) {
   constexpr int NS = 2 * L - 1;        // digit diagonals
   constexpr int NG = (NS + 4) / 5;     // groups of five diagonals (40 bits)
-  __shared__ uint64_t stage[2][16][16][8];
+  // results of one row tile, [row][x][slot]: a (row, x) run is padded to 9 words so that the 16 lanes of a row (x = 0..15,
+  // 72 bytes apart) hit 16 different 8-byte bank pairs when a wave stores its slot (64 bytes apart they hit two)
+  __shared__ uint64_t stage[2][16][16][NW + 1];
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int g = l >> 4, i16 = l & 15;
-  const uint32_t nblocks = kN >> 3;
+  constexpr int LOGNW = NW == 8 ? 3 : 2;
+  const uint32_t nblocks = kN >> LOGNW;
   uint32_t ch = 0;
   while (ch + 1 < plan.nchunks && blockIdx.x >= plan.first[ch + 1]) ++ch;
   const uint32_t wg_in_chunk = blockIdx.x - plan.first[ch], wgs_in_chunk = plan.first[ch + 1] - plan.first[ch];
@@ -188,9 +194,9 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
 
   uint32_t blk = wg_in_chunk;
   if (blk >= nblocks) return;
-  load_B(blk * 8 + w);
+  load_B(blk * NW + w);
   {
-    const uint8_t* abase = dbp + (size_t)(blk * 8 + w) * slab + chunk_base;
+    const uint8_t* abase = dbp + (size_t)(blk * NW + w) * slab + chunk_base;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const uint32_t gl = ks * 4 + g;   // column group inside the chunk
@@ -204,7 +210,7 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
 
   uint32_t parity = 0;
   for (; blk < nblocks; blk += wgs_in_chunk) {
-    const uint32_t j0 = blk * 8;
+    const uint32_t j0 = blk * NW;
     const uint32_t j = j0 + w;
     const ModConst m = P->mod[j >> P->logN];
     // multiple of q that makes every 40-bit group positive: 2^57 <= bias < 2^58, |group| < 2^56.1
@@ -212,7 +218,7 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
     const uint8_t* abase = dbp + (size_t)j * slab + chunk_base;
     const uint32_t nblk = blk + wgs_in_chunk;
     const bool has_next = nblk < nblocks;
-    const uint8_t* nbase = dbp + (size_t)(nblk * 8 + w) * slab + chunk_base;
+    const uint8_t* nbase = dbp + (size_t)(nblk * NW + w) * slab + chunk_base;
 
     for (uint32_t rt = 0; rt < RT; ++rt) {
       v4i T[NS];
@@ -239,7 +245,7 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
           for (int a = 0; a < L; ++a) A[ks][a] = load_tile(next_tile + ((size_t)gl * L + a) * 256);
         }
       }
-      if (last && has_next) load_B(nblk * 8 + w);   // all MFMAs of this block are issued: B is free
+      if (last && has_next) load_B(nblk * NW + w);   // all MFMAs of this block are issued: B is free
       // lane (g, i16) holds rows rt*16 + g*4 + i (i < 4) of column x = i16:  value = sum_s T[s] 2^(8 s)
       const int buf = parity;
       parity ^= 1;
@@ -261,17 +267,18 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
         stage[buf][g * 4 + i][i16][w] = r;
       }
       __syncthreads();
-      // 256 (row, x) runs of 8 slots = 64 B each; 512 threads x 16 B, two rounds
+      // 256 (row, x) runs of NW slots = 8 NW bytes each; 64 NW threads x 16 B, two rounds
 #pragma unroll
       for (int round = 0; round < 2; ++round) {
-        const int run = round * 128 + (threadIdx.x >> 2);
-        const int part = threadIdx.x & 3;
+        const int run = round * 128 + (threadIdx.x >> (LOGNW - 1));
+        const int part = threadIdx.x & (NW / 2 - 1);
         const int r16 = run >> 4, x = run & 15;
         const uint32_t r = rt * 16 + r16;
         if (x < (int)nx && r < rows) {
-          const v4i v = *reinterpret_cast<const v4i*>(&stage[buf][r16][x][part * 2]);
+          typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+          const u64x2 v = {stage[buf][r16][x][part * 2], stage[buf][r16][x][part * 2 + 1]};   // two 8-byte LDS reads
           uint64_t* dst = (uint64_t*)out.p[x >> 1] + ch * chunk_stride + ((size_t)r * 2 + (x & 1)) * kN + j0 + part * 2;
-          *reinterpret_cast<v4i*>(dst) = v;
+          *reinterpret_cast<u64x2*>(dst) = v;
         }
       }
     }
@@ -280,7 +287,7 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
 
 // ------------------------------------------------------------------ host side
 
-MfmaGeom mfma_geometry(const DevParams& hp, uint32_t rows, uint32_t cols) {
+MfmaGeom mfma_geometry(const DevParams& hp, uint32_t rows, uint32_t cols, int wide_override) {
   MfmaGeom gm{};
   uint32_t bits = 0;
   for (uint32_t i = 0; i < hp.k; ++i) bits = std::max<uint32_t>(bits, 64 - (uint32_t)__builtin_clzll(hp.mod[i].q));
@@ -292,13 +299,22 @@ MfmaGeom mfma_geometry(const DevParams& hp, uint32_t rows, uint32_t cols) {
   if (rows < 1 || cols < 1) { gm.L = 0; return gm; }
   gm.RT = (rows + 15) / 16;
   gm.KG = (cols + 15) / 16;
-  const uint32_t max_ks = gm.L <= 6 ? 3 : 2;
+  // k-steps (64 columns) whose selectors a wave keeps in registers: 3 (L <= 6) / 2 (L = 7) with two waves per SIMD
+  // (NW = 8), 7 / 6 with one wave per SIMD and the whole register file (NW = 4, "wide").  Matrices that fit the narrow
+  // budget keep it (cfg 3: 11 column groups); wider ones take the wide kernel so that they are scanned in one chunk
+  // (cfg 4: 27 groups = 7 k-steps, cfg 5: 21 = 6) instead of three chunks with a quarter-full last k-step each.
   const uint32_t steps = (gm.KG + 3) / 4;
+  const uint32_t narrow_ks = gm.L <= 6 ? 3 : 2, wide_ks = gm.L <= 6 ? 7 : 6;
+  bool wide = steps > narrow_ks;
+  if (wide_override >= 0) wide = wide_override != 0;
+  gm.NW = wide ? 4 : 8;
+  const uint32_t max_ks = wide ? wide_ks : narrow_ks;
   gm.KS = std::min(max_ks, steps);
   gm.nchunks = (steps + gm.KS - 1) / gm.KS;
   if (gm.nchunks > (uint32_t)kMaxScanChunks) { gm.L = 0; return gm; }   // wider than 16 x 4 KS x 16 columns: 64-bit kernels
   gm.GC = (gm.KG + gm.nchunks - 1) / gm.nchunks;   // equal chunks (<= 4 KS groups each)
   gm.KS = (gm.GC + 3) / 4;
+  if (wide && gm.KS < 3) gm.NW = 8;                // the wide kernel is instantiated for 3..7 k-steps
   const size_t kN = (size_t)hp.k * hp.N;
   gm.db_bytes = kN * gm.RT * gm.KG * gm.L * 256;
   gm.sel_bytes = kN * gm.KG * gm.L * 256;
@@ -342,7 +358,7 @@ hipError_t launch_sel_pack(hipStream_t st, const DevParams* P, const MfmaGeom& g
   return hipGetLastError();
 }
 
-template <int L, int KS>
+template <int L, int KS, int NW>
 static void launch_scan_mfma_variant(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp,
                                      const uint8_t* selp, const MfmaPtrs& out, uint32_t nq, uint32_t rows, uint32_t kN,
                                      uint64_t chunk_stride, uint32_t wgs_req) {
@@ -361,23 +377,26 @@ static void launch_scan_mfma_variant(hipStream_t st, const DevParams* P, const M
   // equal shares of the chip for the (equal) column chunks
   ChunkPlan plan{};
   plan.nchunks = gm.nchunks;
-  const uint32_t share = std::min<uint32_t>(kN / 8, std::max<uint32_t>(1, wgs / std::min<uint32_t>(gm.nchunks, wgs)));
-  for (uint32_t c = 0; c <= gm.nchunks; ++c) plan.first[c] = (uint16_t)(c * share);
-  hipLaunchKernelGGL((scan_mfma_kernel<L, KS>), dim3(gm.nchunks * share), dim3(512), 0, st, P, dbp, selp, out, nq, rows,
-                     gm.RT, gm.KG, kN, chunk_stride, plan, gm.GC);
+  const uint32_t share = std::min<uint32_t>(kN / NW, std::max<uint32_t>(1, wgs / std::min<uint32_t>(gm.nchunks, wgs)));
+  for (uint32_t c = 0; c <= gm.nchunks; ++c) plan.first[c] = c * share;   // share >= 1: no chunk without workgroups
+  hipLaunchKernelGGL((scan_mfma_kernel<L, KS, NW>), dim3(gm.nchunks * share), dim3(NW * 64), 0, st, P, dbp, selp, out, nq,
+                     rows, gm.RT, gm.KG, kN, chunk_stride, plan, gm.GC);
 }
 
 hipError_t launch_scan_mfma(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp,
                             const uint8_t* selp, const MfmaPtrs& out, uint32_t nq, uint32_t rows, uint32_t kN,
                             uint64_t chunk_stride, uint32_t wgs) {
-#define PIRGPU_MFMA_CASE(L_, KS_)                                                                     \
-  if (gm.L == L_ && gm.KS == KS_) {                                                                   \
-    launch_scan_mfma_variant<L_, KS_>(st, P, gm, dbp, selp, out, nq, rows, kN, chunk_stride, wgs);    \
-    return hipGetLastError();                                                                         \
+#define PIRGPU_MFMA_CASE(L_, KS_, NW_)                                                                    \
+  if (gm.L == L_ && gm.KS == KS_ && gm.NW == NW_) {                                                       \
+    launch_scan_mfma_variant<L_, KS_, NW_>(st, P, gm, dbp, selp, out, nq, rows, kN, chunk_stride, wgs);   \
+    return hipGetLastError();                                                                             \
   }
-  PIRGPU_MFMA_CASE(5, 1) PIRGPU_MFMA_CASE(5, 2) PIRGPU_MFMA_CASE(5, 3)
-  PIRGPU_MFMA_CASE(6, 1) PIRGPU_MFMA_CASE(6, 2) PIRGPU_MFMA_CASE(6, 3)
-  PIRGPU_MFMA_CASE(7, 1) PIRGPU_MFMA_CASE(7, 2)
+  PIRGPU_MFMA_CASE(5, 1, 8) PIRGPU_MFMA_CASE(5, 2, 8) PIRGPU_MFMA_CASE(5, 3, 8)
+  PIRGPU_MFMA_CASE(6, 1, 8) PIRGPU_MFMA_CASE(6, 2, 8) PIRGPU_MFMA_CASE(6, 3, 8)
+  PIRGPU_MFMA_CASE(7, 1, 8) PIRGPU_MFMA_CASE(7, 2, 8)
+  PIRGPU_MFMA_CASE(5, 3, 4) PIRGPU_MFMA_CASE(5, 4, 4) PIRGPU_MFMA_CASE(5, 5, 4) PIRGPU_MFMA_CASE(5, 6, 4) PIRGPU_MFMA_CASE(5, 7, 4)
+  PIRGPU_MFMA_CASE(6, 3, 4) PIRGPU_MFMA_CASE(6, 4, 4) PIRGPU_MFMA_CASE(6, 5, 4) PIRGPU_MFMA_CASE(6, 6, 4) PIRGPU_MFMA_CASE(6, 7, 4)
+  PIRGPU_MFMA_CASE(7, 3, 4) PIRGPU_MFMA_CASE(7, 4, 4) PIRGPU_MFMA_CASE(7, 5, 4) PIRGPU_MFMA_CASE(7, 6, 4)
 #undef PIRGPU_MFMA_CASE
   return hipErrorInvalidValue;
 }

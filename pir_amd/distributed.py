@@ -135,6 +135,22 @@ def all_reduce_batch_replies(server, reply_tensor, dist, comm: Optional[Comm] = 
     server.reduce_fixup_device_n(reply_tensor.data_ptr(), reply_tensor.shape[0] * reply_tensor.shape[1])
 
 
+def sync_zero_plaintexts(server, dist, world: int, comm: Optional[Comm] = None, torch=None, device=None) -> int:
+    """Makes the reference's transparent-ciphertext failure a COLLECTIVE decision (once, after the database is loaded):
+    the reference fails every query as soon as any plaintext of the whole database is identically zero (SEAL's
+    logic_error through database.cpp:313-315), but a row shard only sees its own rows -- without this, the one rank that
+    holds the zero plaintext would raise in the middle of a step and leave its peers blocked in the next collective.
+    One all-reduce of the shards' counts; every rank tells its context how many the others hold.  Returns the total."""
+    mine = int(server.zero_plaintexts())
+    total = mine
+    if world > 1:
+        t = torch.tensor([mine], dtype=torch.int64, device=device)
+        (comm or Comm(dist, world)).all_reduce_sum(t)
+        total = int(t.item())
+    server.set_remote_zero_plaintexts(total - mine)
+    return total
+
+
 def run_batch_query_parallel(server, sv_all, replies, dist, rank: int, world: int, comm: Optional[Comm] = None) -> None:
     """One step over a staged batch on `world` GPUs holding row shards, exchanging whole u64 selection vectors
     (any d, any scan kernel; 2 k N 8 dim_sum bytes per query to every rank):
@@ -148,6 +164,7 @@ def run_batch_query_parallel(server, sv_all, replies, dist, rank: int, world: in
     replies: int64 tensor [count, reply_cts, 2, k, N] (all-reduce buffer; every rank ends with every reply)
     """
     comm = comm or Comm(dist, world)
+    server.check_ready()        # identical on every rank after sync_zero_plaintexts: nobody enters a collective alone
     count = sv_all.shape[0]
     lo, hi = owned_queries(count, rank, world)
     server.batch_expand(lo, hi - lo, sv_all[lo].data_ptr())          # synchronous
@@ -207,6 +224,7 @@ def run_batch_rows_packed(server, bufs: PackedBuffers, dist, rank: int, world: i
     Per query a rank receives (world-1)/world * (14.4 MB + 2.6 MB/world) at cfg 3 instead of 42 MB of u64 selectors.
     """
     comm = comm or Comm(dist, world)
+    server.check_ready()        # identical on every rank after sync_zero_plaintexts: nobody enters a collective alone
     lo, hi = owned_queries(bufs.per * world, rank, world)
     server.batch_expand_packed(lo, bufs.per, bufs.packed[rank].data_ptr(), bufs.rows_send.data_ptr(), bufs.cuts)
     comm.all_gather_inplace(bufs.packed, rank)

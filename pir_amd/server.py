@@ -284,6 +284,18 @@ class PIRServer:
         self._check(self.lib.pirgpu_batch_run_packed(self.db.handle, C.c_void_p(packed_ptr), n_ranks, per_rank,
                                                      C.c_void_p(rows_ptr)))
 
+    def zero_plaintexts(self) -> int:
+        """Identically-zero plaintexts in this server's shard (SEAL's transparent-ciphertext condition)."""
+        return int(self.lib.pirgpu_zero_plaintexts(self.db.handle))
+
+    def set_remote_zero_plaintexts(self, count: int) -> None:
+        """Zero plaintexts held by the OTHER shards of a row-sharded database (distributed.sync_zero_plaintexts)."""
+        self._check(self.lib.pirgpu_set_remote_zero_plaintexts(self.db.handle, int(count)))
+
+    def check_ready(self) -> None:
+        """Raises what the next query would fail with (database not loaded / transparent) before anything runs."""
+        self._check(self.lib.pirgpu_check_ready(self.db.handle))
+
     def shard_rows(self):
         """[begin, end) of dimension 0 held by this server's database."""
         p = self.db._cparams

@@ -133,53 +133,93 @@ class OracleShardServer:
         for j, qj in enumerate(self.orc.moduli[: self.k]):
             a[:, :, j, :] %= np.uint64(qj)
 
+    # -- the collective transparent-ciphertext decision (pirgpu_zero_plaintexts / _set_remote_ / _check_ready) ------
+    remote_zero = 0
 
-def _worker(rank, world, port, d, dbsize, elem, batch, out_q):
+    def zero_plaintexts(self):
+        return int(sum(1 for pt in self.shard_db if not pt.any()))
+
+    def set_remote_zero_plaintexts(self, n):
+        self.remote_zero = int(n)
+
+    def check_ready(self):
+        if self.zero_plaintexts() + self.remote_zero:
+            from pir_amd.server import PirGpuError
+            raise PirGpuError(13, "result ciphertext is transparent")
+
+
+def rows_step_check(rank, world, d, dbsize, elem, batch, zero_pt=None):
+    """One rank of the row-sharded step over an initialised gloo process group with the oracle-backed server: True when
+    every reply this rank ends up with equals the oracle's full-database reply (and decodes to the item).  zero_pt:
+    index of a plaintext made identically zero -- every rank must then fail with the reference's status, none hangs."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from pir_fixtures import PirSetup
+    from pir_amd.server import PirGpuError
+    s = PirSetup(dbsize, elem, d, N=4096, plain_bits=24)      # same seeds on every rank
+    p = s.params
+    if zero_pt is not None:
+        s.db_ntt[zero_pt] = 0
+    indexes = [(dbsize - 2 - 37 * i) % dbsize for i in range(batch)]
+    queries = [s.client.create_query_for(p, i) for i in indexes]
+    srv = OracleShardServer(s, rank, world)
+    srv.stage_batch(queries)
+    comm = D.Comm(dist, world)
+    assert not comm.device_native
+    D.check_sum_fits(max(s.orc.moduli[: s.orc.k]), world)
+    total_zero = D.sync_zero_plaintexts(srv, dist, world, comm, torch, "cpu")
+    ok = True
+    lo, hi = D.owned_queries(batch, rank, world)
+    if zero_pt is not None:
+        # the reference fails EVERY query (database.cpp:313-315); here every rank -- also the one whose shard has no
+        # zero plaintext -- raises before it enters a collective
+        ok &= total_zero == 1
+        bufs = D.PackedBuffers(srv, batch, rank, world, torch, "cpu")
+        for step in (lambda: D.run_batch_rows_packed(srv, bufs, dist, rank, world, comm),
+                     lambda: D.run_batch_query_parallel(srv, None, None, dist, rank, world, comm)):
+            try:
+                step()
+                ok = False
+            except PirGpuError as e:
+                ok &= e.code == 13 and "transparent" in e.message
+        return ok
+    full = [s.orc.process_query(s.db_ntt, p.dimensions, queries[i], s.galois_keys)[1] for i in range(batch)]
+    if d == 2:
+        assert D.packed_exchange_supported(srv, dist, world, comm, torch, "cpu")
+        bufs = D.PackedBuffers(srv, batch, rank, world, torch, "cpu")
+        D.run_batch_rows_packed(srv, bufs, dist, rank, world, comm)
+        mine = bufs.replies.numpy().view(np.uint64)
+        for i in range(lo, hi):                                # rank r ends with the replies of ITS queries
+            ok &= bool(np.array_equal(mine[i - lo], full[i]))
+            ok &= s.client.process_response(p, indexes[i], mine[i - lo]) == s.item(indexes[i])
+    # the whole-selection-vector exchange (any d): every rank ends with every reply
+    sv_all = torch.empty((batch, p.dim_sum, 2, s.orc.k, 4096), dtype=torch.int64)
+    replies = torch.empty((batch, srv.db.reply_ct_count(), 2, s.orc.k, 4096), dtype=torch.int64)
+    D.run_batch_query_parallel(srv, sv_all, replies, dist, rank, world, comm)
+    allr = replies.numpy().view(np.uint64)
+    for i in range(batch):
+        ok &= bool(np.array_equal(allr[i], full[i]))
+    return ok
+
+
+def _worker(rank, world, port, d, dbsize, elem, batch, out_q, zero_pt=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        import sys
-        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-        from pir_fixtures import PirSetup
-        s = PirSetup(dbsize, elem, d, N=4096, plain_bits=24)      # same seeds on every rank
-        p = s.params
-        indexes = [(dbsize - 2 - 37 * i) % dbsize for i in range(batch)]
-        queries = [s.client.create_query_for(p, i) for i in indexes]
-        srv = OracleShardServer(s, rank, world)
-        srv.stage_batch(queries)
-        comm = D.Comm(dist, world)
-        assert not comm.device_native
-        D.check_sum_fits(max(s.orc.moduli[: s.orc.k]), world)
-        ok = True
-        lo, hi = D.owned_queries(batch, rank, world)
-        full = [s.orc.process_query(s.db_ntt, p.dimensions, queries[i], s.galois_keys)[1] for i in range(batch)]
-        if d == 2:
-            assert D.packed_exchange_supported(srv, dist, world, comm, torch, "cpu")
-            bufs = D.PackedBuffers(srv, batch, rank, world, torch, "cpu")
-            D.run_batch_rows_packed(srv, bufs, dist, rank, world, comm)
-            mine = bufs.replies.numpy().view(np.uint64)
-            for i in range(lo, hi):                                # rank r ends with the replies of ITS queries
-                ok &= bool(np.array_equal(mine[i - lo], full[i]))
-                ok &= s.client.process_response(p, indexes[i], mine[i - lo]) == s.item(indexes[i])
-        # the whole-selection-vector exchange (any d): every rank ends with every reply
-        sv_all = torch.empty((batch, p.dim_sum, 2, s.orc.k, 4096), dtype=torch.int64)
-        replies = torch.empty((batch, srv.db.reply_ct_count(), 2, s.orc.k, 4096), dtype=torch.int64)
-        D.run_batch_query_parallel(srv, sv_all, replies, dist, rank, world, comm)
-        allr = replies.numpy().view(np.uint64)
-        for i in range(batch):
-            ok &= bool(np.array_equal(allr[i], full[i]))
-        out_q.put((rank, ok))
+        out_q.put((rank, rows_step_check(rank, world, d, dbsize, elem, batch, zero_pt)))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("d,dbsize,elem,batch", [(2, 300, 288, 4), (1, 120, 288, 2)])
-def test_row_sharded_step_over_gloo(d, dbsize, elem, batch):
+@pytest.mark.parametrize("d,dbsize,elem,batch,zero_pt", [(2, 300, 288, 4, None), (1, 120, 288, 2, None),
+                                                         (2, 300, 288, 2, 1)],
+                         ids=["d2", "d1", "d2-zero-plaintext-in-rank0"])
+def test_row_sharded_step_over_gloo(d, dbsize, elem, batch, zero_pt):
     ctx = mp.get_context("spawn")
     out_q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, d, dbsize, elem, batch, out_q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, d, dbsize, elem, batch, out_q, zero_pt)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:

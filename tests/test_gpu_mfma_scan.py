@@ -48,19 +48,28 @@ def check_queries(s, srv, indexes, decode=True):
             assert s.client.process_response(s.params, idx, got) == s.item(idx)
 
 
-# (label, setup kwargs, expected digits, expected chunks, expected ksteps)
+# (label, setup kwargs, expected digits, expected chunks, expected ksteps, PIRGPU_SCAN_MFMA_WIDE or None)
 GEOMETRIES = [
     # N=4096, 36-bit primes -> 5 digits
-    ("L5 17x70 (2 k-steps, ragged tiles)", dict(dbsize=0, elem=2048, dims=[17, 70], N=4096, plain_bits=24), 5, 1, 2),
-    ("L5 33x9 (1 k-step)", dict(dbsize=0, elem=2048, dims=[33, 9], N=4096, plain_bits=24), 5, 1, 1),
-    ("L5 9x200 (2 column chunks)", dict(dbsize=3, elem=2048, dims=[9, 200], N=4096, plain_bits=24), 5, 2, 2),   # 13 column groups -> 2 equal chunks of 7 and 6 groups = 2 k-steps each
-    ("L5 d=3 4x4x40 (rows = 16)", dict(dbsize=1, elem=2048, dims=[4, 4, 40], N=4096, plain_bits=20), 5, 1, 1),
+    ("L5 17x70 (2 k-steps, ragged tiles)", dict(dbsize=0, elem=2048, dims=[17, 70], N=4096, plain_bits=24), 5, 1, 2, None),
+    ("L5 33x9 (1 k-step)", dict(dbsize=0, elem=2048, dims=[33, 9], N=4096, plain_bits=24), 5, 1, 1, None),
+    # 13 column groups = 4 k-steps: more than two waves per SIMD hold -> the 4-wave kernel, one chunk
+    ("L5 9x200 (wide kernel, 4 k-steps)", dict(dbsize=3, elem=2048, dims=[9, 200], N=4096, plain_bits=24), 5, 1, 4, None),
+    # the same matrix on the 8-wave kernel: 2 equal chunks of 7 and 6 groups = 2 k-steps each
+    ("L5 9x200 (8-wave kernel, 2 column chunks)", dict(dbsize=3, elem=2048, dims=[9, 200], N=4096, plain_bits=24), 5, 2, 2, "0"),
+    # narrow matrix forced onto the 4-wave kernel (3 k-steps is its smallest instantiation)
+    ("L5 17x150 (wide kernel forced, 3 k-steps)", dict(dbsize=5, elem=2048, dims=[17, 150], N=4096, plain_bits=24), 5, 1, 3, "1"),
+    # 31 column groups = 8 k-steps: wider than the 7 the 4-wave kernel holds -> 2 chunks of 16 / 15 groups, 4 k-steps each
+    ("L5 9x490 (wide kernel, 2 chunks of 4 k-steps)", dict(dbsize=1, elem=2048, dims=[9, 490], N=4096, plain_bits=24), 5, 2, 4, None),
+    ("L5 d=3 4x4x40 (rows = 16)", dict(dbsize=1, elem=2048, dims=[4, 4, 40], N=4096, plain_bits=20), 5, 1, 1, None),
 ]
 
 
-@pytest.mark.parametrize("label,kw,digits,chunks,ksteps", GEOMETRIES, ids=[g[0] for g in GEOMETRIES])
-def test_mfma_scan_geometries(label, kw, digits, chunks, ksteps):
+@pytest.mark.parametrize("label,kw,digits,chunks,ksteps,wide", GEOMETRIES, ids=[g[0] for g in GEOMETRIES])
+def test_mfma_scan_geometries(label, kw, digits, chunks, ksteps, wide, monkeypatch):
     kw = dict(kw)
+    if wide is not None:
+        monkeypatch.setenv("PIRGPU_SCAN_MFMA_WIDE", wide)
     s = setup_with_dims(kw.pop("dbsize"), kw.pop("elem"), kw.pop("dims"), **kw)
     db, srv = make(s)
     info = srv.scan_info()
@@ -80,6 +89,7 @@ def test_mfma_scan_geometries(label, kw, digits, chunks, ksteps):
 def test_single_query_through_chunked_mfma_scan(monkeypatch):
     """Matrices wider than one chunk scan single queries with the 64-bit kernels by default; forced onto the
     MFMA scan they fold the per-chunk partial sums (reduce_splits_kernel) to the same bits."""
+    monkeypatch.setenv("PIRGPU_SCAN_MFMA_WIDE", "0")   # 8-wave kernel: 13 column groups = 2 chunks
     s = setup_with_dims(3, 2048, [9, 200], N=4096, plain_bits=24)
     db, srv = make(s)
     assert srv.scan_info()["mfma"] and not srv.scan_info()["single_query_mfma"]
@@ -100,6 +110,18 @@ def test_mfma_scan_six_digits_n8192():
     db, srv = make(s)
     info = srv.scan_info()
     assert info["mfma"] and info["digits"] == 6 and info["ksteps"] == 3 and info["chunks"] == 1, info
+    check_queries(s, srv, [5, s.params.num_items - 1])
+    db.close()
+
+
+def test_mfma_scan_six_digits_wide_kernel_n8192():
+    # 17 column groups = 5 k-steps of 6 digits: the 4-wave kernel (one wave per SIMD, operands in VGPRs + AGPRs)
+    m = oracle.BFV_DEFAULT[8192]
+    s = setup_with_dims(2, 1024, [9, 270], N=8192, moduli=m[:3] + [m[4]],
+                        t=oracle.plain_modulus_batching(8192, 24))
+    db, srv = make(s)
+    info = srv.scan_info()
+    assert info["mfma"] and info["digits"] == 6 and info["ksteps"] == 5 and info["chunks"] == 1, info
     check_queries(s, srv, [5, s.params.num_items - 1])
     db.close()
 
@@ -246,7 +268,7 @@ def test_finalize_and_release_staging():
     assert e.value.code == pir_amd.StatusCode.FAILED_PRECONDITION
     db.close()
     # chunked geometry: releasing the staging copy moves single queries onto the MFMA scan as well
-    s = setup_with_dims(3, 2048, [9, 200], N=4096, plain_bits=24)
+    s = setup_with_dims(1, 2048, [9, 490], N=4096, plain_bits=24)
     db, srv = make(s)
     assert not srv.scan_info()["single_query_mfma"]
     db.finalize(release_staging=True)

@@ -1,0 +1,54 @@
+"""`python bench.py --gpus N` without a launcher environment starts its own N ranks (pir_amd/launcher.py): spawn and
+relay logic on CPU -- two gloo ranks running the row-sharded step with the oracle-backed server, a failing rank, and
+the fail-fast when more GPUs are requested than are visible."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+from pir_amd import launcher
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CHILD = os.path.join(HERE, "launcher_child.py")
+
+
+def test_spawn_two_ranks_relays_rank0_json(tmp_path):
+    out = tmp_path / "out.txt"
+    with open(out, "w") as fo:
+        rc = launcher.spawn_ranks([sys.executable, CHILD, "rows"], 2, check_devices=False, stdout=fo, timeout_s=600)
+    assert rc == 0
+    lines = [l for l in open(out).read().splitlines() if l.strip()]
+    assert len(lines) == 1                                  # exactly rank 0's line, nothing from rank 1
+    j = json.loads(lines[0])
+    assert j == {"n_gpus": 2, "ranks": 2, "backend": "gloo", "all_ranks_ok": True}
+
+
+def test_failing_rank_fails_the_job_and_stops_the_others(tmp_path):
+    out = tmp_path / "out.txt"
+    t0 = time.monotonic()
+    with open(out, "w") as fo, open(tmp_path / "err.txt", "w") as fe:
+        rc = launcher.spawn_ranks([sys.executable, CHILD, "fail"], 2, check_devices=False, stdout=fo, stderr=fe)
+    assert rc == 3
+    assert time.monotonic() - t0 < 30                       # rank 0 (sleeping 60 s) was terminated, not waited for
+    assert open(out).read().strip() == ""
+    assert "rank 1 exited with code 3" in open(tmp_path / "err.txt").read()
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """No GPU in the CPU test environment: --gpus 2 must fail fast with a clear message instead of running one rank."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["HIP_VISIBLE_DEVICES"] = ""                          # also on a GPU box: nothing visible
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 2
+    assert p.stdout.strip() == ""
+    assert "--gpus 2 requested but only 0 GPU(s) are visible" in p.stderr
+
+
+def test_launcher_environment_detection():
+    assert launcher.launched_by_a_launcher({"RANK": "0", "WORLD_SIZE": "2"})
+    assert not launcher.launched_by_a_launcher({"WORLD_SIZE": "2"})
+    assert not launcher.launched_by_a_launcher({})

@@ -20,11 +20,11 @@
  *     reference would have returned (3 InvalidArgument, 9 FailedPrecondition,
  *     12 Unimplemented, 13 Internal); pirgpu_last_error() gives the message;
  *   - one context drives one GPU; every entry point takes the context's lock
- *     for its own duration, and pirgpu_process_request holds it for the whole
- *     request (key installation + every query), so concurrent requests on one
- *     context are serialised as units.  Sequences the CALLER composes out of
- *     several calls (set keys + query, stage / run / fetch) are only atomic if
- *     the caller serialises them itself;
+ *     for its own duration, and pirgpu_process_request(s) holds it while a window of
+ *     requests is served (key lookup / installation + every query); requests that
+ *     arrive meanwhile are queued and served together afterwards.  Sequences the
+ *     CALLER composes out of several calls (set keys + query, stage / run / fetch)
+ *     are only atomic if the caller serialises them itself;
  *   - every result is a canonical residue in [0, q_j) and is bit-identical to
  *     the reference's SEAL CPU path on the same inputs.
  */
@@ -122,9 +122,36 @@ int pirgpu_check_ready(pirgpu_ctx* ctx);
 int pirgpu_db_read_plaintext(pirgpu_ctx* ctx, uint64_t pt_index, uint64_t* out);
 
 /* What SEALDeserialize<GaloisKeys> yields per request (reference server.cpp:46-48):
- * install the key for one Galois element.  Keys stay on the device until cleared. */
+ * install the key for one Galois element.  Keys stay on the device until cleared.
+ * (These two operate on key set slot 0, the default set of every query entry point.) */
 int pirgpu_set_galois_key(pirgpu_ctx* ctx, uint32_t galois_elt, const uint64_t* key);
 int pirgpu_clear_galois_keys(pirgpu_ctx* ctx);
+
+/* Per-client key sets.  In the reference the Galois keys are locals of one ProcessRequest call (server.cpp:46-48),
+ * so requests of different clients are independent; here up to `capacity` clients' keys stay resident in HBM
+ * (slots 1..capacity, least recently used evicted; slot 0 is the set above), every query names the slot it is
+ * switched with, and the queries of ONE batch group may use different slots (the key-switch kernels index the key
+ * of each query's client).
+ *   keyset_lookup   finds the resident set that was claimed with exactly these `id` bytes (the wire layer uses the
+ *                   serialized GaloisKeys object, any client identifier works); *slot = 0 when not resident.
+ *                   verify = 0 accepts a match of length + a sampled fingerprint only; the caller must then confirm
+ *                   with keyset_verify (byte-for-byte) before it releases a result computed with that slot.
+ *   keyset_claim    empties a free slot -- or the least recently used one, after waiting for the work in flight --
+ *                   and tags it with `id`; install the keys with keyset_set_key.  FailedPrecondition when every slot
+ *                   belongs to the requests currently being processed together.
+ *   keyset_release  empties a slot.
+ *   query_use_keyset  slot for pirgpu_process_query / query_run / expand / substitute (default 0).
+ *   batch_set_keysets one slot per staged query of the batch (after pirgpu_batch_stage, which resets them to 0).
+ *   keyset_stats    [0] resident sets, [1] keys uploaded so far, [2] evictions, [3] capacity. */
+int pirgpu_set_keyset_capacity(pirgpu_ctx* ctx, uint32_t capacity);
+int pirgpu_keyset_lookup(pirgpu_ctx* ctx, const uint8_t* id, size_t id_len, int verify, uint32_t* slot);
+int pirgpu_keyset_verify(pirgpu_ctx* ctx, uint32_t slot, const uint8_t* id, size_t id_len);
+int pirgpu_keyset_claim(pirgpu_ctx* ctx, const uint8_t* id, size_t id_len, uint32_t* slot);
+int pirgpu_keyset_release(pirgpu_ctx* ctx, uint32_t slot);
+int pirgpu_keyset_set_key(pirgpu_ctx* ctx, uint32_t slot, uint32_t galois_elt, const uint64_t* key);
+int pirgpu_query_use_keyset(pirgpu_ctx* ctx, uint32_t slot);
+int pirgpu_batch_set_keysets(pirgpu_ctx* ctx, const uint32_t* slots, uint32_t count);
+int pirgpu_keyset_stats(pirgpu_ctx* ctx, uint64_t stats[4]);
 
 /* PIRServer::processQuery minus (de)serialisation (reference server.cpp:173-195):
  * query = nq ciphertexts (coefficient form), reply = reply_count ciphertexts
@@ -229,6 +256,17 @@ int pirgpu_reply_copy_to_device(pirgpu_ctx* ctx, uint64_t* device_dst, uint64_t 
  * present, are parsed and validated like server.cpp:53-58.  Atomic on the context (see Conventions). */
 int pirgpu_process_request(pirgpu_ctx* ctx, const uint8_t* request, size_t request_len, uint8_t** response,
                            size_t* response_len);
+/* The same for n independent requests (different clients) served TOGETHER: every client's Galois keys are looked up
+ * among / installed into the resident key sets, all queries go through the batch pipeline as one batch (groups of 8
+ * expanded together, each query with its own client's keys, one database pass per group), responses[i] answers
+ * requests[i].  status[i] = what pirgpu_process_request would have returned for request i (a failing request does not
+ * affect the others); the return value is the first non-zero status.  Threads that call pirgpu_process_request
+ * concurrently on one context are combined the same way: requests that arrive while another is being served are
+ * served together by the next thread that gets the context.  Host staging buffers the wire layer uses (pinned). */
+int pirgpu_process_requests(pirgpu_ctx* ctx, uint32_t n, const uint8_t* const* requests, const size_t* request_lens,
+                            uint8_t** responses, size_t* response_lens, int* status);
+uint64_t* pirgpu_host_query_buffer(pirgpu_ctx* ctx, uint32_t queries);
+uint64_t* pirgpu_host_reply_buffer(pirgpu_ctx* ctx, uint32_t queries);
 void pirgpu_free(void* p);
 
 /* Measurement: mean duration of the phases of the pirgpu_query_run calls made since

@@ -85,6 +85,19 @@ SIGNATURES = {
     "pirgpu_batch_run_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "pirgpu_set_galois_key": (C.c_int, [C.c_void_p, C.c_uint32, u64p]),
     "pirgpu_clear_galois_keys": (C.c_int, [C.c_void_p]),
+    "pirgpu_set_keyset_capacity": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "pirgpu_keyset_lookup": (C.c_int, [C.c_void_p, u8p, C.c_size_t, C.c_int, C.POINTER(C.c_uint32)]),
+    "pirgpu_keyset_verify": (C.c_int, [C.c_void_p, C.c_uint32, u8p, C.c_size_t]),
+    "pirgpu_keyset_claim": (C.c_int, [C.c_void_p, u8p, C.c_size_t, C.POINTER(C.c_uint32)]),
+    "pirgpu_keyset_release": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "pirgpu_keyset_set_key": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, u64p]),
+    "pirgpu_query_use_keyset": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "pirgpu_batch_set_keysets": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]),
+    "pirgpu_keyset_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "pirgpu_process_requests": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    "pirgpu_host_query_buffer": (C.c_void_p, [C.c_void_p, C.c_uint32]),
+    "pirgpu_host_reply_buffer": (C.c_void_p, [C.c_void_p, C.c_uint32]),
     "pirgpu_process_query": (C.c_int, [C.c_void_p, u64p, C.c_uint32, u64p, C.c_uint64, u64p]),
     "pirgpu_reply_ct_count": (C.c_uint64, [C.c_void_p]),
     "pirgpu_expansion_ratio": (C.c_uint32, [C.c_void_p]),

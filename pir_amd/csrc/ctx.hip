@@ -57,6 +57,7 @@ enum Phase { PH_EXPAND = 0, PH_SVNTT, PH_SCAN, PH_UPPER, PH_FINAL, PH_COUNT };
 // bandwidth-bound scan of another).  Database, keys and tables are shared, read-only.
 struct Worker {
   hipStream_t stream = nullptr;
+  uint32_t keyset = 0;               // key set of the query this worker currently holds
   uint64_t *res_a = nullptr, *res_b = nullptr, *prod = nullptr, *dig = nullptr, *sv_ntt = nullptr;
   uint64_t* d_query = nullptr;
   uint32_t staged_nq = 0;
@@ -104,6 +105,16 @@ struct Stage {
   bool sel_f64 = false;   // the selectors are exact doubles (a lane's own expansion, pirgpu_ctx::sel_f64)
 };
 
+// One client's Galois keys on the device.  The reference deserialises the keys of every request into a local
+// (server.cpp:46-48), so they are per request, not server state; here up to keyset_cap sets stay resident (least
+// recently used evicted), slot 0 being the set the direct pirgpu_set_galois_key API installs.
+struct KeySet {
+  std::map<uint32_t, uint64_t*> keys;   // Galois element -> [k][2][k+1][N], device order, the flavour's element type
+  std::vector<uint8_t> blob;            // wire layer: the serialized GaloisKeys object these keys came from
+  uint64_t fingerprint = 0;             // sampled hash of `blob` (candidate selection before the full compare)
+  uint64_t last_use = 0;
+};
+
 struct pirgpu_ctx {
   pirgpu_params prm{};
   uint32_t N = 0, logN = 0, k = 0, d = 0;
@@ -130,10 +141,13 @@ struct pirgpu_ctx {
   uint64_t* d_db = nullptr;
   std::vector<uint8_t> loaded;  // per local plaintext
   uint64_t n_loaded = 0;
-  std::map<uint32_t, uint64_t*> keys;
+  std::vector<KeySet> keysets{1};           // resident key sets; [0] = pirgpu_set_galois_key's
+  uint32_t keyset_cap = 16;                 // slots the wire layer may use (pirgpu_set_keyset_capacity)
+  uint32_t cur_keyset = 0;                  // slot the single-query entry points use (pirgpu_query_use_keyset)
+  std::vector<uint32_t> batch_keysets;      // per staged query of the batch (all 0 unless pirgpu_batch_set_keysets)
+  uint64_t keyset_clock = 0, key_uploads = 0, keyset_evictions = 0;
+  uint64_t keyset_pin = UINT64_MAX;         // sets touched after this clock value belong to the requests being processed
   std::map<uint32_t, uint64_t*> xpow;       // shift -> NTT_j(x^(-shift)), [k][N] doubles (NTT-domain last expansion level)
-  bool keys_blob_valid = false;    // wire layer: the installed keys came from exactly this blob
-  std::vector<uint8_t> keys_blob;
 
   // workspace geometry (computed on first use) and the workers holding the buffers
   bool ws_ready = false;
@@ -186,6 +200,8 @@ struct pirgpu_ctx {
   bool staging_released = false;            // pirgpu_db_finalize(release): only the operand-layout copy is left
   std::vector<BatchLane> lanes;             // created on the first batch
   uint64_t groups_run = 0;
+  uint64_t *h_query = nullptr, *h_reply = nullptr;   // pinned host staging of the wire layer
+  size_t h_query_words = 0, h_reply_words = 0;
 
   bool prof = false;
   static constexpr int kMaxProfRuns = 256;
@@ -523,11 +539,26 @@ uint32_t galois_inverse(uint32_t g, uint32_t N) {
   return (uint32_t)r;
 }
 
-const uint64_t* find_key(pirgpu_ctx* c, uint32_t g) {
-  auto it = c->keys.find(g);
-  if (it == c->keys.end())
+const uint64_t* find_key(pirgpu_ctx* c, uint32_t slot, uint32_t g) {
+  if (slot >= c->keysets.size()) throw Fail{PIRGPU_INVALID_ARGUMENT, "key set slot out of range"};
+  auto& keys = c->keysets[slot].keys;
+  auto it = keys.find(g);
+  if (it == keys.end())
     throw Fail{PIRGPU_INTERNAL, "Galois key not present"};  // SEAL throws -> InternalError (server.cpp:72-74)
   return it->second;
+}
+
+// Keys for Galois element g of the B queries of a group (ksets[q] = key set slot of query q; nullptr: the context's
+// current slot for all).  One client -> B = 1, the kernels then index a single pointer.
+KeyPtrs keys_for(pirgpu_ctx* c, uint32_t g, const uint32_t* ksets, uint32_t B) {
+  KeyPtrs kp{};
+  bool same = true;
+  for (uint32_t q = 0; q < B; ++q) {
+    kp.p[q] = find_key(c, ksets ? ksets[q] : c->cur_keyset, g);
+    same = same && kp.p[q] == kp.p[0];
+  }
+  kp.B = same ? 1 : B;
+  return kp;
 }
 
 void record(pirgpu_ctx* c, Worker& w, int idx) {
@@ -572,7 +603,8 @@ const uint64_t* xpow_table(pirgpu_ctx* c, hipStream_t st, uint32_t shift) {
 // Levels: narrow ones digit -> products of all moduli -> combine; wide ones digit -> special-prime product -> data
 // products + combine in one kernel, the tree between two such levels in 5-byte polynomials (cur40).
 uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* res_b, uint64_t* dig, uint64_t* prod,
-                      uint32_t n, uint32_t B, const MfmaPtrs* sel_dst = nullptr, bool sel_f64 = false) {
+                      uint32_t n, uint32_t B, const MfmaPtrs* sel_dst = nullptr, bool sel_f64 = false,
+                      const uint32_t* ksets = nullptr) {
   const uint32_t N = c->N, k = c->k;
   if (n > N) throw Fail{PIRGPU_INVALID_ARGUMENT, "Cannot expand more items from a CT than poly modulus degree"};
   const uint32_t logm = hm::ceil_log2(n);
@@ -582,7 +614,7 @@ uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* 
   bool cur40 = false;   // `cur` holds 5-byte polynomials (between fused levels) instead of doubles
   for (uint32_t j = 0; j < logm; ++j) {
     const uint32_t g = (N >> j) + 1;
-    const uint64_t* key = find_key(c, g);
+    const KeyPtrs key = keys_for(c, g, ksets, B);   // per query of the group: its own client's key
     const uint32_t nodes = (1u << j) * B;
     const bool last_ntt = fuse_last && j + 1 == logm && c->last_level_ntt;
     const bool c0_in_digit = last_ntt && ks_digit_takes_c0(nodes);
@@ -629,7 +661,7 @@ uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* 
 
 uint64_t* expand_on_device(pirgpu_ctx* c, Worker& w, uint32_t n) {
   ensure_expansion_buffers(c, w);
-  return expand_core(c, w.stream, w.res_a, w.res_b, w.dig, w.prod, n, 1);
+  return expand_core(c, w.stream, w.res_a, w.res_b, w.dig, w.prod, n, 1, nullptr, false, &w.keyset);
 }
 
 // expansion of all staged query ciphertexts into sv_ntt (NTT form) -- reference
@@ -650,7 +682,7 @@ void expand_query_to_sv(pirgpu_ctx* c, Worker& w, const uint64_t* d_query, uint3
       HIP_TRY(launch_tree_convert(w.stream, c->dp, c->mode, d_query + (size_t)q * ctw, w.res_a, ctw, true));
       MfmaPtrs dst{};
       dst.p[0] = w.sv_ntt + produced * ctw;
-      uint64_t* res = expand_core(c, w.stream, w.res_a, w.res_b, w.dig, w.prod, n, 1, &dst);
+      uint64_t* res = expand_core(c, w.stream, w.res_a, w.res_b, w.dig, w.prod, n, 1, &dst, false, &w.keyset);
       if (res) HIP_TRY(c->ops->ct_ntt_fwd_oop(w.stream, c->mode, c->dp, k, res, w.sv_ntt + produced * ctw, n, true));
     }
     produced += n;
@@ -830,6 +862,7 @@ void run_staged(pirgpu_ctx* c, Worker& w, bool profile) {
     throw Fail{PIRGPU_INVALID_ARGUMENT,
                "Number of ciphertexts doesn't match number of items for oblivious expansion."};
   c->prof_cur = -1;
+  w.keyset = c->cur_keyset;
   // a batch group that borrowed this worker's selection vector (its multiply runs on a lane stream) must be done
   HIP_TRY(hipStreamWaitEvent(w.stream, w.ev_done, 0));
   if (profile) begin_profiled_run(c);
@@ -946,6 +979,7 @@ int pirgpu_create(const pirgpu_params* p, pirgpu_ctx** out) {
 
 void pirgpu_destroy(pirgpu_ctx* c) {
   if (!c) return;
+  pirgpu_wire_forget(c);
   if (c->stream) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
@@ -954,8 +988,11 @@ void pirgpu_destroy(pirgpu_ctx* c) {
     for (size_t i = 1; i < c->workers.size(); ++i)
       if (c->workers[i].stream) (void)hipStreamSynchronize(c->workers[i].stream);
   }
-  for (auto& kv : c->keys) (void)hipFree(kv.second);
+  for (KeySet& ks : c->keysets)
+    for (auto& kv : ks.keys) (void)hipFree(kv.second);
   for (void* p : c->allocs) (void)hipFree(p);
+  if (c->h_query) (void)hipHostFree(c->h_query);
+  if (c->h_reply) (void)hipHostFree(c->h_reply);
   for (auto& e : c->ev) (void)hipEventDestroy(e);
   for (Worker& w : c->workers) {
     if (w.ev_expanded) (void)hipEventDestroy(w.ev_expanded);
@@ -1179,45 +1216,241 @@ int pirgpu_db_read_plaintext(pirgpu_ctx* c, uint64_t pt_index, uint64_t* out) {
   });
 }
 
+// Uploads one Galois key into a key set slot (SEAL's NTT order at the boundary, device order in HBM).
+static void upload_key(pirgpu_ctx* c, uint32_t slot, uint32_t g, const uint64_t* key) {
+  if (slot >= c->keysets.size()) throw Fail{PIRGPU_INVALID_ARGUMENT, "key set slot out of range"};
+  if (!key || !(g & 1) || g >= 2 * c->N) throw Fail{PIRGPU_INVALID_ARGUMENT, "invalid Galois element"};
+  const size_t words = (size_t)c->k * 2 * (c->k + 1) * c->N;
+  auto& keys = c->keysets[slot].keys;
+  uint64_t* dev = nullptr;
+  auto it = keys.find(g);
+  if (it != keys.end()) {
+    // overwriting a key that queued work may still read: wait for it (never happens on the request path, where a
+    // slot is emptied -- after a drain -- before it is refilled)
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    sync_batch_streams(c);
+    dev = it->second;
+  } else {
+    HIP_TRY(hipMalloc((void**)&dev, words * 8));
+    keys[g] = dev;
+  }
+  uint64_t* stage = nullptr;
+  HIP_TRY(hipMalloc((void**)&stage, words * 8));
+  try {
+    HIP_TRY(hipMemcpyAsync(stage, key, words * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_ntt_reorder(c->stream, c->N, stage, dev, (uint64_t)c->k * 2 * (c->k + 1), true, c->mode != kNttInt));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  } catch (...) {
+    (void)hipFree(stage);
+    throw;
+  }
+  HIP_TRY(hipFree(stage));
+  ++c->key_uploads;
+}
+
+// Empties a slot; waits for everything in flight first (queued kernels may still read its keys).
+static void clear_keyset(pirgpu_ctx* c, uint32_t slot) {
+  KeySet& ks = c->keysets[slot];
+  if (!ks.keys.empty()) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    sync_batch_streams(c);
+    for (auto& kv : ks.keys) HIP_TRY(hipFree(kv.second));
+    ks.keys.clear();
+  }
+  ks.blob.clear();
+  ks.fingerprint = 0;
+}
+
+// cheap candidate filter before the byte-for-byte compare: length + 64 words sampled across the blob
+static uint64_t blob_fingerprint(const uint8_t* blob, size_t len) {
+  uint64_t h = 0xcbf29ce484222325ull ^ len;
+  const size_t words = len / 8, step = std::max<size_t>(1, words / 64);
+  for (size_t i = 0; i < words; i += step) {
+    uint64_t w;
+    memcpy(&w, blob + i * 8, 8);
+    h = (h ^ w) * 0x100000001b3ull;
+    h ^= h >> 29;
+  }
+  return h | 1;   // never 0 (0 = no blob)
+}
+
 int pirgpu_set_galois_key(pirgpu_ctx* c, uint32_t g, const uint64_t* key) {
   return guarded(c, [&]() -> int {
-    c->keys_blob_valid = false;
-    if (!key || !(g & 1) || g >= 2 * c->N) return fail(c, PIRGPU_INVALID_ARGUMENT, "invalid Galois element");
-    const size_t words = (size_t)c->k * 2 * (c->k + 1) * c->N;
-    uint64_t* dev = nullptr;
-    auto it = c->keys.find(g);
-    if (it != c->keys.end()) {
-      dev = it->second;
-    } else {
-      HIP_TRY(hipMalloc((void**)&dev, words * 8));
-      c->keys[g] = dev;
-    }
-    // keys arrive in SEAL's NTT order; HBM holds every NTT-domain array in device order
-    uint64_t* stage = nullptr;
-    HIP_TRY(hipMalloc((void**)&stage, words * 8));
-    try {
-      HIP_TRY(hipMemcpyAsync(stage, key, words * 8, hipMemcpyHostToDevice, c->stream));
-      HIP_TRY(launch_ntt_reorder(c->stream, c->N, stage, dev, (uint64_t)c->k * 2 * (c->k + 1), true,
-                                 c->mode != kNttInt));
-      HIP_TRY(hipStreamSynchronize(c->stream));
-    } catch (...) {
-      (void)hipFree(stage);
-      throw;
-    }
-    HIP_TRY(hipFree(stage));
+    c->keysets[0].blob.clear();
+    c->keysets[0].fingerprint = 0;
+    upload_key(c, 0, g, key);
     return PIRGPU_OK;
   });
 }
 
 int pirgpu_clear_galois_keys(pirgpu_ctx* c) {
   return guarded(c, [&]() -> int {
-    c->keys_blob_valid = false;
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    sync_batch_streams(c);
-    for (auto& kv : c->keys) HIP_TRY(hipFree(kv.second));
-    c->keys.clear();
+    clear_keyset(c, 0);
     return PIRGPU_OK;
   });
+}
+
+int pirgpu_set_keyset_capacity(pirgpu_ctx* c, uint32_t slots) {
+  return guarded(c, [&]() -> int {
+    if (slots < 1 || slots > 1024) return fail(c, PIRGPU_INVALID_ARGUMENT, "key set capacity must be in [1, 1024]");
+    while (c->keysets.size() > (size_t)slots + 1) {   // shrinking drops the highest slots
+      clear_keyset(c, (uint32_t)c->keysets.size() - 1);
+      c->keysets.pop_back();
+    }
+    c->keyset_cap = slots;
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_keyset_lookup(pirgpu_ctx* c, const uint8_t* blob, size_t len, int verify, uint32_t* slot) {
+  return guarded(c, [&]() -> int {
+    if (!slot || (!blob && len)) return fail(c, PIRGPU_INVALID_ARGUMENT, "null buffer");
+    *slot = 0;
+    if (!len) return PIRGPU_OK;
+    const uint64_t fp = blob_fingerprint(blob, len);
+    for (uint32_t i = 1; i < c->keysets.size(); ++i) {
+      KeySet& ks = c->keysets[i];
+      if (ks.fingerprint == fp && ks.blob.size() == len && (!verify || memcmp(ks.blob.data(), blob, len) == 0)) {
+        ks.last_use = ++c->keyset_clock;
+        *slot = i;
+        break;
+      }
+    }
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_keyset_verify(pirgpu_ctx* c, uint32_t slot, const uint8_t* blob, size_t len) {
+  if (!c || !blob) return 0;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  if (slot == 0 || slot >= c->keysets.size()) return 0;
+  const KeySet& ks = c->keysets[slot];
+  return ks.blob.size() == len && memcmp(ks.blob.data(), blob, len) == 0 ? 1 : 0;
+}
+
+int pirgpu_keyset_claim(pirgpu_ctx* c, const uint8_t* blob, size_t len, uint32_t* slot) {
+  return guarded(c, [&]() -> int {
+    if (!slot || (!blob && len)) return fail(c, PIRGPU_INVALID_ARGUMENT, "null buffer");
+    uint32_t pick = 0;
+    for (uint32_t i = 1; i < c->keysets.size() && !pick; ++i)
+      if (c->keysets[i].keys.empty() && c->keysets[i].blob.empty()) pick = i;
+    if (!pick && c->keysets.size() < (size_t)c->keyset_cap + 1) {
+      c->keysets.emplace_back();
+      pick = (uint32_t)c->keysets.size() - 1;
+    }
+    if (!pick) {   // least recently used, but never a set the requests being processed already refer to
+      uint64_t best = UINT64_MAX;
+      for (uint32_t i = 1; i < c->keysets.size(); ++i)
+        if (c->keysets[i].last_use < best && c->keysets[i].last_use <= c->keyset_pin) {
+          best = c->keysets[i].last_use;
+          pick = i;
+        }
+      if (!pick)
+        return fail(c, PIRGPU_FAILED_PRECONDITION,
+                    "every key set slot is in use by the requests being processed (pirgpu_set_keyset_capacity)");
+      clear_keyset(c, pick);
+      ++c->keyset_evictions;
+    }
+    KeySet& ks = c->keysets[pick];
+    if (len) {
+      ks.blob.assign(blob, blob + len);
+      ks.fingerprint = blob_fingerprint(blob, len);
+    }
+    ks.last_use = ++c->keyset_clock;
+    *slot = pick;
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_keyset_release(pirgpu_ctx* c, uint32_t slot) {
+  return guarded(c, [&]() -> int {
+    if (slot == 0 || slot >= c->keysets.size()) return fail(c, PIRGPU_INVALID_ARGUMENT, "key set slot out of range");
+    clear_keyset(c, slot);
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_keyset_set_key(pirgpu_ctx* c, uint32_t slot, uint32_t g, const uint64_t* key) {
+  return guarded(c, [&]() -> int {
+    upload_key(c, slot, g, key);
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_query_use_keyset(pirgpu_ctx* c, uint32_t slot) {
+  return guarded(c, [&]() -> int {
+    if (slot >= c->keysets.size()) return fail(c, PIRGPU_INVALID_ARGUMENT, "key set slot out of range");
+    c->cur_keyset = slot;
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_batch_set_keysets(pirgpu_ctx* c, const uint32_t* slots, uint32_t count) {
+  return guarded(c, [&]() -> int {
+    if (!slots || count != c->staged_count) return fail(c, PIRGPU_INVALID_ARGUMENT, "one key set slot per staged query");
+    for (uint32_t i = 0; i < count; ++i)
+      if (slots[i] >= c->keysets.size()) return fail(c, PIRGPU_INVALID_ARGUMENT, "key set slot out of range");
+    c->batch_keysets.assign(slots, slots + count);
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_keyset_stats(pirgpu_ctx* c, uint64_t stats[4]) {
+  return guarded(c, [&]() -> int {
+    if (!stats) return fail(c, PIRGPU_INVALID_ARGUMENT, "null buffer");
+    uint64_t resident = 0;
+    for (uint32_t i = 1; i < c->keysets.size(); ++i) resident += c->keysets[i].keys.empty() ? 0 : 1;
+    stats[0] = resident;
+    stats[1] = c->key_uploads;
+    stats[2] = c->keyset_evictions;
+    stats[3] = c->keyset_cap;
+    return PIRGPU_OK;
+  });
+}
+
+void pirgpu_keyset_pin_begin(pirgpu_ctx* c) {
+  if (!c) return;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  c->keyset_pin = c->keyset_clock;
+}
+void pirgpu_keyset_pin_end(pirgpu_ctx* c) {
+  if (!c) return;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  c->keyset_pin = UINT64_MAX;
+}
+
+// Pinned host staging owned by the context (the wire layer parses queries straight into it and serialises replies
+// straight out of it: H2D / D2H then run at link speed and asynchronously instead of through pageable bounce buffers).
+static uint64_t* host_buffer(pirgpu_ctx* c, uint64_t*& buf, size_t& cap, size_t words) {
+  if (words > cap) {
+    if (buf) {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      HIP_TRY(hipHostFree(buf));
+      buf = nullptr;
+      cap = 0;
+    }
+    HIP_TRY(hipHostMalloc((void**)&buf, words * 8, hipHostMallocDefault));
+    cap = words;
+  }
+  return buf;
+}
+
+uint64_t* pirgpu_host_query_buffer(pirgpu_ctx* c, uint32_t count) {
+  uint64_t* out = nullptr;
+  (void)guarded(c, [&]() -> int {
+    out = host_buffer(c, c->h_query, c->h_query_words, (size_t)std::max<uint32_t>(count, 1) * (c->dim_sum / c->N + 1) * c->ctw);
+    return PIRGPU_OK;
+  });
+  return out;
+}
+
+uint64_t* pirgpu_host_reply_buffer(pirgpu_ctx* c, uint32_t count) {
+  uint64_t* out = nullptr;
+  (void)guarded(c, [&]() -> int {
+    out = host_buffer(c, c->h_reply, c->h_reply_words, (size_t)std::max<uint32_t>(count, 1) * c->reply_cts * c->ctw);
+    return PIRGPU_OK;
+  });
+  return out;
 }
 
 int pirgpu_query_stage(pirgpu_ctx* c, const uint64_t* query, uint32_t nq) {
@@ -1301,6 +1534,7 @@ int pirgpu_expand(pirgpu_ctx* c, const uint64_t* ct, uint32_t num_items, uint64_
     const uint64_t m_max = std::min<uint64_t>(c->N, hm::next_power_two(std::max<uint32_t>(c->dim_sum, 1)));
     if (hm::next_power_two(num_items) > m_max)
       return fail(c, PIRGPU_INVALID_ARGUMENT, "num_items exceeds this context's expansion workspace");
+    w.keyset = c->cur_keyset;
     HIP_TRY(hipMemcpyAsync(w.res_b, ct, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(launch_tree_convert(c->stream, c->dp, c->mode, w.res_b, w.res_a, c->ctw, true));
     uint64_t* res = expand_on_device(c, w, num_items);
@@ -1323,6 +1557,7 @@ int pirgpu_expand_multi(pirgpu_ctx* c, const uint64_t* cts, uint32_t num_cts, ui
                   "Number of ciphertexts doesn't match number of items for oblivious expansion.");
     const uint64_t m_max = std::min<uint64_t>(c->N, hm::next_power_two(std::max<uint32_t>(c->dim_sum, 1)));
     uint64_t remaining = total_items, produced = 0;
+    w.keyset = c->cur_keyset;
     for (uint32_t q = 0; q < num_cts && remaining; ++q) {
       uint32_t n = (uint32_t)std::min<uint64_t>(remaining, c->N);
       if (hm::next_power_two(n) > m_max)
@@ -1347,7 +1582,9 @@ int pirgpu_substitute_power_x(pirgpu_ctx* c, uint64_t* ct, uint32_t power) {
     if (!ct) return fail(c, PIRGPU_INVALID_ARGUMENT, "null buffer");
     if (!(power & 1) || power >= 2 * c->N)  // SEAL: "Galois element is not valid" -> InternalError
       return fail(c, PIRGPU_INTERNAL, "Galois element is not valid");
-    const uint64_t* key = find_key(c, power);
+    KeyPtrs key{};
+    key.p[0] = find_key(c, c->cur_keyset, power);
+    key.B = 1;
     HIP_TRY(hipMemcpyAsync(w.res_b, ct, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(launch_tree_convert(c->stream, c->dp, c->mode, w.res_b, w.res_a, c->ctw, true));
     HIP_TRY(c->ops->ks_digit(c->stream, c->mode, c->dp, c->k, w.res_a, power, 1, w.dig, c->pack40, nullptr, false));
@@ -1432,6 +1669,7 @@ int pirgpu_batch_stage(pirgpu_ctx* c, const uint64_t* queries, uint32_t nq, uint
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->batch_count = count;
     c->staged_count = count;
+    c->batch_keysets.assign(count, 0);   // pirgpu_batch_set_keysets assigns other clients' key sets
     c->batch_valid = false;
     return PIRGPU_OK;
   });
@@ -1514,8 +1752,12 @@ static void expand_group_on_lane(pirgpu_ctx* c, BatchLane& ln, Worker* const* me
                              ctw * 8, B, hipMemcpyDeviceToDevice, ln.stream));
     HIP_TRY(launch_tree_convert(ln.stream, c->dp, c->mode, ln.res_b, ln.res_a, (uint64_t)B * ctw, true));
     MfmaPtrs dst{};
-    for (uint32_t q = 0; q < B; ++q) dst.p[q] = members[q]->sv_ntt + produced * ctw;
-    uint64_t* res = expand_core(c, ln.stream, ln.res_a, ln.res_b, ln.dig, ln.prod, slots, B, &dst, sel_f64);
+    uint32_t ksets[kMaxMfmaQueries];   // every query of the group is switched with its own client's keys
+    for (uint32_t q = 0; q < B; ++q) {
+      dst.p[q] = members[q]->sv_ntt + produced * ctw;
+      ksets[q] = first + q < c->batch_keysets.size() ? c->batch_keysets[first + q] : 0;
+    }
+    uint64_t* res = expand_core(c, ln.stream, ln.res_a, ln.res_b, ln.dig, ln.prod, slots, B, &dst, sel_f64, ksets);
     if (res) HIP_TRY(c->ops->ct_ntt_fwd_split(ln.stream, c->mode, c->dp, k, res, dst, B, (uint64_t)slots * B));
     produced += slots;
     remaining -= slots;
@@ -1714,6 +1956,7 @@ int pirgpu_batch_expand(pirgpu_ctx* c, uint32_t first, uint32_t count, uint64_t*
       HIP_TRY(hipMemcpyAsync(w.d_query, c->d_bquery + (size_t)(first + i) * qwords, qwords * 8,
                              hipMemcpyDeviceToDevice, w.stream));
       w.staged_nq = nq;
+      w.keyset = first + i < c->batch_keysets.size() ? c->batch_keysets[first + i] : 0;
       expand_query_to_sv(c, w, w.d_query, nq);
       HIP_TRY(hipMemcpyAsync(device_dst + (size_t)i * svwords, w.sv_ntt, svwords * 8, hipMemcpyDeviceToDevice,
                              w.stream));
@@ -1942,19 +2185,6 @@ int pirgpu_last_timings(pirgpu_ctx* c, float ms[6], uint32_t* runs) {
     memcpy(ms, c->timings, sizeof(c->timings));
     return PIRGPU_OK;
   });
-}
-
-int pirgpu_keys_blob_matches(pirgpu_ctx* c, const uint8_t* blob, size_t len) {
-  if (!c) return 0;
-  std::lock_guard<std::recursive_mutex> lock(c->mu);
-  return c->keys_blob_valid && c->keys_blob.size() == len && memcmp(c->keys_blob.data(), blob, len) == 0;
-}
-
-void pirgpu_keys_blob_set(pirgpu_ctx* c, const uint8_t* blob, size_t len) {
-  if (!c) return;
-  std::lock_guard<std::recursive_mutex> lock(c->mu);
-  c->keys_blob.assign(blob, blob + len);
-  c->keys_blob_valid = true;
 }
 
 uint32_t pirgpu_get_concurrency(pirgpu_ctx* c) { return c ? c->n_active : 0; }

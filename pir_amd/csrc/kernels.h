@@ -17,6 +17,14 @@ struct MfmaPtrs {                    // one pointer per query of a group (by-val
   const void* p[kMaxMfmaQueries];
 };
 
+// Galois keys for ONE Galois element of the queries expanded together: tree ciphertext n (= node * B + query) is
+// switched with p[n % B].  Keys are per request in the reference (PIRServer::ProcessRequest deserialises them into a
+// local, server.cpp:46-48), so the queries of one group may come from different clients; B = 1: one key for all.
+struct KeyPtrs {
+  const uint64_t* p[kMaxMfmaQueries];
+  uint32_t B;
+};
+
 // Kernels that contain an NTT, for one ring degree (ntt_kernels.hip is compiled once
 // per degree).  `mode` is an NttMode.
 struct NttOps {
@@ -39,7 +47,7 @@ struct NttOps {
                          uint32_t galois_elt, uint32_t nodes, uint64_t* dig, bool pack40, uint64_t* c0_out, bool tree40);
   // key-level moduli I_base .. I_base + I_count - 1 (all: 0, k + 1; the special prime alone: k, 1)
   hipError_t (*ks_mac_intt)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* dig,
-                            const uint64_t* key, uint32_t nodes, uint64_t* prod, bool pack40, uint32_t I_base,
+                            const KeyPtrs& key, uint32_t nodes, uint64_t* prod, bool pack40, uint32_t I_base,
                             uint32_t I_count);
   // n_queries queries in one launch: query q reads src + q * src_qstride, selectors svq.p[q], writes part + q * part_qstride;
   // sel_f64 (fp64 flavours): the selectors are canonical residues stored as exact doubles (lane-internal form)
@@ -63,13 +71,13 @@ struct NttOps {
   // (already in `prod`) + tree butterfly, tree_in -> tree_out (fp64 flavours); tin40 / tout40: that tree buffer holds
   // 5-byte polynomials (5 N bytes each, offset form) instead of doubles -- tout40 needs shift_pow < N / 16
   hipError_t (*ks_mac_combine)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* dig,
-                               const uint64_t* key, const uint64_t* prod, const uint64_t* tree_in, uint32_t galois_elt,
+                               const KeyPtrs& key, const uint64_t* prod, const uint64_t* tree_in, uint32_t galois_elt,
                                uint32_t nodes, uint32_t shift_pow, uint64_t* tree_out, bool pack40, bool tin40,
                                bool tout40);
   // last expansion level in the NTT domain (fp64 flavours): `prod` holds the special-prime products (ks_mac_intt with
   // I_base = k) and receives NTT(a_0); xpow = NTT_j(x^(-shift_pow)), [k][N] doubles; galois_inv = galois_elt^-1 mod 2N
   hipError_t (*ks_last_ntt)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* tree,
-                            const uint64_t* dig, const uint64_t* key, uint64_t* prod, const uint64_t* xpow,
+                            const uint64_t* dig, const KeyPtrs& key, uint64_t* prod, const uint64_t* xpow,
                             uint32_t galois_elt, uint32_t galois_inv, uint32_t shift_pow, uint32_t n_items, uint32_t B,
                             const MfmaPtrs& dst, uint32_t nodes, bool pack40, bool out_f64, bool c0_done);
 };

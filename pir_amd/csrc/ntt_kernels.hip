@@ -441,9 +441,8 @@ __device__ __forceinline__ void ks_mac_core(const DevParams* __restrict__ P, con
 // through ks_mac_combine_kernel instead.
 template <int MODE, bool P40>
 __global__ void __launch_bounds__(NT)
-ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ dig_raw,
-                   const uint64_t* __restrict__ key_raw, uint64_t* __restrict__ prod, uint32_t I_base,
-                   uint32_t I_count) {
+ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ dig_raw, KeyPtrs keys,
+                   uint64_t* __restrict__ prod, uint32_t I_base, uint32_t I_count) {
   using A = Arith<MODE>;
   using T = typename A::T;
   const uint32_t tid = threadIdx.x;
@@ -461,7 +460,7 @@ ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
   I += I_base;
   const typename A::Mod m = A::mod(P, I);
   T x[16];
-  ks_mac_core<MODE, P40>(P, dig_raw, key_raw, node, I, comp, tid, x);
+  ks_mac_core<MODE, P40>(P, dig_raw, keys.p[node % keys.B], node, I, comp, tid, x);   // the key of this node's query
   const size_t opoly = ((size_t)node * 2 + comp) * km + I;
   if constexpr (P40 && MODE != kNttInt) {
     uint8_t* out = reinterpret_cast<uint8_t*>(prod) + opoly * kPoly40;
@@ -492,7 +491,7 @@ ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
 template <int MODE, bool P40, bool TIN40 = false, bool TOUT40 = false>
 __global__ void __launch_bounds__(NT)
 ks_mac_combine_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ dig_raw,
-                      const uint64_t* __restrict__ key_raw, const uint64_t* __restrict__ prod,
+                      KeyPtrs keys, const uint64_t* __restrict__ prod,
                       const uint64_t* __restrict__ tree_in_raw, uint32_t galois_elt, uint32_t nodes, uint32_t shift_pow,
                       uint64_t* __restrict__ tree_out_raw) {
   using A = Arith<MODE>;
@@ -509,7 +508,7 @@ ks_mac_combine_kernel(const DevParams* __restrict__ P, const uint64_t* __restric
   }
   const typename A::Mod m = A::mod(P, j);
   double g[16];
-  ks_mac_core<MODE, P40>(P, dig_raw, key_raw, node, j, comp, tid, g);
+  ks_mac_core<MODE, P40>(P, dig_raw, keys.p[node % keys.B], node, j, comp, tid, g);
   {
     const double pf = P->p_f, half = P->p_half_f, pinv = P->p_inv_f[j];
     const size_t spoly = ((size_t)node * 2 + comp) * km + k;
@@ -717,7 +716,7 @@ __device__ __forceinline__ uint32_t galois_ntt_slot(uint32_t P, uint32_t g) {
 template <int MODE, bool P40, bool OUTF64 = false>
 __global__ void __launch_bounds__(NT)
 ks_last_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ dig_raw,
-                   const uint64_t* __restrict__ key_raw, const uint64_t* __restrict__ prod,
+                   KeyPtrs keys, const uint64_t* __restrict__ prod,
                    const double* __restrict__ xpow, uint32_t galois_elt, uint32_t galois_inv, uint32_t shift_pow,
                    uint32_t n_items, uint32_t B, MfmaPtrs dst) {
   using A = Arith<MODE>;
@@ -774,7 +773,7 @@ ks_last_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
     // the digit and key loads of one J to be in flight together (the MAC then costs more than the transform)
 #pragma unroll
     for (int e = 0; e < 16; ++e) x[e] = -x[e];
-    const double* key = reinterpret_cast<const double*>(key_raw);
+    const double* key = reinterpret_cast<const double*>(keys.p[node % keys.B]);   // the key of this node's query
     for (uint32_t J = 0; J < k; ++J) {
       const double* kj = key + (((size_t)J * 2 + comp) * km + j) * N;
       double d[16];
@@ -1224,7 +1223,7 @@ static hipError_t op_ks_digit(hipStream_t st, int mode, const DevParams* P, uint
 }
 
 static hipError_t op_ks_mac_intt(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* dig,
-                                 const uint64_t* key, uint32_t nodes, uint64_t* prod, bool pack40, uint32_t I_base,
+                                 const KeyPtrs& key, uint32_t nodes, uint64_t* prod, bool pack40, uint32_t I_base,
                                  uint32_t I_count) {
   const dim3 grid = nodes >= kWideLevel && nodes % 8 == 0 ? dim3(nodes * I_count * 2) : dim3(nodes, I_count, 2);
   if (pack40) {
@@ -1239,7 +1238,7 @@ static hipError_t op_ks_mac_intt(hipStream_t st, int mode, const DevParams* P, u
 
 // data residues of a level below the last, fused with the combine step (fp64 flavours)
 static hipError_t op_ks_mac_combine(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* dig,
-                                    const uint64_t* key, const uint64_t* prod, const uint64_t* tree_in,
+                                    const KeyPtrs& key, const uint64_t* prod, const uint64_t* tree_in,
                                     uint32_t galois_elt, uint32_t nodes, uint32_t shift_pow, uint64_t* tree_out,
                                     bool pack40, bool tin40, bool tout40) {
   const dim3 grid = nodes >= kWideLevel && nodes % 8 == 0 ? dim3(nodes * k * 2) : dim3(nodes, k, 2);
@@ -1291,7 +1290,7 @@ static hipError_t op_ks_last_level(hipStream_t st, int mode, const DevParams* P,
 
 // fp64 flavours: A_0 into the product buffer, then the NTT-domain last level
 static hipError_t op_ks_last_ntt(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* tree,
-                                 const uint64_t* dig, const uint64_t* key, uint64_t* prod, const uint64_t* xpow,
+                                 const uint64_t* dig, const KeyPtrs& key, uint64_t* prod, const uint64_t* xpow,
                                  uint32_t galois_elt, uint32_t galois_inv, uint32_t shift_pow, uint32_t n_items,
                                  uint32_t B, const MfmaPtrs& dst, uint32_t nodes, bool pack40, bool out_f64,
                                  bool c0_done) {

@@ -17,6 +17,12 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -134,115 +140,387 @@ int pirgpu_wire_validate_request(const pirgpu_params* params, const uint8_t* req
 // request can claim (query + reply staging grow with the batch); longer requests run as several batches.
 static const uint32_t kMaxRequestBatch = 64;
 
+}  // extern "C"
+
+namespace {
+
+// One pir.Request being served.  Requests of different clients that are in flight at the same time (threads calling
+// pirgpu_process_request concurrently, or one pirgpu_process_requests call) are served TOGETHER: their queries go through
+// the batch pipeline as one batch -- grouped expansion with every query switched by its own client's Galois keys, one
+// database pass per group of 8 -- instead of one after the other at the single-query rate.
+struct Job {
+  const uint8_t* request = nullptr;
+  size_t request_len = 0;
+  int rc = 0;
+  std::string err;
+  std::string out;            // serialized pir.Response
+  bool done = false;
+  // filled while serving
+  ParsedRequest pr;
+  uint32_t slot = 0;          // resident key set of this client
+  bool uniform = true;        // every query has the ciphertext count the dimensions call for (server.cpp:154)
+};
+
+struct Server {               // what serving needs to know about a context
+  pirgpu_ctx* ctx;
+  pirgpu_params prm;
+  Shape sh;
+  size_t ctw;
+  uint64_t n_reply;
+  uint32_t nq_expected;
+};
+
+// Response.reply (payload.proto:39-42) for one query: n ciphertexts, written straight into the response buffer
+void append_reply(std::string& out, const Shape& sh, const uint64_t* cts_words, uint64_t n, size_t ctw) {
+  const size_t ct_size = saved_ciphertext_size(sh);
+  std::string len_prefix;
+  put_varint(len_prefix, ct_size);
+  const size_t per_ct = 1 + len_prefix.size() + ct_size;     // tag + length + object
+  out.push_back((char)((1 << 3) | 2));                        // Response.reply = 1, length-delimited
+  put_varint(out, n * per_ct);
+  for (uint64_t i = 0; i < n; ++i) {
+    out.push_back((char)((1 << 3) | 2));                      // Ciphertexts.ct = 1
+    out.append(len_prefix);
+    append_ciphertext(out, sh, cts_words + i * ctw);
+  }
+}
+
+// SEALDeserialize<GaloisKeys> (server.cpp:46-48) with the device-resident key cache: a client that
+// repeats its (multi-MB) key object byte for byte finds its keys resident; a new client's keys are parsed, validated
+// as a whole (a malformed object must not leave half-installed keys behind) and uploaded into a free or the least
+// recently used slot.  `speculative`: accept a resident set on its fingerprint alone -- the caller verifies the bytes
+// (pirgpu_keyset_verify) while the GPU already works and discards the result on a mismatch.
+void resolve_keys(const Server& sv, Job& job, bool speculative, bool* unverified) {
+  if (unverified) *unverified = false;
+  uint32_t slot = 0;
+  int rc = 0;
+  if (job.pr.galois_keys_len) {
+    rc = pirgpu_keyset_lookup(sv.ctx, job.pr.galois_keys, job.pr.galois_keys_len, speculative ? 0 : 1, &slot);
+    if (rc) throw Err{rc, pirgpu_last_error(sv.ctx)};
+  }
+  if (slot) {
+    if (unverified) *unverified = speculative;
+    job.slot = slot;
+    return;
+  }
+  // empty bytes -> load throws -> InvalidArgument, like the reference
+  std::vector<std::pair<uint32_t, std::vector<uint64_t>>> parsed;
+  const size_t key_words = (size_t)sv.sh.k * 2 * (sv.sh.k + 1) * sv.sh.N;
+  load_kswitch_keys(sv.sh, job.pr.galois_keys, job.pr.galois_keys_len, [&](uint64_t index, const uint64_t* key) {
+    parsed.emplace_back((uint32_t)(2 * index + 1), std::vector<uint64_t>(key, key + key_words));
+  });
+  rc = pirgpu_keyset_claim(sv.ctx, job.pr.galois_keys, job.pr.galois_keys_len, &slot);
+  if (rc) throw Err{rc, pirgpu_last_error(sv.ctx)};
+  for (auto& kv : parsed) {
+    rc = pirgpu_keyset_set_key(sv.ctx, slot, kv.first, kv.second.data());
+    if (rc) {
+      const std::string msg = pirgpu_last_error(sv.ctx);
+      (void)pirgpu_keyset_release(sv.ctx, slot);
+      throw Err{rc, msg};
+    }
+  }
+  job.slot = slot;
+}
+
+// One query through the single-query path (lowest latency; also reports a wrong ciphertext count at the offending
+// query like the reference, server.cpp:154-158).  Query parsed into pinned staging, reply serialised out of it.
+// `while_running` (optional) is host work done between enqueueing the kernels and waiting for the reply.
+void run_single(const Server& sv, Job& job, const std::pair<const uint8_t*, size_t>& qm,
+                const std::function<void()>& while_running = nullptr) {
+  uint64_t* hq = pirgpu_host_query_buffer(sv.ctx, 1);
+  uint64_t* hr = pirgpu_host_reply_buffer(sv.ctx, 1);
+  if (!hq || !hr) throw Err{PIRGPU_INTERNAL, pirgpu_last_error(sv.ctx)};
+  const uint32_t nq = load_query_into(sv.sh, qm.first, qm.second, hq, sv.nq_expected);
+  int rc = pirgpu_query_use_keyset(sv.ctx, job.slot);
+  uint64_t got = 0;
+  if (!rc) rc = pirgpu_query_stage(sv.ctx, hq, nq);
+  if (!rc) rc = pirgpu_query_run(sv.ctx);      // asynchronous: every kernel of the path is queued
+  const std::string msg = rc ? pirgpu_last_error(sv.ctx) : "";
+  (void)pirgpu_query_use_keyset(sv.ctx, 0);
+  if (rc) throw Err{rc, msg};
+  if (while_running) while_running();
+  rc = pirgpu_query_fetch(sv.ctx, hr, sv.n_reply, &got);
+  if (rc) throw Err{rc, pirgpu_last_error(sv.ctx)};
+  append_reply(job.out, sv.sh, hr, got, sv.ctw);
+}
+
+void fail_job(Job& job, int code, const std::string& msg) {
+  job.rc = code;
+  job.err = msg;
+  job.out.clear();
+}
+
+// Serves a window of requests under the context's request lock.
+void serve_window(const Server& sv, Job* const* jobs, size_t n) {
+  // (1) parse, resolve keys, validate relin keys -- per request; a failing request does not affect the others
+  uint32_t total_queries = 0;
+  bool unverified = false;
+  const bool lone = n == 1;
+  for (size_t i = 0; i < n; ++i) {
+    Job& job = *jobs[i];
+    if (job.rc) continue;
+    try {
+      job.pr = parse_request(job.request, job.request_len);
+      // a lone single-query request starts on a fingerprint match and verifies the key bytes under the GPU work
+      const bool spec = lone && job.pr.queries.size() == 1;
+      resolve_keys(sv, job, spec, spec ? &unverified : nullptr);
+      // SEALDeserialize<RelinKeys> when present (server.cpp:53-58): only CT-multiplication mode uses them, but a
+      // malformed non-empty field is InvalidArgument in the reference, so it is parsed and validated here too
+      if (job.pr.relin_keys_len) load_kswitch_keys(sv.sh, job.pr.relin_keys, job.pr.relin_keys_len, nullptr);
+      total_queries += (uint32_t)job.pr.queries.size();
+    } catch (const Err& e) {
+      fail_job(job, e.code, e.msg);
+    } catch (const std::exception& e) {
+      fail_job(job, PIRGPU_INTERNAL, e.what());
+    }
+  }
+  // (2) one query in the whole window: the single-query path
+  if (total_queries == 1) {
+    for (size_t i = 0; i < n; ++i) {
+      Job& job = *jobs[i];
+      if (job.rc || job.pr.queries.empty()) continue;
+      try {
+        bool verified = true;
+        job.out.reserve(sv.n_reply * (saved_ciphertext_size(sv.sh) + 16) + 16);
+        run_single(sv, job, job.pr.queries[0], [&]() {   // the byte-for-byte key compare runs under the GPU work
+          if (unverified) verified = pirgpu_keyset_verify(sv.ctx, job.slot, job.pr.galois_keys, job.pr.galois_keys_len) != 0;
+        });
+        if (!verified) {
+          // same fingerprint, different bytes: not this client's keys after all -- install them and run again
+          job.out.clear();
+          resolve_keys(sv, job, false, nullptr);
+          run_single(sv, job, job.pr.queries[0]);
+        }
+      } catch (const Err& e) {
+        fail_job(job, e.code, e.msg);
+      } catch (const std::exception& e) {
+        fail_job(job, PIRGPU_INTERNAL, e.what());
+      }
+    }
+    return;
+  }
+  // (3) several queries: the batch pipeline in chunks of <= kMaxRequestBatch, every query with its client's key set.
+  // Requests whose queries do not all have the expected ciphertext count take the sequential path, which reports the
+  // error at the offending query like the reference does (nothing of theirs has run on the device at that point).
+  struct Item { Job* job; uint32_t qi; };
+  std::vector<Item> items;
+  for (size_t i = 0; i < n; ++i) {
+    Job& job = *jobs[i];
+    if (job.rc) continue;
+    for (uint32_t q = 0; q < job.pr.queries.size(); ++q) items.push_back({&job, q});
+  }
+  const uint32_t before = pirgpu_get_concurrency(sv.ctx);
+  int rc = pirgpu_set_concurrency(sv.ctx, std::max<uint32_t>(before, std::min<uint32_t>((uint32_t)items.size(), 16)));
+  if (rc) {
+    const std::string msg = pirgpu_last_error(sv.ctx);
+    for (size_t i = 0; i < n; ++i)
+      if (!jobs[i]->rc) fail_job(*jobs[i], rc, msg);
+    return;
+  }
+  const size_t qwords = (size_t)sv.nq_expected * sv.ctw, rwords = (size_t)sv.n_reply * sv.ctw;
+  size_t pos = 0;
+  std::vector<uint32_t> slots;
+  while (pos < items.size()) {
+    uint64_t* hq = pirgpu_host_query_buffer(sv.ctx, kMaxRequestBatch);
+    uint64_t* hr = pirgpu_host_reply_buffer(sv.ctx, kMaxRequestBatch);
+    std::vector<Item> chunk;
+    slots.clear();
+    while (pos < items.size() && chunk.size() < kMaxRequestBatch) {
+      Item it = items[pos++];
+      Job& job = *it.job;
+      if (job.rc || !job.uniform) continue;
+      try {
+        if (!hq || !hr) throw Err{PIRGPU_INTERNAL, pirgpu_last_error(sv.ctx)};
+        const auto& qm = job.pr.queries[it.qi];
+        const uint32_t nq = load_query_into(sv.sh, qm.first, qm.second, hq + chunk.size() * qwords, sv.nq_expected);
+        if (nq != sv.nq_expected) {
+          job.uniform = false;     // sequential path below (its earlier queries are recomputed there: error path only)
+          continue;
+        }
+        chunk.push_back(it);
+        slots.push_back(job.slot);
+      } catch (const Err& e) {
+        fail_job(job, e.code, e.msg);
+      } catch (const std::exception& e) {
+        fail_job(job, PIRGPU_INTERNAL, e.what());
+      }
+    }
+    // queries of requests that failed or turned non-uniform while the chunk was being filled are dropped from it
+    size_t keep = 0;
+    for (size_t i = 0; i < chunk.size(); ++i) {
+      if (chunk[i].job->rc || !chunk[i].job->uniform) continue;
+      if (keep != i) {
+        memmove(hq + keep * qwords, hq + i * qwords, qwords * 8);
+        chunk[keep] = chunk[i];
+        slots[keep] = slots[i];
+      }
+      ++keep;
+    }
+    chunk.resize(keep);
+    slots.resize(keep);
+    if (chunk.empty()) continue;
+    const uint32_t count = (uint32_t)chunk.size();
+    rc = pirgpu_batch_stage(sv.ctx, hq, sv.nq_expected, count);
+    if (!rc) rc = pirgpu_batch_set_keysets(sv.ctx, slots.data(), count);
+    if (!rc) rc = pirgpu_batch_run(sv.ctx);
+    uint64_t got = 0;
+    if (!rc) rc = pirgpu_batch_fetch(sv.ctx, hr, (uint64_t)count * sv.n_reply, &got);
+    if (rc) {
+      const std::string msg = pirgpu_last_error(sv.ctx);
+      for (auto& it : chunk)
+        if (!it.job->rc) fail_job(*it.job, rc, msg);
+      continue;
+    }
+    // replies in request order: a request's queries are consecutive items, so appending in item order keeps
+    // reply[i] answering query[i] (server.cpp:60-63)
+    for (uint32_t i = 0; i < count; ++i)
+      if (!chunk[i].job->rc && chunk[i].job->uniform) append_reply(chunk[i].job->out, sv.sh, hr + (size_t)i * rwords, sv.n_reply, sv.ctw);
+  }
+  (void)pirgpu_set_concurrency(sv.ctx, before);
+  // sequential path for the requests with a wrong ciphertext count somewhere
+  for (size_t i = 0; i < n; ++i) {
+    Job& job = *jobs[i];
+    if (job.rc || job.uniform) continue;
+    job.out.clear();
+    try {
+      for (auto& qm : job.pr.queries) run_single(sv, job, qm);
+    } catch (const Err& e) {
+      fail_job(job, e.code, e.msg);
+    } catch (const std::exception& e) {
+      fail_job(job, PIRGPU_INTERNAL, e.what());
+    }
+  }
+}
+
+// Serves `n` requests: windows of at most `capacity` clients (so that every client's key set of a window can be
+// resident at once) and kMaxRequestBatch queries' worth of requests.
+void serve(pirgpu_ctx* ctx, Job* const* jobs, size_t n) {
+  Server sv{};
+  sv.ctx = ctx;
+  if (pirgpu_get_params(ctx, &sv.prm)) {
+    for (size_t i = 0; i < n; ++i) fail_job(*jobs[i], PIRGPU_INVALID_ARGUMENT, "invalid context");
+    return;
+  }
+  sv.sh = make_shape(sv.prm);
+  sv.ctw = (size_t)2 * sv.sh.k * sv.sh.N;
+  sv.n_reply = pirgpu_reply_ct_count(ctx);
+  uint64_t dim_sum = 0;
+  for (uint32_t l = 0; l < sv.prm.num_dimensions; ++l) dim_sum += sv.prm.dimensions[l];
+  sv.nq_expected = (uint32_t)(dim_sum / sv.sh.N + 1);  // server.cpp:154
+  // One window = one critical section on the context (the batch staging, the lanes and the key set slots are
+  // context state); PIRServer::ProcessRequest is const and re-entrant in the reference because everything is local.
+  pirgpu_request_lock(ctx);
+  struct Unlock {
+    pirgpu_ctx* c;
+    ~Unlock() {
+      pirgpu_keyset_pin_end(c);
+      pirgpu_request_unlock(c);
+    }
+  } unlock{ctx};
+  uint64_t stats[4] = {0, 0, 0, 16};
+  (void)pirgpu_keyset_stats(ctx, stats);
+  const size_t window = std::max<size_t>(1, std::min<size_t>(stats[3], kMaxRequestBatch));
+  for (size_t first = 0; first < n; first += window) {
+    pirgpu_keyset_pin_begin(ctx);   // key sets touched from here on are not evicted until the window is done
+    serve_window(sv, jobs + first, std::min(window, n - first));
+  }
+}
+
+int finish(pirgpu_ctx* ctx, Job& job, uint8_t** response, size_t* response_len) {
+  if (job.rc) {
+    pirgpu_set_error(ctx, job.err.c_str());   // on the CALLING thread: pirgpu_last_error is per thread
+    return job.rc;
+  }
+  uint8_t* buf = (uint8_t*)malloc(job.out.size() ? job.out.size() : 1);
+  if (!buf) return PIRGPU_INTERNAL;
+  memcpy(buf, job.out.data(), job.out.size());
+  *response = buf;
+  *response_len = job.out.size();
+  return PIRGPU_OK;
+}
+
+// Requests that arrive while another thread is serving are queued and served together by whichever thread gets the
+// context next (flat combining): no extra latency when the server is idle, cross-client batching under load.
+struct Combiner {
+  std::mutex m;
+  std::condition_variable cv;
+  std::deque<Job*> pending;
+  bool leader = false;
+};
+std::mutex g_combiners_mu;
+std::map<pirgpu_ctx*, std::shared_ptr<Combiner>> g_combiners;
+
+std::shared_ptr<Combiner> combiner_for(pirgpu_ctx* ctx) {
+  std::lock_guard<std::mutex> lock(g_combiners_mu);
+  auto& p = g_combiners[ctx];
+  if (!p) p = std::make_shared<Combiner>();
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+void pirgpu_wire_forget(pirgpu_ctx* ctx) {
+  std::lock_guard<std::mutex> lock(g_combiners_mu);
+  g_combiners.erase(ctx);
+}
+
 int pirgpu_process_request(pirgpu_ctx* ctx, const uint8_t* request, size_t request_len, uint8_t** response,
                            size_t* response_len) {
   if (!ctx || (!request && request_len) || !response || !response_len) return PIRGPU_INVALID_ARGUMENT;
   *response = nullptr;
   *response_len = 0;
-  pirgpu_params prm;
-  if (pirgpu_get_params(ctx, &prm)) return PIRGPU_INVALID_ARGUMENT;
-  const Shape sh = make_shape(prm);
-  const size_t ctw = (size_t)2 * sh.k * sh.N;
-  // One request = one critical section on the context: the installed Galois keys are context state, so
-  // two threads serving different clients must not interleave "install keys" and "run queries"
-  // (PIRServer::ProcessRequest is const and re-entrant in the reference because its keys are locals).
-  pirgpu_request_lock(ctx);
-  struct Unlock {
-    pirgpu_ctx* c;
-    ~Unlock() { pirgpu_request_unlock(c); }
-  } unlock{ctx};
-  try {
-    ParsedRequest pr = parse_request(request, request_len);
-    // --- SEALDeserialize<GaloisKeys> (server.cpp:46-48): empty bytes -> load throws -> InvalidArgument.
-    // The reference re-parses the keys on every request; here a client that repeats its (multi-MB)
-    // key blob byte for byte keeps the device-resident keys of its previous request.
-    int rc = 0;
-    if (!pr.galois_keys_len || !pirgpu_keys_blob_matches(ctx, pr.galois_keys, pr.galois_keys_len)) {
-      // parse and validate the whole object first: a malformed blob must not leave half-installed keys behind
-      std::vector<std::pair<uint32_t, std::vector<uint64_t>>> parsed;
-      const size_t key_words = (size_t)sh.k * 2 * (sh.k + 1) * sh.N;
-      load_kswitch_keys(sh, pr.galois_keys, pr.galois_keys_len, [&](uint64_t index, const uint64_t* key) {
-        parsed.emplace_back((uint32_t)(2 * index + 1), std::vector<uint64_t>(key, key + key_words));
-      });
-      rc = pirgpu_clear_galois_keys(ctx);
-      if (rc) throw Err{rc, pirgpu_last_error(ctx)};
-      for (auto& kv : parsed) {
-        rc = pirgpu_set_galois_key(ctx, kv.first, kv.second.data());
-        if (rc) throw Err{rc, pirgpu_last_error(ctx)};
+  Job job;
+  job.request = request;
+  job.request_len = request_len;
+  std::shared_ptr<Combiner> cb = combiner_for(ctx);
+  {
+    std::unique_lock<std::mutex> lk(cb->m);
+    cb->pending.push_back(&job);
+    while (!job.done) {
+      if (cb->leader) {
+        cb->cv.wait(lk);
+        continue;
       }
-      pirgpu_keys_blob_set(ctx, pr.galois_keys, pr.galois_keys_len);
+      // lead: serve what is queued (this thread's own request is in there) and hand over
+      cb->leader = true;
+      std::vector<Job*> batch;
+      while (!cb->pending.empty() && batch.size() < kMaxRequestBatch) {
+        batch.push_back(cb->pending.front());
+        cb->pending.pop_front();
+      }
+      lk.unlock();
+      serve(ctx, batch.data(), batch.size());
+      lk.lock();
+      for (Job* j : batch) j->done = true;
+      cb->leader = false;
+      cb->cv.notify_all();
     }
-    // --- SEALDeserialize<RelinKeys> when present (server.cpp:53-58): only CT-multiplication mode uses them,
-    // but a malformed non-empty field is InvalidArgument in the reference, so it is parsed and validated here too.
-    if (pr.relin_keys_len) load_kswitch_keys(sh, pr.relin_keys, pr.relin_keys_len, nullptr);
-    // --- per query: LoadCiphertexts -> processQuery -> SaveCiphertexts (server.cpp:60-63,173-195)
-    const uint64_t n_reply = pirgpu_reply_ct_count(ctx);
-    uint64_t dim_sum = 0;
-    for (uint32_t l = 0; l < prm.num_dimensions; ++l) dim_sum += prm.dimensions[l];
-    const uint32_t nq_expected = (uint32_t)(dim_sum / sh.N + 1);  // server.cpp:154
-    std::vector<uint64_t> reply, qbuf;
-    std::string out;
-    auto append_reply = [&](const uint64_t* cts_words, uint64_t n) {
-      std::string cts;
-      for (uint64_t i = 0; i < n; ++i) put_bytes_field(cts, 1, save_ciphertext(sh, cts_words + i * ctw));
-      put_bytes_field(out, 1, cts);  // Response.reply (payload.proto:39-42)
-    };
-    // Several queries in one request (the loop of server.cpp:60-63) run through the batch pipeline (grouped
-    // expansion, shared database passes) when every query has the ciphertext count the dimensions call for;
-    // otherwise the sequential path reports the error at the offending query like the reference does
-    // (nothing has run on the device at that point: parsing is host work).
-    bool batched = false;
-    if (pr.queries.size() > 1) {
-      std::vector<uint64_t> all;
-      bool uniform = true;
-      for (size_t i = 0; i < pr.queries.size() && uniform; ++i) {
-        const uint32_t nq = load_query(sh, pr.queries[i].first, pr.queries[i].second, qbuf);
-        uniform = nq == nq_expected;
-        if (uniform) all.insert(all.end(), qbuf.begin(), qbuf.end());
-      }
-      if (uniform) {
-        const uint32_t total = (uint32_t)pr.queries.size();
-        const uint32_t before = pirgpu_get_concurrency(ctx);
-        rc = pirgpu_set_concurrency(ctx, std::max<uint32_t>(before, std::min<uint32_t>(total, 16)));
-        for (uint32_t first = 0; first < total && !rc; first += kMaxRequestBatch) {
-          const uint32_t count = std::min<uint32_t>(kMaxRequestBatch, total - first);
-          rc = pirgpu_batch_stage(ctx, all.data() + (size_t)first * nq_expected * ctw, nq_expected, count);
-          if (!rc) rc = pirgpu_batch_run(ctx);
-          reply.resize((size_t)count * n_reply * ctw);
-          uint64_t got = 0;
-          if (!rc) rc = pirgpu_batch_fetch(ctx, reply.data(), (uint64_t)count * n_reply, &got);
-          if (rc) break;
-          for (uint32_t i = 0; i < count; ++i) append_reply(reply.data() + (size_t)i * n_reply * ctw, n_reply);
-        }
-        const std::string msg = rc ? pirgpu_last_error(ctx) : "";
-        (void)pirgpu_set_concurrency(ctx, before);
-        if (rc) throw Err{rc, msg};
-        batched = true;
-      }
-    }
-    if (!batched) {
-      reply.resize(n_reply * ctw);
-      for (auto& qm : pr.queries) {
-        const uint32_t nq = load_query(sh, qm.first, qm.second, qbuf);
-        uint64_t got = 0;
-        rc = pirgpu_process_query(ctx, qbuf.data(), nq, reply.data(), n_reply, &got);
-        if (rc) throw Err{rc, pirgpu_last_error(ctx)};
-        append_reply(reply.data(), got);
-      }
-    }
-    uint8_t* buf = (uint8_t*)malloc(out.size() ? out.size() : 1);
-    if (!buf) return PIRGPU_INTERNAL;
-    memcpy(buf, out.data(), out.size());
-    *response = buf;
-    *response_len = out.size();
-    return PIRGPU_OK;
-  } catch (const Err& e) {
-    pirgpu_set_error(ctx, e.msg.c_str());
-    return e.code;
-  } catch (const std::exception& e) {
-    pirgpu_set_error(ctx, e.what());
-    return PIRGPU_INTERNAL;
   }
+  return finish(ctx, job, response, response_len);
+}
+
+int pirgpu_process_requests(pirgpu_ctx* ctx, uint32_t n, const uint8_t* const* requests, const size_t* request_lens,
+                            uint8_t** responses, size_t* response_lens, int* status) {
+  if (!ctx || (n && (!requests || !request_lens || !responses || !response_lens || !status))) return PIRGPU_INVALID_ARGUMENT;
+  std::vector<Job> jobs(n);
+  std::vector<Job*> ptrs(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    responses[i] = nullptr;
+    response_lens[i] = 0;
+    jobs[i].request = requests[i];
+    jobs[i].request_len = request_lens[i];
+    ptrs[i] = &jobs[i];
+    if (!requests[i] && request_lens[i]) fail_job(jobs[i], PIRGPU_INVALID_ARGUMENT, "null request");
+  }
+  serve(ctx, ptrs.data(), n);
+  int worst = PIRGPU_OK;
+  for (uint32_t i = 0; i < n; ++i) {
+    status[i] = finish(ctx, jobs[i], &responses[i], &response_lens[i]);
+    if (status[i] && !worst) worst = status[i];
+  }
+  return worst;
 }
 
 }  // extern "C"

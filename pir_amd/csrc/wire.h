@@ -20,11 +20,13 @@ int pirgpu_wire_load_kswitch_key(const struct pirgpu_params* params, const uint8
 struct pirgpu_params;
 int pirgpu_wire_validate_request(const struct pirgpu_params* params, const uint8_t* request, size_t request_len,
                                  uint32_t* n_queries);
-// Device-resident Galois key cache: the serialized key blob the installed keys came from
-// (forgotten by pirgpu_set_galois_key / pirgpu_clear_galois_keys); compared byte for byte.
+// Key sets touched between pin_begin and pin_end belong to the requests being processed together: pirgpu_keyset_claim
+// does not evict them.
 struct pirgpu_ctx;
-int pirgpu_keys_blob_matches(struct pirgpu_ctx* ctx, const uint8_t* blob, size_t len);
-void pirgpu_keys_blob_set(struct pirgpu_ctx* ctx, const uint8_t* blob, size_t len);
+void pirgpu_keyset_pin_begin(struct pirgpu_ctx* ctx);
+void pirgpu_keyset_pin_end(struct pirgpu_ctx* ctx);
+// Drops the wire layer's per-context state (called by pirgpu_destroy).
+void pirgpu_wire_forget(struct pirgpu_ctx* ctx);
 // Request-level critical section (recursive with the per-call lock of the ABI entry points): held by
 // pirgpu_process_request for its whole body so that concurrent requests on one context cannot interleave.
 void pirgpu_request_lock(struct pirgpu_ctx* ctx);

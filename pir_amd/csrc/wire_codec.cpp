@@ -236,6 +236,11 @@ void put_header(std::string& s, uint64_t total_size) {
 
 // Ciphertext::load (+ is_valid_for): returns residues [2][nres][N].
 void load_ciphertext(Cursor& c, const Shape& sh, bool key_level, std::vector<uint64_t>& out) {
+  out.resize(2ull * (key_level ? sh.k + 1 : sh.k) * sh.N);
+  load_ciphertext_into(c, sh, key_level, out.data());
+}
+
+void load_ciphertext_into(Cursor& c, const Shape& sh, bool key_level, uint64_t* out) {
   const uint8_t* obj_end = c.header();
   Cursor o{c.p, obj_end};
   uint64_t id[4];
@@ -257,8 +262,7 @@ void load_ciphertext(Cursor& c, const Shape& sh, bool key_level, std::vector<uin
   if (count != full && count != full / 2)
     throw Err{PIRGPU_INVALID_ARGUMENT, "ciphertext data is invalid (coefficient count)"};
   a.need(count * 8);
-  out.resize(full);
-  memcpy(out.data(), a.p, count * 8);
+  memcpy(out, a.p, count * 8);
   if (count == full / 2) {
     // Seed-compressed object (Serializable<>, what PIRClient::initialize sends for its keys, client.cpp:47-54):
     // only c0 was saved; the 64-byte seed follows the IntArray and c1 is re-sampled from it
@@ -268,15 +272,16 @@ void load_ciphertext(Cursor& c, const Shape& sh, bool key_level, std::vector<uin
     SealPrng rng(sc.p);
     uint64_t mods[PIRGPU_MAX_PRIMES + 1];
     for (uint32_t j = 0; j < nres; ++j) mods[j] = sh.q[j];
-    sample_poly_uniform(rng, mods, nres, sh.N, out.data() + full / 2);
+    sample_poly_uniform(rng, mods, nres, sh.N, out + full / 2);
   }
   // is_data_valid_for: every coefficient below its modulus
   for (uint32_t poly = 0; poly < 2; ++poly)
     for (uint32_t j = 0; j < nres; ++j) {
       const uint64_t q = (key_level && j == sh.k) ? sh.q[sh.k] : sh.q[j];
-      const uint64_t* v = out.data() + ((size_t)poly * nres + j) * sh.N;
-      for (uint32_t i = 0; i < sh.N; ++i)
-        if (v[i] >= q) throw Err{PIRGPU_INVALID_ARGUMENT, "ciphertext data is invalid (coefficient out of range)"};
+      const uint64_t* v = out + ((size_t)poly * nres + j) * sh.N;
+      uint64_t bad = 0;   // branch-free scan (vectorises): any coefficient >= q
+      for (uint32_t i = 0; i < sh.N; ++i) bad |= (uint64_t)(v[i] >= q);
+      if (bad) throw Err{PIRGPU_INVALID_ARGUMENT, "ciphertext data is invalid (coefficient out of range)"};
     }
   c.p = obj_end;
 }
@@ -306,6 +311,28 @@ std::string save_ciphertext(const Shape& sh, const uint64_t* ct, bool key_level,
   put_header(out, kHeader + body.size());
   out.append(body);
   return out;
+}
+
+// Data-level ciphertexts are saved into one pre-sized buffer (responses are MBs: no per-ciphertext temporaries).
+size_t saved_ciphertext_size(const Shape& sh) {
+  return kHeader + 32 + 1 + 4 * 8 + kHeader + 8 + 2ull * sh.k * sh.N * 8;
+}
+
+void append_ciphertext(std::string& out, const Shape& sh, const uint64_t* ct) {
+  const uint64_t count = 2ull * sh.k * sh.N;
+  put_header(out, saved_ciphertext_size(sh));
+  for (int i = 0; i < 4; ++i) put_u64(out, sh.data_id[i]);
+  out.push_back(0);  // is_ntt_form
+  put_u64(out, 2);
+  put_u64(out, sh.N);
+  put_u64(out, sh.k);
+  double scale = 1.0;
+  uint64_t sbits;
+  memcpy(&sbits, &scale, 8);
+  put_u64(out, sbits);
+  put_header(out, kHeader + 8 + count * 8);
+  put_u64(out, count);
+  out.append(reinterpret_cast<const char*>(ct), count * 8);
 }
 
 std::string save_public_key(const Shape& sh, const uint64_t* pk, const uint8_t* seed) {
@@ -378,6 +405,32 @@ Shape make_shape(const pirgpu_params& prm) {
 
 
 // LoadCiphertexts (serialization.cpp:32-42) of one Ciphertexts message -> residues, count
+uint32_t load_query_into(const Shape& sh, const uint8_t* data, size_t len, uint64_t* dst, uint32_t max_cts) {
+  Reader qr{data, data + len};
+  const size_t ctw = 2ull * sh.k * sh.N;
+  std::vector<uint64_t> spill;   // ciphertexts beyond max_cts are still parsed and validated, not kept
+  uint32_t nq = 0;
+  while (qr.p < qr.end) {
+    uint64_t tag;
+    if (!qr.varint(tag)) throw Err{PIRGPU_INVALID_ARGUMENT, "malformed Ciphertexts"};
+    const uint8_t* d;
+    size_t l;
+    if ((tag >> 3) == 1 && (tag & 7) == 2) {
+      if (!qr.bytes(d, l)) throw Err{PIRGPU_INVALID_ARGUMENT, "malformed Ciphertexts.ct"};
+      Cursor c{d, d + l};
+      if (nq < max_cts) {
+        load_ciphertext_into(c, sh, false, dst + (size_t)nq * ctw);
+      } else {
+        load_ciphertext(c, sh, false, spill);
+      }
+      ++nq;
+    } else if (!qr.skip((uint32_t)(tag & 7))) {
+      throw Err{PIRGPU_INVALID_ARGUMENT, "malformed Ciphertexts"};
+    }
+  }
+  return nq;
+}
+
 uint32_t load_query(const Shape& sh, const uint8_t* data, size_t len, std::vector<uint64_t>& qbuf) {
   Reader qr{data, data + len};
   std::vector<uint64_t> one;

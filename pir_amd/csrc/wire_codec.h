@@ -133,6 +133,11 @@ Shape make_shape(const pirgpu_params& prm);
 
 // Ciphertext::load (+ is_valid_for): residues [2][nres][N]; key_level = (k+1)-prime NTT-form object.
 void load_ciphertext(Cursor& c, const Shape& sh, bool key_level, std::vector<uint64_t>& out);
+// the same into caller-owned memory of 2 * nres * N words (e.g. pinned staging)
+void load_ciphertext_into(Cursor& c, const Shape& sh, bool key_level, uint64_t* out);
+// Ciphertext::save of a data-level ciphertext appended to `out` (exactly saved_ciphertext_size bytes)
+size_t saved_ciphertext_size(const Shape& sh);
+void append_ciphertext(std::string& out, const Shape& sh, const uint64_t* ct);
 // Ciphertext::save of a size-2 ciphertext: data level (k primes, coefficient form) or, with
 // key_level, the (k+1)-prime NTT-form body of a PublicKey.
 std::string save_ciphertext(const Shape& sh, const uint64_t* ct, bool key_level = false,
@@ -149,6 +154,9 @@ std::string save_kswitch_keys(const Shape& sh, const std::vector<const uint64_t*
 
 // LoadCiphertexts (serialization.cpp:32-42) of one pir.Ciphertexts message -> residues [n][2][k][N]; returns n.
 uint32_t load_query(const Shape& sh, const uint8_t* data, size_t len, std::vector<uint64_t>& qbuf);
+// the same into caller-owned memory with room for max_cts ciphertexts; returns the number of ciphertexts in the message
+// (all of them parsed and validated; those beyond max_cts are not stored)
+uint32_t load_query_into(const Shape& sh, const uint8_t* data, size_t len, uint64_t* dst, uint32_t max_cts);
 
 }  // namespace wire
 }  // namespace pirgpu

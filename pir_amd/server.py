@@ -196,6 +196,48 @@ class PIRServer:
                                   % (self.k, self.k + 1, self.N, list(key.shape)))
             self._check(self.lib.pirgpu_set_galois_key(self.db.handle, int(g), _ptr(key)))
 
+    # -- per-client key sets (keys are per request in the reference, server.cpp:46-48) ------------
+    def set_keyset_capacity(self, capacity: int) -> None:
+        self._check(self.lib.pirgpu_set_keyset_capacity(self.db.handle, capacity))
+
+    def install_keyset(self, client_id: bytes, galois_keys: Dict[int, np.ndarray]) -> int:
+        """Makes one client's Galois keys resident under `client_id` (any bytes that identify the client; the wire
+        layer uses the serialized GaloisKeys object) and returns the slot; a resident set is reused, not re-uploaded."""
+        ident = np.frombuffer(client_id, dtype=np.uint8)
+        slot = C.c_uint32(0)
+        self._check(self.lib.pirgpu_keyset_lookup(self.db.handle, ident.ctypes.data_as(capi.u8p), len(client_id), 1,
+                                                  C.byref(slot)))
+        if slot.value:
+            return int(slot.value)
+        self._check(self.lib.pirgpu_keyset_claim(self.db.handle, ident.ctypes.data_as(capi.u8p), len(client_id),
+                                                 C.byref(slot)))
+        for g, key in galois_keys.items():
+            key = _u64(key)
+            if key.shape != (self.k, 2, self.k + 1, self.N):
+                self.lib.pirgpu_keyset_release(self.db.handle, slot.value)
+                raise PirGpuError(3, "Galois key must have shape [%d, 2, %d, %d], got %s"
+                                  % (self.k, self.k + 1, self.N, list(key.shape)))
+            self._check(self.lib.pirgpu_keyset_set_key(self.db.handle, slot.value, int(g), _ptr(key)))
+        return int(slot.value)
+
+    def release_keyset(self, slot: int) -> None:
+        self._check(self.lib.pirgpu_keyset_release(self.db.handle, slot))
+
+    def use_keyset(self, slot: int) -> None:
+        """Key set of the single-query entry points (process_query, run_staged, oblivious_expansion, ...); 0 = the
+        set installed with set_galois_keys."""
+        self._check(self.lib.pirgpu_query_use_keyset(self.db.handle, slot))
+
+    def set_batch_keysets(self, slots: Sequence[int]) -> None:
+        """One key set slot per query of the staged batch (stage_batch resets them to 0)."""
+        arr = (C.c_uint32 * len(slots))(*[int(x) for x in slots])
+        self._check(self.lib.pirgpu_batch_set_keysets(self.db.handle, arr, len(slots)))
+
+    def keyset_stats(self) -> Dict[str, int]:
+        st = (C.c_uint64 * 4)()
+        self._check(self.lib.pirgpu_keyset_stats(self.db.handle, st))
+        return {"resident": int(st[0]), "key_uploads": int(st[1]), "evictions": int(st[2]), "capacity": int(st[3])}
+
     # -- query path -------------------------------------------------------------------
     def process_query(self, query, galois_keys: Optional[Dict[int, np.ndarray]] = None) -> np.ndarray:
         """processQuery (server.cpp:173-195) on residue arrays: query [nq, 2, k, N] -> reply cts."""
@@ -219,6 +261,25 @@ class PIRServer:
             return C.string_at(resp.value, rlen.value)
         finally:
             self.lib.pirgpu_free(resp)
+
+    def ProcessRequests(self, requests: Sequence[bytes]):
+        """n independent requests (different clients) served together: [(status, response bytes or error text)]."""
+        n = len(requests)
+        bufs = [np.frombuffer(r, dtype=np.uint8) for r in requests]
+        ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+        lens = (C.c_size_t * n)(*[len(r) for r in requests])
+        resp = (C.c_void_p * n)()
+        rlen = (C.c_size_t * n)()
+        status = (C.c_int * n)()
+        self.lib.pirgpu_process_requests(self.db.handle, n, ptrs, lens, resp, rlen, status)
+        out = []
+        for i in range(n):
+            if status[i] == 0:
+                out.append((0, C.string_at(resp[i], rlen[i])))
+                self.lib.pirgpu_free(resp[i])
+            else:
+                out.append((int(status[i]), None))
+        return out
 
     # -- device-resident split (bench / pipelining) -----------------------------------
     def stage_query(self, query) -> None:

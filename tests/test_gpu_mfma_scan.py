@@ -58,7 +58,7 @@ GEOMETRIES = [
     # the same matrix on the 8-wave kernel: 2 equal chunks of 7 and 6 groups = 2 k-steps each
     ("L5 9x200 (8-wave kernel, 2 column chunks)", dict(dbsize=3, elem=2048, dims=[9, 200], N=4096, plain_bits=24), 5, 2, 2, "0"),
     # narrow matrix forced onto the 4-wave kernel (3 k-steps is its smallest instantiation)
-    ("L5 17x150 (wide kernel forced, 3 k-steps)", dict(dbsize=5, elem=2048, dims=[17, 150], N=4096, plain_bits=24), 5, 1, 3, "1"),
+    ("L5 17x150 (wide kernel forced, 3 k-steps)", dict(dbsize=4, elem=2048, dims=[17, 150], N=4096, plain_bits=24), 5, 1, 3, "1"),
     # 31 column groups = 8 k-steps: wider than the 7 the 4-wave kernel holds -> 2 chunks of 16 / 15 groups, 4 k-steps each
     ("L5 9x490 (wide kernel, 2 chunks of 4 k-steps)", dict(dbsize=1, elem=2048, dims=[9, 490], N=4096, plain_bits=24), 5, 2, 4, None),
     ("L5 d=3 4x4x40 (rows = 16)", dict(dbsize=1, elem=2048, dims=[4, 4, 40], N=4096, plain_bits=20), 5, 1, 1, None),

@@ -1,0 +1,192 @@
+"""Serving several clients at once ("What's missing" #2).  In the reference the Galois keys are
+locals of one ProcessRequest call (server.cpp:46-48): requests of different clients are independent.  Here the keys
+of up to `capacity` clients stay resident (pirgpu_keyset_*), every query names its client's key set, and the queries
+of ONE batch group may belong to different clients -- the key-switch kernels pick the key of each query's client.
+
+Checked: 8 clients with different keys, one query each, expanded as one group, every reply bit-exact against the
+oracle run with THAT client's keys (all arithmetic flavours; d = 1 and d = 2); pirgpu_process_requests == the
+requests served one by one, byte for byte; alternating clients never re-upload; LRU eviction; a bad request inside
+a batch; the speculative fingerprint match (same sampled fingerprint, different bytes must not reuse the keys)."""
+import threading
+
+import numpy as np
+import pytest
+
+import pir_amd
+from pir_amd import parameters as P
+from gpu_helpers import to_product_params
+from oracle.client import Client
+from pir_fixtures import PirSetup, generate_test_db
+
+pytestmark = pytest.mark.gpu
+
+
+def _server(s):
+    pp = to_product_params(s.params)
+    db = pir_amd.PIRDatabase.Create(pp, s.raw)
+    return db, pir_amd.PIRServer.Create(db, pp)
+
+
+@pytest.mark.parametrize("mode", ["default", "0", "2"])
+@pytest.mark.parametrize("d,items,elem", [(2, 3000, 288), (1, 300, 288)], ids=["d2-mfma-scan", "d1"])
+def test_eight_clients_with_different_keys_in_one_group(d, items, elem, mode, monkeypatch):
+    if mode != "default":
+        monkeypatch.setenv("PIRGPU_NTT_MODE", mode)
+    s = PirSetup(items, elem, d, N=4096, plain_bits=24)
+    p = s.params
+    db, srv = _server(s)
+    clients = [Client(s.orc, seed=1000 + i) for i in range(8)]
+    keys = [c.galois_keys() for c in clients]
+    slots = [srv.install_keyset(b"client-%d" % i, keys[i]) for i in range(8)]
+    assert sorted(slots) == list(range(1, 9))
+    idx = [(items - 1 - 311 * i) % items for i in range(8)]
+    queries = np.stack([clients[i].create_query_for(p, idx[i]) for i in range(8)])
+    srv.set_concurrency(8)                       # 8 workers = ONE group of 8 on one lane
+    srv.stage_batch(queries)
+    srv.set_batch_keysets(slots)
+    srv.run_batch()
+    got = srv.fetch_batch()
+    for i in range(8):
+        rc, exp = s.orc.process_query(s.db_ntt, p.dimensions, queries[i], keys[i])
+        assert rc == 0
+        assert np.array_equal(got[i], exp), "client %d" % i
+        assert clients[i].process_response(p, idx[i], got[i]) == s.item(idx[i])
+    # the wrong client's keys give a different reply (the test would not notice a kernel that ignored the slots)
+    srv.stage_batch(queries)
+    srv.set_batch_keysets(slots[1:] + slots[:1])
+    srv.run_batch()
+    wrong = srv.fetch_batch()
+    assert not np.array_equal(wrong[0], got[0])
+    rc, exp = s.orc.process_query(s.db_ntt, p.dimensions, queries[0], keys[1])
+    assert np.array_equal(wrong[0], exp)
+    # single-query entry points with a named slot
+    srv.use_keyset(slots[5])
+    assert np.array_equal(srv.process_query(queries[5]), got[5])
+    srv.use_keyset(0)
+    srv.set_galois_keys(keys[2])                # slot 0: the classic API
+    assert np.array_equal(srv.process_query(queries[2]), got[2])
+    assert srv.keyset_stats()["resident"] == 8
+    # re-installing a resident client uploads nothing
+    before = srv.keyset_stats()["key_uploads"]
+    assert srv.install_keyset(b"client-3", keys[3]) == slots[3]
+    assert srv.keyset_stats()["key_uploads"] == before
+    db.close()
+
+
+def _product_setup(items=2000, elem=128, d=2, n_clients=3):
+    enc = P.generate_encryption_params(4096, 24)
+    pp = P.create_pir_parameters(items, elem, d, enc)
+    raw = generate_test_db(items, elem)
+    server = pir_amd.PIRServer.Create(pir_amd.PIRDatabase.Create(pp, raw), pp)
+    clients = [pir_amd.PIRClient.Create(pp, seed=b"mc%d" % i) for i in range(n_clients)]
+    return pp, raw, server, clients
+
+
+def test_process_requests_equals_one_by_one():
+    pp, raw, server, clients = _product_setup(n_clients=5)
+    wants = [[(97 * i + 3) % 2000] if i % 2 else [(97 * i + 3) % 2000, (411 * i + 9) % 2000] for i in range(5)]
+    requests = [c.CreateRequest(w) for c, w in zip(clients, wants)]
+    together = server.ProcessRequests(requests)
+    assert [st for st, _ in together] == [0] * 5
+    for c, w, (st, resp) in zip(clients, wants, together):
+        assert c.ProcessResponse(w, resp) == [raw[i].tobytes() for i in w]
+    st = server.keyset_stats()
+    assert st["resident"] == 5 and st["evictions"] == 0
+    uploads = st["key_uploads"]
+    # the server is deterministic: served one by one (keys now resident) the same bytes come back
+    for req, (_, resp) in zip(requests, together):
+        assert server.ProcessRequest(req) == resp
+    assert server.keyset_stats()["key_uploads"] == uploads          # nothing re-uploaded
+    # a malformed request in the middle fails alone
+    bad = requests[1][:-7]
+    mixed = server.ProcessRequests([requests[0], bad, requests[2]])
+    assert mixed[0] == together[0] and mixed[2] == together[2]
+    assert mixed[1][0] == pir_amd.StatusCode.INVALID_ARGUMENT and mixed[1][1] is None
+
+
+def test_alternating_clients_never_reupload_and_threads_are_combined():
+    pp, raw, server, clients = _product_setup(n_clients=2)
+    errors = []
+
+    def work(ci):
+        try:
+            c = clients[ci]
+            for it in range(8):
+                idx = [(37 * it + 11 * ci) % 2000]
+                items = c.ProcessResponse(idx, server.ProcessRequest(c.CreateRequest(idx)))
+                if items != [raw[i].tobytes() for i in idx]:
+                    errors.append((ci, it))
+        except Exception as ex:            # noqa: BLE001
+            errors.append((ci, repr(ex)))
+
+    # strictly alternating on one thread first, then two threads at once
+    for it in range(3):
+        for ci in range(2):
+            idx = [it * 5 + ci]
+            assert clients[ci].ProcessResponse(idx, server.ProcessRequest(clients[ci].CreateRequest(idx))) == \
+                [raw[idx[0]].tobytes()]
+    n_keys = len(pir_amd.generate_galois_elts(4096))
+    assert server.keyset_stats()["key_uploads"] == 2 * n_keys        # each client's keys went up exactly once
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    st = server.keyset_stats()
+    assert st["key_uploads"] == 2 * n_keys and st["evictions"] == 0 and st["resident"] == 2
+
+
+def test_least_recently_used_key_set_is_evicted():
+    pp, raw, server, clients = _product_setup(n_clients=3)
+    server.set_keyset_capacity(2)
+    n_keys = len(pir_amd.generate_galois_elts(4096))
+    for rnd in range(2):
+        for ci, c in enumerate(clients):
+            idx = [100 * rnd + ci]
+            assert c.ProcessResponse(idx, server.ProcessRequest(c.CreateRequest(idx))) == [raw[idx[0]].tobytes()]
+    st = server.keyset_stats()
+    assert st["resident"] == 2 and st["capacity"] == 2
+    assert st["evictions"] == 4 and st["key_uploads"] == 6 * n_keys   # 3 clients round robin on 2 slots: always a miss
+    # more clients in one ProcessRequests call than slots: served in windows of `capacity` clients
+    wants = [[5], [6], [7]]
+    out = server.ProcessRequests([c.CreateRequest(w) for c, w in zip(clients, wants)])
+    for c, w, (st_, resp) in zip(clients, wants, out):
+        assert st_ == 0 and c.ProcessResponse(w, resp) == [raw[w[0]].tobytes()]
+
+
+def test_fingerprint_match_with_different_bytes_does_not_reuse_the_keys():
+    """A lone single-query request starts on a match of length + sampled fingerprint and verifies the key bytes while
+    the GPU works.  A key object that differs from a resident one only in bytes the fingerprint does not sample must
+    be treated as another client's: the reply has to be the one a fresh server computes for it."""
+    import seal_wire as W
+    pp, raw, server, clients = _product_setup(n_clients=1)
+    c = clients[0]
+    enc = pp.encryption_parameters
+    N, mods = enc.poly_modulus_degree, enc.coeff_modulus
+    key_pid, data_pid = W.parms_id(N, mods, enc.plain_modulus), W.parms_id(N, mods[:-1], enc.plain_modulus)
+    keys = c.galois_keys()
+    query = c.create_query_for(123)
+    blob_a = W.save_galois_keys(keys, N, key_pid)
+    words = len(blob_a) // 8
+    step = max(1, words // 64)                  # the library samples 8-byte words 0, step, 2 step, ... of the object
+    blob_b = None
+    for coeff in range(7, 200):                 # change one key coefficient until the changed word is not a sampled one
+        k2 = {g: v.copy() for g, v in keys.items()}
+        g0 = sorted(k2)[3]
+        k2[g0][1, 0, 1, coeff] ^= np.uint64(1)
+        cand = W.save_galois_keys(k2, N, key_pid)
+        diff = [i for i in range(0, len(cand), 8) if cand[i:i + 8] != blob_a[i:i + 8]]
+        if len(cand) == len(blob_a) and diff and all((i // 8) % step for i in diff):
+            blob_b = cand
+            break
+    assert blob_b is not None
+    req_a, req_b = W.save_request([query], blob_a, data_pid), W.save_request([query], blob_b, data_pid)
+    good = server.ProcessRequest(req_a)
+    assert c.ProcessResponse([123], good) == [raw[123].tobytes()]
+    got = server.ProcessRequest(req_b)          # same length, same fingerprint, different key bytes
+    fresh = pir_amd.PIRServer.Create(pir_amd.PIRDatabase.Create(pp, raw), pp)
+    want = fresh.ProcessRequest(req_b)
+    assert got == want and got != good
+    assert server.keyset_stats()["resident"] == 2            # the other object became its own key set
+    assert server.ProcessRequest(req_a) == good              # and the first client's set is intact

@@ -12,7 +12,22 @@ int pirgpu_set_concurrency(pirgpu_ctx*, uint32_t) { return 13; }
 int pirgpu_batch_stage(pirgpu_ctx*, const uint64_t*, uint32_t, uint32_t) { return 13; }
 int pirgpu_batch_run(pirgpu_ctx*) { return 13; }
 int pirgpu_batch_fetch(pirgpu_ctx*, uint64_t*, uint64_t, uint64_t*) { return 13; }
-int pirgpu_keys_blob_matches(pirgpu_ctx*, const uint8_t*, size_t) { return 0; }
-void pirgpu_keys_blob_set(pirgpu_ctx*, const uint8_t*, size_t) {}
+int pirgpu_keyset_lookup(pirgpu_ctx*, const uint8_t*, size_t, int, uint32_t*) { return 13; }
+int pirgpu_keyset_verify(pirgpu_ctx*, uint32_t, const uint8_t*, size_t) { return 0; }
+int pirgpu_keyset_claim(pirgpu_ctx*, const uint8_t*, size_t, uint32_t*) { return 13; }
+int pirgpu_keyset_release(pirgpu_ctx*, uint32_t) { return 13; }
+int pirgpu_keyset_set_key(pirgpu_ctx*, uint32_t, uint32_t, const uint64_t*) { return 13; }
+int pirgpu_keyset_stats(pirgpu_ctx*, uint64_t*) { return 13; }
+int pirgpu_query_use_keyset(pirgpu_ctx*, uint32_t) { return 13; }
+int pirgpu_batch_set_keysets(pirgpu_ctx*, const uint32_t*, uint32_t) { return 13; }
+int pirgpu_query_stage(pirgpu_ctx*, const uint64_t*, uint32_t) { return 13; }
+int pirgpu_query_run(pirgpu_ctx*) { return 13; }
+int pirgpu_query_fetch(pirgpu_ctx*, uint64_t*, uint64_t, uint64_t*) { return 13; }
+uint64_t* pirgpu_host_query_buffer(pirgpu_ctx*, uint32_t) { return nullptr; }
+uint64_t* pirgpu_host_reply_buffer(pirgpu_ctx*, uint32_t) { return nullptr; }
+void pirgpu_keyset_pin_begin(pirgpu_ctx*) {}
+void pirgpu_keyset_pin_end(pirgpu_ctx*) {}
+void pirgpu_request_lock(pirgpu_ctx*) {}
+void pirgpu_request_unlock(pirgpu_ctx*) {}
 uint32_t pirgpu_get_concurrency(pirgpu_ctx*) { return 1; }
 }

@@ -274,8 +274,12 @@ def main():
         srv.set_galois_keys(keys)
         return db, srv, t_pop
 
+    pipes = []                              # the pipelined rows step (multi-GPU): drained before every barrier
+
     def barrier_for(srv):
         def barrier():
+            for pp_ in pipes:
+                pp_.flush()                 # multiply + reduce of the last submitted step, then wait
             srv.sync()                      # the library's own streams (not torch's current stream)
             torch.cuda.synchronize()
             if use_dist:
@@ -322,8 +326,25 @@ def main():
     # ---- (2) throughput: `batch` queries per step (the whole job's), `workers` in flight per GPU
     srv.set_concurrency(workers)
     srv.stage_batch(queries)
+    pipe = None
+    serial_phases = None
+    if use_dist:
+        D.sync_zero_plaintexts(srv, dist, world, comm, torch, dev)   # the transparent-ciphertext decision is collective
     if use_dist and exchange == "packed":
         bufs = D.PackedBuffers(srv, batch, rank, world, torch, dev)
+        # serial phase times from the synchronous form of the step (every phase followed by a host wait) ...
+        for _ in range(2):
+            D.run_batch_rows_packed(srv, bufs, dist, rank, world, comm)
+        acc = None
+        for _ in range(5):
+            ph = D.run_batch_rows_packed(srv, bufs, dist, rank, world, comm)
+            acc = ph if acc is None else {kk: acc[kk] + v for kk, v in ph.items()}
+        serial_phases = {kk: round(v / 5, 4) for kk, v in acc.items()}
+        # ... and the pipelined form for the timed steps: exchange of step s under the multiply of step s - 1 and the
+        # expansion of step s + 1, streams ordered by events, no host waits (PIRGPU_ROWS_PIPELINE=0: synchronous step)
+        if os.environ.get("PIRGPU_ROWS_PIPELINE", "1") != "0":
+            pipe = D.RowsPipeline(srv, batch, rank, world, dist, torch, dev)
+            pipes.append(pipe)
     elif use_dist:
         sv_all = torch.empty((batch, pp.dim_sum, 2, k, N), dtype=torch.int64, device=dev)
         redb = torch.empty((batch, reply_cts, 2, k, N), dtype=torch.int64, device=dev)
@@ -331,6 +352,8 @@ def main():
     def step_rows():
         if not use_dist:
             srv.run_batch()
+        elif pipe is not None:
+            pipe.submit()
         elif exchange == "packed":
             D.run_batch_rows_packed(srv, bufs, dist, rank, world, comm)
         else:
@@ -340,7 +363,8 @@ def main():
     qps = args.steps * batch / elapsed
     forced_check = None
     if use_dist and world == 1:   # forced single-rank run: the reduced replies must equal the plain ones
-        got = (bufs.replies if exchange == "packed" else redb).cpu().numpy().view(np.uint64)
+        got = ((pipe.replies(pipe.step - 1) if pipe is not None else bufs.replies) if exchange == "packed"
+               else redb).cpu().numpy().view(np.uint64)
         srv.stage_batch(queries)
         srv.run_batch()
         forced_check = bool(np.array_equal(got, srv.fetch_batch()))
@@ -348,6 +372,7 @@ def main():
     scan_bytes = srv.scan_bytes()
     info = srv.scan_info()
     batch_replies = srv.fetch_batch() if world == 1 and not use_dist else None
+    pipes.clear()
 
     # =========================== replicas (reference point, multi-GPU only) ===========================
     if run_replicas:
@@ -451,6 +476,13 @@ def main():
             out["forced_dist_replies_equal_plain"] = forced_check
         if use_dist and bufs is not None:
             out["exchange_bytes_received_per_query_per_gpu"] = bufs.exchange_bytes_per_query(world)
+            out["rows_step"] = {"pipelined": pipe is not None,
+                                "phases_ms_serial": serial_phases,
+                                "serial_sum_ms": round(sum(serial_phases.values()), 4) if serial_phases else None,
+                                "note": "phases_ms_serial: expand / exchange (all-gather + all-to-all) / multiply / "
+                                        "reduce (reduce-scatter + mod q) of one step with a host wait after every phase; "
+                                        "the timed steps run them pipelined (exchange of step s under the multiply of "
+                                        "step s-1 and the expansion of step s+1, no host waits): ms_per_step"}
         if world == 1 and not use_dist and args.config == 3:
             # wire-level ProcessRequest (what benchmark.cpp:71-79 times): serialized pir.Request in host
             # memory -> serialized pir.Response, incl. parsing, H2D of keys + query, D2H, serialisation
@@ -481,6 +513,7 @@ def main():
             try:
                 mods = enc.coeff_modulus
                 n_cl = batch
+                srv.set_keyset_capacity(max(64, n_cl))
                 slots = []
                 for cidx in range(n_cl):
                     ck = {}
@@ -490,7 +523,6 @@ def main():
                             kk[:, :, i, :] = (kk[:, :, i, :] + np.uint64(cidx + 1)) % np.uint64(mods[i])
                         ck[g] = kk
                     slots.append(srv.install_keyset(b"bench-client-%d" % cidx, ck))
-                srv.set_keyset_capacity(max(64, n_cl))
                 srv.set_concurrency(workers)
                 srv.stage_batch(queries)
                 srv.set_batch_keysets(slots)

@@ -215,6 +215,24 @@ int pirgpu_batch_run_packed(pirgpu_ctx* ctx, const uint8_t* device_packed, uint3
 /* Waits for the batch and copies its replies into caller-owned DEVICE memory (multi-GPU reduce). */
 int pirgpu_batch_reply_copy_to_device(pirgpu_ctx* ctx, uint64_t* device_dst, uint64_t capacity);
 
+/* Pipelined multi-GPU step: the same entry points without any host synchronisation, plus the
+ * device-side ordering a caller needs to hang its collectives between them.  The library queues work on its own HIP
+ * streams (a main stream, the batch lanes, the workers):
+ *   stream_handle   the main stream (a hipStream_t), e.g. for torch.cuda.ExternalStream -- record / wait events on it;
+ *   join            the main stream waits, on the device, for everything queued on lanes and workers so far;
+ *   fork            lanes and workers wait for everything the main stream has been made to wait for;
+ *   batch_expand_packed_async      = batch_expand_packed, returns once the work is queued (join to get a completion point);
+ *   batch_reply_copy_to_device_async  join + copy on the main stream, no wait;
+ *   reduce_fixup_device_async      x mod q_j queued on `stream` (a hipStream_t of the caller; NULL = the main stream).
+ * pirgpu_batch_run_packed / _run_selectors / _batch_run never wait for the device in either form. */
+void* pirgpu_stream_handle(pirgpu_ctx* ctx);
+int pirgpu_join(pirgpu_ctx* ctx);
+int pirgpu_fork(pirgpu_ctx* ctx);
+int pirgpu_batch_expand_packed_async(pirgpu_ctx* ctx, uint32_t first, uint32_t count, uint8_t* device_packed,
+                                     uint64_t* device_rows, const uint32_t* row_cuts, uint32_t n_ranks);
+int pirgpu_batch_reply_copy_to_device_async(pirgpu_ctx* ctx, uint64_t* device_dst, uint64_t capacity);
+int pirgpu_reduce_fixup_device_async(pirgpu_ctx* ctx, uint64_t* device_ptr, uint64_t count, void* stream);
+
 /* PIRServer::oblivious_expansion (reference server.cpp:105-146): one ciphertext
  * -> num_items ciphertexts, coefficient form. */
 int pirgpu_expand(pirgpu_ctx* ctx, const uint64_t* ct, uint32_t num_items, uint64_t* out);

@@ -111,6 +111,13 @@ SIGNATURES = {
     "pirgpu_batch_fetch": (C.c_int, [C.c_void_p, u64p, C.c_uint64, u64p]),
     "pirgpu_batch_reply_copy_to_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "pirgpu_batch_expand": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "pirgpu_stream_handle": (C.c_void_p, [C.c_void_p]),
+    "pirgpu_join": (C.c_int, [C.c_void_p]),
+    "pirgpu_fork": (C.c_int, [C.c_void_p]),
+    "pirgpu_batch_expand_packed_async": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                                   C.POINTER(C.c_uint32), C.c_uint32]),
+    "pirgpu_batch_reply_copy_to_device_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "pirgpu_reduce_fixup_device_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "pirgpu_batch_run_selectors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "pirgpu_expand": (C.c_int, [C.c_void_p, u64p, C.c_uint32, u64p]),
     "pirgpu_expand_multi": (C.c_int, [C.c_void_p, u64p, C.c_uint32, C.c_uint64, u64p]),

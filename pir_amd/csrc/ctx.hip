@@ -72,6 +72,7 @@ struct Worker {
   bool reply_valid = false;
   hipEvent_t ev_expanded = nullptr, ev_scanned = nullptr;  // batch mode: cross-stream hand-offs
   hipEvent_t ev_done = nullptr;      // batch mode: this worker's reply is complete (its buffers may be reused)
+  hipEvent_t ev_join = nullptr;      // pirgpu_join: everything queued on this worker's stream so far
 };
 
 // Batch mode with the MFMA scan: a group of up to 8 queries is expanded TOGETHER on one lane (the
@@ -83,6 +84,7 @@ struct BatchLane {
   uint64_t *res_a = nullptr, *res_b = nullptr, *prod = nullptr, *dig = nullptr;
   uint8_t* selp = nullptr;
   hipEvent_t ev_scanned = nullptr;
+  hipEvent_t ev_join = nullptr;      // pirgpu_join: everything queued on this lane so far
   // the multiply of a whole group runs on the lane's stream in these query-major buffers: one launch per kernel
   // for the (up to) 8 queries instead of one stream + one launch per query
   std::vector<uint64_t*> lvl;        // [level][query][lvl_cts[level]][2][k][N]
@@ -142,7 +144,7 @@ struct pirgpu_ctx {
   std::vector<uint8_t> loaded;  // per local plaintext
   uint64_t n_loaded = 0;
   std::vector<KeySet> keysets{1};           // resident key sets; [0] = pirgpu_set_galois_key's
-  uint32_t keyset_cap = 16;                 // slots the wire layer may use (pirgpu_set_keyset_capacity)
+  uint32_t keyset_cap = 64;                 // client slots (pirgpu_set_keyset_capacity); 4.7 MB each at N = 4096, k = 2
   uint32_t cur_keyset = 0;                  // slot the single-query entry points use (pirgpu_query_use_keyset)
   std::vector<uint32_t> batch_keysets;      // per staged query of the batch (all 0 unless pirgpu_batch_set_keysets)
   uint64_t keyset_clock = 0, key_uploads = 0, keyset_evictions = 0;
@@ -200,6 +202,7 @@ struct pirgpu_ctx {
   bool staging_released = false;            // pirgpu_db_finalize(release): only the operand-layout copy is left
   std::vector<BatchLane> lanes;             // created on the first batch
   uint64_t groups_run = 0;
+  hipEvent_t ev_fork = nullptr;             // pirgpu_fork: the main stream's position
   uint64_t *h_query = nullptr, *h_reply = nullptr;   // pinned host staging of the wire layer
   size_t h_query_words = 0, h_reply_words = 0;
 
@@ -998,11 +1001,14 @@ void pirgpu_destroy(pirgpu_ctx* c) {
     if (w.ev_expanded) (void)hipEventDestroy(w.ev_expanded);
     if (w.ev_scanned) (void)hipEventDestroy(w.ev_scanned);
     if (w.ev_done) (void)hipEventDestroy(w.ev_done);
+    if (w.ev_join) (void)hipEventDestroy(w.ev_join);
   }
   for (BatchLane& ln : c->lanes) {
     if (ln.ev_scanned) (void)hipEventDestroy(ln.ev_scanned);
+    if (ln.ev_join) (void)hipEventDestroy(ln.ev_join);
     if (ln.stream) (void)hipStreamDestroy(ln.stream);
   }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   for (size_t i = 1; i < c->workers.size(); ++i)
     if (c->workers[i].stream) (void)hipStreamDestroy(c->workers[i].stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1483,6 +1489,47 @@ int pirgpu_sync(pirgpu_ctx* c) {
       if (ln.stream) HIP_TRY(hipStreamSynchronize(ln.stream));
     for (Worker& w : c->workers)
       if (w.stream) HIP_TRY(hipStreamSynchronize(w.stream));
+    return PIRGPU_OK;
+  });
+}
+
+// ---- device-side ordering with the caller's streams (pipelined multi-GPU step) ----
+//
+// The library queues its work on its own HIP streams (one main stream, the batch lanes, the workers).  A caller that
+// runs collectives on ITS streams orders them against that work without stopping the host: pirgpu_join makes the main
+// stream wait -- on the device -- for everything queued on the lanes and workers so far, so the main stream (handed
+// out by pirgpu_stream_handle, e.g. for torch.cuda.ExternalStream) becomes the completion point an event can be
+// recorded on; pirgpu_fork makes the lanes and workers wait for everything the main stream has been made to wait for
+// (e.g. an event of the caller's collective), so work queued afterwards starts behind it.
+
+void* pirgpu_stream_handle(pirgpu_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int pirgpu_join(pirgpu_ctx* c) {
+  return guarded(c, [&]() -> int {
+    for (BatchLane& ln : c->lanes) {
+      if (!ln.stream) continue;
+      if (!ln.ev_join) HIP_TRY(hipEventCreateWithFlags(&ln.ev_join, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(ln.ev_join, ln.stream));
+      HIP_TRY(hipStreamWaitEvent(c->stream, ln.ev_join, 0));
+    }
+    for (Worker& w : c->workers) {
+      if (!w.stream || w.stream == c->stream) continue;
+      if (!w.ev_join) HIP_TRY(hipEventCreateWithFlags(&w.ev_join, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(w.ev_join, w.stream));
+      HIP_TRY(hipStreamWaitEvent(c->stream, w.ev_join, 0));
+    }
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_fork(pirgpu_ctx* c) {
+  return guarded(c, [&]() -> int {
+    if (!c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+    for (BatchLane& ln : c->lanes)
+      if (ln.stream) HIP_TRY(hipStreamWaitEvent(ln.stream, c->ev_fork, 0));
+    for (Worker& w : c->workers)
+      if (w.stream && w.stream != c->stream) HIP_TRY(hipStreamWaitEvent(w.stream, c->ev_fork, 0));
     return PIRGPU_OK;
   });
 }
@@ -1990,8 +2037,8 @@ uint64_t pirgpu_packed_selector_bytes(pirgpu_ctx* c) {
   return bytes;
 }
 
-int pirgpu_batch_expand_packed(pirgpu_ctx* c, uint32_t first_query, uint32_t count, uint8_t* device_packed,
-                               uint64_t* device_rows, const uint32_t* row_cuts, uint32_t n_ranks) {
+static int batch_expand_packed_impl(pirgpu_ctx* c, uint32_t first_query, uint32_t count, uint8_t* device_packed,
+                                    uint64_t* device_rows, const uint32_t* row_cuts, uint32_t n_ranks, bool wait) {
   return guarded(c, [&]() -> int {
     ensure_workspace(c);
     if (c->d != 2 || !c->mfma_on)
@@ -2039,9 +2086,20 @@ int pirgpu_batch_expand_packed(pirgpu_ctx* c, uint32_t first_query, uint32_t cou
         HIP_TRY(hipEventRecord(members[q]->ev_done, ln.stream));
       }
     }
-    for (BatchLane& ln : c->lanes) HIP_TRY(hipStreamSynchronize(ln.stream));
+    if (wait)
+      for (BatchLane& ln : c->lanes) HIP_TRY(hipStreamSynchronize(ln.stream));
     return PIRGPU_OK;
   });
+}
+
+int pirgpu_batch_expand_packed(pirgpu_ctx* c, uint32_t first_query, uint32_t count, uint8_t* device_packed,
+                               uint64_t* device_rows, const uint32_t* row_cuts, uint32_t n_ranks) {
+  return batch_expand_packed_impl(c, first_query, count, device_packed, device_rows, row_cuts, n_ranks, true);
+}
+
+int pirgpu_batch_expand_packed_async(pirgpu_ctx* c, uint32_t first_query, uint32_t count, uint8_t* device_packed,
+                                     uint64_t* device_rows, const uint32_t* row_cuts, uint32_t n_ranks) {
+  return batch_expand_packed_impl(c, first_query, count, device_packed, device_rows, row_cuts, n_ranks, false);
 }
 
 int pirgpu_batch_run_packed(pirgpu_ctx* c, const uint8_t* device_packed, uint32_t n_ranks, uint32_t per_rank,
@@ -2082,6 +2140,18 @@ int pirgpu_batch_reply_copy_to_device(pirgpu_ctx* c, uint64_t* dst, uint64_t cap
     // streams are non-blocking (not ordered with the null stream): copy on the context's stream and wait
     HIP_TRY(hipMemcpyAsync(dst, c->d_breply, total * c->ctw * 8, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_batch_reply_copy_to_device_async(pirgpu_ctx* c, uint64_t* dst, uint64_t cap) {
+  int rc = pirgpu_join(c);   // the main stream now follows every lane: the copy below sees the finished batch
+  if (rc) return rc;
+  return guarded(c, [&]() -> int {
+    if (!c->batch_valid) return fail(c, PIRGPU_FAILED_PRECONDITION, "no batch has been run");
+    const uint64_t total = (uint64_t)c->batch_count * c->reply_cts;
+    if (!dst || cap < total) return fail(c, PIRGPU_INVALID_ARGUMENT, "reply buffer too small");
+    HIP_TRY(hipMemcpyAsync(dst, c->d_breply, total * c->ctw * 8, hipMemcpyDeviceToDevice, c->stream));
     return PIRGPU_OK;
   });
 }
@@ -2141,6 +2211,15 @@ int pirgpu_reduce_fixup_device(pirgpu_ctx* c, uint64_t* device_ptr, uint64_t cou
     if (!device_ptr) return fail(c, PIRGPU_INVALID_ARGUMENT, "null buffer");
     HIP_TRY(launch_reduce_splits(c->stream, c->dp, device_ptr, 1, count * c->ctw, device_ptr));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_reduce_fixup_device_async(pirgpu_ctx* c, uint64_t* device_ptr, uint64_t count, void* stream) {
+  return guarded(c, [&]() -> int {
+    if (!device_ptr) return fail(c, PIRGPU_INVALID_ARGUMENT, "null buffer");
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    HIP_TRY(launch_reduce_splits(st, c->dp, device_ptr, 1, count * c->ctw, device_ptr));
     return PIRGPU_OK;
   });
 }

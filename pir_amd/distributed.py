@@ -42,22 +42,26 @@ def owned_queries(count: int, rank: int, world: int):
 
 
 class Comm:
-    """The four collectives of a step.  backend 'nccl' (RCCL): on the tensors' device, on torch's current stream,
-    followed by a stream synchronise (the library runs on its own HIP streams).  Any other backend (gloo in the
-    tests): tensors are staged through host memory, so the same glue runs with two processes on one GPU or on CPU."""
+    """The four collectives of a step.  backend 'nccl' (RCCL): on the tensors' device, on torch's current stream.
+    With host_sync (the synchronous steps: run_batch_rows_packed, run_batch_query_parallel) every collective is followed
+    by a stream synchronise, because the library runs on its own HIP streams; RowsPipeline passes host_sync=False and
+    orders streams with events instead.  Any other backend (gloo in the tests): tensors are staged through host
+    memory, so the same glue runs with two processes on one GPU or on CPU."""
 
-    def __init__(self, dist, world: int):
+    def __init__(self, dist, world: int, host_sync: bool = True):
         self.dist, self.world = dist, world
-        self.device_native = world > 1 and dist.get_backend() == "nccl"
+        self.host_sync = host_sync
+        # RCCL process group (also a forced single-rank one): collectives run on the device
+        self.device_native = dist is not None and dist.is_initialized() and dist.get_backend() == "nccl"
 
     def _sync(self, t):
-        if t.is_cuda:
+        if t.is_cuda and self.host_sync:
             import torch
             torch.cuda.current_stream(t.device).synchronize()
 
     def all_gather_inplace(self, full, rank: int):
         """full: [world, ...]; every rank has filled full[rank]."""
-        if self.world == 1:
+        if self.world == 1 and not self.device_native:
             return
         d = self.dist
         if self.device_native:
@@ -73,7 +77,7 @@ class Comm:
 
     def all_to_all(self, recv, send, recv_splits, send_splits):
         """1-D tensors; split sizes in elements."""
-        if self.world == 1:
+        if self.world == 1 and not self.device_native:
             recv.copy_(send)
             self._sync(recv)
             return
@@ -89,7 +93,7 @@ class Comm:
 
     def reduce_scatter_sum(self, out, full, rank: int):
         """full: [world * n] int64 partial sums, out: [n] = sum over ranks of full[rank*n:(rank+1)*n]."""
-        if self.world == 1:
+        if self.world == 1 and not self.device_native:
             out.copy_(full.view(-1)[: out.numel()].view(out.shape))
             self._sync(out)
             return
@@ -105,7 +109,7 @@ class Comm:
         self._sync(out)
 
     def all_reduce_sum(self, t):
-        if self.world == 1:
+        if self.world == 1 and not self.device_native:
             return
         d = self.dist
         if self.device_native:
@@ -211,7 +215,7 @@ def packed_exchange_supported(server, dist, world: int, comm: Optional[Comm] = N
     return int(t.item()) == world
 
 
-def run_batch_rows_packed(server, bufs: PackedBuffers, dist, rank: int, world: int, comm: Optional[Comm] = None) -> None:
+def run_batch_rows_packed(server, bufs: PackedBuffers, dist, rank: int, world: int, comm: Optional[Comm] = None) -> dict:
     """One step over a staged batch on `world` GPUs holding row shards, with the PACKED exchange (d = 2):
 
       1. every rank expands its own `per` queries (groups of 8 expanded together), packs their column selectors
@@ -225,11 +229,152 @@ def run_batch_rows_packed(server, bufs: PackedBuffers, dist, rank: int, world: i
     """
     comm = comm or Comm(dist, world)
     server.check_ready()        # identical on every rank after sync_zero_plaintexts: nobody enters a collective alone
+    import time
+    t = [time.perf_counter()]
     lo, hi = owned_queries(bufs.per * world, rank, world)
     server.batch_expand_packed(lo, bufs.per, bufs.packed[rank].data_ptr(), bufs.rows_send.data_ptr(), bufs.cuts)
+    t.append(time.perf_counter())
     comm.all_gather_inplace(bufs.packed, rank)
     comm.all_to_all(bufs.rows_recv, bufs.rows_send, bufs.recv_splits, bufs.send_splits)
+    t.append(time.perf_counter())
     server.batch_run_packed(bufs.packed.data_ptr(), world, bufs.per, bufs.rows_recv.data_ptr())
     server.batch_reply_copy_to_device(bufs.partial.data_ptr())
+    t.append(time.perf_counter())
     comm.reduce_scatter_sum(bufs.replies, bufs.partial, rank)
     server.reduce_fixup_device_n(bufs.replies.data_ptr(), bufs.replies.shape[0] * bufs.replies.shape[1])
+    t.append(time.perf_counter())
+    # every phase above ends with a host wait in this (synchronous) form of the step: its serial phase times
+    return {"expand_ms": (t[1] - t[0]) * 1e3, "exchange_ms": (t[2] - t[1]) * 1e3, "multiply_ms": (t[3] - t[2]) * 1e3,
+            "reduce_ms": (t[4] - t[3]) * 1e3}
+
+
+class _NoStreams:
+    """Stand-in for the stream plumbing when the tensors live on the CPU (oracle-backed server in the gloo tests)."""
+
+    class _Ctx:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    def comm(self):
+        return self._Ctx()
+
+    def comm_after_main(self):
+        pass
+
+    def record_exchange(self, b):
+        pass
+
+    def main_after_exchange(self, b):
+        pass
+
+    def comm_handle(self):
+        return 0
+
+    def synchronize(self):
+        pass
+
+
+class _GpuStreams:
+    """The library's main stream (wrapped, not owned) and one communication stream of ours; the two are ordered
+    against each other with events only -- the host never waits inside a step."""
+
+    def __init__(self, server, torch, device):
+        self.torch = torch
+        self.main = torch.cuda.ExternalStream(server.stream_handle(), device=device)
+        self.side = torch.cuda.Stream(device=device)
+        self.ev_x = [torch.cuda.Event(), torch.cuda.Event()]
+
+    def comm(self):
+        return self.torch.cuda.stream(self.side)
+
+    def comm_after_main(self):
+        self.side.wait_stream(self.main)
+
+    def record_exchange(self, b):
+        self.ev_x[b].record(self.side)
+
+    def main_after_exchange(self, b):
+        self.main.wait_event(self.ev_x[b])
+
+    def comm_handle(self):
+        return int(self.side.cuda_stream)
+
+    def synchronize(self):
+        self.side.synchronize()
+        self.main.synchronize()
+
+
+class RowsPipeline:
+    """The row-sharded step of run_batch_rows_packed, PIPELINED over consecutive steps and free of host waits:
+
+        lanes (library):  E_s   M_(s-1)   E_(s+1)   M_s      ...      E = expand + pack own queries, M = scans + upper level
+        comm stream:         X_s    R_(s-1)    X_(s+1)   R_s ...      X = all-gather + all-to-all, R = reduce-scatter + mod q
+
+    so the exchange of step s (the long pole: every rank receives the packed column selectors of every query) runs under
+    the multiply of step s-1 and the expansion of step s+1 instead of between them.  Two buffer sets; the library's
+    streams and the communication stream are ordered with events (pirgpu_join / pirgpu_fork on the library side,
+    ExternalStream / wait_stream on ours); nothing in submit() blocks the host under RCCL.  Reply i of a step still
+    answers query i (reference server.cpp:60-63): rank r ends with the replies of the queries it expanded, in
+    `replies(step)`, valid once the step has been flushed or two later steps have been submitted.
+
+    submit(first) expands the staged queries [first + rank * per, first + (rank + 1) * per) -- with several batches
+    staged back to back, consecutive steps can serve different queries."""
+
+    def __init__(self, server, batch: int, rank: int, world: int, dist, torch, device, comm: Optional[Comm] = None):
+        self.server, self.rank, self.world, self.dist = server, rank, world, dist
+        self.sets = [PackedBuffers(server, batch, rank, world, torch, device) for _ in range(2)]
+        self.per = self.sets[0].per
+        on_gpu = str(device).startswith("cuda")
+        self.comm = comm or Comm(dist, world, host_sync=False)
+        self.comm.host_sync = False
+        self.streams = _GpuStreams(server, torch, device) if on_gpu else _NoStreams()
+        self.step = 0            # steps submitted
+        self.pending = None      # buffer set whose multiply + reduce is still to be queued
+        self.n_reply_cts = self.sets[0].replies.shape[0] * self.sets[0].replies.shape[1]
+
+    def _finish(self, b: int) -> None:
+        """Multiply + reduce of the step whose exchange went into set b."""
+        srv, st, bufs = self.server, self.streams, self.sets[b]
+        st.main_after_exchange(b)             # the main stream waits for X of that step ...
+        srv.fork()                            # ... and with it the lanes
+        srv.batch_run_packed(bufs.packed.data_ptr(), self.world, bufs.per, bufs.rows_recv.data_ptr())
+        srv.batch_reply_copy_to_device_async(bufs.partial.data_ptr())      # join + copy on the main stream
+        st.comm_after_main()
+        with st.comm():
+            self.comm.reduce_scatter_sum(bufs.replies, bufs.partial, self.rank)
+            srv.reduce_fixup_device_async(bufs.replies.data_ptr(), self.n_reply_cts, st.comm_handle())
+
+    def submit(self, first: int = 0) -> None:
+        srv, st = self.server, self.streams
+        srv.check_ready()
+        b = self.step & 1
+        bufs = self.sets[b]
+        # the lanes must be done with the multiply that last read this set (two steps ago) before it is refilled
+        srv.fork()
+        srv.batch_expand_packed_async(first + self.rank * bufs.per, bufs.per, bufs.packed[self.rank].data_ptr(),
+                                      bufs.rows_send.data_ptr(), bufs.cuts)
+        srv.join()
+        st.comm_after_main()
+        with st.comm():
+            self.comm.all_gather_inplace(bufs.packed, self.rank)
+            self.comm.all_to_all(bufs.rows_recv, bufs.rows_send, bufs.recv_splits, bufs.send_splits)
+            st.record_exchange(b)
+        if self.pending is not None:
+            self._finish(self.pending)
+        self.pending = b
+        self.step += 1
+
+    def flush(self) -> None:
+        """Queues the multiply + reduce of the last submitted step and waits for everything."""
+        if self.pending is not None:
+            self._finish(self.pending)
+            self.pending = None
+        self.streams.synchronize()
+        self.server.sync()
+
+    def replies(self, step: int):
+        """The replies tensor of `step` (0-based submit index): [per, reply_cts, 2, k, N] int64."""
+        return self.sets[step & 1].replies

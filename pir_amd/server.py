@@ -340,6 +340,32 @@ class PIRServer:
         self._check(self.lib.pirgpu_batch_expand_packed(self.db.handle, first, count, C.c_void_p(packed_ptr),
                                                         C.c_void_p(rows_ptr), cuts, len(row_cuts) - 1))
 
+    # -- the same without host synchronisation + device-side ordering (pipelined multi-GPU step) --------
+    def stream_handle(self) -> int:
+        """The library's main HIP stream (for torch.cuda.ExternalStream)."""
+        return int(self.lib.pirgpu_stream_handle(self.db.handle) or 0)
+
+    def join(self) -> None:
+        """Main stream waits (on the device) for everything queued on the lanes / workers so far."""
+        self._check(self.lib.pirgpu_join(self.db.handle))
+
+    def fork(self) -> None:
+        """Lanes / workers wait (on the device) for everything the main stream has been made to wait for."""
+        self._check(self.lib.pirgpu_fork(self.db.handle))
+
+    def batch_expand_packed_async(self, first: int, count: int, packed_ptr: int, rows_ptr: int, row_cuts) -> None:
+        cuts = (C.c_uint32 * len(row_cuts))(*row_cuts)
+        self._check(self.lib.pirgpu_batch_expand_packed_async(self.db.handle, first, count, C.c_void_p(packed_ptr),
+                                                              C.c_void_p(rows_ptr), cuts, len(row_cuts) - 1))
+
+    def batch_reply_copy_to_device_async(self, device_ptr: int) -> None:
+        self._check(self.lib.pirgpu_batch_reply_copy_to_device_async(self.db.handle, C.c_void_p(device_ptr),
+                                                                     self._batch_count * self.db.reply_ct_count()))
+
+    def reduce_fixup_device_async(self, device_ptr: int, n_cts: int, stream: int = 0) -> None:
+        self._check(self.lib.pirgpu_reduce_fixup_device_async(self.db.handle, C.c_void_p(device_ptr), n_cts,
+                                                              C.c_void_p(stream)))
+
     def batch_run_packed(self, packed_ptr: int, n_ranks: int, per_rank: int, rows_ptr: int) -> None:
         self._batch_count = n_ranks * per_rank
         self._check(self.lib.pirgpu_batch_run_packed(self.db.handle, C.c_void_p(packed_ptr), n_ranks, per_rank,

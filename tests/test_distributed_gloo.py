@@ -133,6 +133,28 @@ class OracleShardServer:
         for j, qj in enumerate(self.orc.moduli[: self.k]):
             a[:, :, j, :] %= np.uint64(qj)
 
+    # -- the pipelined step's entry points: no streams on the CPU, so ordering calls are no-ops -----------------
+    def stream_handle(self):
+        return 0
+
+    def fork(self):
+        pass
+
+    def join(self):
+        pass
+
+    def sync(self):
+        pass
+
+    def batch_expand_packed_async(self, first, count, packed_ptr, rows_ptr, cuts):
+        self.batch_expand_packed(first, count, packed_ptr, rows_ptr, cuts)
+
+    def batch_reply_copy_to_device_async(self, dst_ptr):
+        self.batch_reply_copy_to_device(dst_ptr)
+
+    def reduce_fixup_device_async(self, ptr, n_cts, stream=0):
+        self.reduce_fixup_device_n(ptr, n_cts)
+
     # -- the collective transparent-ciphertext decision (pirgpu_zero_plaintexts / _set_remote_ / _check_ready) ------
     remote_zero = 0
 
@@ -192,6 +214,28 @@ def rows_step_check(rank, world, d, dbsize, elem, batch, zero_pt=None):
         for i in range(lo, hi):                                # rank r ends with the replies of ITS queries
             ok &= bool(np.array_equal(mine[i - lo], full[i]))
             ok &= s.client.process_response(p, indexes[i], mine[i - lo]) == s.item(indexes[i])
+        # the PIPELINED step (RowsPipeline): three consecutive steps over different queries -- step t serves the staged
+        # queries [t * batch, (t + 1) * batch); the multiply + reduce of step t are queued by submit t + 1 (or flush),
+        # the two buffer sets alternate, every rank checks the replies of ITS queries of every step
+        steps = 3
+        idx_all = indexes + [(dbsize - 5 - 53 * i) % dbsize for i in range(batch * (steps - 1))]
+        q_all = queries + [s.client.create_query_for(p, i) for i in idx_all[batch:]]
+        srv.stage_batch(q_all)
+        pipe = D.RowsPipeline(srv, batch, rank, world, dist, torch, "cpu", comm=D.Comm(dist, world))
+        seen = {}
+        for t in range(steps):
+            pipe.submit(first=t * batch)
+            if t >= 1:                                         # step t - 1 is complete (CPU: everything is synchronous)
+                seen[t - 1] = pipe.replies(t - 1).numpy().view(np.uint64).copy()
+        pipe.flush()
+        seen[steps - 1] = pipe.replies(steps - 1).numpy().view(np.uint64).copy()
+        for t in range(steps):
+            for i in range(lo, hi):
+                g = t * batch + i
+                want = full[i] if t == 0 else s.orc.process_query(s.db_ntt, p.dimensions, q_all[g], s.galois_keys)[1]
+                ok &= bool(np.array_equal(seen[t][i - lo], want))
+                ok &= s.client.process_response(p, idx_all[g], seen[t][i - lo]) == s.item(idx_all[g])
+        srv.stage_batch(queries)
     # the whole-selection-vector exchange (any d): every rank ends with every reply
     sv_all = torch.empty((batch, p.dim_sum, 2, s.orc.k, 4096), dtype=torch.int64)
     replies = torch.empty((batch, srv.db.reply_ct_count(), 2, s.orc.k, 4096), dtype=torch.int64)

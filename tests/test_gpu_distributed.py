@@ -55,6 +55,35 @@ def _step(rank, world, dist, items, batch, out):
             if not same:
                 print("rank %d: packed step, query %d differs" % (rank, i), flush=True)
             ok &= same
+    # the PIPELINED step: four consecutive steps over different queries (step t serves the staged queries
+    # [t * batch, (t + 1) * batch)), no host synchronisation between the library's streams and the communication
+    # stream -- ordering is by events only; replies of step t are read after step t + 2 was submitted or after flush
+    steps = 4
+    idx_all = indexes + [(items - 7 - 59 * i) % items for i in range(batch * (steps - 1))]
+    q_all = np.concatenate([queries, np.stack([s.client.create_query_for(p, i) for i in idx_all[batch:]])])
+    srv.stage_batch(q_all)
+    pipe = D.RowsPipeline(srv, batch, rank, world, dist, torch, dev)
+    lo, hi = D.owned_queries(batch, rank, world)
+    seen = {}
+    for t in range(steps):
+        pipe.submit(first=t * batch)
+        if t >= 2:      # the reduce of step t - 2 was queued by submit t - 1: wait for the comm stream, then read
+            pipe.streams.side.synchronize()
+            seen[t - 2] = pipe.replies(t - 2).cpu().numpy().view(np.uint64).copy()
+    pipe.flush()
+    seen[steps - 1] = pipe.replies(steps - 1).cpu().numpy().view(np.uint64).copy()
+    # step steps - 2 shares its buffer set with step steps - 4 ... its replies were overwritten only by step `steps`,
+    # which does not exist: still there
+    seen[steps - 2] = pipe.replies(steps - 2).cpu().numpy().view(np.uint64).copy()
+    for t in range(steps):
+        for i in range(lo, hi):
+            g = t * batch + i
+            want = full[i] if t == 0 else s.orc.process_query(s.db_ntt, p.dimensions, q_all[g], s.galois_keys)[1]
+            same = bool(np.array_equal(seen[t][i - lo], want))
+            if not same:
+                print("rank %d: pipelined step %d, query %d differs" % (rank, t, i), flush=True)
+            ok &= same
+    srv.stage_batch(queries)
     sv_all = torch.empty((batch, p.dim_sum, 2, srv.k, srv.N), dtype=torch.int64, device=dev)
     replies = torch.empty((batch, db.reply_ct_count(), 2, srv.k, srv.N), dtype=torch.int64, device=dev)
     D.run_batch_query_parallel(srv, sv_all, replies, dist, rank, world, comm)

@@ -305,6 +305,15 @@ uint64_t pirgpu_scan_bytes(const pirgpu_ctx* ctx);
  * info[5] = rows, info[6] = columns of the scanned matrix, info[7] = 1 if single queries use the MFMA
  * scan as well (matrices wider than one column chunk scan single queries with the 64-bit kernels). */
 int pirgpu_scan_info(pirgpu_ctx* ctx, uint32_t info[8]);
+/* Options by name (case-insensitive), e.g. "scan_mfma" (0 keeps the 64-bit multiply-accumulate scan for d >= 2),
+ * "scan_mfma_wide" (0 / 1 forces the 8-wave / 4-wave scan kernel), "lanes", "upper_blocks", "fuse_last", "last_ntt",
+ * "tree40", "sel_f64", "split_upper", "scan_mfma_wgs_batch" (workgroups of a database pass that shares the chip with
+ * another group) -- DESIGN.md section 6 lists them.  A name that was not set falls back to the environment variable
+ * PIRGPU_<NAME> (the A/B scripts under tools/ use that), then to the built-in default; get_option returns -1 for
+ * "built-in default".  Options that shape the workspace must be set before the context is first used
+ * (FailedPrecondition afterwards).  The arithmetic flavour (PIRGPU_NTT_MODE) is fixed at pirgpu_create. */
+int pirgpu_set_option(pirgpu_ctx* ctx, const char* name, int64_t value);
+int pirgpu_get_option(pirgpu_ctx* ctx, const char* name, int64_t* value);
 /* Arithmetic flavour of the transform kernels of this context: 0 = 64-bit integer Shoup/Harvey butterflies (any
  * modulus < 2^61), 1 = exact fp64 (all moduli < 2^46), 2 = exact fp64 with per-stage renormalisation (< 2^49).
  * Chosen from the largest modulus; PIRGPU_NTT_MODE=0|2 in the environment at pirgpu_create forces a more general

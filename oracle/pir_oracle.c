@@ -36,6 +36,8 @@ struct orc_ctx {
   uint64_t phalf_mod[ORC_MAXK]; /* floor(p/2) mod q_j */
   /* plain lift: q_j - (t mod q_j) */
   uint64_t lift_inc[ORC_MAXK];
+  /* Barrett ratio floor(2^128 / q) per modulus (SEAL Modulus::const_ratio), for the dyadic products */
+  uint64_t br_lo[ORC_MAXK + 1], br_hi[ORC_MAXK + 1];
 };
 
 /* ---------------------------------------------------------------- arithmetic */
@@ -168,6 +170,11 @@ orc_ctx* orc_create(uint32_t N, uint32_t k, const uint64_t* moduli, uint64_t t) 
       ip = orc_mulmod(ip, ipsi, q);
     }
     c->ninv[i] = orc_invmod(N % q, q);
+    {
+      const u128 ratio = (~(u128)0) / q; /* floor((2^128 - 1) / q) == floor(2^128 / q) for odd q > 1 */
+      c->br_lo[i] = (uint64_t)ratio;
+      c->br_hi[i] = (uint64_t)(ratio >> 64);
+    }
     c->ninvs[i] = shoup(c->ninv[i], q);
   }
   for (uint32_t j = 0; j < k; ++j) {
@@ -255,8 +262,27 @@ void orc_ct_ntt_inv(const orc_ctx* c, uint64_t* ct) {
     for (uint32_t j = 0; j < c->k; ++j) orc_ntt_inv(c, j, ct + ((size_t)p * c->k + j) * c->N);
 }
 
+/* (hi:lo) mod q with the precomputed ratio floor(2^128 / q): SEAL 3.5.6 util::barrett_reduce_128 -- what
+ * Evaluator::multiply_plain's dyadic product (util::dyadic_product_coeffmod) uses; canonical result. */
+static inline uint64_t barrett_reduce_128(uint64_t lo, uint64_t hi, uint64_t q, uint64_t br_lo, uint64_t br_hi) {
+  const uint64_t carry = (uint64_t)(((u128)lo * br_lo) >> 64);
+  const u128 t2 = (u128)lo * br_hi;
+  const uint64_t t1 = (uint64_t)t2 + carry;
+  const uint64_t t3 = (uint64_t)(t2 >> 64) + (t1 < (uint64_t)t2);
+  const u128 t4 = (u128)hi * br_lo;
+  const uint64_t t1b = t1 + (uint64_t)t4;
+  const uint64_t carry2 = (uint64_t)(t4 >> 64) + (t1b < t1);
+  const uint64_t qhat = hi * br_hi + t3 + carry2;
+  const uint64_t r = lo - qhat * q;
+  return r >= q ? r - q : r;
+}
+
 void orc_dyadic_mul(const orc_ctx* c, uint32_t mi, const uint64_t* a, const uint64_t* b, uint64_t* out) {
-  for (uint32_t i = 0; i < c->N; ++i) out[i] = orc_mulmod(a[i], b[i], c->q[mi]);
+  const uint64_t q = c->q[mi], bl = c->br_lo[mi], bh = c->br_hi[mi];
+  for (uint32_t i = 0; i < c->N; ++i) {
+    const u128 z = (u128)a[i] * b[i];
+    out[i] = barrett_reduce_128((uint64_t)z, (uint64_t)(z >> 64), q, bl, bh);
+  }
 }
 void orc_poly_add(const orc_ctx* c, uint32_t mi, const uint64_t* a, const uint64_t* b, uint64_t* out) {
   for (uint32_t i = 0; i < c->N; ++i) out[i] = addmod(a[i], b[i], c->q[mi]);
@@ -340,7 +366,10 @@ static void switch_key_inplace(const orc_ctx* c, uint64_t* ct, const uint64_t* t
     }
     for (uint32_t comp = 0; comp < 2; ++comp) {
       uint64_t* dst = prod + ((size_t)comp * km + I) * N;
-      for (uint32_t i = 0; i < N; ++i) dst[i] = (uint64_t)(acc[(size_t)comp * N + i] % m);
+      for (uint32_t i = 0; i < N; ++i) {   /* lazy 128-bit sums, one Barrett reduction (as SEAL's key switch) */
+        const u128 a = acc[(size_t)comp * N + i];
+        dst[i] = barrett_reduce_128((uint64_t)a, (uint64_t)(a >> 64), m, c->br_lo[I], c->br_hi[I]);
+      }
       orc_ntt_inv(c, I, dst);
     }
   }

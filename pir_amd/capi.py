@@ -79,6 +79,8 @@ SIGNATURES = {
     "pirgpu_set_remote_zero_plaintexts": (C.c_int, [C.c_void_p, C.c_uint64]),
     "pirgpu_check_ready": (C.c_int, [C.c_void_p]),
     "pirgpu_ntt_mode": (C.c_int, [C.c_void_p]),
+    "pirgpu_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "pirgpu_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
     "pirgpu_packed_selector_bytes": (C.c_uint64, [C.c_void_p]),
     "pirgpu_batch_expand_packed": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                              C.POINTER(C.c_uint32), C.c_uint32]),

@@ -5,6 +5,7 @@
 // database, the Galois keys and every intermediate live in HBM; the host only
 // sequences kernel launches on the context's stream.
 #include <hip/hip_runtime.h>
+#include <ctype.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -213,6 +214,9 @@ struct pirgpu_ctx {
   int prof_cur = -1;           // event set of the run being recorded (-1: not recording)
   float timings[6]{};
 
+  // options by name (pirgpu_set_option); a name not set here falls back to the environment variable PIRGPU_<NAME>
+  // (A/B scripts under tools/), then to the built-in default
+  std::map<std::string, int64_t> opts;
   std::string err;
   uint64_t gen = 0;         // unique per context (thread-local error messages are keyed on it, not on the address)
   std::recursive_mutex mu;  // per ABI call; pirgpu_process_request holds it across its whole body
@@ -359,6 +363,19 @@ void build_tables(pirgpu_ctx* c) {
 
 uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
+// Option `name` (upper case, without the PIRGPU_ prefix): pirgpu_set_option's value, else the environment variable
+// PIRGPU_<name>, else dflt.  *present reports whether either was given.
+int64_t option(const pirgpu_ctx* c, const char* name, int64_t dflt, bool* present = nullptr) {
+  if (present) *present = true;
+  auto it = c->opts.find(name);
+  if (it != c->opts.end()) return it->second;
+  const std::string env = std::string("PIRGPU_") + name;
+  const char* v = getenv(env.c_str());
+  if (v && *v) return strtoll(v, nullptr, 10);
+  if (present) *present = false;
+  return dflt;
+}
+
 // waits for everything the batch pipeline has enqueued: lane streams (grouped expansion + multiply) and worker streams
 void sync_batch_streams(pirgpu_ctx* c) {
   for (BatchLane& ln : c->lanes)
@@ -405,9 +422,9 @@ void ensure_workspace(pirgpu_ctx* c) {
   c->m_max = m_max;
   // per-level node counts inside this shard and result buffers
   const uint64_t shard_pts = c->pt_end - c->pt_begin;
-  if (const char* v = getenv("PIRGPU_UPPER_BLOCKS")) c->upper_blocks = std::max(1, atoi(v));
-  if (const char* v = getenv("PIRGPU_UPPER_BLOCKS_BATCH")) c->upper_blocks_batch = std::max(1, atoi(v));
-  if (const char* v = getenv("PIRGPU_SCAN_MFMA_WGS_BATCH")) c->scan_wgs_batch = (uint32_t)std::max(0, atoi(v));
+  c->upper_blocks = (uint32_t)std::max<int64_t>(1, option(c, "UPPER_BLOCKS", c->upper_blocks));
+  c->upper_blocks_batch = (uint32_t)std::max<int64_t>(1, option(c, "UPPER_BLOCKS_BATCH", c->upper_blocks_batch));
+  c->scan_wgs_batch = (uint32_t)std::max<int64_t>(0, option(c, "SCAN_MFMA_WGS_BATCH", c->scan_wgs_batch));
   c->upper_blocks_batch = std::min(c->upper_blocks_batch, c->upper_blocks);  // the scratch is sized for upper_blocks
   c->lvl_rows.assign(d, 0);
   c->lvl_cts.assign(d, 0);
@@ -440,9 +457,8 @@ void ensure_workspace(pirgpu_ctx* c) {
     //   PIRGPU_SCAN_ROWS   rows accumulated per thread (1,2,3,4,6,8)
     //   PIRGPU_SCAN_BLOCK  workgroup size (64..256)
     //   PIRGPU_SCAN_NSPLIT column splits (partial sums reduced by reduce_splits_kernel)
-    auto env_u32 = [](const char* name, uint32_t dflt) {
-      const char* v = getenv(name);
-      return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
+    auto env_u32 = [c](const char* name, uint32_t dflt) {   // name = "PIRGPU_<OPTION>"
+      return (uint32_t)option(c, name + 7, dflt);
     };
     //   PIRGPU_SCAN_LIMB   0 forces the generic 128-bit accumulators
     c->scan_limb = true;
@@ -482,7 +498,9 @@ void ensure_workspace(pirgpu_ctx* c) {
     // 5-byte storage of the key-switch intermediates: the fp64 flavours store x + q (|x| <= q), so q < 2^39
     for (uint32_t j = 0; j <= k; ++j) c->pack40 = c->pack40 && (c->hp.mod[j].q >> 39) == 0;
     //   PIRGPU_SCAN_MFMA_WIDE  0 / 1 forces the 8-wave / 4-wave (one wave per SIMD, up to 7 k-steps) scan kernel
-    c->mg = mfma_geometry(c->hp, c->scan_rows, c->scan_cols, getenv("PIRGPU_SCAN_MFMA_WIDE") ? (int)env_u32("PIRGPU_SCAN_MFMA_WIDE", 0) : -1);
+    bool wide_given = false;
+    const int64_t wide = option(c, "SCAN_MFMA_WIDE", 0, &wide_given);
+    c->mg = mfma_geometry(c->hp, c->scan_rows, c->scan_cols, wide_given ? (int)(wide != 0) : -1);
     c->mfma_on = env_u32("PIRGPU_SCAN_MFMA", 1) != 0 && d >= 2 && c->mg.L != 0 && c->scan_rows >= 8 && shard_pts > 0;
     c->mfma_nq = std::max<uint32_t>(1, std::min<uint32_t>(env_u32("PIRGPU_SCAN_MFMA_NQ", kMaxMfmaQueries),
                                                           kMaxMfmaQueries));
@@ -717,7 +735,8 @@ void ensure_packed(pirgpu_ctx* c) {
 // the column selectors (unless they arrive packed), scan, fold column chunks.  Row sums of query q go to
 // out + q * scan_rows ciphertexts; `part` (query-major as well) holds the per-chunk sums of matrices wider than one chunk.
 void scan_group_mfma(pirgpu_ctx* c, hipStream_t st, uint8_t*& selp, const MfmaPtrs& col_sel, uint32_t n, uint64_t* out_base,
-                     uint64_t* part, Worker* profiled, const uint8_t* packed = nullptr, bool sel_f64 = false) {
+                     uint64_t* part, Worker* profiled, const uint8_t* packed = nullptr, bool sel_f64 = false,
+                     bool share_chip = false) {
   const uint32_t kN = c->k * c->N;
   const uint64_t words = (uint64_t)c->scan_rows * c->ctw;
   ensure_packed(c);
@@ -730,14 +749,10 @@ void scan_group_mfma(pirgpu_ctx* c, hipStream_t st, uint8_t*& selp, const MfmaPt
     packed = selp;
   }
   if (profiled) record(c, *profiled, PH_SCAN);  // selector packing counts as selector preparation, not as the scan
-  // batch pipeline: the pass runs on part of the chip and overlaps the other lane's transform kernels
-  // ... when another lane has work queued (asked at enqueue time; the host runs ahead of the GPU, so a lane that is
-  // busy now still is when this launch starts); a lone group gets the whole chip
-  bool share = false;
-  if (!profiled && c->in_batch && c->scan_wgs_batch)
-    for (const BatchLane& ln : c->lanes)
-      if (ln.stream && ln.stream != st && hipStreamQuery(ln.stream) == hipErrorNotReady) share = true;
-  (void)hipGetLastError();   // hipErrorNotReady is not an error here
+  // batch pipeline: the pass runs on part of the chip and overlaps the other lane's transform kernels whenever the
+  // call that queued it has a second group for the other lane (share_chip: decided from the batch's shape, not from
+  // the streams' state at enqueue time); a lone group gets the whole chip
+  const bool share = share_chip && !profiled && c->scan_wgs_batch;
   const uint32_t wgs = share ? c->scan_wgs_batch : 0;
   HIP_TRY(launch_scan_mfma(st, c->dp, c->mg, c->d_dbp, packed, out, n, c->scan_rows, kN, words, wgs));
   if (c->mg.nchunks > 1)
@@ -1035,6 +1050,49 @@ int pirgpu_set_transparent_policy(pirgpu_ctx* c, int allow) {
   return guarded(c, [&]() -> int {
     c->allow_transparent = allow != 0;
     return PIRGPU_OK;
+  });
+}
+
+// Options the library understands (upper case in the environment: PIRGPU_<NAME>); `early` ones shape the workspace
+// and must be set before the context is first used.
+static const struct { const char* name; bool early; } kOptions[] = {
+    {"UPPER_BLOCKS", true}, {"UPPER_BLOCKS_BATCH", true}, {"SCAN_MFMA_WGS_BATCH", false}, {"SCAN_LIMB", true},
+    {"SCAN_NQ", true}, {"SCAN_MQ_ROWS", true}, {"SCAN_MQ_SINGLE", true}, {"SCAN_MQ_SINGLE_ROWS", true},
+    {"SCAN_MQ_SINGLE_LIMB", true}, {"SCAN_ROWS", true}, {"SCAN_BLOCK", true}, {"SCAN_NSPLIT", true},
+    {"FUSE_LAST", true}, {"FUSE_MAC_COMBINE", true}, {"LAST_NTT", true}, {"SEL_F64", true}, {"TREE40", true},
+    {"FUSE_MAC_NODES", true}, {"SPLIT_UPPER", true}, {"SPLIT_UPPER_MB", true}, {"PACK40", true},
+    {"SCAN_MFMA", true}, {"SCAN_MFMA_WIDE", true}, {"SCAN_MFMA_NQ", true}, {"SCAN_MFMA_SINGLE", true}, {"LANES", true},
+};
+
+int pirgpu_set_option(pirgpu_ctx* c, const char* name, int64_t value) {
+  return guarded(c, [&]() -> int {
+    if (!name) return fail(c, PIRGPU_INVALID_ARGUMENT, "null option name");
+    std::string up(name);
+    for (char& ch : up) ch = (char)toupper((unsigned char)ch);
+    for (const auto& o : kOptions) {
+      if (up != o.name) continue;
+      if (o.early && c->ws_ready)
+        return fail(c, PIRGPU_FAILED_PRECONDITION, "option " + up + " shapes the workspace: set it before the context is first used");
+      c->opts[up] = value;
+      if (up == "SCAN_MFMA_WGS_BATCH") c->scan_wgs_batch = (uint32_t)std::max<int64_t>(0, value);
+      return PIRGPU_OK;
+    }
+    return fail(c, PIRGPU_INVALID_ARGUMENT, "unknown option " + up);
+  });
+}
+
+int pirgpu_get_option(pirgpu_ctx* c, const char* name, int64_t* value) {
+  return guarded(c, [&]() -> int {
+    if (!name || !value) return fail(c, PIRGPU_INVALID_ARGUMENT, "null argument");
+    std::string up(name);
+    for (char& ch : up) ch = (char)toupper((unsigned char)ch);
+    for (const auto& o : kOptions)
+      if (up == o.name) {
+        bool present = false;
+        *value = option(c, o.name, -1, &present);   // -1: not set anywhere, the built-in default applies
+        return PIRGPU_OK;
+      }
+    return fail(c, PIRGPU_INVALID_ARGUMENT, "unknown option " + up);
   });
 }
 
@@ -1757,7 +1815,7 @@ static void ensure_lanes(pirgpu_ctx* c, bool with_expansion_buffers) {
   const uint32_t N = c->N, k = c->k;
   if (c->lanes.empty()) {
     uint32_t n_lanes = 2;   // PIRGPU_LANES: groups in flight (each lane = one stream + one set of group buffers)
-    if (const char* v = getenv("PIRGPU_LANES")) n_lanes = (uint32_t)std::min(4, std::max(1, atoi(v)));
+    n_lanes = (uint32_t)std::min<int64_t>(4, std::max<int64_t>(1, option(c, "LANES", n_lanes)));
     c->lanes.resize(n_lanes);
     for (BatchLane& ln : c->lanes) {
       HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
@@ -1840,6 +1898,13 @@ static void batch_run_mfma(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
   // groups: runs of up to G consecutive queries; with packed input a group is what ONE source rank packed together
   // (its queries in runs of kMaxMfmaQueries), so the walk restarts at every source-rank boundary
   const uint32_t span = pk ? pk->per_rank : count;
+  // groups this call queues: with two or more (and two lanes) every pass runs on half the chip
+  uint32_t n_groups = 0;
+  for (uint32_t rank0 = 0; rank0 < count; rank0 += span) {
+    const uint32_t in_span = std::min<uint32_t>(span, count - rank0);
+    n_groups += (in_span + (pk ? (uint32_t)kMaxMfmaQueries : G) - 1) / (pk ? (uint32_t)kMaxMfmaQueries : G);
+  }
+  const bool share_chip = n_groups >= 2 && nl >= 2;
   for (uint32_t rank0 = 0; rank0 < count; rank0 += span) {
     const uint32_t step = pk ? (uint32_t)kMaxMfmaQueries : G;
     const uint32_t in_span = std::min<uint32_t>(span, count - rank0);
@@ -1872,7 +1937,8 @@ static void batch_run_mfma(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
           col.p[q] = sv + (size_t)c->sv_off[c->d - 1] * c->ctw;
         }
       }
-      scan_group_mfma(c, ln.stream, ln.selp, col, B, ln.lvl[c->d - 1], ln.scan_part, nullptr, packed, sg.sel_f64);
+      scan_group_mfma(c, ln.stream, ln.selp, col, B, ln.lvl[c->d - 1], ln.scan_part, nullptr, packed, sg.sel_f64,
+                      share_chip);
       post_scan_stage(c, sg, nullptr);
       HIP_TRY(hipMemcpyAsync(c->d_breply + (size_t)first * rwords, ln.lvl[0], (size_t)B * rwords * 8,
                              hipMemcpyDeviceToDevice, ln.stream));

@@ -48,9 +48,18 @@ class Comm:
     orders streams with events instead.  Any other backend (gloo in the tests): tensors are staged through host
     memory, so the same glue runs with two processes on one GPU or on CPU."""
 
+    # Largest per-peer message handed to one RCCL call.  RCCL 2.26.6 (ROCm 7.0) copies only the first half of an
+    # all_to_all_single message above 1 GiB (tools/r03_a2a_probe.py, MI355X: every size <= 1024 MiB exact, 1100 MiB
+    # and up wrong from the middle on); larger messages are cut into pieces at sub-block boundaries.  Real 8-GPU
+    # steps stay far below (21 MB per peer at cfg 3); a forced single-rank run of the same step does not.
+    MAX_MESSAGE_BYTES = 512 << 20
+
     def __init__(self, dist, world: int, host_sync: bool = True):
         self.dist, self.world = dist, world
         self.host_sync = host_sync
+        import os
+        if os.environ.get("PIRGPU_MAX_COLLECTIVE_MB"):      # tests: force the piecewise paths with small messages
+            self.MAX_MESSAGE_BYTES = max(1, int(os.environ["PIRGPU_MAX_COLLECTIVE_MB"])) << 20
         # RCCL process group (also a forced single-rank one): collectives run on the device
         self.device_native = dist is not None and dist.is_initialized() and dist.get_backend() == "nccl"
 
@@ -65,7 +74,14 @@ class Comm:
             return
         d = self.dist
         if self.device_native:
-            d.all_gather_into_tensor(full.view(-1), full[rank].reshape(-1))
+            flat = full.view(self.world, -1)
+            n, limit = flat.shape[1], max(1, self.MAX_MESSAGE_BYTES // full.element_size())
+            if n <= limit:
+                d.all_gather_into_tensor(full.view(-1), full[rank].reshape(-1))
+            else:
+                for o in range(0, n, limit):
+                    e = min(n, o + limit)
+                    d.all_gather([flat[r, o:e] for r in range(self.world)], flat[rank, o:e])
             self._sync(full)
             return
         mine = full[rank].cpu().contiguous()
@@ -75,15 +91,33 @@ class Comm:
             full[r].copy_(p)
         self._sync(full)
 
-    def all_to_all(self, recv, send, recv_splits, send_splits):
-        """1-D tensors; split sizes in elements."""
+    def all_to_all(self, recv, send, recv_splits, send_splits, units: int = 1):
+        """1-D tensors; split sizes in elements.  units: every per-peer block consists of `units` equal sub-blocks
+        (the queries of a step); a block larger than MAX_MESSAGE_BYTES is exchanged in pieces of whole sub-blocks."""
         if self.world == 1 and not self.device_native:
             recv.copy_(send)
             self._sync(recv)
             return
         d = self.dist
         if self.device_native:
-            d.all_to_all_single(recv, send, list(recv_splits), list(send_splits))
+            limit = max(1, self.MAX_MESSAGE_BYTES // recv.element_size())
+            biggest = max(max(recv_splits), max(send_splits))
+            pieces = min(max(1, units), -(-biggest // limit))
+            if pieces <= 1:
+                d.all_to_all_single(recv, send, list(recv_splits), list(send_splits))
+            else:
+                ro, so = [0], [0]
+                for x in recv_splits:
+                    ro.append(ro[-1] + x)
+                for x in send_splits:
+                    so.append(so[-1] + x)
+                for pc in range(pieces):
+                    u0, u1 = units * pc // pieces, units * (pc + 1) // pieces
+                    outs = [recv[ro[r] + recv_splits[r] // units * u0: ro[r] + recv_splits[r] // units * u1]
+                            for r in range(self.world)]
+                    ins = [send[so[r] + send_splits[r] // units * u0: so[r] + send_splits[r] // units * u1]
+                           for r in range(self.world)]
+                    d.all_to_all(outs, ins)
             self._sync(recv)
             return
         s, r = send.cpu(), recv.new_empty(recv.shape, device="cpu")
@@ -99,7 +133,14 @@ class Comm:
             return
         d = self.dist
         if self.device_native:
-            d.reduce_scatter_tensor(out.view(-1), full.view(-1), op=d.ReduceOp.SUM)
+            o1, f2 = out.view(-1), full.view(self.world, -1)
+            n, limit = o1.numel(), max(1, self.MAX_MESSAGE_BYTES // out.element_size())
+            if n <= limit:
+                d.reduce_scatter_tensor(o1, full.view(-1), op=d.ReduceOp.SUM)
+            else:
+                for o in range(0, n, limit):
+                    e = min(n, o + limit)
+                    d.reduce_scatter(o1[o:e], [f2[r, o:e] for r in range(self.world)], op=d.ReduceOp.SUM)
             self._sync(out)
             return
         c = full.cpu()
@@ -235,7 +276,7 @@ def run_batch_rows_packed(server, bufs: PackedBuffers, dist, rank: int, world: i
     server.batch_expand_packed(lo, bufs.per, bufs.packed[rank].data_ptr(), bufs.rows_send.data_ptr(), bufs.cuts)
     t.append(time.perf_counter())
     comm.all_gather_inplace(bufs.packed, rank)
-    comm.all_to_all(bufs.rows_recv, bufs.rows_send, bufs.recv_splits, bufs.send_splits)
+    comm.all_to_all(bufs.rows_recv, bufs.rows_send, bufs.recv_splits, bufs.send_splits, units=bufs.per)
     t.append(time.perf_counter())
     server.batch_run_packed(bufs.packed.data_ptr(), world, bufs.per, bufs.rows_recv.data_ptr())
     server.batch_reply_copy_to_device(bufs.partial.data_ptr())
@@ -360,7 +401,7 @@ class RowsPipeline:
         st.comm_after_main()
         with st.comm():
             self.comm.all_gather_inplace(bufs.packed, self.rank)
-            self.comm.all_to_all(bufs.rows_recv, bufs.rows_send, bufs.recv_splits, bufs.send_splits)
+            self.comm.all_to_all(bufs.rows_recv, bufs.rows_send, bufs.recv_splits, bufs.send_splits, units=bufs.per)
             st.record_exchange(b)
         if self.pending is not None:
             self._finish(self.pending)

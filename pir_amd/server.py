@@ -122,6 +122,15 @@ class PIRDatabase:
         "result ciphertext is transparent" through database.cpp:313-315; True: return the defined reply."""
         self._check(self.lib.pirgpu_set_transparent_policy(self._h, 1 if allow else 0))
 
+    def set_option(self, name: str, value: int) -> None:
+        """pirgpu_set_option: a tuning / behaviour option by name (before the first query for workspace-shaping ones)."""
+        self._check(self.lib.pirgpu_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int64(0)
+        self._check(self.lib.pirgpu_get_option(self._h, name.encode(), C.byref(v)))
+        return int(v.value)
+
     def finalize(self, release_staging: bool = False) -> None:
         """Pack the operand-layout copy now; optionally free the u64 staging copy (no reloads afterwards)."""
         self._check(self.lib.pirgpu_db_finalize(self._h, 1 if release_staging else 0))

@@ -148,6 +148,31 @@ def test_valu_scan_still_selectable(monkeypatch):
     db.close()
 
 
+def test_options_by_name_replace_the_environment():
+    """pirgpu_set_option: the same switches without touching the environment; workspace-shaping options are refused
+    once the context has been used, unknown names are InvalidArgument."""
+    s = setup_with_dims(0, 2048, [17, 17], N=4096, plain_bits=24)
+    pp = to_product_params(s.params)
+    db = pir_amd.PIRDatabase.Create(pp)
+    assert db.get_option("scan_mfma") == -1                    # built-in default
+    db.set_option("scan_mfma", 0)
+    db.set_option("Lanes", 1)                                  # case-insensitive
+    assert db.get_option("SCAN_MFMA") == 0
+    db.populate(s.raw)
+    srv = pir_amd.PIRServer(db, pp)
+    srv.set_galois_keys(s.galois_keys)
+    assert not srv.scan_info()["mfma"]
+    check_queries(s, srv, [3])
+    with pytest.raises(pir_amd.PirGpuError) as e:
+        db.set_option("scan_mfma", 1)
+    assert e.value.code == pir_amd.StatusCode.FAILED_PRECONDITION
+    with pytest.raises(pir_amd.PirGpuError) as e:
+        db.set_option("no_such_option", 1)
+    assert e.value.code == pir_amd.StatusCode.INVALID_ARGUMENT
+    db.set_option("scan_mfma_wgs_batch", 96)                   # a run-time option: accepted at any time
+    db.close()
+
+
 def test_small_row_counts_use_the_valu_scan():
     s = PirSetup(300, 2048, 2, N=4096, plain_bits=24)        # 60 plaintexts -> dims [8, 8]: rows = 8 -> MFMA
     db, srv = make(s)

@@ -173,7 +173,7 @@ def test_fingerprint_match_with_different_bytes_does_not_reuse_the_keys():
     blob_b = None
     for coeff in range(7, 200):                 # change one key coefficient until the changed word is not a sampled one
         k2 = {g: v.copy() for g, v in keys.items()}
-        g0 = sorted(k2)[3]
+        g0 = sorted(k2)[-1]                      # N + 1: the first expansion level always uses it
         k2[g0][1, 0, 1, coeff] ^= np.uint64(1)
         cand = W.save_galois_keys(k2, N, key_pid)
         diff = [i for i in range(0, len(cand), 8) if cand[i:i + 8] != blob_a[i:i + 8]]

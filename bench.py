@@ -50,8 +50,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PMC_FILE = "r01_pmc_scan_mfma_traffic.json"
-VALU_FILE = "r02_valu_roofline.json"
+PMC_GLOB = "r*_pmc_scan_traffic.json"     # newest round's PMC passes (tools/pmc_scan_traffic.sh), per config
+VALU_GLOB = "r*_valu_roofline.json"
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -396,16 +396,23 @@ def main():
         u64_bytes = pp.num_pt * k * N * 8          # B_q = num_pt * k * N * 8
         scan_ms = timings["scan_ms"]
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-        traffic = None
-        try:   # HBM bytes per scan launch: a RECORDED constant from the committed PMC passes, same workload only
-            pm = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
-            if args.config == 3 and args.log_items == 20 and args.dims == 2 and world == 1 and info["single_query_mfma"]:
-                traffic = pm["traffic_bytes_per_launch"]
+        import glob
+        traffic, traffic_src = None, None
+        try:   # HBM bytes per single-query scan launch: RECORDED by the newest committed PMC passes, same workload only
+            pmf = sorted(glob.glob(os.path.join(ROOT, "profiles", PMC_GLOB)))[-1]
+            pm = json.load(open(pmf))
+            ent = pm["configs"].get("cfg%d" % args.config)
+            default_shape = args.log_items == {2: 16, 3: 20, 4: 22, 5: 24}[args.config]
+            if ent and "traffic_bytes_per_launch" in ent and default_shape and world == 1 and info["single_query_mfma"]:
+                traffic = ent["traffic_bytes_per_launch"]
+                traffic_src = "RECORDED, not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes " \
+                              "(gfx950 x2 correction on FETCH_SIZE) of this workload at commit %s, profiles/%s" \
+                              % (pm.get("commit"), os.path.basename(pmf))
         except Exception:
             pass
         compute = None
         try:   # VALU-issue roofline of the transform kernels (recorded: tools/valu_roofline.py over PMC passes)
-            compute = json.load(open(os.path.join(ROOT, "profiles", VALU_FILE)))
+            compute = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", VALU_GLOB)))[-1]))
         except Exception:
             pass
         if world == 1:
@@ -439,8 +446,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "frac_definition": "bytes the kernel must read (packed operand layout) / HIP-event duration / 8 TB/s",
                          "traffic": traffic,
-                         "traffic_source": "RECORDED constant, not measured in this run: rocprofv3 --pmc FETCH_SIZE/"
-                                           "WRITE_SIZE passes of round 1 on this workload, profiles/" + PMC_FILE,
+                         "traffic_source": traffic_src,
                          "kernel": ("scan_mfma_kernel<%d digits, %d k-steps> (int8 MFMA digit products, 1 query; "
                                     "the same pass serves up to 8)" % (info["digits"], info["ksteps"])) if info["single_query_mfma"]
                          else ("scan_mq_kernel<4 rows/wave, 1 query>" if args.dims > 1

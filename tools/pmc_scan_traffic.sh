@@ -1,26 +1,62 @@
 #!/bin/bash
-# HBM traffic of the scan kernel from rocprofv3 PMC counters: FETCH_SIZE and WRITE_SIZE in separate
-# passes (they do not fit one pass), kernel trace only.  Run on the GPU box from the repo root:
-#   bash tools/pmc_scan_traffic.sh   -> gpurun_out/pmc_fetch/*.csv, gpurun_out/pmc_write/*.csv
+# HBM traffic of the single-query scan launch from rocprofv3 PMC counters, for BASELINE configs 3, 4 and 5:
+# FETCH_SIZE and WRITE_SIZE in separate passes (they do not fit one pass), kernel trace only.  Run on the GPU box
+# from the repo root:
+#   bash tools/pmc_scan_traffic.sh <out.json> [commit] [configs...]
+# gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half the bytes of a 16 B/lane coalesced
+# streaming read -> x2; WRITE_SIZE as reported.
 export TMPDIR=/tmp
-for c in FETCH_SIZE WRITE_SIZE; do
-  d=gpurun_out/pmc_$(echo $c | tr A-Z a-z | cut -d_ -f1)
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -o pmc -- \
-    python3 bench.py --no-cpu-baseline --batch 8 --workers 8 --steps 2 --warmup 1 --latency-runs 6 > $d.log 2>&1
+OUT=${1:-gpurun_out/pmc_scan_traffic.json}
+COMMIT=${2:-unknown}
+shift; shift
+CFGS=${@:-3 4 5}
+for cfg in $CFGS; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    d=gpurun_out/pmc_scan_cfg${cfg}_$(echo $c | tr A-Z a-z | cut -d_ -f1)
+    rm -rf $d
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -o pmc -- \
+      python3 bench.py --config $cfg --no-cpu-baseline --batch 8 --workers 8 --steps 1 --warmup 1 --latency-runs 4 > $d.log 2>&1
+  done
 done
-python3 - <<'PY'
-import csv, glob, json, collections
-out = {}
-for name in ("fetch", "write"):
-    files = glob.glob("gpurun_out/pmc_%s/*counter_collection.csv" % name)
-    acc = collections.defaultdict(list)
-    for f in files:
-        for r in csv.DictReader(open(f)):
-            kn = r["Kernel_Name"]
-            if "scan_mfma_kernel" in kn or "sel_pack" in kn:
-                acc[(kn.split("(")[0][-40:], r["Counter_Name"], r.get("Grid_Size", ""))].append(float(r["Counter_Value"]))
-    for k, v in acc.items():
-        out["%s | %s | grid %s" % k] = {"mean": sum(v) / len(v), "n": len(v), "min": min(v), "max": max(v)}
-json.dump(out, open("gpurun_out/pmc_scan_raw.json", "w"), indent=1)
+python3 - "$OUT" "$COMMIT" $CFGS <<'PY'
+import csv, glob, json, collections, sys
+out_path, commit, cfgs = sys.argv[1], sys.argv[2], sys.argv[3:]
+out = {"collection": "bash tools/pmc_scan_traffic.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes with "
+                     "--kernel-trace over `bench.py --config C --batch 8 --steps 1 --latency-runs 4`; the single-query "
+                     "launches are the ones with the smallest WRITE_SIZE",
+       "correction": "FETCH_SIZE x2 on gfx950 for 16 B/lane coalesced streaming reads (MI355X_MICROARCH.md, HBM "
+                     "section); WRITE_SIZE as reported; both in KB", "commit": commit, "configs": {}}
+for cfg in cfgs:
+    per = {}
+    for name in ("fetch", "write"):
+        rows = []
+        for f in glob.glob("gpurun_out/pmc_scan_cfg%s_%s/**/*counter_collection.csv" % (cfg, name), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "scan_mfma_kernel" in r["Kernel_Name"]:
+                    rows.append((r["Kernel_Name"].split("(")[0].replace("void ", ""), int(r.get("Grid_Size", 0) or 0),
+                                 float(r["Counter_Value"])))
+        per[name] = rows
+    if not per["fetch"] or not per["write"]:
+        out["configs"]["cfg" + cfg] = {"error": "no scan_mfma_kernel dispatches found"}
+        continue
+    # single-query launches: the full-chip grid (the batch launches of 8 queries share the chip: smaller grid) with
+    # the smallest write volume
+    grid = max(g for _, g, _ in per["fetch"])
+    fetch = [v for _, g, v in per["fetch"] if g == grid]
+    write = [v for _, g, v in per["write"] if g == grid]
+    wmin = min(write)
+    write1 = [v for v in write if v <= 1.01 * wmin]
+    # fetch launches come in the same order as write launches of the other pass: pair by position
+    fetch1 = [f for f, w in zip(fetch, write) if w <= 1.01 * wmin] or fetch
+    j = json.loads(open("gpurun_out/pmc_scan_cfg%s_fetch.log" % cfg).read().strip().splitlines()[-1])
+    alg = j["roofline"]["algorithmic_bytes"]
+    rd, wr = 2 * 1024 * sum(fetch1) / len(fetch1), 1024 * sum(write1) / len(write1)
+    out["configs"]["cfg" + cfg] = {
+        "kernel": per["fetch"][0][0], "grid_threads": grid, "launches": len(fetch1),
+        "FETCH_SIZE_KB_mean": sum(fetch1) / len(fetch1), "WRITE_SIZE_KB_mean": sum(write1) / len(write1),
+        "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "traffic_bytes_per_launch": rd + wr,
+        "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": (rd + wr) / alg,
+        "workload": j["config"]["workload"], "roofline_kernel": j["roofline"]["kernel"]}
+json.dump(out, open(out_path, "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY

@@ -815,9 +815,12 @@ void post_scan_stage(pirgpu_ctx* c, const Stage& sg, Worker* profiled) {
     // enough workgroups to fill the chip: ~1024 over (queries * rows * C * chunks * E * k)
     const uint64_t per_chunk = rows * C * c->E * k;
     const uint32_t target = sg.n > 1 || c->in_batch ? c->upper_blocks_batch : c->upper_blocks;
-    uint32_t n_chunks = (uint32_t)std::min<uint64_t>(c->dims[l], std::max<uint64_t>(1, ceil_div(target, per_chunk)));
-    const uint32_t chunk_len = (uint32_t)ceil_div(c->dims[l], n_chunks);
-    n_chunks = (uint32_t)ceil_div(c->dims[l], chunk_len);
+    // children one output row actually has in this shard: dims[l], or -- at the top level of a row shard -- only the
+    // shard's rows (a 20-row shard of 162 used to leave three of its four chunks empty)
+    const uint64_t kids = rows == 1 ? std::min<uint64_t>(c->dims[l], std::max<uint64_t>(nch, 1)) : c->dims[l];
+    uint32_t n_chunks = (uint32_t)std::min<uint64_t>(kids, std::max<uint64_t>(1, ceil_div(target, per_chunk)));
+    const uint32_t chunk_len = (uint32_t)ceil_div(kids, n_chunks);
+    n_chunks = (uint32_t)ceil_div(kids, chunk_len);
     const uint64_t out_polys = rows * C * c->E * 2 * k;
     if (out_polys * n_chunks * N > c->pt_words)
       throw Fail{PIRGPU_INTERNAL, "upper-level scratch undersized"};

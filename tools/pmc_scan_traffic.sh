@@ -15,7 +15,7 @@ for cfg in $CFGS; do
     d=gpurun_out/pmc_scan_cfg${cfg}_$(echo $c | tr A-Z a-z | cut -d_ -f1)
     rm -rf $d
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -o pmc -- \
-      python3 bench.py --config $cfg --no-cpu-baseline --batch 8 --workers 8 --steps 1 --warmup 1 --latency-runs 4 > $d.log 2>&1
+      python3 bench.py --config $cfg --no-cpu-baseline --batch 8 --workers 8 --steps 1 --warmup 1 --latency-runs 4 > $d.json 2> $d.err
   done
 done
 python3 - "$OUT" "$COMMIT" $CFGS <<'PY'
@@ -48,7 +48,7 @@ for cfg in cfgs:
     write1 = [v for v in write if v <= 1.01 * wmin]
     # fetch launches come in the same order as write launches of the other pass: pair by position
     fetch1 = [f for f, w in zip(fetch, write) if w <= 1.01 * wmin] or fetch
-    j = json.loads(open("gpurun_out/pmc_scan_cfg%s_fetch.log" % cfg).read().strip().splitlines()[-1])
+    j = json.loads(open("gpurun_out/pmc_scan_cfg%s_fetch.json" % cfg).read().strip().splitlines()[-1])
     alg = j["roofline"]["algorithmic_bytes"]
     rd, wr = 2 * 1024 * sum(fetch1) / len(fetch1), 1024 * sum(write1) / len(write1)
     out["configs"]["cfg" + cfg] = {

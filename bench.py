@@ -166,7 +166,7 @@ def timed_steps(step, barrier, steps, warmup, dist, use_dist, torch, dev):
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed
@@ -209,9 +209,14 @@ def main():
 
     # `python bench.py --gpus N` without a launcher environment: start the N ranks ourselves (fresh child processes,
     # before anything here touches a GPU), relay rank 0's JSON line, fail if any rank fails
+    # PIRGPU_BENCH_SHARE_GPU=1 (a test facility for one-GPU boxes): all ranks use device 0 and the collectives go
+    # over gloo (RCCL refuses two ranks on one device) -- every line of the multi-rank flow except the RCCL calls;
+    # the line then says backend gloo / rccl_ranks 0 and is NOT a multi-GPU measurement
+    share_gpu = os.environ.get("PIRGPU_BENCH_SHARE_GPU", "") == "1"
     from pir_amd import launcher
     if args.gpus > 1 and not launcher.launched_by_a_launcher():
-        sys.exit(launcher.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+        sys.exit(launcher.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
+                                      check_devices=not share_gpu))
 
     # stdout carries exactly one JSON line: anything native libraries print there (RCCL's version banner)
     # is sent to stderr instead
@@ -220,7 +225,7 @@ def main():
     os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
@@ -244,7 +249,10 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     dev = "cuda:%d" % local_rank
 
     enc, pp, item_bytes = build_workload(args, pir_amd)
@@ -428,6 +436,7 @@ def main():
             "value": qps, "unit": "queries/s", "n_gpus": world,
             # ranks of the RCCL process group the collectives of this run went through (null: no process group)
             "rccl_ranks": (dist.get_world_size() if dist.get_backend() == "nccl" else 0) if use_dist else None,
+            **({"backend": "gloo (ranks share one GPU: test facility, not a multi-GPU measurement)"} if share_gpu else {}),
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",

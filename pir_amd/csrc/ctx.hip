@@ -1444,6 +1444,12 @@ int pirgpu_keyset_set_key(pirgpu_ctx* c, uint32_t slot, uint32_t g, const uint64
   });
 }
 
+uint32_t pirgpu_current_keyset(pirgpu_ctx* c) {
+  if (!c) return 0;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  return c->cur_keyset;
+}
+
 int pirgpu_query_use_keyset(pirgpu_ctx* c, uint32_t slot) {
   return guarded(c, [&]() -> int {
     if (slot >= c->keysets.size()) return fail(c, PIRGPU_INVALID_ARGUMENT, "key set slot out of range");

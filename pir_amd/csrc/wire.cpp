@@ -231,12 +231,13 @@ void run_single(const Server& sv, Job& job, const std::pair<const uint8_t*, size
   uint64_t* hr = pirgpu_host_reply_buffer(sv.ctx, 1);
   if (!hq || !hr) throw Err{PIRGPU_INTERNAL, pirgpu_last_error(sv.ctx)};
   const uint32_t nq = load_query_into(sv.sh, qm.first, qm.second, hq, sv.nq_expected);
+  const uint32_t callers_slot = pirgpu_current_keyset(sv.ctx);   // the direct API's selection survives a request
   int rc = pirgpu_query_use_keyset(sv.ctx, job.slot);
   uint64_t got = 0;
   if (!rc) rc = pirgpu_query_stage(sv.ctx, hq, nq);
   if (!rc) rc = pirgpu_query_run(sv.ctx);      // asynchronous: every kernel of the path is queued
   const std::string msg = rc ? pirgpu_last_error(sv.ctx) : "";
-  (void)pirgpu_query_use_keyset(sv.ctx, 0);
+  (void)pirgpu_query_use_keyset(sv.ctx, callers_slot);
   if (rc) throw Err{rc, msg};
   if (while_running) while_running();
   rc = pirgpu_query_fetch(sv.ctx, hr, sv.n_reply, &got);

@@ -25,6 +25,8 @@ int pirgpu_wire_validate_request(const struct pirgpu_params* params, const uint8
 struct pirgpu_ctx;
 void pirgpu_keyset_pin_begin(struct pirgpu_ctx* ctx);
 void pirgpu_keyset_pin_end(struct pirgpu_ctx* ctx);
+// Slot pirgpu_query_use_keyset last selected (the wire layer restores it after serving a request).
+uint32_t pirgpu_current_keyset(struct pirgpu_ctx* ctx);
 // Drops the wire layer's per-context state (called by pirgpu_destroy).
 void pirgpu_wire_forget(struct pirgpu_ctx* ctx);
 // Request-level critical section (recursive with the per-call lock of the ABI entry points): held by

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Randomised soak of the batch pipeline on one GPU: random matrix shapes, batch sizes, worker counts and
 repeat counts; every batch reply must equal the single-query reply of the same query, and one reply per
-configuration is checked against the CPU oracle.  Run on the GPU box:  python tools/soak.py [seconds]"""
+configuration is checked against the CPU oracle.  Round 3: every configuration also serves a random number of
+CLIENTS with different Galois keys -- every query of a batch is assigned a random client's resident key set, so the
+groups of 8 mix clients (sometimes with fewer slots than clients: evictions) -- and replies are checked against the
+oracle run with that client's keys.  Run on the GPU box:  python tools/soak.py [seconds]"""
 import os
 import sys
 import time
@@ -16,6 +19,7 @@ import oracle  # noqa: E402
 import pir_amd  # noqa: E402
 from gpu_helpers import to_product_params  # noqa: E402
 from pir_fixtures import PirSetup  # noqa: E402
+from oracle.client import Client  # noqa: E402
 
 
 def main():
@@ -45,17 +49,35 @@ def main():
         srv.set_galois_keys(s.galois_keys)
         info = srv.scan_info()
         n_cfg += 1
+        # clients: client 0 = the fixture's (its keys also sit in slot 0 through set_galois_keys)
+        n_clients = int(rng.choice([1, 1, 2, 3, 5, 9]))
+        clients = [s.client] + [Client(s.orc, seed=int(rng.integers(1 << 30))) for _ in range(n_clients - 1)]
+        ckeys = [s.galois_keys] + [c.galois_keys() for c in clients[1:]]
+        if n_clients > 2 and rng.integers(0, 2):
+            srv.set_keyset_capacity(n_clients - 1)       # fewer slots than clients: re-installs evict
         for _ in range(int(rng.integers(1, 4))):
             count = int(rng.integers(1, 21))
             workers = int(rng.choice([1, 2, 3, 5, 8, 9, 16]))
             idx = [int(rng.integers(0, dbsize)) for _ in range(count)]
-            queries = np.stack([s.client.create_query_for(s.params, i) for i in idx])
-            got = srv.process_batch(queries, n_workers=workers)
+            who = [int(rng.integers(0, n_clients)) for _ in range(count)]
+            queries = np.stack([clients[w].create_query_for(s.params, i) for w, i in zip(who, idx)])
+            cap = srv.keyset_stats()["capacity"]
+            if len(set(who)) > cap:                       # a batch can only name resident sets
+                who = [w % cap for w in who]
+                queries = np.stack([clients[w].create_query_for(s.params, i) for w, i in zip(who, idx)])
+            slots = {w: srv.install_keyset(b"soak-client-%d" % w, ckeys[w]) for w in sorted(set(who))}
+            srv.set_concurrency(workers)
+            srv.stage_batch(queries)
+            srv.set_batch_keysets([slots[w] for w in who])
+            srv.run_batch()
+            got = srv.fetch_batch()
             pick = int(rng.integers(0, count))
-            rc, exp = s.orc.process_query(s.db_ntt, s.params.dimensions, queries[pick], s.galois_keys)
-            assert rc == 0 and np.array_equal(got[pick], exp), ("oracle mismatch", dims, count, workers, pick)
+            rc, exp = s.orc.process_query(s.db_ntt, s.params.dimensions, queries[pick], ckeys[who[pick]])
+            assert rc == 0 and np.array_equal(got[pick], exp), ("oracle mismatch", dims, count, workers, pick, who)
             for i in range(count):
-                assert np.array_equal(got[i], srv.process_query(queries[i])), ("batch != single", dims, count, workers, i)
+                srv.use_keyset(slots[who[i]])
+                assert np.array_equal(got[i], srv.process_query(queries[i])), ("batch != single", dims, count, workers, i, who)
+            srv.use_keyset(0)
             n_batches += 1
             n_queries += count
         db.close()

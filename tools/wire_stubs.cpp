@@ -19,6 +19,7 @@ int pirgpu_keyset_release(pirgpu_ctx*, uint32_t) { return 13; }
 int pirgpu_keyset_set_key(pirgpu_ctx*, uint32_t, uint32_t, const uint64_t*) { return 13; }
 int pirgpu_keyset_stats(pirgpu_ctx*, uint64_t*) { return 13; }
 int pirgpu_query_use_keyset(pirgpu_ctx*, uint32_t) { return 13; }
+uint32_t pirgpu_current_keyset(pirgpu_ctx*) { return 0; }
 int pirgpu_batch_set_keysets(pirgpu_ctx*, const uint32_t*, uint32_t) { return 13; }
 int pirgpu_query_stage(pirgpu_ctx*, const uint64_t*, uint32_t) { return 13; }
 int pirgpu_query_run(pirgpu_ctx*) { return 13; }

@@ -399,6 +399,42 @@ def main():
             "note": "every GPU holds the whole database and serves batch/gpus queries of the same global batch; no "
                     "data-path collective (barrier + max-over-ranks timing only). Reference point, not the headline."}
 
+    # ============ hybrid (reference point, multi-GPU only): R replica groups x S row shards ============
+    # "report a 2 x 4 hybrid -- 4-way rows inside 2 replica groups -- as a named extra, not the
+    # headline".  Every group of S ranks holds the whole database row-sharded S ways and serves batch / R of the
+    # step's queries with the same pipelined step, its collectives confined to the group's own process group.
+    hyb_R = int(os.environ.get("PIRGPU_HYBRID_GROUPS", "2"))
+    run_hybrid = (use_dist and world > 1 and args.dist_mode == "both" and args.dims == 2 and hyb_R >= 1
+                  and world % hyb_R == 0 and batch % world == 0
+                  and (world // hyb_R >= 2 or os.environ.get("PIRGPU_HYBRID_FORCE") == "1"))
+    if run_hybrid:
+        gi, gr, S, groups = D.hybrid_layout(rank, world, hyb_R)
+        pgs = [dist.new_group(g) for g in groups]          # every rank creates every group, in the same order
+        db.close()
+        db, srv, _ = make_server(D.shard_range(pp.dimensions[0], gr, S) if S > 1 else None)
+        barrier = barrier_for(srv)
+        hcomm = D.Comm(dist, S, host_sync=True, group=pgs[gi])
+        D.sync_zero_plaintexts(srv, dist, S, hcomm, torch, dev)
+        mine_ok = D.packed_exchange_supported(srv, dist, S, hcomm, torch, dev)
+        t_ok = torch.tensor([1 if mine_ok else 0], dtype=torch.int64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t_ok)                                # every group must be able to take the packed path
+        if int(t_ok.item()) == world:
+            bpg = batch // hyb_R
+            srv.set_concurrency(workers)
+            srv.stage_batch(queries)
+            hpipe = D.RowsPipeline(srv, bpg, gr, S, dist, torch, dev, comm=D.Comm(dist, S, host_sync=False, group=pgs[gi]))
+            pipes.append(hpipe)
+            el3 = timed_steps(lambda: hpipe.submit(first=gi * bpg), barrier, args.steps, args.warmup, dist, use_dist, torch, dev)
+            pipes.clear()
+            out_extra["hybrid_rows_reference"] = {
+                "value": args.steps * batch / el3, "unit": "queries/s", "ms_per_step": el3 / args.steps * 1e3,
+                "replica_groups": hyb_R, "row_shards_per_group": S, "scaling": "strong", "queries_per_step": batch,
+                "queries_per_step_per_group": bpg,
+                "exchange_bytes_received_per_query_per_gpu": hpipe.sets[0].exchange_bytes_per_query(S) * bpg / batch,
+                "note": "%d replica groups x %d row shards: every group holds the whole database sharded %d ways and "
+                        "serves %d of the %d queries of a step with the pipelined rows step inside its own process "
+                        "group. Reference point, not the headline." % (hyb_R, S, S, bpg, batch)}
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         u64_bytes = pp.num_pt * k * N * 8          # B_q = num_pt * k * N * 8

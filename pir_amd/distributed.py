@@ -33,6 +33,16 @@ def check_sum_fits(q_max: int, world: int) -> None:
                          % (world, q_max.bit_length()))
 
 
+def hybrid_layout(rank: int, world: int, replica_groups: int):
+    """R replica groups of S = world / R row shards each (ranks g*S .. g*S+S-1 form group g): returns
+    (group index, rank inside the group, S, [ranks of every group])."""
+    if replica_groups < 1 or world % replica_groups:
+        raise ValueError("world size must be a multiple of the number of replica groups")
+    S = world // replica_groups
+    groups = [list(range(g * S, (g + 1) * S)) for g in range(replica_groups)]
+    return rank // S, rank % S, S, groups
+
+
 def owned_queries(count: int, rank: int, world: int):
     """Queries of a batch this rank expands: the contiguous block [begin, end) (count % world == 0)."""
     if count % world:
@@ -54,8 +64,10 @@ class Comm:
     # steps stay far below (21 MB per peer at cfg 3); a forced single-rank run of the same step does not.
     MAX_MESSAGE_BYTES = 512 << 20
 
-    def __init__(self, dist, world: int, host_sync: bool = True):
+    def __init__(self, dist, world: int, host_sync: bool = True, group=None):
+        """world: ranks taking part (the size of `group`, a torch.distributed process group; None = the default one)."""
         self.dist, self.world = dist, world
+        self.group = group
         self.host_sync = host_sync
         import os
         if os.environ.get("PIRGPU_MAX_COLLECTIVE_MB"):      # tests: force the piecewise paths with small messages
@@ -77,16 +89,16 @@ class Comm:
             flat = full.view(self.world, -1)
             n, limit = flat.shape[1], max(1, self.MAX_MESSAGE_BYTES // full.element_size())
             if n <= limit:
-                d.all_gather_into_tensor(full.view(-1), full[rank].reshape(-1))
+                d.all_gather_into_tensor(full.view(-1), full[rank].reshape(-1), group=self.group)
             else:
                 for o in range(0, n, limit):
                     e = min(n, o + limit)
-                    d.all_gather([flat[r, o:e] for r in range(self.world)], flat[rank, o:e])
+                    d.all_gather([flat[r, o:e] for r in range(self.world)], flat[rank, o:e], group=self.group)
             self._sync(full)
             return
         mine = full[rank].cpu().contiguous()
         parts = [mine.new_empty(mine.shape) for _ in range(self.world)]
-        d.all_gather(parts, mine)
+        d.all_gather(parts, mine, group=self.group)
         for r, p in enumerate(parts):
             full[r].copy_(p)
         self._sync(full)
@@ -104,7 +116,7 @@ class Comm:
             biggest = max(max(recv_splits), max(send_splits))
             pieces = min(max(1, units), -(-biggest // limit))
             if pieces <= 1:
-                d.all_to_all_single(recv, send, list(recv_splits), list(send_splits))
+                d.all_to_all_single(recv, send, list(recv_splits), list(send_splits), group=self.group)
             else:
                 ro, so = [0], [0]
                 for x in recv_splits:
@@ -117,11 +129,11 @@ class Comm:
                             for r in range(self.world)]
                     ins = [send[so[r] + send_splits[r] // units * u0: so[r] + send_splits[r] // units * u1]
                            for r in range(self.world)]
-                    d.all_to_all(outs, ins)
+                    d.all_to_all(outs, ins, group=self.group)
             self._sync(recv)
             return
         s, r = send.cpu(), recv.new_empty(recv.shape, device="cpu")
-        d.all_to_all_single(r, s, list(recv_splits), list(send_splits))
+        d.all_to_all_single(r, s, list(recv_splits), list(send_splits), group=self.group)
         recv.copy_(r)
         self._sync(recv)
 
@@ -136,15 +148,16 @@ class Comm:
             o1, f2 = out.view(-1), full.view(self.world, -1)
             n, limit = o1.numel(), max(1, self.MAX_MESSAGE_BYTES // out.element_size())
             if n <= limit:
-                d.reduce_scatter_tensor(o1, full.view(-1), op=d.ReduceOp.SUM)
+                d.reduce_scatter_tensor(o1, full.view(-1), op=d.ReduceOp.SUM, group=self.group)
             else:
                 for o in range(0, n, limit):
                     e = min(n, o + limit)
-                    d.reduce_scatter(o1[o:e], [f2[r, o:e] for r in range(self.world)], op=d.ReduceOp.SUM)
+                    d.reduce_scatter(o1[o:e], [f2[r, o:e] for r in range(self.world)], op=d.ReduceOp.SUM,
+                                     group=self.group)
             self._sync(out)
             return
         c = full.cpu()
-        d.all_reduce(c, op=d.ReduceOp.SUM)          # gloo has no reduce-scatter: reduce everything, keep the slice
+        d.all_reduce(c, op=d.ReduceOp.SUM, group=self.group)   # gloo has no reduce-scatter: reduce everything, keep the slice
         n = out.numel()
         out.copy_(c.view(-1)[rank * n:(rank + 1) * n].view(out.shape))
         self._sync(out)
@@ -154,11 +167,11 @@ class Comm:
             return
         d = self.dist
         if self.device_native:
-            d.all_reduce(t, op=d.ReduceOp.SUM)
+            d.all_reduce(t, op=d.ReduceOp.SUM, group=self.group)
             self._sync(t)
             return
         c = t.cpu()
-        d.all_reduce(c, op=d.ReduceOp.SUM)
+        d.all_reduce(c, op=d.ReduceOp.SUM, group=self.group)
         t.copy_(c)
         self._sync(t)
 

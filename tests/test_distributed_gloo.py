@@ -235,6 +235,23 @@ def rows_step_check(rank, world, d, dbsize, elem, batch, zero_pt=None):
                 want = full[i] if t == 0 else s.orc.process_query(s.db_ntt, p.dimensions, q_all[g], s.galois_keys)[1]
                 ok &= bool(np.array_equal(seen[t][i - lo], want))
                 ok &= s.client.process_response(p, idx_all[g], seen[t][i - lo]) == s.item(idx_all[g])
+        # hybrid layout, degenerate at two ranks: 2 replica groups of ONE shard each -- every rank holds the whole
+        # database, runs the pipelined step inside its own one-rank process group and serves its half of the queries
+        gi, gr, S, groups = D.hybrid_layout(rank, world, 2)
+        pgs = [dist.new_group(g, backend="gloo") for g in groups]
+        whole = OracleShardServer(s, 0, 1)
+        whole.stage_batch(q_all)
+        bpg = batch // 2
+        hp = D.RowsPipeline(whole, bpg, gr, S, dist, torch, "cpu", comm=D.Comm(dist, S, group=pgs[gi]))
+        hp.submit(first=gi * bpg)
+        hp.submit(first=batch + gi * bpg)
+        hp.flush()
+        for t, base in ((0, 0), (1, batch)):
+            mine_h = hp.replies(t).numpy().view(np.uint64)
+            for i in range(bpg):
+                g = base + gi * bpg + i
+                want = s.orc.process_query(s.db_ntt, p.dimensions, q_all[g], s.galois_keys)[1]
+                ok &= bool(np.array_equal(mine_h[i], want))
         srv.stage_batch(queries)
     # the whole-selection-vector exchange (any d): every rank ends with every reply
     sv_all = torch.empty((batch, p.dim_sum, 2, s.orc.k, 4096), dtype=torch.int64)

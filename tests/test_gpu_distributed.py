@@ -83,6 +83,31 @@ def _step(rank, world, dist, items, batch, out):
             if not same:
                 print("rank %d: pipelined step %d, query %d differs" % (rank, t, i), flush=True)
             ok &= same
+    # hybrid layout (bench.py's `hybrid_rows_reference`), degenerate at two ranks: 2 replica groups of ONE shard each --
+    # every rank holds the whole database and serves its half of the queries inside its own one-rank process group
+    if world == 2 and batch % 2 == 0:
+        gi, gr, S, groups = D.hybrid_layout(rank, world, 2)
+        pgs = [dist.new_group(g, backend="gloo") for g in groups]
+        dbw = pir_amd.PIRDatabase.Create(pp, s.raw)
+        whole = pir_amd.PIRServer.Create(dbw, pp)
+        whole.set_galois_keys(s.galois_keys)
+        whole.set_concurrency(8)
+        whole.stage_batch(q_all)
+        bpg = batch // 2
+        hp = D.RowsPipeline(whole, bpg, gr, S, dist, torch, dev, comm=D.Comm(dist, S, host_sync=False, group=pgs[gi]))
+        hp.submit(first=gi * bpg)
+        hp.submit(first=batch + gi * bpg)
+        hp.flush()
+        for t, base in ((0, 0), (1, batch)):
+            mine_h = hp.replies(t).cpu().numpy().view(np.uint64)
+            for i in range(bpg):
+                g = base + gi * bpg + i
+                want = full[g] if g < batch else s.orc.process_query(s.db_ntt, p.dimensions, q_all[g], s.galois_keys)[1]
+                same = bool(np.array_equal(mine_h[i], want))
+                if not same:
+                    print("rank %d: hybrid step %d, query %d differs" % (rank, t, g), flush=True)
+                ok &= same
+        dbw.close()
     srv.stage_batch(queries)
     sv_all = torch.empty((batch, p.dim_sum, 2, srv.k, srv.N), dtype=torch.int64, device=dev)
     replies = torch.empty((batch, db.reply_ct_count(), 2, srv.k, srv.N), dtype=torch.int64, device=dev)

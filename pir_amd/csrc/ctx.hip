@@ -150,6 +150,8 @@ struct pirgpu_ctx {
   std::vector<uint32_t> batch_keysets;      // per staged query of the batch (all 0 unless pirgpu_batch_set_keysets)
   uint64_t keyset_clock = 0, key_uploads = 0, keyset_evictions = 0;
   uint64_t keyset_pin = UINT64_MAX;         // sets touched after this clock value belong to the requests being processed
+  std::vector<uint64_t*> key_pool;          // device key buffers of emptied sets, reused by the next upload (no hipMalloc)
+  uint64_t* d_key_stage = nullptr;          // one key in SEAL order on its way to device order (allocated once)
   std::map<uint32_t, uint64_t*> xpow;       // shift -> NTT_j(x^(-shift)), [k][N] doubles (NTT-domain last expansion level)
 
   // workspace geometry (computed on first use) and the workers holding the buffers
@@ -1011,6 +1013,7 @@ void pirgpu_destroy(pirgpu_ctx* c) {
   }
   for (KeySet& ks : c->keysets)
     for (auto& kv : ks.keys) (void)hipFree(kv.second);
+  for (uint64_t* p : c->key_pool) (void)hipFree(p);
   for (void* p : c->allocs) (void)hipFree(p);
   if (c->h_query) (void)hipHostFree(c->h_query);
   if (c->h_reply) (void)hipHostFree(c->h_reply);
@@ -1283,7 +1286,9 @@ int pirgpu_db_read_plaintext(pirgpu_ctx* c, uint64_t pt_index, uint64_t* out) {
   });
 }
 
-// Uploads one Galois key into a key set slot (SEAL's NTT order at the boundary, device order in HBM).
+// Uploads one Galois key into a key set slot (SEAL's NTT order at the boundary, device order in HBM).  A new client's
+// first request pays for 12 of these (N = 4096): the staging buffer is allocated once per context and the key buffers
+// of emptied sets are recycled, so the steady state of a server whose clients come and go allocates nothing.
 static void upload_key(pirgpu_ctx* c, uint32_t slot, uint32_t g, const uint64_t* key) {
   if (slot >= c->keysets.size()) throw Fail{PIRGPU_INVALID_ARGUMENT, "key set slot out of range"};
   if (!key || !(g & 1) || g >= 2 * c->N) throw Fail{PIRGPU_INVALID_ARGUMENT, "invalid Galois element"};
@@ -1298,20 +1303,20 @@ static void upload_key(pirgpu_ctx* c, uint32_t slot, uint32_t g, const uint64_t*
     sync_batch_streams(c);
     dev = it->second;
   } else {
-    HIP_TRY(hipMalloc((void**)&dev, words * 8));
+    if (!c->key_pool.empty()) {
+      dev = c->key_pool.back();
+      c->key_pool.pop_back();
+    } else {
+      HIP_TRY(hipMalloc((void**)&dev, words * 8));
+    }
     keys[g] = dev;
   }
-  uint64_t* stage = nullptr;
-  HIP_TRY(hipMalloc((void**)&stage, words * 8));
-  try {
-    HIP_TRY(hipMemcpyAsync(stage, key, words * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(launch_ntt_reorder(c->stream, c->N, stage, dev, (uint64_t)c->k * 2 * (c->k + 1), true, c->mode != kNttInt));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-  } catch (...) {
-    (void)hipFree(stage);
-    throw;
-  }
-  HIP_TRY(hipFree(stage));
+  if (!c->d_key_stage) c->d_key_stage = c->dalloc<uint64_t>(words);
+  // stream order on the main stream covers the reuse of the staging buffer by the next key
+  HIP_TRY(hipMemcpyAsync(c->d_key_stage, key, words * 8, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(launch_ntt_reorder(c->stream, c->N, c->d_key_stage, dev, (uint64_t)c->k * 2 * (c->k + 1), true,
+                             c->mode != kNttInt));
+  HIP_TRY(hipStreamSynchronize(c->stream));   // the lanes / workers that will read the key do not follow this stream
   ++c->key_uploads;
 }
 
@@ -1321,7 +1326,7 @@ static void clear_keyset(pirgpu_ctx* c, uint32_t slot) {
   if (!ks.keys.empty()) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     sync_batch_streams(c);
-    for (auto& kv : ks.keys) HIP_TRY(hipFree(kv.second));
+    for (auto& kv : ks.keys) c->key_pool.push_back(kv.second);   // recycled by the next upload
     ks.keys.clear();
   }
   ks.blob.clear();

@@ -112,3 +112,43 @@ def test_n8192_transform_kernels(isa13, kernel):
     if "digit" not in kernel:
         batches = _loop_load_batches(_function(isa13, P13 + kernel))
         assert batches and max(batches) >= 30, (kernel, batches)
+
+
+# ---- the database scan (scan_mfma.hip): register budgets of the two workgroup shapes ---------------------------------
+SCAN_SRC = os.path.join(ROOT, "pir_amd", "csrc", "scan_mfma.hip")
+
+
+@pytest.fixture(scope="module")
+def scan_isa(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / "scan.s"
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-x", "hip", "--cuda-device-only", "-S", SCAN_SRC,
+                    "-o", str(out)], check=True, capture_output=True, timeout=600)
+    return out.read_text().split("\n")
+
+
+def _scan_descriptor(isa, L, KS, NW):
+    name = "_ZN6pirgpu16scan_mfma_kernelILi%dELi%dELi%dEEE" % (L, KS, NW)
+    i = next(i for i, l in enumerate(isa) if ".amdhsa_kernel " + name in l)
+    block = "\n".join(isa[i:i + 40])
+    get = lambda key: int(re.search(r"\.amdhsa_%s (\d+)" % key, block).group(1))
+    return get("next_free_vgpr"), get("accum_offset"), get("private_segment_fixed_size")
+
+
+@pytest.mark.parametrize("L,KS", [(5, 1), (5, 2), (5, 3), (6, 1), (6, 2), (7, 1), (7, 2)])
+def test_eight_wave_scan_fits_two_waves_per_simd(scan_isa, L, KS):
+    """8-wave workgroups run two waves per SIMD: 256 registers per wave, no scratch (<6, 3, 8> is known to spill two
+    registers and is only used when the 4-wave kernel is forced off)."""
+    total, _, scratch = _scan_descriptor(scan_isa, L, KS, 8)
+    assert total <= 256 and scratch == 0, (L, KS, total, scratch)
+
+
+@pytest.mark.parametrize("L,KS", [(5, 7), (6, 4), (6, 7), (7, 5)])
+def test_four_wave_scan_uses_the_unified_register_file_without_scratch(scan_isa, L, KS):
+    """4-wave workgroups run one wave per SIMD and may take the whole 512-entry VGPR + AGPR file: the selectors of up to
+    7 k-steps live there (cfg 4: <6, 7, 4>).  More than 256 registers in use shows the AGPR half is really used; no
+    scratch (<7, 6, 4>, cfg 5, is the one known exception: 20 spilled registers, still faster than two chunks)."""
+    total, accum_offset, scratch = _scan_descriptor(scan_isa, L, KS, 4)
+    assert scratch == 0, (L, KS, scratch)
+    assert total <= 512 and (KS < 5 or total > 256), (L, KS, total, accum_offset)

@@ -190,3 +190,66 @@ def test_fingerprint_match_with_different_bytes_does_not_reuse_the_keys():
     assert got == want and got != good
     assert server.keyset_stats()["resident"] == 2            # the other object became its own key set
     assert server.ProcessRequest(req_a) == good              # and the first client's set is intact
+
+
+def test_many_threads_many_clients_are_combined_correctly():
+    """8 threads hammer ONE context with requests of 4 clients (one or two queries each, some threads sharing a
+    client): whichever thread leads serves the queued requests together; every response must decode under its own
+    client's keys and equal what the same request gets when served alone."""
+    pp, raw, server, clients = _product_setup(n_clients=4)
+    errors, results = [], {}
+    lock = threading.Lock()
+
+    def work(t):
+        try:
+            c = clients[t % 4]
+            for it in range(5):
+                idx = [(131 * t + 17 * it) % 2000] + ([(7 * t + 3 * it + 1) % 2000] if (t + it) % 3 == 0 else [])
+                req = c.CreateRequest(idx)
+                resp = server.ProcessRequest(req)
+                if c.ProcessResponse(idx, resp) != [raw[i].tobytes() for i in idx]:
+                    errors.append(("decode", t, it))
+                with lock:
+                    results[(t, it)] = (req, resp)
+        except Exception as ex:            # noqa: BLE001
+            errors.append((t, repr(ex)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    assert len(results) == 40
+    for (t, it), (req, resp) in sorted(results.items())[::7]:       # the server is deterministic: alone = combined
+        assert server.ProcessRequest(req) == resp, (t, it)
+    st = server.keyset_stats()
+    assert st["resident"] == 4 and st["evictions"] == 0
+    assert st["key_uploads"] == 4 * len(pir_amd.generate_galois_elts(4096))
+
+
+def test_malformed_requests_inside_a_batch_fail_alone():
+    """Truncations, bit flips and garbage between good requests of two clients: every bad request gets its own
+    InvalidArgument, every good one the bytes it gets when served alone; nothing is left half-installed."""
+    pp, raw, server, clients = _product_setup(n_clients=2)
+    good = [clients[0].CreateRequest([5]), clients[1].CreateRequest([6, 7]), clients[0].CreateRequest([8])]
+    alone = [server.ProcessRequest(r) for r in good]
+    rng = np.random.default_rng(11)
+    bad = [good[0][:len(good[0]) // 2], good[1][:-1], b"\x0a\x05hello", b"", bytes(rng.integers(0, 256, 300, dtype=np.uint8))]
+    flipped = bytearray(good[2])
+    flipped[40] ^= 0xFF                                   # inside the first ciphertext's SEAL header
+    bad.append(bytes(flipped))
+    mixed = [bad[0], good[0], bad[1], bad[2], good[1], bad[3], bad[4], good[2], bad[5]]
+    out = server.ProcessRequests(mixed)
+    expect_good = {1: alone[0], 4: alone[1], 7: alone[2]}
+    for i, (st, resp) in enumerate(out):
+        if i in expect_good:
+            assert st == 0 and resp == expect_good[i], i
+        elif mixed[i] == b"":
+            # an empty Request has no keys: SEALDeserialize<GaloisKeys> of empty bytes throws -> InvalidArgument
+            assert st == pir_amd.StatusCode.INVALID_ARGUMENT, i
+        else:
+            assert st == pir_amd.StatusCode.INVALID_ARGUMENT and resp is None, (i, st)
+    assert server.keyset_stats()["resident"] == 2
+    for r, a in zip(good, alone):                          # the context is still fine afterwards
+        assert server.ProcessRequest(r) == a

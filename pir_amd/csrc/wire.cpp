@@ -322,11 +322,13 @@ void serve_window(const Server& sv, Job* const* jobs, size_t n) {
   size_t pos = 0;
   std::vector<uint32_t> slots;
   while (pos < items.size()) {
-    uint64_t* hq = pirgpu_host_query_buffer(sv.ctx, kMaxRequestBatch);
-    uint64_t* hr = pirgpu_host_reply_buffer(sv.ctx, kMaxRequestBatch);
+    // pinned staging for this chunk only (a reply is (2 ER)^(d-1) ciphertexts: 24 MiB per query at N = 16384, k = 4)
+    const uint32_t room = (uint32_t)std::min<size_t>(kMaxRequestBatch, items.size() - pos);
+    uint64_t* hq = pirgpu_host_query_buffer(sv.ctx, room);
+    uint64_t* hr = pirgpu_host_reply_buffer(sv.ctx, room);
     std::vector<Item> chunk;
     slots.clear();
-    while (pos < items.size() && chunk.size() < kMaxRequestBatch) {
+    while (pos < items.size() && chunk.size() < room) {
       Item it = items[pos++];
       Job& job = *it.job;
       if (job.rc || !job.uniform) continue;

@@ -283,6 +283,8 @@ int pirgpu_process_request(pirgpu_ctx* ctx, const uint8_t* request, size_t reque
  * served together by the next thread that gets the context.  Host staging buffers the wire layer uses (pinned). */
 int pirgpu_process_requests(pirgpu_ctx* ctx, uint32_t n, const uint8_t* const* requests, const size_t* request_lens,
                             uint8_t** responses, size_t* response_lens, int* status);
+/* Message of request i of the calling thread's last pirgpu_process_requests call ("" if it succeeded). */
+const char* pirgpu_request_error(uint32_t i);
 uint64_t* pirgpu_host_query_buffer(pirgpu_ctx* ctx, uint32_t queries);
 uint64_t* pirgpu_host_reply_buffer(pirgpu_ctx* ctx, uint32_t queries);
 void pirgpu_free(void* p);

@@ -203,6 +203,32 @@ class PIRServer {
     return out;
   }
 
+  // The same for several independent requests (different clients) served TOGETHER -- no reference counterpart (the
+  // reference is single-threaded); result[i] is what ProcessRequest(requests[i]) would have returned.
+  std::vector<StatusOr<std::string>> ProcessRequests(const std::vector<std::string>& requests) const {
+    const uint32_t n = static_cast<uint32_t>(requests.size());
+    std::vector<const uint8_t*> ptrs(n);
+    std::vector<size_t> lens(n), rlens(n, 0);
+    std::vector<uint8_t*> resps(n, nullptr);
+    std::vector<int> status(n, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+      ptrs[i] = reinterpret_cast<const uint8_t*>(requests[i].data());
+      lens[i] = requests[i].size();
+    }
+    pirgpu_process_requests(db_->handle(), n, ptrs.data(), lens.data(), resps.data(), rlens.data(), status.data());
+    std::vector<StatusOr<std::string>> out;
+    out.reserve(n);
+    for (uint32_t i = 0; i < n; ++i) {
+      if (status[i]) {
+        out.emplace_back(Status(static_cast<StatusCode>(status[i]), pirgpu_request_error(i)));
+      } else {
+        out.emplace_back(std::string(reinterpret_cast<const char*>(resps[i]), rlens[i]));
+        pirgpu_free(resps[i]);
+      }
+    }
+    return out;
+  }
+
   // what SEALDeserialize<GaloisKeys> yields (server.cpp:46-48)
   Status SetGaloisKeys(const GaloisKeys& keys) const {
     const size_t k = params_->coeff_modulus.size() - 1;

@@ -450,6 +450,7 @@ struct Combiner {
   std::deque<Job*> pending;
   bool leader = false;
 };
+thread_local std::vector<std::string> t_request_errors;   // per request of this thread's last pirgpu_process_requests
 std::mutex g_combiners_mu;
 std::map<pirgpu_ctx*, std::shared_ptr<Combiner>> g_combiners;
 
@@ -519,11 +520,17 @@ int pirgpu_process_requests(pirgpu_ctx* ctx, uint32_t n, const uint8_t* const* r
   }
   serve(ctx, ptrs.data(), n);
   int worst = PIRGPU_OK;
+  t_request_errors.assign(n, std::string());
   for (uint32_t i = 0; i < n; ++i) {
     status[i] = finish(ctx, jobs[i], &responses[i], &response_lens[i]);
+    if (status[i]) t_request_errors[i] = jobs[i].err;
     if (status[i] && !worst) worst = status[i];
   }
   return worst;
+}
+
+const char* pirgpu_request_error(uint32_t i) {
+  return i < t_request_errors.size() ? t_request_errors[i].c_str() : "";
 }
 
 }  // extern "C"

@@ -288,6 +288,7 @@ class PIRServer:
                 self.lib.pirgpu_free(resp[i])
             else:
                 out.append((int(status[i]), None))
+        self.request_errors = [self.lib.pirgpu_request_error(i).decode() for i in range(n)]   # "" where it succeeded
         return out
 
     # -- device-resident split (bench / pipelining) -----------------------------------

@@ -98,6 +98,19 @@ int main(int argc, char** argv) {
   auto items = (*client)->ProcessResponse(indexes, *response);
   EXPECT(items.ok() && items->size() == indexes.size());
   for (size_t i = 0; i < indexes.size(); ++i) EXPECT((*items)[i] == rawdb[indexes[i]]);
+  // two clients, served together (pirgpu_process_requests): each decodes its own items; a malformed request in
+  // between fails alone
+  auto client2 = pir::PIRClient::Create(params);
+  EXPECT(client2.ok());
+  const std::vector<std::size_t> idx2 = {params->num_items / 3};
+  auto request2 = (*client2)->CreateRequest(idx2);
+  EXPECT(request2.ok());
+  auto both = (*server)->ProcessRequests({*request, std::string("\x12\x03zzz", 5), *request2});
+  EXPECT(both.size() == 3 && both[0].ok() && !both[1].ok() && both[2].ok());
+  EXPECT(both[1].status().code() == pir::StatusCode::kInvalidArgument);
+  EXPECT(*both[0] == *response);                       // the server is deterministic: together == alone
+  auto items2 = (*client2)->ProcessResponse(idx2, *both[2]);
+  EXPECT(items2.ok() && items2->size() == 1 && (*items2)[0] == rawdb[idx2[0]]);
   std::puts("client_facade_test round trip OK");
   return 0;
 }

@@ -102,6 +102,7 @@ def test_process_requests_equals_one_by_one():
     mixed = server.ProcessRequests([requests[0], bad, requests[2]])
     assert mixed[0] == together[0] and mixed[2] == together[2]
     assert mixed[1][0] == pir_amd.StatusCode.INVALID_ARGUMENT and mixed[1][1] is None
+    assert server.request_errors[0] == "" and server.request_errors[2] == "" and server.request_errors[1] != ""
 
 
 def test_alternating_clients_never_reupload_and_threads_are_combined():

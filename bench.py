@@ -383,7 +383,12 @@ def main():
     pipes.clear()
 
     # =========================== replicas (reference point, multi-GPU only) ===========================
-    if run_replicas:
+    # the two reference legs below must never cost the headline: a failure (the same on every rank: they run the same
+    # program on the same inputs) is reported in the extra's place
+    import traceback
+
+    def replicas_leg():
+        nonlocal db, srv, barrier
         if shard is not None:
             db.close()
             db, srv, _ = make_server(None)
@@ -399,6 +404,13 @@ def main():
             "note": "every GPU holds the whole database and serves batch/gpus queries of the same global batch; no "
                     "data-path collective (barrier + max-over-ranks timing only). Reference point, not the headline."}
 
+    if run_replicas:
+        try:
+            replicas_leg()
+        except Exception as e:     # noqa: BLE001
+            traceback.print_exc()
+            out_extra["replicas_reference"] = {"error": repr(e)}
+
     # ============ hybrid (reference point, multi-GPU only): R replica groups x S row shards ============
     # "report a 2 x 4 hybrid -- 4-way rows inside 2 replica groups -- as a named extra, not the
     # headline".  Every group of S ranks holds the whole database row-sharded S ways and serves batch / R of the
@@ -407,7 +419,8 @@ def main():
     run_hybrid = (use_dist and world > 1 and args.dist_mode == "both" and args.dims == 2 and hyb_R >= 1
                   and world % hyb_R == 0 and batch % world == 0
                   and (world // hyb_R >= 2 or os.environ.get("PIRGPU_HYBRID_FORCE") == "1"))
-    if run_hybrid:
+    def hybrid_leg():
+        nonlocal db, srv, barrier
         gi, gr, S, groups = D.hybrid_layout(rank, world, hyb_R)
         pgs = [dist.new_group(g) for g in groups]          # every rank creates every group, in the same order
         db.close()
@@ -434,6 +447,14 @@ def main():
                 "note": "%d replica groups x %d row shards: every group holds the whole database sharded %d ways and "
                         "serves %d of the %d queries of a step with the pipelined rows step inside its own process "
                         "group. Reference point, not the headline." % (hyb_R, S, S, bpg, batch)}
+
+    if run_hybrid:
+        try:
+            hybrid_leg()
+        except Exception as e:     # noqa: BLE001
+            traceback.print_exc()
+            pipes.clear()
+            out_extra["hybrid_rows_reference"] = {"error": repr(e)}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

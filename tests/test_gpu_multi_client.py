@@ -254,3 +254,16 @@ def test_malformed_requests_inside_a_batch_fail_alone():
     assert server.keyset_stats()["resident"] == 2
     for r, a in zip(good, alone):                          # the context is still fine afterwards
         assert server.ProcessRequest(r) == a
+
+
+def test_more_queries_than_one_batch_chunk():
+    """3 clients x 30 queries = 90 queries in one pirgpu_process_requests call: served in chunks of <= 64 queries that
+    cut through a request; reply i of every response still answers query i of its request (server.cpp:60-63)."""
+    pp, raw, server, clients = _product_setup(items=600, elem=64, d=2, n_clients=3)
+    wants = [[(17 * c + 7 * i) % 600 for i in range(30)] for c in range(3)]
+    requests = [cl.CreateRequest(w) for cl, w in zip(clients, wants)]
+    out = server.ProcessRequests(requests)
+    for cl, w, (st, resp) in zip(clients, wants, out):
+        assert st == 0
+        assert cl.ProcessResponse(w, resp) == [raw[i].tobytes() for i in w]
+    assert server.ProcessRequest(requests[1]) == out[1][1]

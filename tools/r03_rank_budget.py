@@ -14,7 +14,7 @@ import bench
 class A: pass
 args = A(); args.config = int(sys.argv[1]) if len(sys.argv) > 1 else 3; args.log_items = 20; args.dims = 2
 enc, pp, _ = bench.build_workload(args, pir_amd)
-batch = 64
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else 64     # queries the group of G shards serves per step (hybrid: 64 / R)
 raw, keys, queries = bench.synthetic_inputs(pp, n_queries=batch)
 out = {}
 for G in ([int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else (1, 2, 4, 8)):
@@ -55,4 +55,4 @@ for G in ([int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else (1,
     out["G=%d" % G] = {k: round(v, 3) for k, v in res.items()}
     print("G=%d" % G, out["G=%d" % G], flush=True)
     db.close()
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "rank_budget_cfg%d.json" % args.config), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "rank_budget_cfg%d%s.json" % (args.config, "" if batch == 64 else "_q%d" % batch)), "w"), indent=1)

@@ -643,14 +643,17 @@ uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* 
     const bool c0_in_digit = last_ntt && ks_digit_takes_c0(nodes);
     if (cur40 && c0_in_digit != last_ntt) throw Fail{PIRGPU_INTERNAL, "5-byte tree reached a level that cannot read it"};
     HIP_TRY(c->ops->ks_digit(st, c->mode, c->dp, k, cur, g, nodes, dig, c->pack40, c0_in_digit ? prod : nullptr, cur40));
-    if (c->mode != kNttInt && c->fuse_mac_combine && nodes >= c->fuse_mac_nodes && !(fuse_last && j + 1 == logm)) {
+    // (a group of B queries reaches the width at which the fused form pays one level earlier than a single query:
+    // measured +0.6 % batched with the threshold at 64 tree ciphertexts, while a single query loses latency below 128)
+    const uint32_t fuse_from = B > 1 ? std::max<uint32_t>(c->fuse_mac_nodes / 2, 1) : c->fuse_mac_nodes;
+    if (c->mode != kNttInt && c->fuse_mac_combine && nodes >= fuse_from && !(fuse_last && j + 1 == logm)) {
       // special-prime product first (the only one that goes through HBM), then the data residues with the combine
       // step in their epilogue: no data products in HBM, no separate combine pass.  Between two fused levels (and into
       // the NTT-domain last level) the tree is written as 5-byte polynomials: these launches are HBM-bound
       const uint32_t next_nodes = nodes * 2;
       const bool next_last = j + 2 == logm;
       const bool next_reads40 = next_last ? (fuse_last && c->last_level_ntt && ks_digit_takes_c0(next_nodes))
-                                          : (next_nodes >= c->fuse_mac_nodes);
+                                          : (next_nodes >= fuse_from);
       const bool out40 = c->tree40 && c->pack40 && j + 1 < logm && next_reads40 && (1u << j) < N / 16;
       HIP_TRY(c->ops->ks_mac_intt(st, c->mode, c->dp, k, dig, key, nodes, prod, c->pack40, k, 1));
       HIP_TRY(c->ops->ks_mac_combine(st, c->mode, c->dp, k, dig, key, prod, cur, g, nodes, 1u << j, nxt, c->pack40, cur40,
@@ -1934,7 +1937,13 @@ static void batch_run_mfma(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
       }
       const uint32_t first = rank0 + j0;  // global index of the group's first query
       const uint8_t* packed = nullptr;
-      Stage sg{ln.stream, ln.lvl.data(), ln.pt_buf, B, MfmaPtrs{}, pk != nullptr, &ln.up_scratch, &ln.up_scratch_words};
+      // level 0 of the group = its replies, query-major with the reply buffer's own stride: the last fold and the final
+      // inverse transform write them where pirgpu_batch_fetch reads them (no device-to-device copy per group)
+      uint64_t* lvl_ptrs[PIRGPU_MAX_DIMS];
+      for (uint32_t l = 0; l < c->d; ++l) lvl_ptrs[l] = ln.lvl[l];
+      const bool direct_reply = c->d >= 2;   // d = 1 would make the scan itself write there: keep the lane buffer
+      if (direct_reply) lvl_ptrs[0] = c->d_breply + (size_t)first * rwords;
+      Stage sg{ln.stream, lvl_ptrs, ln.pt_buf, B, MfmaPtrs{}, pk != nullptr, &ln.up_scratch, &ln.up_scratch_words};
       MfmaPtrs col{};
       if (pk) {
         const uint32_t groups_per_rank = (pk->per_rank + kMaxMfmaQueries - 1) / kMaxMfmaQueries;
@@ -1954,8 +1963,9 @@ static void batch_run_mfma(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
       scan_group_mfma(c, ln.stream, ln.selp, col, B, ln.lvl[c->d - 1], ln.scan_part, nullptr, packed, sg.sel_f64,
                       share_chip);
       post_scan_stage(c, sg, nullptr);
-      HIP_TRY(hipMemcpyAsync(c->d_breply + (size_t)first * rwords, ln.lvl[0], (size_t)B * rwords * 8,
-                             hipMemcpyDeviceToDevice, ln.stream));
+      if (!direct_reply)
+        HIP_TRY(hipMemcpyAsync(c->d_breply + (size_t)first * rwords, ln.lvl[0], (size_t)B * rwords * 8,
+                               hipMemcpyDeviceToDevice, ln.stream));
       for (uint32_t q = 0; q < B; ++q) {
         HIP_TRY(hipEventRecord(members[q]->ev_done, ln.stream));
         members[q]->reply_valid = false;  // the group's replies live in the lane / batch buffers, not in the worker

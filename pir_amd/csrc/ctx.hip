@@ -1869,10 +1869,10 @@ static void expand_group_on_lane(pirgpu_ctx* c, BatchLane& ln, Worker* const* me
   uint64_t remaining = c->dim_sum, produced = 0;
   for (uint32_t qc = 0; qc < nq && remaining; ++qc) {
     const uint32_t slots = (uint32_t)std::min<uint64_t>(remaining, N);
-    // the B query ciphertexts side by side (staged in res_b) become the roots of the B interleaved trees
-    HIP_TRY(hipMemcpy2DAsync(ln.res_b, ctw * 8, c->d_bquery + (size_t)first * qwords + (size_t)qc * ctw, qwords * 8,
-                             ctw * 8, B, hipMemcpyDeviceToDevice, ln.stream));
-    HIP_TRY(launch_tree_convert(ln.stream, c->dp, c->mode, ln.res_b, ln.res_a, (uint64_t)B * ctw, true));
+    // the B query ciphertexts, gathered side by side out of the staged batch, become the roots of the B interleaved
+    // trees (one strided import launch: no separate 2-D copy)
+    HIP_TRY(launch_tree_convert(ln.stream, c->dp, c->mode, c->d_bquery + (size_t)first * qwords + (size_t)qc * ctw, ln.res_a,
+                                (uint64_t)B * ctw, true, ctw, qwords));
     MfmaPtrs dst{};
     uint32_t ksets[kMaxMfmaQueries];   // every query of the group is switched with its own client's keys
     for (uint32_t q = 0; q < B; ++q) {

@@ -89,8 +89,9 @@ hipError_t launch_ntt_reorder(hipStream_t st, uint32_t N, const uint64_t* in, ui
 hipError_t launch_ks_combine(hipStream_t st, const DevParams* P, int mode, uint32_t N, uint32_t k,
                              const uint64_t* res_in, const uint64_t* prod, uint32_t galois_inv, uint32_t nodes,
                              uint32_t shift_pow, bool expand_step, uint32_t hi_limit, bool pack40, uint64_t* res_out);
+// to_tree with chunk_words != 0: the input consists of chunks of chunk_words words that lie in_stride words apart
 hipError_t launch_tree_convert(hipStream_t st, const DevParams* P, int mode, const uint64_t* in, uint64_t* out,
-                               uint64_t words, bool to_tree);
+                               uint64_t words, bool to_tree, uint64_t chunk_words = 0, uint64_t in_stride = 0);
 hipError_t launch_monomial_shift(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* in,
                                  uint32_t shift, uint64_t count, uint64_t* out);
 hipError_t launch_scan(hipStream_t st, const DevParams* P, uint32_t N, uint32_t k, const uint64_t* db,

@@ -199,12 +199,15 @@ __global__ void ks_combine_f64_kernel(const DevParams* __restrict__ P, const dou
 }
 
 // Expansion tree <-> canonical u64 ciphertexts for the fp64 flavours (query import, test-hook export).
+// chunk_words / in_stride: the input is a sequence of chunks of chunk_words words, in_stride words apart (the B query
+// ciphertexts of a group inside the staged batch); contiguous input: in_stride == chunk_words.
 __global__ void tree_import_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ in,
-                                   double* __restrict__ out, uint64_t words) {
+                                   double* __restrict__ out, uint64_t words, uint64_t chunk_words, uint64_t in_stride) {
   const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= words) return;
   const uint32_t j = (uint32_t)((gid >> P->logN) % P->k);
-  out[gid] = f64_norm(f64_from_u64(in[gid]), F64Mod{P->tab[j].qd, P->tab[j].qinvd});
+  const uint64_t chunk = gid / chunk_words;
+  out[gid] = f64_norm(f64_from_u64(in[chunk * in_stride + (gid - chunk * chunk_words)]), F64Mod{P->tab[j].qd, P->tab[j].qinvd});
 }
 
 __global__ void tree_export_kernel(const DevParams* __restrict__ P, const double* __restrict__ in,
@@ -807,12 +810,18 @@ hipError_t launch_ks_combine(hipStream_t st, const DevParams* P, int mode, uint3
 // canonical u64 ciphertext words <-> the expansion tree's element type (doubles in the fp64 flavours; a plain
 // copy for the integer flavour)
 hipError_t launch_tree_convert(hipStream_t st, const DevParams* P, int mode, const uint64_t* in, uint64_t* out,
-                               uint64_t words, bool to_tree) {
+                               uint64_t words, bool to_tree, uint64_t chunk_words, uint64_t in_stride) {
   if (!words) return hipSuccess;
-  if (mode == kNttInt) return hipMemcpyAsync(out, in, words * 8, hipMemcpyDeviceToDevice, st);
+  if (!chunk_words) chunk_words = in_stride = words;
+  if (mode == kNttInt) {
+    if (in_stride == chunk_words) return hipMemcpyAsync(out, in, words * 8, hipMemcpyDeviceToDevice, st);
+    return hipMemcpy2DAsync(out, chunk_words * 8, in, in_stride * 8, chunk_words * 8, words / chunk_words,
+                            hipMemcpyDeviceToDevice, st);
+  }
   const dim3 grid((uint32_t)((words + 255) / 256)), block(256);
   if (to_tree)
-    hipLaunchKernelGGL(tree_import_kernel, grid, block, 0, st, P, in, reinterpret_cast<double*>(out), words);
+    hipLaunchKernelGGL(tree_import_kernel, grid, block, 0, st, P, in, reinterpret_cast<double*>(out), words, chunk_words,
+                       in_stride);
   else
     hipLaunchKernelGGL(tree_export_kernel, grid, block, 0, st, P, reinterpret_cast<const double*>(in), out, words);
   PIRGPU_LAUNCH_CHECK();

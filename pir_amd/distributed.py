@@ -115,6 +115,8 @@ class Comm:
             limit = max(1, self.MAX_MESSAGE_BYTES // recv.element_size())
             biggest = max(max(recv_splits), max(send_splits))
             pieces = min(max(1, units), -(-biggest // limit))
+            if pieces > 1 and any(x % units for x in list(recv_splits) + list(send_splits)):
+                raise ValueError("all_to_all: split sizes must be multiples of `units` to be exchanged in pieces")
             if pieces <= 1:
                 d.all_to_all_single(recv, send, list(recv_splits), list(send_splits), group=self.group)
             else:

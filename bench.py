@@ -193,10 +193,14 @@ def main():
                          "north-star mode and always the headline `value`; 'queries' = every GPU holds the whole "
                          "database and serves its own share of the batch (replicas, no data-path collective); "
                          "'both' (default) = time rows for `value` and replicas as the named extra `replicas_reference`")
-    ap.add_argument("--exchange", choices=["auto", "packed", "u64"], default=os.environ.get("PIRGPU_EXCHANGE", "auto"),
+    ap.add_argument("--exchange", choices=["auto", "packed", "u64", "replicated"],
+                    default=os.environ.get("PIRGPU_EXCHANGE", "auto"),
                     help="rows mode: what is exchanged per query -- packed = column selectors in the scan's operand "
                          "layout (all-gather) + each rank's own row selectors (all-to-all); u64 = whole NTT-form "
-                         "selection vectors (all-gather); auto = packed when every shard supports it (d = 2, MFMA scan)")
+                         "selection vectors (all-gather); replicated = nothing: every rank expands every query itself "
+                         "and only the partial replies are reduced; auto = replicated at 2 GPUs (ONE xGMI link between "
+                         "them: 0.8 GB of selectors per step would take twice the step's compute), else packed when "
+                         "every shard supports it (d = 2, MFMA scan), else u64")
     ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5],
                     help="BASELINE.json config (1-based as in SURVEY.md section 8): 3 = the headline workload; "
                          "2/4/5 are reference points (other ring degrees / database shapes)")
@@ -311,6 +315,8 @@ def main():
         if args.exchange == "packed" and not packed_ok:
             raise SystemExit("--exchange packed needs d = 2 and an int8-MFMA-scanned shard (>= 8 rows) on every rank")
         exchange = "packed" if packed_ok else "u64"
+        if args.exchange == "replicated" or (args.exchange == "auto" and world == 2):
+            exchange = "replicated"
 
     # ---- (1) single-query latency + scan-kernel roofline (one scan launch per query)
     srv.stage_query(query)
@@ -334,7 +340,7 @@ def main():
     # ---- (2) throughput: `batch` queries per step (the whole job's), `workers` in flight per GPU
     srv.set_concurrency(workers)
     srv.stage_batch(queries)
-    pipe = None
+    pipe = rpipe = None
     serial_phases = None
     if use_dist:
         D.sync_zero_plaintexts(srv, dist, world, comm, torch, dev)   # the transparent-ciphertext decision is collective
@@ -353,6 +359,9 @@ def main():
         if os.environ.get("PIRGPU_ROWS_PIPELINE", "1") != "0":
             pipe = D.RowsPipeline(srv, batch, rank, world, dist, torch, dev)
             pipes.append(pipe)
+    elif use_dist and exchange == "replicated":
+        rpipe = D.RowsReplicatedPipeline(srv, batch, rank, world, dist, torch, dev)
+        pipes.append(rpipe)
     elif use_dist:
         sv_all = torch.empty((batch, pp.dim_sum, 2, k, N), dtype=torch.int64, device=dev)
         redb = torch.empty((batch, reply_cts, 2, k, N), dtype=torch.int64, device=dev)
@@ -362,6 +371,8 @@ def main():
             srv.run_batch()
         elif pipe is not None:
             pipe.submit()
+        elif rpipe is not None:
+            rpipe.submit()
         elif exchange == "packed":
             D.run_batch_rows_packed(srv, bufs, dist, rank, world, comm)
         else:
@@ -372,7 +383,7 @@ def main():
     forced_check = None
     if use_dist and world == 1:   # forced single-rank run: the reduced replies must equal the plain ones
         got = ((pipe.replies(pipe.step - 1) if pipe is not None else bufs.replies) if exchange == "packed"
-               else redb).cpu().numpy().view(np.uint64)
+               else (rpipe.replies(rpipe.step - 1) if rpipe is not None else redb)).cpu().numpy().view(np.uint64)
         srv.stage_batch(queries)
         srv.run_batch()
         forced_check = bool(np.array_equal(got, srv.fetch_batch()))
@@ -484,9 +495,11 @@ def main():
             parallelism = "single GPU" + (" (collective code path forced with one rank)" if use_dist else "")
         else:
             parallelism = ("database row-sharded over %d GPUs; every rank expands %d of the %d queries of a step; "
-                           % (world, per_rank, batch)) + \
+                           % (world, batch if exchange == "replicated" else per_rank, batch)) + \
                           ("all-gather of packed column selectors + all-to-all of row selectors, reduce-scatter of replies (RCCL)"
-                           if exchange == "packed" else "all-gather of u64 selection vectors, all-reduce of replies (RCCL)")
+                           if exchange == "packed" else
+                           "no selector exchange (every rank expands all %d queries itself), reduce-scatter of replies (RCCL)" % batch
+                           if exchange == "replicated" else "all-gather of u64 selection vectors, all-reduce of replies (RCCL)")
         out = {
             "metric": "PIR queries/sec (ms/query in ms_per_step), N=%d DB=2^%d x %dB d=%d"
                       % (N, args.log_items, item_bytes, args.dims),

@@ -434,3 +434,56 @@ class RowsPipeline:
     def replies(self, step: int):
         """The replies tensor of `step` (0-based submit index): [per, reply_cts, 2, k, N] int64."""
         return self.sets[step & 1].replies
+
+
+class RowsReplicatedPipeline:
+    """Row-sharded database with the oblivious expansion REPLICATED: every rank expands every query of the step itself
+    (the plain batch pipeline on its own shard), so no selectors cross GPUs at all -- the only collective is the
+    reduce-scatter (SUM) of the per-shard partial replies + x mod q_j, the literal reading of "the database shards
+    row-wise ... per-shard reply ciphertexts summed by an RCCL reduce".  It costs every rank the whole expansion work
+    (7.5 of a single GPU's 11.9 ms per step of 64 queries at cfg 3), so it scales only as far as the multiply does --
+    but at TWO GPUs, where the packed exchange would push 0.8 GB per step through the one xGMI link between them
+    (about 16 ms against 6.9 ms of compute), it is the better form: 7.5 + 3.05 ms of compute, 34 MB to reduce.  The
+    reduce of step s runs on the communication stream under the compute of step s + 1 (two buffer sets, event-ordered
+    streams, no host waits); rank r ends with the replies of queries [r * per, (r + 1) * per) in `replies(step)`."""
+
+    def __init__(self, server, batch: int, rank: int, world: int, dist, torch, device, comm: Optional[Comm] = None):
+        if batch % world:
+            raise ValueError("batch size must be a multiple of the world size")
+        self.server, self.rank, self.world, self.batch = server, rank, world, batch
+        self.per = batch // world
+        k, N = server.k, server.N
+        reply_cts = server.db.reply_ct_count()
+        self.partial = [torch.empty((batch, reply_cts, 2, k, N), dtype=torch.int64, device=device) for _ in range(2)]
+        self._replies = [torch.empty((self.per, reply_cts, 2, k, N), dtype=torch.int64, device=device) for _ in range(2)]
+        self.comm = comm or Comm(dist, world, host_sync=False)
+        self.comm.host_sync = False
+        on_gpu = str(device).startswith("cuda")
+        self.streams = _GpuStreams(server, torch, device) if on_gpu else _NoStreams()
+        self.ev_r = [torch.cuda.Event(), torch.cuda.Event()] if on_gpu else None
+        self.step = 0
+        self.n_reply_cts = self.per * reply_cts
+
+    def submit(self) -> None:
+        srv, st = self.server, self.streams
+        srv.check_ready()
+        b = self.step & 1
+        if self.ev_r is not None and self.step >= 2:
+            st.main.wait_event(self.ev_r[b])       # the reduce that last read partial[b] (two steps ago) is done
+        srv.fork()                                  # the previous step's reply copy precedes this step's multiply
+        srv.run_batch()                             # every staged query on this rank's shard (asynchronous)
+        srv.batch_reply_copy_to_device_async(self.partial[b].data_ptr())   # join + copy on the main stream
+        st.comm_after_main()
+        with st.comm():
+            self.comm.reduce_scatter_sum(self._replies[b], self.partial[b], self.rank)
+            srv.reduce_fixup_device_async(self._replies[b].data_ptr(), self.n_reply_cts, st.comm_handle())
+            if self.ev_r is not None:
+                self.ev_r[b].record(st.side)
+        self.step += 1
+
+    def flush(self) -> None:
+        self.streams.synchronize()
+        self.server.sync()
+
+    def replies(self, step: int):
+        return self._replies[step & 1]

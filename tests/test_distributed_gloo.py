@@ -119,6 +119,15 @@ class OracleShardServer:
         self.partials = [self._partial(rows[r * per_rank + i], packed[r, i // D.GROUP, i % D.GROUP])
                          for r in range(n_ranks) for i in range(per_rank)]
 
+    def run_batch(self):
+        """The plain batch pipeline on this shard: every staged query expanded here, multiplied against the shard."""
+        self._batch_count = len(self.queries)
+        self.partials = []
+        for i in range(len(self.queries)):
+            sv = self._sv(i).reshape(self.params.dim_sum, self.ctw)
+            self.partials.append(self._partial(sv[self.lo:self.hi], sv[self.dims[0]:]) if len(self.dims) > 1
+                                 else self._partial(sv[self.lo:self.hi], sv[:0]))
+
     def batch_run_selectors(self, sv_ptr, count):
         ds = self.params.dim_sum
         sv = _view(sv_ptr, count * ds * self.ctw).reshape(count, ds, self.ctw)
@@ -252,6 +261,17 @@ def rows_step_check(rank, world, d, dbsize, elem, batch, zero_pt=None):
                 g = base + gi * bpg + i
                 want = s.orc.process_query(s.db_ntt, p.dimensions, q_all[g], s.galois_keys)[1]
                 ok &= bool(np.array_equal(mine_h[i], want))
+        # replicated expansion (what bench.py uses at two GPUs): every rank expands every query itself, the only
+        # collective is the reduce-scatter of the partial replies; two steps (both buffer sets)
+        srv.stage_batch(queries)
+        rp = D.RowsReplicatedPipeline(srv, batch, rank, world, dist, torch, "cpu", comm=D.Comm(dist, world))
+        rp.submit()
+        rp.submit()
+        rp.flush()
+        for t in range(2):
+            mine_r = rp.replies(t).numpy().view(np.uint64)
+            for i in range(lo, hi):
+                ok &= bool(np.array_equal(mine_r[i - lo], full[i]))
         srv.stage_batch(queries)
     # the whole-selection-vector exchange (any d): every rank ends with every reply
     sv_all = torch.empty((batch, p.dim_sum, 2, s.orc.k, 4096), dtype=torch.int64)

@@ -83,6 +83,20 @@ def _step(rank, world, dist, items, batch, out):
             if not same:
                 print("rank %d: pipelined step %d, query %d differs" % (rank, t, i), flush=True)
             ok &= same
+    # replicated expansion (bench.py's form of the rows step at two GPUs): every rank expands every query itself on its
+    # shard context, the only collective is the reduce-scatter of the partial replies; three steps, two buffer sets
+    srv.stage_batch(queries)
+    rp = D.RowsReplicatedPipeline(srv, batch, rank, world, dist, torch, dev)
+    for _ in range(3):
+        rp.submit()
+    rp.flush()
+    for t in (1, 2):
+        mine_r = rp.replies(t).cpu().numpy().view(np.uint64)
+        for i in range(lo, hi):
+            same = bool(np.array_equal(mine_r[i - lo], full[i]))
+            if not same:
+                print("rank %d: replicated-expansion step %d, query %d differs" % (rank, t, i), flush=True)
+            ok &= same
     # hybrid layout (bench.py's `hybrid_rows_reference`), degenerate at two ranks: 2 replica groups of ONE shard each --
     # every rank holds the whole database and serves its half of the queries inside its own one-rank process group
     if world == 2 and batch % 2 == 0:

@@ -380,6 +380,8 @@ def main():
 
     elapsed = timed_steps(step_rows, barrier, args.steps, args.warmup, dist, use_dist, torch, dev)
     qps = args.steps * batch / elapsed
+    if rpipe is not None:
+        rpipe.close()   # later plain batches write to the context's own reply buffer again
     forced_check = None
     if use_dist and world == 1:   # forced single-rank run: the reduced replies must equal the plain ones
         got = ((pipe.replies(pipe.step - 1) if pipe is not None else bufs.replies) if exchange == "packed"

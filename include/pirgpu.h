@@ -220,13 +220,19 @@ int pirgpu_batch_reply_copy_to_device(pirgpu_ctx* ctx, uint64_t* device_dst, uin
  * streams (a main stream, the batch lanes, the workers):
  *   stream_handle   the main stream (a hipStream_t), e.g. for torch.cuda.ExternalStream -- record / wait events on it;
  *   join            the main stream waits, on the device, for everything queued on lanes and workers so far;
+ *   join_stream     the same, but it is `stream` (a hipStream_t of the caller) that waits -- the main stream does not,
+ *                   so a later fork does not make every lane wait for every other lane's earlier work;
  *   fork            lanes and workers wait for everything the main stream has been made to wait for;
+ *   batch_set_reply_buffer  later batches write their replies into the caller's device buffer (capacity in
+ *                   ciphertexts; NULL restores the context's own buffer): a collective can read them where they are;
  *   batch_expand_packed_async      = batch_expand_packed, returns once the work is queued (join to get a completion point);
  *   batch_reply_copy_to_device_async  join + copy on the main stream, no wait;
  *   reduce_fixup_device_async      x mod q_j queued on `stream` (a hipStream_t of the caller; NULL = the main stream).
  * pirgpu_batch_run_packed / _run_selectors / _batch_run never wait for the device in either form. */
 void* pirgpu_stream_handle(pirgpu_ctx* ctx);
 int pirgpu_join(pirgpu_ctx* ctx);
+int pirgpu_join_stream(pirgpu_ctx* ctx, void* stream);
+int pirgpu_batch_set_reply_buffer(pirgpu_ctx* ctx, uint64_t* device_buf, uint64_t capacity);
 int pirgpu_fork(pirgpu_ctx* ctx);
 int pirgpu_batch_expand_packed_async(pirgpu_ctx* ctx, uint32_t first, uint32_t count, uint8_t* device_packed,
                                      uint64_t* device_rows, const uint32_t* row_cuts, uint32_t n_ranks);

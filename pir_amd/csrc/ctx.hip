@@ -163,6 +163,8 @@ struct pirgpu_ctx {
   uint64_t pt_words = 0;
   // batch mode (pirgpu_batch_*): queries and replies of one batch, device resident
   uint64_t *d_bquery = nullptr, *d_breply = nullptr;
+  uint64_t* ext_reply = nullptr;   // pirgpu_batch_set_reply_buffer: the caller's device buffer batches write replies to
+  uint64_t ext_reply_cts = 0;      // its capacity in ciphertexts
   uint32_t batch_cap = 0, batch_count = 0, n_active = 1;   // batch_count: replies the reply buffer holds
   uint32_t staged_count = 0;   // queries pirgpu_batch_stage left in d_bquery (0 again when the buffers are reallocated)
   bool batch_valid = false;
@@ -206,6 +208,7 @@ struct pirgpu_ctx {
   std::vector<BatchLane> lanes;             // created on the first batch
   uint64_t groups_run = 0;
   hipEvent_t ev_fork = nullptr;             // pirgpu_fork: the main stream's position
+  hipEvent_t ev_main_join = nullptr;        // pirgpu_join_stream onto a caller's stream: the main stream's position
   uint64_t *h_query = nullptr, *h_reply = nullptr;   // pinned host staging of the wire layer
   size_t h_query_words = 0, h_reply_words = 0;
 
@@ -1033,6 +1036,7 @@ void pirgpu_destroy(pirgpu_ctx* c) {
     if (ln.stream) (void)hipStreamDestroy(ln.stream);
   }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_main_join) (void)hipEventDestroy(c->ev_main_join);
   for (size_t i = 1; i < c->workers.size(); ++i)
     if (c->workers[i].stream) (void)hipStreamDestroy(c->workers[i].stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1579,20 +1583,39 @@ int pirgpu_sync(pirgpu_ctx* c) {
 
 void* pirgpu_stream_handle(pirgpu_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
-int pirgpu_join(pirgpu_ctx* c) {
+int pirgpu_join(pirgpu_ctx* c) { return pirgpu_join_stream(c, nullptr); }
+
+int pirgpu_join_stream(pirgpu_ctx* c, void* stream) {
   return guarded(c, [&]() -> int {
+    hipStream_t target = stream ? (hipStream_t)stream : c->stream;
     for (BatchLane& ln : c->lanes) {
       if (!ln.stream) continue;
       if (!ln.ev_join) HIP_TRY(hipEventCreateWithFlags(&ln.ev_join, hipEventDisableTiming));
       HIP_TRY(hipEventRecord(ln.ev_join, ln.stream));
-      HIP_TRY(hipStreamWaitEvent(c->stream, ln.ev_join, 0));
+      HIP_TRY(hipStreamWaitEvent(target, ln.ev_join, 0));
     }
     for (Worker& w : c->workers) {
       if (!w.stream || w.stream == c->stream) continue;
       if (!w.ev_join) HIP_TRY(hipEventCreateWithFlags(&w.ev_join, hipEventDisableTiming));
       HIP_TRY(hipEventRecord(w.ev_join, w.stream));
-      HIP_TRY(hipStreamWaitEvent(c->stream, w.ev_join, 0));
+      HIP_TRY(hipStreamWaitEvent(target, w.ev_join, 0));
     }
+    if (target != c->stream) {   // the main stream carries work too (worker 0, copies): the target follows it as well
+      if (!c->ev_main_join) HIP_TRY(hipEventCreateWithFlags(&c->ev_main_join, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(c->ev_main_join, c->stream));
+      HIP_TRY(hipStreamWaitEvent(target, c->ev_main_join, 0));
+    }
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_batch_set_reply_buffer(pirgpu_ctx* c, uint64_t* device_buf, uint64_t cap) {
+  return guarded(c, [&]() -> int {
+    if (c->in_batch) return fail(c, PIRGPU_FAILED_PRECONDITION, "a batch is being queued");
+    if (device_buf && cap == 0) return fail(c, PIRGPU_INVALID_ARGUMENT, "empty reply buffer");
+    c->ext_reply = device_buf;
+    c->ext_reply_cts = device_buf ? cap : 0;
+    c->batch_valid = false;   // replies of an earlier batch live in the other buffer
     return PIRGPU_OK;
   });
 }
@@ -1778,6 +1801,12 @@ int pirgpu_set_concurrency(pirgpu_ctx* c, uint32_t n_workers) {
 }
 
 static void ensure_batch_capacity(pirgpu_ctx* c, uint32_t count);
+// Where a batch's replies are written and read: the context's own buffer, or the caller's (pirgpu_batch_set_reply_buffer).
+static inline uint64_t* reply_base(pirgpu_ctx* c) { return c->ext_reply ? c->ext_reply : c->d_breply; }
+static void check_reply_target(pirgpu_ctx* c, uint64_t count) {
+  if (c->ext_reply && count * c->reply_cts > c->ext_reply_cts)
+    throw Fail{PIRGPU_INVALID_ARGUMENT, "the caller's reply buffer (pirgpu_batch_set_reply_buffer) is too small for this batch"};
+}
 
 int pirgpu_batch_stage(pirgpu_ctx* c, const uint64_t* queries, uint32_t nq, uint32_t count) {
   return guarded(c, [&]() -> int {
@@ -1942,7 +1971,7 @@ static void batch_run_mfma(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
       uint64_t* lvl_ptrs[PIRGPU_MAX_DIMS];
       for (uint32_t l = 0; l < c->d; ++l) lvl_ptrs[l] = ln.lvl[l];
       const bool direct_reply = c->d >= 2;   // d = 1 would make the scan itself write there: keep the lane buffer
-      if (direct_reply) lvl_ptrs[0] = c->d_breply + (size_t)first * rwords;
+      if (direct_reply) lvl_ptrs[0] = reply_base(c) + (size_t)first * rwords;
       Stage sg{ln.stream, lvl_ptrs, ln.pt_buf, B, MfmaPtrs{}, pk != nullptr, &ln.up_scratch, &ln.up_scratch_words};
       MfmaPtrs col{};
       if (pk) {
@@ -1964,7 +1993,7 @@ static void batch_run_mfma(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
                       share_chip);
       post_scan_stage(c, sg, nullptr);
       if (!direct_reply)
-        HIP_TRY(hipMemcpyAsync(c->d_breply + (size_t)first * rwords, ln.lvl[0], (size_t)B * rwords * 8,
+        HIP_TRY(hipMemcpyAsync(reply_base(c) + (size_t)first * rwords, ln.lvl[0], (size_t)B * rwords * 8,
                                hipMemcpyDeviceToDevice, ln.stream));
       for (uint32_t q = 0; q < B; ++q) {
         HIP_TRY(hipEventRecord(members[q]->ev_done, ln.stream));
@@ -1996,6 +2025,7 @@ static void batch_run_impl_body(pirgpu_ctx* c, uint32_t count, const uint64_t* e
   if (c->n_loaded != c->pt_end - c->pt_begin)
     throw Fail{PIRGPU_FAILED_PRECONDITION, "database not fully loaded"};
   check_transparent(c);
+  check_reply_target(c, count);
   ensure_packed(c);
   c->prof_cur = -1;
   if (c->mfma_on) {
@@ -2058,7 +2088,7 @@ static void batch_run_impl_body(pirgpu_ctx* c, uint32_t count, const uint64_t* e
     for (uint32_t j = 0; j < n; ++j) {
       Worker& w = c->workers[j];
       post_scan_on_device(c, w);
-      HIP_TRY(hipMemcpyAsync(c->d_breply + (base + j) * rwords, w.lvl[0], rwords * 8, hipMemcpyDeviceToDevice,
+      HIP_TRY(hipMemcpyAsync(reply_base(c) + (base + j) * rwords, w.lvl[0], rwords * 8, hipMemcpyDeviceToDevice,
                              w.stream));
       HIP_TRY(hipEventRecord(w.ev_done, w.stream));
       w.reply_valid = true;
@@ -2202,6 +2232,7 @@ int pirgpu_batch_run_packed(pirgpu_ctx* c, const uint8_t* device_packed, uint32_
     if (!device_packed || !device_rows || count == 0 || count > 4096) return fail(c, PIRGPU_INVALID_ARGUMENT, "invalid batch");
     if (c->n_loaded != c->pt_end - c->pt_begin) return fail(c, PIRGPU_FAILED_PRECONDITION, "database not fully loaded");
     check_transparent(c);
+    check_reply_target(c, count);
     ensure_packed(c);
     ensure_batch_capacity(c, (uint32_t)count);
     c->prof_cur = -1;
@@ -2228,7 +2259,7 @@ int pirgpu_batch_reply_copy_to_device(pirgpu_ctx* c, uint64_t* dst, uint64_t cap
     sync_batch_streams(c);
     // a device-to-device hipMemcpy on the null stream may return before the copy has run, and the context's
     // streams are non-blocking (not ordered with the null stream): copy on the context's stream and wait
-    HIP_TRY(hipMemcpyAsync(dst, c->d_breply, total * c->ctw * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dst, reply_base(c), total * c->ctw * 8, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PIRGPU_OK;
   });
@@ -2241,7 +2272,7 @@ int pirgpu_batch_reply_copy_to_device_async(pirgpu_ctx* c, uint64_t* dst, uint64
     if (!c->batch_valid) return fail(c, PIRGPU_FAILED_PRECONDITION, "no batch has been run");
     const uint64_t total = (uint64_t)c->batch_count * c->reply_cts;
     if (!dst || cap < total) return fail(c, PIRGPU_INVALID_ARGUMENT, "reply buffer too small");
-    HIP_TRY(hipMemcpyAsync(dst, c->d_breply, total * c->ctw * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dst, reply_base(c), total * c->ctw * 8, hipMemcpyDeviceToDevice, c->stream));
     return PIRGPU_OK;
   });
 }
@@ -2252,7 +2283,7 @@ int pirgpu_batch_fetch(pirgpu_ctx* c, uint64_t* replies, uint64_t cap, uint64_t*
     const uint64_t total = (uint64_t)c->batch_count * c->reply_cts;
     if (!replies || cap < total) return fail(c, PIRGPU_INVALID_ARGUMENT, "reply buffer too small");
     sync_batch_streams(c);
-    HIP_TRY(hipMemcpy(replies, c->d_breply, total * c->ctw * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(replies, reply_base(c), total * c->ctw * 8, hipMemcpyDeviceToHost));
     if (count) *count = total;
     return PIRGPU_OK;
   });

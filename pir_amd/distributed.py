@@ -444,7 +444,8 @@ class RowsReplicatedPipeline:
     (7.5 of a single GPU's 11.9 ms per step of 64 queries at cfg 3), so it scales only as far as the multiply does --
     but at TWO GPUs, where the packed exchange would push 0.8 GB per step through the one xGMI link between them
     (about 16 ms against 6.9 ms of compute), it is the better form: 7.5 + 3.05 ms of compute, 34 MB to reduce.  The
-    reduce of step s runs on the communication stream under the compute of step s + 1 (two buffer sets, event-ordered
+    groups write their replies straight into the reduce's send buffer (pirgpu_batch_set_reply_buffer); the reduce of
+    step s runs on the communication stream under the compute of step s + 1 (two buffer sets, event-ordered
     streams, no host waits); rank r ends with the replies of queries [r * per, (r + 1) * per) in `replies(step)`."""
 
     def __init__(self, server, batch: int, rank: int, world: int, dist, torch, device, comm: Optional[Comm] = None):
@@ -469,11 +470,16 @@ class RowsReplicatedPipeline:
         srv.check_ready()
         b = self.step & 1
         if self.ev_r is not None and self.step >= 2:
-            st.main.wait_event(self.ev_r[b])       # the reduce that last read partial[b] (two steps ago) is done
-        srv.fork()                                  # the previous step's reply copy precedes this step's multiply
+            # the reduce that last read partial[b] (two steps ago) is done before a lane writes there again.  The main
+            # stream carries nothing else -- in particular it never joins the lanes -- so this fork does not make a
+            # lane wait for the other lane's tail of the previous step: groups keep alternating over the lanes across
+            # step boundaries exactly as in the single-GPU pipeline
+            st.main.wait_event(self.ev_r[b])
+            srv.fork()
+        # the groups write their replies straight into partial[b] (no device-to-device copy of the batch)
+        srv.batch_set_reply_buffer(self.partial[b].data_ptr(), self.partial[b].shape[0] * self.partial[b].shape[1])
         srv.run_batch()                             # every staged query on this rank's shard (asynchronous)
-        srv.batch_reply_copy_to_device_async(self.partial[b].data_ptr())   # join + copy on the main stream
-        st.comm_after_main()
+        srv.join_stream(st.comm_handle())           # the communication stream -- not the main one -- follows the lanes
         with st.comm():
             self.comm.reduce_scatter_sum(self._replies[b], self.partial[b], self.rank)
             srv.reduce_fixup_device_async(self._replies[b].data_ptr(), self.n_reply_cts, st.comm_handle())
@@ -484,6 +490,11 @@ class RowsReplicatedPipeline:
     def flush(self) -> None:
         self.streams.synchronize()
         self.server.sync()
+
+    def close(self) -> None:
+        """Gives the context its own reply buffer back (the plain batch calls fetch from there)."""
+        self.flush()
+        self.server.batch_set_reply_buffer(0, 0)
 
     def replies(self, step: int):
         return self._replies[step & 1]

@@ -359,6 +359,15 @@ class PIRServer:
         """Main stream waits (on the device) for everything queued on the lanes / workers so far."""
         self._check(self.lib.pirgpu_join(self.db.handle))
 
+    def join_stream(self, stream: int) -> None:
+        """The caller's stream (a hipStream_t) waits for everything queued so far; the main stream does not."""
+        self._check(self.lib.pirgpu_join_stream(self.db.handle, C.c_void_p(stream)))
+
+    def batch_set_reply_buffer(self, device_ptr: int, capacity_cts: int) -> None:
+        """Later batches write their replies into this device buffer (0 restores the context's own)."""
+        self._check(self.lib.pirgpu_batch_set_reply_buffer(self.db.handle, C.c_void_p(device_ptr or None),
+                                                           int(capacity_cts)))
+
     def fork(self) -> None:
         """Lanes / workers wait (on the device) for everything the main stream has been made to wait for."""
         self._check(self.lib.pirgpu_fork(self.db.handle))

@@ -119,6 +119,11 @@ class OracleShardServer:
         self.partials = [self._partial(rows[r * per_rank + i], packed[r, i // D.GROUP, i % D.GROUP])
                          for r in range(n_ranks) for i in range(per_rank)]
 
+    reply_buffer = None   # pirgpu_batch_set_reply_buffer: (pointer, capacity in ciphertexts)
+
+    def batch_set_reply_buffer(self, ptr, cap_cts):
+        self.reply_buffer = (ptr, cap_cts) if ptr else None
+
     def run_batch(self):
         """The plain batch pipeline on this shard: every staged query expanded here, multiplied against the shard."""
         self._batch_count = len(self.queries)
@@ -127,6 +132,10 @@ class OracleShardServer:
             sv = self._sv(i).reshape(self.params.dim_sum, self.ctw)
             self.partials.append(self._partial(sv[self.lo:self.hi], sv[self.dims[0]:]) if len(self.dims) > 1
                                  else self._partial(sv[self.lo:self.hi], sv[:0]))
+        if self.reply_buffer:
+            ptr, cap = self.reply_buffer
+            assert cap >= len(self.partials) * self.db.reply_ct_count()
+            self.batch_reply_copy_to_device(ptr)
 
     def batch_run_selectors(self, sv_ptr, count):
         ds = self.params.dim_sum
@@ -150,6 +159,9 @@ class OracleShardServer:
         pass
 
     def join(self):
+        pass
+
+    def join_stream(self, stream):
         pass
 
     def sync(self):
@@ -267,7 +279,7 @@ def rows_step_check(rank, world, d, dbsize, elem, batch, zero_pt=None):
         rp = D.RowsReplicatedPipeline(srv, batch, rank, world, dist, torch, "cpu", comm=D.Comm(dist, world))
         rp.submit()
         rp.submit()
-        rp.flush()
+        rp.close()
         for t in range(2):
             mine_r = rp.replies(t).numpy().view(np.uint64)
             for i in range(lo, hi):

@@ -89,7 +89,7 @@ def _step(rank, world, dist, items, batch, out):
     rp = D.RowsReplicatedPipeline(srv, batch, rank, world, dist, torch, dev)
     for _ in range(3):
         rp.submit()
-    rp.flush()
+    rp.close()
     for t in (1, 2):
         mine_r = rp.replies(t).cpu().numpy().view(np.uint64)
         for i in range(lo, hi):
@@ -167,3 +167,43 @@ def test_row_sharded_step_world_size_one():
     out = []
     _step(0, 1, None, 10800, 3, out)
     assert out == [True]
+
+
+def test_batch_replies_into_a_caller_buffer():
+    """pirgpu_batch_set_reply_buffer: groups write their replies straight into the caller's device buffer (the send
+    buffer of the multi-GPU reduce); a buffer too small for the batch is refused before anything runs."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import pir_amd
+    from pir_amd.server import PirGpuError
+    from gpu_helpers import to_product_params
+    from pir_fixtures import PirSetup
+    s = PirSetup(10800, 288, 2, N=4096, plain_bits=24)
+    pp = to_product_params(s.params)
+    db = pir_amd.PIRDatabase.Create(pp, s.raw)
+    srv = pir_amd.PIRServer(db, pp)
+    srv.set_galois_keys(s.galois_keys)
+    srv.set_concurrency(8)
+    batch = 11                                             # one full group of 8 and a ragged one
+    queries = [s.client.create_query_for(s.params, (7 + 977 * i) % 10800) for i in range(batch)]
+    srv.stage_batch(queries)
+    srv.run_batch()
+    plain = srv.fetch_batch()
+    n = db.reply_ct_count()
+    mine = torch.zeros((batch, n, 2, srv.k, srv.N), dtype=torch.int64, device="cuda:0")
+    srv.batch_set_reply_buffer(mine.data_ptr(), batch * n)
+    srv.stage_batch(queries)
+    srv.run_batch()
+    srv.sync()
+    assert np.array_equal(mine.cpu().numpy().view(np.uint64), plain)
+    assert np.array_equal(srv.fetch_batch(), plain)        # fetch reads where the batch wrote
+    srv.batch_set_reply_buffer(mine.data_ptr(), batch * n - 1)
+    srv.stage_batch(queries)
+    with pytest.raises(PirGpuError) as e:
+        srv.run_batch()
+    assert e.value.code == 3 and "reply buffer" in e.value.message
+    srv.batch_set_reply_buffer(0, 0)                       # back to the context's own buffer
+    srv.stage_batch(queries)
+    srv.run_batch()
+    assert np.array_equal(srv.fetch_batch(), plain)
+    db.close()

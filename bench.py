@@ -198,9 +198,10 @@ def main():
                     help="rows mode: what is exchanged per query -- packed = column selectors in the scan's operand "
                          "layout (all-gather) + each rank's own row selectors (all-to-all); u64 = whole NTT-form "
                          "selection vectors (all-gather); replicated = nothing: every rank expands every query itself "
-                         "and only the partial replies are reduced; auto = replicated at 2 GPUs (ONE xGMI link between "
-                         "them: 0.8 GB of selectors per step would take twice the step's compute), else packed when "
-                         "every shard supports it (d = 2, MFMA scan), else u64")
+                         "and only the partial replies are reduced; auto = with several GPUs, replicated and packed are both run for a few "
+                         "steps on this machine's links and the faster one is timed (`exchange_autotune` in the line; "
+                         "PIRGPU_EXCHANGE_AUTOTUNE=0: replicated at 2 GPUs -- one xGMI link --, packed beyond); u64 when a "
+                         "shard cannot take the packed path (d != 2, no MFMA scan)")
     ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5],
                     help="BASELINE.json config (1-based as in SURVEY.md section 8): 3 = the headline workload; "
                          "2/4/5 are reference points (other ring degrees / database shapes)")
@@ -315,7 +316,11 @@ def main():
         if args.exchange == "packed" and not packed_ok:
             raise SystemExit("--exchange packed needs d = 2 and an int8-MFMA-scanned shard (>= 8 rows) on every rank")
         exchange = "packed" if packed_ok else "u64"
-        if args.exchange == "replicated" or (args.exchange == "auto" and world == 2):
+        if args.exchange == "replicated":
+            exchange = "replicated"
+        # auto with several ranks and both forms available: measured below, not assumed (`autotune`)
+        autotune = args.exchange == "auto" and world > 1 and packed_ok and os.environ.get("PIRGPU_EXCHANGE_AUTOTUNE", "1") != "0"
+        if args.exchange == "auto" and world == 2 and not autotune:
             exchange = "replicated"
 
     # ---- (1) single-query latency + scan-kernel roofline (one scan launch per query)
@@ -344,6 +349,29 @@ def main():
     serial_phases = None
     if use_dist:
         D.sync_zero_plaintexts(srv, dist, world, comm, torch, dev)   # the transparent-ciphertext decision is collective
+    if use_dist and autotune:
+        # Which form of the rows step is faster depends on what the links between THESE GPUs sustain (DESIGN.md section
+        # 7: replicated expansion costs every rank the whole expansion but moves only replies; the packed exchange
+        # partitions the expansion but ships ~14 MB of selectors per query to every rank).  Both are run for a few steps
+        # -- same barrier + max-over-ranks timing as the headline, so every rank sees the same numbers -- and the
+        # faster one is timed as the headline; both measurements are reported.
+        trial = {}
+        tp = D.RowsReplicatedPipeline(srv, batch, rank, world, dist, torch, dev)
+        pipes.append(tp)
+        trial["replicated"] = timed_steps(tp.submit, barrier, 6, 2, dist, use_dist, torch, dev) / 6 * 1e3
+        pipes.clear()
+        tp.close()
+        del tp
+        tp = D.RowsPipeline(srv, batch, rank, world, dist, torch, dev)
+        pipes.append(tp)
+        trial["packed"] = timed_steps(tp.submit, barrier, 6, 2, dist, use_dist, torch, dev) / 6 * 1e3
+        pipes.clear()
+        del tp
+        torch.cuda.empty_cache()
+        exchange = min(trial, key=trial.get)
+        out_extra["exchange_autotune"] = {"ms_per_step": {kk: round(v, 4) for kk, v in trial.items()}, "chosen": exchange,
+                                          "note": "6 steps of each form of the row-sharded step on this machine's "
+                                                  "links; the faster one is the headline"}
     if use_dist and exchange == "packed":
         bufs = D.PackedBuffers(srv, batch, rank, world, torch, dev)
         # serial phase times from the synchronous form of the step (every phase followed by a host wait) ...

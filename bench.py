@@ -343,87 +343,6 @@ def main():
     srv.set_profiling(False)
     single_reply = srv.fetch_reply() if world == 1 else None
 
-    # ---- (2) throughput: `batch` queries per step (the whole job's), `workers` in flight per GPU
-    srv.set_concurrency(workers)
-    srv.stage_batch(queries)
-    pipe = rpipe = None
-    serial_phases = None
-    if use_dist:
-        D.sync_zero_plaintexts(srv, dist, world, comm, torch, dev)   # the transparent-ciphertext decision is collective
-    if use_dist and autotune:
-        # Which form of the rows step is faster depends on what the links between THESE GPUs sustain (DESIGN.md section
-        # 7: replicated expansion costs every rank the whole expansion but moves only replies; the packed exchange
-        # partitions the expansion but ships ~14 MB of selectors per query to every rank).  Both are run for a few steps
-        # -- same barrier + max-over-ranks timing as the headline, so every rank sees the same numbers -- and the
-        # faster one is timed as the headline; both measurements are reported.
-        trial = {}
-        tp = D.RowsReplicatedPipeline(srv, batch, rank, world, dist, torch, dev)
-        pipes.append(tp)
-        trial["replicated"] = timed_steps(tp.submit, barrier, 6, 2, dist, use_dist, torch, dev) / 6 * 1e3
-        pipes.clear()
-        tp.close()
-        del tp
-        tp = D.RowsPipeline(srv, batch, rank, world, dist, torch, dev)
-        pipes.append(tp)
-        trial["packed"] = timed_steps(tp.submit, barrier, 6, 2, dist, use_dist, torch, dev) / 6 * 1e3
-        pipes.clear()
-        del tp
-        torch.cuda.empty_cache()
-        exchange = min(trial, key=trial.get)
-        out_extra["exchange_autotune"] = {"ms_per_step": {kk: round(v, 4) for kk, v in trial.items()}, "chosen": exchange,
-                                          "note": "6 steps of each form of the row-sharded step on this machine's "
-                                                  "links; the faster one is the headline"}
-    if use_dist and exchange == "packed":
-        bufs = D.PackedBuffers(srv, batch, rank, world, torch, dev)
-        # serial phase times from the synchronous form of the step (every phase followed by a host wait) ...
-        for _ in range(2):
-            D.run_batch_rows_packed(srv, bufs, dist, rank, world, comm)
-        acc = None
-        for _ in range(5):
-            ph = D.run_batch_rows_packed(srv, bufs, dist, rank, world, comm)
-            acc = ph if acc is None else {kk: acc[kk] + v for kk, v in ph.items()}
-        serial_phases = {kk: round(v / 5, 4) for kk, v in acc.items()}
-        # ... and the pipelined form for the timed steps: exchange of step s under the multiply of step s - 1 and the
-        # expansion of step s + 1, streams ordered by events, no host waits (PIRGPU_ROWS_PIPELINE=0: synchronous step)
-        if os.environ.get("PIRGPU_ROWS_PIPELINE", "1") != "0":
-            pipe = D.RowsPipeline(srv, batch, rank, world, dist, torch, dev)
-            pipes.append(pipe)
-    elif use_dist and exchange == "replicated":
-        rpipe = D.RowsReplicatedPipeline(srv, batch, rank, world, dist, torch, dev)
-        pipes.append(rpipe)
-    elif use_dist:
-        sv_all = torch.empty((batch, pp.dim_sum, 2, k, N), dtype=torch.int64, device=dev)
-        redb = torch.empty((batch, reply_cts, 2, k, N), dtype=torch.int64, device=dev)
-
-    def step_rows():
-        if not use_dist:
-            srv.run_batch()
-        elif pipe is not None:
-            pipe.submit()
-        elif rpipe is not None:
-            rpipe.submit()
-        elif exchange == "packed":
-            D.run_batch_rows_packed(srv, bufs, dist, rank, world, comm)
-        else:
-            D.run_batch_query_parallel(srv, sv_all, redb, dist, rank, world, comm)
-
-    elapsed = timed_steps(step_rows, barrier, args.steps, args.warmup, dist, use_dist, torch, dev)
-    qps = args.steps * batch / elapsed
-    if rpipe is not None:
-        rpipe.close()   # later plain batches write to the context's own reply buffer again
-    forced_check = None
-    if use_dist and world == 1:   # forced single-rank run: the reduced replies must equal the plain ones
-        got = ((pipe.replies(pipe.step - 1) if pipe is not None else bufs.replies) if exchange == "packed"
-               else (rpipe.replies(rpipe.step - 1) if rpipe is not None else redb)).cpu().numpy().view(np.uint64)
-        srv.stage_batch(queries)
-        srv.run_batch()
-        forced_check = bool(np.array_equal(got, srv.fetch_batch()))
-        print("forced-dist check: replies through the collective path equal plain replies: %s" % forced_check, file=sys.stderr)
-    scan_bytes = srv.scan_bytes()
-    info = srv.scan_info()
-    batch_replies = srv.fetch_batch() if world == 1 and not use_dist else None
-    pipes.clear()
-
     # The line is assembled by emit(): at the very end normally, or by the watchdog below if a reference leg stalls
     emit_lock, emitted = threading.Lock(), [False]
 
@@ -527,7 +446,7 @@ def main():
         out.update(out_extra)
         if forced_check is not None:
             out["forced_dist_replies_equal_plain"] = forced_check
-        if use_dist and bufs is not None:
+        if use_dist and bufs is not None and exchange == "packed":
             out["exchange_bytes_received_per_query_per_gpu"] = bufs.exchange_bytes_per_query(world)
             out["rows_step"] = {"pipelined": pipe is not None,
                                 "phases_ms_serial": serial_phases,
@@ -620,15 +539,17 @@ def main():
         print(json.dumps(out), file=result_out)
         result_out.flush()
 
-    # The reference legs below (replicas, hybrid) run AFTER the headline is measured and must never cost it: an
-    # exception is caught per leg, and a leg that stalls (a collective that never completes on some fabric) is cut off
-    # by a watchdog -- rank 0 prints the line with what it has, every rank leaves.
+    # Everything that runs AFTER a complete headline measurement exists (the second candidate form of the rows step, the
+    # replicas and hybrid reference legs) must never cost it: an exception is caught per leg, and a part that STALLS (a
+    # collective that never completes on some fabric) is cut off by a watchdog armed as soon as the first complete
+    # measurement is in hand -- rank 0 prints the line with what it has, every rank leaves.
     watchdog = []
     aborting = threading.Event()
 
     deadline = [None]
 
-    cut_off_note = "reference legs exceeded their time budget and were cut off; the headline above is complete"
+    cut_off_note = ("what runs after the first complete headline measurement (second candidate form / reference legs) "
+                    "exceeded its time budget and was cut off; the headline above is complete")
 
     def past_deadline():
         return aborting.is_set() or (deadline[0] is not None and time.monotonic() > deadline[0])
@@ -640,8 +561,10 @@ def main():
             emit(cut_off_note)
             os._exit(0)
 
-    if use_dist and world > 1:
-        budget = float(os.environ.get("PIRGPU_EXTRAS_TIMEOUT_S", "240"))
+    def arm_watchdog():
+        if not (use_dist and world > 1) or watchdog:
+            return
+        budget = float(os.environ.get("PIRGPU_EXTRAS_TIMEOUT_S", "300"))
 
         def _abort():
             aborting.set()
@@ -654,6 +577,103 @@ def main():
         watchdog.append(threading.Timer(budget + (0.0 if rank == 0 else 5.0), _abort))   # rank 0 prints first
         watchdog[0].daemon = True
         watchdog[0].start()
+
+
+    # ---- (2) throughput: `batch` queries per step (the whole job's), `workers` in flight per GPU
+    srv.set_concurrency(workers)
+    srv.stage_batch(queries)
+    pipe = rpipe = None
+    serial_phases = None
+    forced_check = None
+    batch_replies = None
+    scan_bytes = srv.scan_bytes()
+    info = srv.scan_info()
+    if use_dist:
+        D.sync_zero_plaintexts(srv, dist, world, comm, torch, dev)   # the transparent-ciphertext decision is collective
+
+    def step_rows():
+        if not use_dist:
+            srv.run_batch()
+        elif pipe is not None:
+            pipe.submit()
+        elif rpipe is not None:
+            rpipe.submit()
+        elif active[0] == "packed":
+            D.run_batch_rows_packed(srv, bufs, dist, rank, world, comm)
+        else:
+            D.run_batch_query_parallel(srv, sv_all, redb, dist, rank, world, comm)
+
+    active = [exchange]     # the form being built / timed; `exchange` is the one the line reports
+
+    def measure(form):
+        """Builds what `form` of the step needs and times the contract's W + K steps with it."""
+        nonlocal bufs, sv_all, redb, pipe, rpipe, serial_phases
+        pipe = rpipe = None
+        active[0] = form
+        if use_dist and form == "packed":
+            bufs = D.PackedBuffers(srv, batch, rank, world, torch, dev)
+            # serial phase times from the synchronous form of the step (every phase followed by a host wait) ...
+            for _ in range(2):
+                D.run_batch_rows_packed(srv, bufs, dist, rank, world, comm)
+            acc = None
+            for _ in range(5):
+                ph = D.run_batch_rows_packed(srv, bufs, dist, rank, world, comm)
+                acc = ph if acc is None else {kk: acc[kk] + v for kk, v in ph.items()}
+            serial_phases = {kk: round(v / 5, 4) for kk, v in acc.items()}
+            # ... and the pipelined form for the timed steps: exchange of step s under the multiply of step s - 1 and
+            # the expansion of step s + 1, streams ordered by events, no host waits (PIRGPU_ROWS_PIPELINE=0: synchronous)
+            if os.environ.get("PIRGPU_ROWS_PIPELINE", "1") != "0":
+                pipe = D.RowsPipeline(srv, batch, rank, world, dist, torch, dev)
+                pipes.append(pipe)
+        elif use_dist and form == "replicated":
+            rpipe = D.RowsReplicatedPipeline(srv, batch, rank, world, dist, torch, dev)
+            pipes.append(rpipe)
+        elif use_dist:
+            sv_all = torch.empty((batch, pp.dim_sum, 2, k, N), dtype=torch.int64, device=dev)
+            redb = torch.empty((batch, reply_cts, 2, k, N), dtype=torch.int64, device=dev)
+        el = timed_steps(step_rows, barrier, args.steps, args.warmup, dist, use_dist, torch, dev)
+        if rpipe is not None:
+            rpipe.close()   # later plain batches write to the context's own reply buffer again
+        pipes.clear()
+        return el
+
+    if use_dist and autotune:
+        # Which form of the rows step is faster depends on what the links between THESE GPUs sustain (DESIGN.md section
+        # 7: replicated expansion costs every rank the whole expansion but moves only replies; the packed exchange
+        # partitions the expansion but ships ~14 MB of selectors per query to every rank) -- so it is measured, not
+        # assumed: BOTH forms run the contract's W + K steps (same barrier + max-over-ranks timing, every rank sees the
+        # same two numbers) and the faster one is the headline.  Replicated goes first (its only collective is a
+        # reduce-scatter); once it is in hand the watchdog guarantees a line even if the second form stalls.
+        exchange = "replicated"
+        el_r = measure("replicated")
+        elapsed, qps = el_r, args.steps * batch / el_r
+        arm_watchdog()
+        el_p = measure("packed")
+        tune = {"ms_per_step": {"replicated": round(el_r / args.steps * 1e3, 4), "packed": round(el_p / args.steps * 1e3, 4)},
+                "steps_each": args.steps,
+                "note": "both forms of the row-sharded step timed over the full W + K steps on this machine's links; "
+                        "the faster one is the headline"}
+        if el_p < el_r:
+            exchange = "packed"
+            elapsed, qps = el_p, args.steps * batch / el_p
+        else:
+            tune["packed_details"] = {"exchange_bytes_received_per_query_per_gpu": bufs.exchange_bytes_per_query(world),
+                                      "phases_ms_serial": serial_phases}
+            bufs = pipe = serial_phases = None
+        tune["chosen"] = exchange
+        out_extra["exchange_autotune"] = tune
+    else:
+        elapsed = measure(exchange)
+        qps = args.steps * batch / elapsed
+    if use_dist and world == 1:   # forced single-rank run: the reduced replies must equal the plain ones
+        got = ((pipe.replies(pipe.step - 1) if pipe is not None else bufs.replies) if exchange == "packed"
+               else (rpipe.replies(rpipe.step - 1) if rpipe is not None else redb)).cpu().numpy().view(np.uint64)
+        srv.stage_batch(queries)
+        srv.run_batch()
+        forced_check = bool(np.array_equal(got, srv.fetch_batch()))
+        print("forced-dist check: replies through the collective path equal plain replies: %s" % forced_check, file=sys.stderr)
+    batch_replies = srv.fetch_batch() if world == 1 and not use_dist else None
+    arm_watchdog()
 
     # =========================== replicas (reference point, multi-GPU only) ===========================
     # the two reference legs below must never cost the headline: a failure (the same on every rank: they run the same

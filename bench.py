@@ -25,7 +25,11 @@ step whatever the GPU count):
            selectors) and one all-to-all (each rank receives only its own rows' selectors); every rank scans
            its shard once per group of 8 queries and runs the upper level on its rows; one reduce-scatter
            sums the per-shard reply ciphertexts (rank r ends with the replies of the queries it expanded),
-           then x mod q_j.  `--exchange u64` all-gathers whole selection vectors instead (any d).
+           then x mod q_j ("packed").  A second form moves no selectors at all: every rank expands all queries
+           itself on its shard and only the reduce-scatter remains ("replicated").  With several ranks BOTH forms
+           are timed over the full W + K steps and the faster one is the headline (`exchange_autotune`,
+           `config.exchange`): which one wins depends on what the links of the machine sustain.
+           `--exchange u64` all-gathers whole selection vectors instead (any d).
   queries  (reference point, reported in the same JSON line as `replicas_reference` when --dist-mode both,
            the default): every GPU holds the whole database and serves batch/G of the same queries, no
            data-path collective.

@@ -429,6 +429,34 @@ void serve(pirgpu_ctx* ctx, Job* const* jobs, size_t n) {
   }
 }
 
+// serve() catches what a request can cause per request; anything that still escapes (out of memory while queueing, ...)
+// must not leave the combiner without a leader or cross the C ABI: every request of the call fails with Internal.
+void serve_guarded(pirgpu_ctx* ctx, Job* const* jobs, size_t n) noexcept {
+  const char* what = nullptr;
+  std::string msg;
+  int code = PIRGPU_INTERNAL;
+  try {
+    serve(ctx, jobs, n);
+    return;
+  } catch (const Err& e) {
+    code = e.code;
+    msg = e.msg;
+    what = msg.c_str();
+  } catch (const std::exception& e) {
+    msg = e.what();
+    what = msg.c_str();
+  } catch (...) {
+    what = "unexpected failure while serving";
+  }
+  for (size_t i = 0; i < n; ++i) {
+    try {
+      fail_job(*jobs[i], code, what);
+    } catch (...) {
+      jobs[i]->rc = code;
+    }
+  }
+}
+
 int finish(pirgpu_ctx* ctx, Job& job, uint8_t** response, size_t* response_len) {
   if (job.rc) {
     pirgpu_set_error(ctx, job.err.c_str());   // on the CALLING thread: pirgpu_last_error is per thread
@@ -495,7 +523,7 @@ int pirgpu_process_request(pirgpu_ctx* ctx, const uint8_t* request, size_t reque
         cb->pending.pop_front();
       }
       lk.unlock();
-      serve(ctx, batch.data(), batch.size());
+      serve_guarded(ctx, batch.data(), batch.size());
       lk.lock();
       for (Job* j : batch) j->done = true;
       cb->leader = false;
@@ -518,7 +546,7 @@ int pirgpu_process_requests(pirgpu_ctx* ctx, uint32_t n, const uint8_t* const* r
     ptrs[i] = &jobs[i];
     if (!requests[i] && request_lens[i]) fail_job(jobs[i], PIRGPU_INVALID_ARGUMENT, "null request");
   }
-  serve(ctx, ptrs.data(), n);
+  serve_guarded(ctx, ptrs.data(), n);
   int worst = PIRGPU_OK;
   t_request_errors.assign(n, std::string());
   for (uint32_t i = 0; i < n; ++i) {

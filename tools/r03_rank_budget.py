@@ -49,6 +49,11 @@ for G in ([int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else (1,
     srv.sync(); t0 = time.perf_counter()
     for _ in range(nn): EM()
     srv.sync(); res["E_then_M_queued_together_ms"] = (time.perf_counter() - t0) / nn * 1e3
+    # replicated-expansion form of the step (RowsReplicatedPipeline): the plain batch pipeline for ALL queries on the shard
+    for _ in range(2): srv.run_batch()
+    srv.sync(); t0 = time.perf_counter()
+    for _ in range(nn): srv.run_batch()
+    srv.sync(); res["replicated_form_step_ms"] = (time.perf_counter() - t0) / nn * 1e3
     res["recv_MB_per_step"] = bufs.exchange_bytes_per_query(G) * batch / 1e6
     res["packed_group_MB"] = bufs.sel_bytes / 1e6
     res["reduce_scatter_MB"] = (G - 1) / G * batch * db.reply_ct_count() * 2 * srv.k * srv.N * 8 / 1e6

@@ -422,6 +422,11 @@ def main():
                          else ("scan_mq_kernel<4 rows/wave, 1 query>" if args.dims > 1
                                else "scan_kernel + reduce_splits (column split)"),
                          "kernel_ms": scan_ms, "algorithmic_bytes": scan_bytes,
+                         # stored bytes per database residue: L signed base-256 digits, the top one a nibble when the
+                         # moduli allow (36-bit residues: 4.5 instead of 5 -- round 3: 10 % fewer bytes per pass, the
+                         # single-query pass 5-10 % shorter on the same box)
+                         **({"bytes_per_residue": info["digits"] - (0.5 if info.get("top_digit_nibble") else 0.0)}
+                            if info["single_query_mfma"] else {}),
                          "algorithmic_bytes_definition": "packed operand-layout bytes of this GPU's shard = what one "
                                                          "launch must read (DESIGN.md section 5)",
                          "launches_averaged": timings["runs"],

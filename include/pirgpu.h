@@ -310,8 +310,9 @@ uint64_t pirgpu_scan_bytes(const pirgpu_ctx* ctx);
 /* How this context scans its database.  info[0] = 1 if the digit-sliced int8-MFMA scan is active
  * (0: 64-bit multiply-accumulate kernels), info[1] = digits per residue, info[2] = column chunks per
  * pass, info[3] = k-steps (64 columns) per chunk, info[4] = queries per database pass in batch mode,
- * info[5] = rows, info[6] = columns of the scanned matrix, info[7] = 1 if single queries use the MFMA
- * scan as well (matrices wider than one column chunk scan single queries with the 64-bit kernels). */
+ * info[5] = rows, info[6] = columns of the scanned matrix, info[7] = flags: bit 0 = single queries use the MFMA
+ * scan as well (matrices wider than one column chunk may scan single queries with the 64-bit kernels), bit 1 = the top
+ * digit of database and selectors is stored as a nibble (L - 1/2 bytes per residue instead of L). */
 int pirgpu_scan_info(pirgpu_ctx* ctx, uint32_t info[8]);
 /* Options by name (case-insensitive), e.g. "scan_mfma" (0 keeps the 64-bit multiply-accumulate scan for d >= 2),
  * "scan_mfma_wide" (0 / 1 forces the 8-wave / 4-wave scan kernel), "lanes", "upper_blocks", "fuse_last", "last_ntt",

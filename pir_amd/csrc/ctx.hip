@@ -505,7 +505,9 @@ void ensure_workspace(pirgpu_ctx* c) {
     //   PIRGPU_SCAN_MFMA_WIDE  0 / 1 forces the 8-wave / 4-wave (one wave per SIMD, up to 7 k-steps) scan kernel
     bool wide_given = false;
     const int64_t wide = option(c, "SCAN_MFMA_WIDE", 0, &wide_given);
-    c->mg = mfma_geometry(c->hp, c->scan_rows, c->scan_cols, wide_given ? (int)(wide != 0) : -1);
+    //   PIRGPU_SCAN_MFMA_TOP4=0 keeps the top digit of database and selectors as a full byte (scan_mfma.hip TOP4)
+    c->mg = mfma_geometry(c->hp, c->scan_rows, c->scan_cols, wide_given ? (int)(wide != 0) : -1,
+                          env_u32("PIRGPU_SCAN_MFMA_TOP4", 1) != 0);
     c->mfma_on = env_u32("PIRGPU_SCAN_MFMA", 1) != 0 && d >= 2 && c->mg.L != 0 && c->scan_rows >= 8 && shard_pts > 0;
     c->mfma_nq = std::max<uint32_t>(1, std::min<uint32_t>(env_u32("PIRGPU_SCAN_MFMA_NQ", kMaxMfmaQueries),
                                                           kMaxMfmaQueries));
@@ -1074,7 +1076,7 @@ static const struct { const char* name; bool early; } kOptions[] = {
     {"SCAN_MQ_SINGLE_LIMB", true}, {"SCAN_ROWS", true}, {"SCAN_BLOCK", true}, {"SCAN_NSPLIT", true},
     {"FUSE_LAST", true}, {"FUSE_MAC_COMBINE", true}, {"LAST_NTT", true}, {"SEL_F64", true}, {"TREE40", true},
     {"FUSE_MAC_NODES", true}, {"SPLIT_UPPER", true}, {"SPLIT_UPPER_MB", true}, {"PACK40", true},
-    {"SCAN_MFMA", true}, {"SCAN_MFMA_WIDE", true}, {"SCAN_MFMA_NQ", true}, {"SCAN_MFMA_SINGLE", true}, {"LANES", true},
+    {"SCAN_MFMA", true}, {"SCAN_MFMA_WIDE", true}, {"SCAN_MFMA_TOP4", true}, {"SCAN_MFMA_NQ", true}, {"SCAN_MFMA_SINGLE", true}, {"LANES", true},
 };
 
 int pirgpu_set_option(pirgpu_ctx* c, const char* name, int64_t value) {
@@ -1163,7 +1165,7 @@ int pirgpu_scan_info(pirgpu_ctx* c, uint32_t info[8]) {
     info[4] = c->mfma_on ? c->mfma_nq : (mq_usable(c) ? std::min<uint32_t>(c->mq_nq, kMaxScanQueries) : 1);
     info[5] = c->scan_rows;
     info[6] = c->scan_cols;
-    info[7] = c->mfma_on && c->mfma_single ? 1 : 0;
+    info[7] = (c->mfma_on && c->mfma_single ? 1u : 0u) | (c->mfma_on && c->mg.top4 ? 2u : 0u);
     return PIRGPU_OK;
   });
 }

@@ -124,11 +124,13 @@ struct MfmaGeom {
   uint32_t GC;       // column groups per chunk = ceil(KG / nchunks) <= 4 KS
   uint32_t nchunks;  // column chunks (grid.y); > 1 leaves partial sums to reduce_splits_kernel
   uint32_t NW;       // waves (= slots) per workgroup: 8 (two waves per SIMD, KS <= 3) or 4 (one per SIMD, KS <= 7)
+  uint32_t top4;     // 1: the top digit of both operands is stored as nibbles (residues < 2^(8 (L - 1) + 4))
+  uint32_t tile_bytes;  // bytes of the L digit tiles of one (row tile, column group): L * 256, or (L - 1) * 256 + 128
   size_t db_bytes, sel_bytes;
 };
 
 // wide_override: -1 = choose by width, 0 / 1 = force the 8-wave / 4-wave kernel
-MfmaGeom mfma_geometry(const DevParams& hp, uint32_t rows, uint32_t cols, int wide_override = -1);
+MfmaGeom mfma_geometry(const DevParams& hp, uint32_t rows, uint32_t cols, int wide_override = -1, bool allow_top4 = true);
 hipError_t launch_db_pack(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint64_t* db, uint8_t* dbp,
                           uint32_t rows, uint32_t cols, uint32_t kN);
 hipError_t launch_db_unpack(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp, uint64_t* out,

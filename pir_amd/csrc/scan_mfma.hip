@@ -21,6 +21,8 @@
 //   database   [j][chunk][rt = r / 16][kg within the chunk][a][r % 16][c % 16]   (kg = c / 16; a chunk = the 4 * KS
 //              column groups one launch row keeps selectors for; one chunk -> [j][rt][kg][a][..] as before)
 //   selectors  [j][kg][b][x = 2 * query + comp][c % 16]
+//   TOP4 (moduli below 2^(8 (L-1) + 4): 36 bits at L = 5, 44 at L = 6): the top digit's 16 x 16 tile is 128 bytes of
+//   nibbles instead of 256 bytes (pack_top4 / expand_top4 below) -- L - 1/2 bytes per residue in both operands.
 // A workgroup is 8 waves = 8 consecutive slots j (one per wave); results are staged through LDS so
 // that each (row, x) is written as one 64-byte run of 8 slots.
 #include <hip/hip_runtime.h>
@@ -40,17 +42,57 @@ typedef unsigned __int128 u128;
 // Byte offset of tile (slot j, row tile rt, column group kg, digit a) in the packed database.  Column chunks are
 // the outer dimension inside a slot, so the part of a slot's slab one workgroup row streams is contiguous
 // (a matrix wider than one chunk used to be read as 14-18 KB pieces with gaps: 3.8-4.2 TB/s instead of ~5.8).
-__host__ __device__ __forceinline__ size_t db_tile_offset(uint32_t j, uint32_t rt, uint32_t kg, uint32_t a, uint32_t L,
+// TB = bytes of the L digit tiles of one (row tile, column group): L * 256, or (L - 1) * 256 + 128 when the top digit is
+// stored as nibbles (tile_bytes below); digit a starts a * 256 bytes into the block.
+__host__ __device__ __forceinline__ size_t db_tile_offset(uint32_t j, uint32_t rt, uint32_t kg, uint32_t a, uint32_t TB,
                                                           uint32_t RT, uint32_t KG, uint32_t GC) {
   const uint32_t ch = kg / GC, kg0 = ch * GC;
   const uint32_t gc = KG - kg0 < GC ? KG - kg0 : GC;   // groups of this chunk
-  return (((size_t)j * RT * KG + (size_t)RT * kg0 + (size_t)rt * gc + (kg - kg0)) * L + a) * 256;
+  return ((size_t)j * RT * KG + (size_t)RT * kg0 + (size_t)rt * gc + (kg - kg0)) * TB + (size_t)a * 256;
 }
 
-// centred residue -> L balanced base-256 digits
+// Top digit as a NIBBLE (TOP4).  A residue below 2^(8 (L-1) + 4) -- 36 bits at L = 5, 44 at L = 6, 52 at L = 7: every
+// BASELINE chain -- needs only 4 bits of its top digit if it is centred asymmetrically: v = x for x <= vmax, else x - q,
+// with vmax = 7 * 256^(L-1) + 127 (256^(L-1) - 1) / 255 the largest value whose balanced low digits leave a top digit of
+// 7; x - q then never goes below the value whose top digit is -8 (the two ranges together span exactly 2^(8 (L-1) + 4)).
+// The top digit tile of 16 x 16 entries is stored in 128 bytes, 8 per row: byte i of the first word holds columns i
+// (low nibble) and i + 4, byte i of the second word columns 8 + i and 12 + i, so that a row unpacks to its 16 signed
+// bytes with shifts and masks only (expand_top4).  Database and packed selectors shrink from L to L - 1/2 bytes per
+// residue: 10 % fewer bytes to stream per pass -- and to send to every GPU of a row-sharded job -- at L = 5.
 template <int L>
+__host__ __device__ __forceinline__ constexpr int64_t top4_vmax() {
+  int64_t p = 1;
+  for (int a = 0; a < L - 1; ++a) p *= 256;
+  return 7 * p + 127 * ((p - 1) / 255);
+}
+__host__ __device__ __forceinline__ constexpr uint32_t tile_bytes(uint32_t L, bool top4) {
+  return top4 ? (L - 1) * 256 + 128 : L * 256;
+}
+typedef int v2i __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t sx4(uint32_t v) {   // four nibbles (one per byte, 0..15) -> four signed bytes
+  return v | (((v >> 3) & 0x01010101u) * 0xF0u);
+}
+__device__ __forceinline__ v4i expand_top4(v2i w) {
+  const uint32_t w0 = (uint32_t)w[0], w1 = (uint32_t)w[1];
+  return v4i{(int)sx4(w0 & 0x0F0F0F0Fu), (int)sx4((w0 >> 4) & 0x0F0F0F0Fu), (int)sx4(w1 & 0x0F0F0F0Fu),
+              (int)sx4((w1 >> 4) & 0x0F0F0F0Fu)};
+}
+// 16 signed bytes of a row (each in [-8, 7]) -> the 8 bytes above
+__device__ __forceinline__ v2i pack_top4(const uint8_t (&o)[16]) {
+  uint32_t w[2] = {0, 0};
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      w[h] |= (uint32_t)((o[8 * h + i] & 0xF) | ((o[8 * h + 4 + i] & 0xF) << 4)) << (8 * i);
+  return v2i{(int)w[0], (int)w[1]};
+}
+
+// centred residue -> L balanced base-256 digits (TOP4: centred so that the top digit lies in [-8, 7])
+template <int L, bool TOP4 = false>
 __device__ __forceinline__ void to_digits(uint64_t x, uint64_t q, int8_t (&d)[L]) {
-  int64_t v = x > (q >> 1) ? (int64_t)x - (int64_t)q : (int64_t)x;
+  int64_t v = TOP4 ? ((int64_t)x > top4_vmax<L>() ? (int64_t)x - (int64_t)q : (int64_t)x)
+                   : (x > (q >> 1) ? (int64_t)x - (int64_t)q : (int64_t)x);
 #pragma unroll
   for (int a = 0; a < L; ++a) {
     d[a] = (int8_t)(v & 0xFF);
@@ -59,10 +101,11 @@ __device__ __forceinline__ void to_digits(uint64_t x, uint64_t q, int8_t (&d)[L]
 }
 
 // database u64 [rows][cols][kN] (zero-padded rows) -> packed.  block = 16 rows x 16 slots; grid = (kN/16, RT, KG)
-template <int L>
+template <int L, bool TOP4>
 __global__ void __launch_bounds__(256)
 db_pack_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ db, uint8_t* __restrict__ dbp,
                uint32_t rows, uint32_t cols, uint32_t kN, uint32_t RT, uint32_t KG, uint32_t GC) {
+  constexpr uint32_t TB = tile_bytes(L, TOP4);
   const uint32_t j = blockIdx.x * 16 + (threadIdx.x & 15);
   const uint32_t r16 = threadIdx.x >> 4;
   const uint32_t rt = blockIdx.y, kg = blockIdx.z;
@@ -75,23 +118,28 @@ db_pack_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ db,
     uint64_t x = 0;
     if (r < rows && c < cols) x = db[((size_t)r * cols + c) * kN + j];
     int8_t d[L];
-    to_digits<L>(x, q, d);
+    to_digits<L, TOP4>(x, q, d);
 #pragma unroll
     for (int a = 0; a < L; ++a) o[a][t] = (uint8_t)d[a];
   }
 #pragma unroll
   for (int a = 0; a < L; ++a) {
-    v4i v;
-    __builtin_memcpy(&v, o[a], 16);
-    *reinterpret_cast<v4i*>(dbp + db_tile_offset(j, rt, kg, a, L, RT, KG, GC) + r16 * 16) = v;
+    if (TOP4 && a == L - 1) {
+      *reinterpret_cast<v2i*>(dbp + db_tile_offset(j, rt, kg, a, TB, RT, KG, GC) + r16 * 8) = pack_top4(o[a]);
+    } else {
+      v4i v;
+      __builtin_memcpy(&v, o[a], 16);
+      *reinterpret_cast<v4i*>(dbp + db_tile_offset(j, rt, kg, a, TB, RT, KG, GC) + r16 * 16) = v;
+    }
   }
 }
 
 // selectors (per query u64 [cols][2][kN], NTT form) -> packed.  block = 16 x * 16 slots; grid = (kN/16, KG)
-template <int L>
+template <int L, bool TOP4>
 __global__ void __launch_bounds__(256)
 sel_pack_kernel(const DevParams* __restrict__ P, MfmaPtrs sv, uint32_t nq, uint8_t* __restrict__ selp, uint32_t cols,
                 uint32_t kN, uint32_t KG, int sel_f64) {
+  constexpr uint32_t TB = tile_bytes(L, TOP4);
   const uint32_t j = blockIdx.x * 16 + (threadIdx.x & 15);
   const uint32_t x = threadIdx.x >> 4;
   const uint32_t kg = blockIdx.y;
@@ -107,35 +155,54 @@ sel_pack_kernel(const DevParams* __restrict__ P, MfmaPtrs sv, uint32_t nq, uint8
     if (c < cols) v = src[((size_t)c * 2 + comp) * kN + j];
     if (sel_f64) v = f64_to_u64(__longlong_as_double((long long)v));   // lane-internal selectors: exact doubles
     int8_t d[L];
-    to_digits<L>(v, q, d);
+    to_digits<L, TOP4>(v, q, d);
 #pragma unroll
     for (int b = 0; b < L; ++b) o[b][t] = (uint8_t)d[b];
   }
+  uint8_t* blk = selp + ((size_t)j * KG + kg) * TB;
 #pragma unroll
   for (int b = 0; b < L; ++b) {
-    v4i v;
-    __builtin_memcpy(&v, o[b], 16);
-    *reinterpret_cast<v4i*>(selp + (((size_t)j * KG + kg) * L + b) * 256 + x * 16) = v;
+    if (TOP4 && b == L - 1) {
+      *reinterpret_cast<v2i*>(blk + b * 256 + x * 8) = pack_top4(o[b]);
+    } else {
+      v4i v;
+      __builtin_memcpy(&v, o[b], 16);
+      *reinterpret_cast<v4i*>(blk + b * 256 + x * 16) = v;
+    }
   }
 }
 
 // one plaintext (row r, column c) back from the operand layout: out[j] = residue in [0, q_j), device slot order
-template <int L>
+template <int L, bool TOP4>
 __global__ void __launch_bounds__(256)
 db_unpack_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ dbp, uint64_t* __restrict__ out,
                  uint32_t r, uint32_t c, uint32_t kN, uint32_t RT, uint32_t KG, uint32_t GC) {
+  constexpr uint32_t TB = tile_bytes(L, TOP4);
   const uint32_t j = blockIdx.x * 256 + threadIdx.x;
   if (j >= kN) return;
   const uint64_t q = P->mod[j >> P->logN].q;
-  const uint8_t* p = dbp + db_tile_offset(j, r >> 4, c >> 4, 0, L, RT, KG, GC) + (r & 15) * 16 + (c & 15);
+  const uint8_t* blk = dbp + db_tile_offset(j, r >> 4, c >> 4, 0, TB, RT, KG, GC);
+  const uint8_t* p = blk + (r & 15) * 16 + (c & 15);
   int64_t v = 0;
 #pragma unroll
-  for (int a = L - 1; a >= 0; --a) v = v * 256 + (int8_t)p[(size_t)a * 256];
+  for (int a = L - 1; a >= 0; --a) {
+    if (TOP4 && a == L - 1) {
+      const uint32_t cc = c & 15;
+      const uint8_t byte = blk[(size_t)a * 256 + (r & 15) * 8 + (cc >> 3) * 4 + (cc & 3)];
+      const int nib = (cc & 4) ? (byte >> 4) : (byte & 0xF);
+      v = nib >= 8 ? nib - 16 : nib;
+    } else {
+      v = v * 256 + (int8_t)p[(size_t)a * 256];
+    }
+  }
   out[j] = v < 0 ? (uint64_t)(v + (int64_t)q) : (uint64_t)v;
 }
 
 __device__ __forceinline__ v4i load_tile(const uint8_t* p) {
   return __builtin_nontemporal_load(reinterpret_cast<const v4i*>(p));
+}
+__device__ __forceinline__ v2i load_tile8(const uint8_t* p) {
+  return __builtin_nontemporal_load(reinterpret_cast<const v2i*>(p));
 }
 
 // Workgroups per column chunk: first[c] .. first[c+1] run chunk c (equal shares of equal chunks).
@@ -154,11 +221,15 @@ struct ChunkPlan {
 // Chunk ch covers column groups [ch * GC, (ch + 1) * GC) with GC = ceil(KG / nchunks) <= 4 KS -- equal chunks, so
 // that equal shares of the chip finish together (7 k-steps split 3/3/1 left a third of the CUs idle for two thirds
 // of the pass) -- and writes to out.p[q] + ch * chunk_stride (partial sums when nchunks > 1).
-template <int L, int KS, int NW>
+// TOP4: the top digit of both operands is stored as nibbles (above): its database tiles stay packed in two registers per
+// lane until their k-step is due; the selectors' are unpacked once per slot block.
+template <int L, int KS, int NW, bool TOP4>
 __global__ void __launch_bounds__(NW * 64)
 scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ dbp, const uint8_t* __restrict__ selp,
                  MfmaPtrs out, uint32_t nq, uint32_t rows, uint32_t RT, uint32_t KG, uint32_t kN,
                  uint64_t chunk_stride, ChunkPlan plan, uint32_t GC) {
+  constexpr uint32_t TB = tile_bytes(L, TOP4);
+  constexpr int LF = TOP4 ? L - 1 : L;   // digits stored as full bytes
   constexpr int NS = 2 * L - 1;        // digit diagonals
   constexpr int NG = (NS + 4) / 5;     // groups of five diagonals (40 bits)
   // results of one row tile, [row][x][slot]: a (row, x) run is padded to 9 words so that the 16 lanes of a row (x = 0..15,
@@ -174,22 +245,34 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
   const uint32_t kg0 = ch * GC;                                   // GC <= 4 KS column groups per chunk
   const uint32_t gc = KG - kg0 < GC ? KG - kg0 : GC;              // column groups of this chunk
   const uint32_t nx = 2 * nq;
-  const size_t slab = (size_t)RT * KG * L * 256;                  // database bytes of one slot
-  const size_t chunk_base = (size_t)RT * kg0 * L * 256 + i16 * 16;  // this chunk inside a slot (+ the lane's 16 bytes)
-  const size_t rt_stride = (size_t)gc * L * 256;
+  const size_t slab = (size_t)RT * KG * TB;                       // database bytes of one slot
+  const size_t chunk_base = (size_t)RT * kg0 * TB;                // this chunk inside a slot
+  const size_t rt_stride = (size_t)gc * TB;
+  const uint32_t lane16 = i16 * 16, lane8 = i16 * 8;              // the lane's bytes inside a full / a nibble tile
 
-  v4i B[KS][L], A[KS][L];
+  v4i B[KS][L], A[KS][LF];
+  v2i A4[KS];                           // TOP4: the top digit's tiles, packed
   auto load_B = [&](uint32_t j) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const uint32_t gl = ks * 4 + g, kg = kg0 + gl;
+      const uint8_t* blk = selp + ((size_t)j * KG + kg) * TB;
 #pragma unroll
       for (int b = 0; b < L; ++b) {
         B[ks][b] = v4i{0, 0, 0, 0};   // columns beyond the group's queries stay zero and are neither packed nor read
-        if (gl < gc && (uint32_t)i16 < nx)
-          B[ks][b] = *reinterpret_cast<const v4i*>(selp + (((size_t)j * KG + kg) * L + b) * 256 + i16 * 16);
+        if (gl < gc && (uint32_t)i16 < nx) {
+          if (TOP4 && b == L - 1) B[ks][b] = expand_top4(*reinterpret_cast<const v2i*>(blk + b * 256 + lane8));
+          else B[ks][b] = *reinterpret_cast<const v4i*>(blk + b * 256 + lane16);
+        }
       }
     }
+  };
+  // the L tiles of column group gl (inside the chunk) of one row tile, from `base` = that row tile's first byte
+  auto load_A = [&](int ks, const uint8_t* base, uint32_t gl) {
+    const uint8_t* blk = base + (size_t)gl * TB;
+#pragma unroll
+    for (int a = 0; a < LF; ++a) A[ks][a] = load_tile(blk + a * 256 + lane16);
+    if constexpr (TOP4) A4[ks] = load_tile8(blk + (L - 1) * 256 + lane8);
   };
 
   uint32_t blk = wg_in_chunk;
@@ -201,10 +284,9 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
     for (int ks = 0; ks < KS; ++ks) {
       const uint32_t gl = ks * 4 + g;   // column group inside the chunk
 #pragma unroll
-      for (int a = 0; a < L; ++a) {
-        A[ks][a] = v4i{0, 0, 0, 0};
-        if (gl < gc) A[ks][a] = load_tile(abase + ((size_t)gl * L + a) * 256);
-      }
+      for (int a = 0; a < LF; ++a) A[ks][a] = v4i{0, 0, 0, 0};
+      A4[ks] = v2i{0, 0};
+      if (gl < gc) load_A(ks, abase, gl);
     }
   }
 
@@ -231,19 +313,21 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
       const bool refill = !last || has_next;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
+        [[maybe_unused]] v4i Atop;
+        if constexpr (TOP4) Atop = expand_top4(A4[ks]);
         // the L*L digit products, ordered so that consecutive MFMAs accumulate into different diagonals
 #pragma unroll
         for (int off = 0; off < L; ++off)
 #pragma unroll
           for (int a = 0; a < L; ++a) {
             const int b = (a + off) % L;
-            T[a + b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks][a], B[ks][b], T[a + b], 0, 0, 0);
+            if (TOP4 && a == L - 1)
+              T[a + b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Atop, B[ks][b], T[a + b], 0, 0, 0);
+            else
+              T[a + b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks][a < LF ? a : 0], B[ks][b], T[a + b], 0, 0, 0);
           }
         const uint32_t gl = ks * 4 + g;
-        if (refill && gl < gc) {
-#pragma unroll
-          for (int a = 0; a < L; ++a) A[ks][a] = load_tile(next_tile + ((size_t)gl * L + a) * 256);
-        }
+        if (refill && gl < gc) load_A(ks, next_tile, gl);
       }
       if (last && has_next) load_B(nblk * NW + w);   // all MFMAs of this block are issued: B is free
       // lane (g, i16) holds rows rt*16 + g*4 + i (i < 4) of column x = i16:  value = sum_s T[s] 2^(8 s)
@@ -287,7 +371,7 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
 
 // ------------------------------------------------------------------ host side
 
-MfmaGeom mfma_geometry(const DevParams& hp, uint32_t rows, uint32_t cols, int wide_override) {
+MfmaGeom mfma_geometry(const DevParams& hp, uint32_t rows, uint32_t cols, int wide_override, bool allow_top4) {
   MfmaGeom gm{};
   uint32_t bits = 0;
   for (uint32_t i = 0; i < hp.k; ++i) bits = std::max<uint32_t>(bits, 64 - (uint32_t)__builtin_clzll(hp.mod[i].q));
@@ -315,9 +399,14 @@ MfmaGeom mfma_geometry(const DevParams& hp, uint32_t rows, uint32_t cols, int wi
   gm.GC = (gm.KG + gm.nchunks - 1) / gm.nchunks;   // equal chunks (<= 4 KS groups each)
   gm.KS = (gm.GC + 3) / 4;
   if (wide && gm.KS < 3) gm.NW = 8;                // the wide kernel is instantiated for 3..7 k-steps
+  // top digit as a nibble when every residue is below 2^(8 (L - 1) + 4) (36 / 44 bits at L = 5 / 6: cfg 2, 3 and 4).
+  // Not at L = 7 (cfg 5, 49 bits < 2^52 would allow it): the 4-wave kernel with 6 k-steps is out of registers there and
+  // the unpacking temporaries spill (scan 9.4 against 8.6 ms) -- the L = 7 variants are not even instantiated.
+  gm.top4 = allow_top4 && gm.L <= 6 && bits <= 8 * (gm.L - 1) + 4 ? 1 : 0;
+  gm.tile_bytes = tile_bytes(gm.L, gm.top4 != 0);
   const size_t kN = (size_t)hp.k * hp.N;
-  gm.db_bytes = kN * gm.RT * gm.KG * gm.L * 256;
-  gm.sel_bytes = kN * gm.KG * gm.L * 256;
+  gm.db_bytes = kN * gm.RT * gm.KG * gm.tile_bytes;
+  gm.sel_bytes = kN * gm.KG * gm.tile_bytes;
   return gm;
 }
 
@@ -325,9 +414,15 @@ hipError_t launch_db_pack(hipStream_t st, const DevParams* P, const MfmaGeom& gm
                           uint32_t rows, uint32_t cols, uint32_t kN) {
   const dim3 grid(kN / 16, gm.RT, gm.KG);
   switch (gm.L) {
-    case 5: hipLaunchKernelGGL(db_pack_kernel<5>, grid, dim3(256), 0, st, P, db, dbp, rows, cols, kN, gm.RT, gm.KG, gm.GC); break;
-    case 6: hipLaunchKernelGGL(db_pack_kernel<6>, grid, dim3(256), 0, st, P, db, dbp, rows, cols, kN, gm.RT, gm.KG, gm.GC); break;
-    case 7: hipLaunchKernelGGL(db_pack_kernel<7>, grid, dim3(256), 0, st, P, db, dbp, rows, cols, kN, gm.RT, gm.KG, gm.GC); break;
+    case 5:
+      if (gm.top4) hipLaunchKernelGGL((db_pack_kernel<5, true>), grid, dim3(256), 0, st, P, db, dbp, rows, cols, kN, gm.RT, gm.KG, gm.GC);
+      else hipLaunchKernelGGL((db_pack_kernel<5, false>), grid, dim3(256), 0, st, P, db, dbp, rows, cols, kN, gm.RT, gm.KG, gm.GC);
+      break;
+    case 6:
+      if (gm.top4) hipLaunchKernelGGL((db_pack_kernel<6, true>), grid, dim3(256), 0, st, P, db, dbp, rows, cols, kN, gm.RT, gm.KG, gm.GC);
+      else hipLaunchKernelGGL((db_pack_kernel<6, false>), grid, dim3(256), 0, st, P, db, dbp, rows, cols, kN, gm.RT, gm.KG, gm.GC);
+      break;
+    case 7: hipLaunchKernelGGL((db_pack_kernel<7, false>), grid, dim3(256), 0, st, P, db, dbp, rows, cols, kN, gm.RT, gm.KG, gm.GC); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -337,9 +432,15 @@ hipError_t launch_db_unpack(hipStream_t st, const DevParams* P, const MfmaGeom& 
                             uint32_t row, uint32_t col, uint32_t kN) {
   const dim3 grid((kN + 255) / 256);
   switch (gm.L) {
-    case 5: hipLaunchKernelGGL(db_unpack_kernel<5>, grid, dim3(256), 0, st, P, dbp, out, row, col, kN, gm.RT, gm.KG, gm.GC); break;
-    case 6: hipLaunchKernelGGL(db_unpack_kernel<6>, grid, dim3(256), 0, st, P, dbp, out, row, col, kN, gm.RT, gm.KG, gm.GC); break;
-    case 7: hipLaunchKernelGGL(db_unpack_kernel<7>, grid, dim3(256), 0, st, P, dbp, out, row, col, kN, gm.RT, gm.KG, gm.GC); break;
+    case 5:
+      if (gm.top4) hipLaunchKernelGGL((db_unpack_kernel<5, true>), grid, dim3(256), 0, st, P, dbp, out, row, col, kN, gm.RT, gm.KG, gm.GC);
+      else hipLaunchKernelGGL((db_unpack_kernel<5, false>), grid, dim3(256), 0, st, P, dbp, out, row, col, kN, gm.RT, gm.KG, gm.GC);
+      break;
+    case 6:
+      if (gm.top4) hipLaunchKernelGGL((db_unpack_kernel<6, true>), grid, dim3(256), 0, st, P, dbp, out, row, col, kN, gm.RT, gm.KG, gm.GC);
+      else hipLaunchKernelGGL((db_unpack_kernel<6, false>), grid, dim3(256), 0, st, P, dbp, out, row, col, kN, gm.RT, gm.KG, gm.GC);
+      break;
+    case 7: hipLaunchKernelGGL((db_unpack_kernel<7, false>), grid, dim3(256), 0, st, P, dbp, out, row, col, kN, gm.RT, gm.KG, gm.GC); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -350,15 +451,21 @@ hipError_t launch_sel_pack(hipStream_t st, const DevParams* P, const MfmaGeom& g
   const int f = sel_f64 ? 1 : 0;
   const dim3 grid(kN / 16, gm.KG);
   switch (gm.L) {
-    case 5: hipLaunchKernelGGL(sel_pack_kernel<5>, grid, dim3(256), 0, st, P, sv, nq, selp, cols, kN, gm.KG, f); break;
-    case 6: hipLaunchKernelGGL(sel_pack_kernel<6>, grid, dim3(256), 0, st, P, sv, nq, selp, cols, kN, gm.KG, f); break;
-    case 7: hipLaunchKernelGGL(sel_pack_kernel<7>, grid, dim3(256), 0, st, P, sv, nq, selp, cols, kN, gm.KG, f); break;
+    case 5:
+      if (gm.top4) hipLaunchKernelGGL((sel_pack_kernel<5, true>), grid, dim3(256), 0, st, P, sv, nq, selp, cols, kN, gm.KG, f);
+      else hipLaunchKernelGGL((sel_pack_kernel<5, false>), grid, dim3(256), 0, st, P, sv, nq, selp, cols, kN, gm.KG, f);
+      break;
+    case 6:
+      if (gm.top4) hipLaunchKernelGGL((sel_pack_kernel<6, true>), grid, dim3(256), 0, st, P, sv, nq, selp, cols, kN, gm.KG, f);
+      else hipLaunchKernelGGL((sel_pack_kernel<6, false>), grid, dim3(256), 0, st, P, sv, nq, selp, cols, kN, gm.KG, f);
+      break;
+    case 7: hipLaunchKernelGGL((sel_pack_kernel<7, false>), grid, dim3(256), 0, st, P, sv, nq, selp, cols, kN, gm.KG, f); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
-template <int L, int KS, int NW>
+template <int L, int KS, int NW, bool TOP4>
 static void launch_scan_mfma_variant(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp,
                                      const uint8_t* selp, const MfmaPtrs& out, uint32_t nq, uint32_t rows, uint32_t kN,
                                      uint64_t chunk_stride, uint32_t wgs_req) {
@@ -379,7 +486,7 @@ static void launch_scan_mfma_variant(hipStream_t st, const DevParams* P, const M
   plan.nchunks = gm.nchunks;
   const uint32_t share = std::min<uint32_t>(kN / NW, std::max<uint32_t>(1, wgs / std::min<uint32_t>(gm.nchunks, wgs)));
   for (uint32_t c = 0; c <= gm.nchunks; ++c) plan.first[c] = c * share;   // share >= 1: no chunk without workgroups
-  hipLaunchKernelGGL((scan_mfma_kernel<L, KS, NW>), dim3(gm.nchunks * share), dim3(NW * 64), 0, st, P, dbp, selp, out, nq,
+  hipLaunchKernelGGL((scan_mfma_kernel<L, KS, NW, TOP4>), dim3(gm.nchunks * share), dim3(NW * 64), 0, st, P, dbp, selp, out, nq,
                      rows, gm.RT, gm.KG, kN, chunk_stride, plan, gm.GC);
 }
 
@@ -387,9 +494,16 @@ hipError_t launch_scan_mfma(hipStream_t st, const DevParams* P, const MfmaGeom& 
                             const uint8_t* selp, const MfmaPtrs& out, uint32_t nq, uint32_t rows, uint32_t kN,
                             uint64_t chunk_stride, uint32_t wgs) {
 #define PIRGPU_MFMA_CASE(L_, KS_, NW_)                                                                    \
-  if (gm.L == L_ && gm.KS == KS_ && gm.NW == NW_) {                                                       \
-    launch_scan_mfma_variant<L_, KS_, NW_>(st, P, gm, dbp, selp, out, nq, rows, kN, chunk_stride, wgs);   \
-    return hipGetLastError();                                                                             \
+  if (gm.L == L_ && gm.KS == KS_ && gm.NW == NW_) {                                                                 \
+    if constexpr (L_ <= 6) {                                                                                         \
+      if (gm.top4) {                                                                                                 \
+        launch_scan_mfma_variant<L_, KS_, NW_, true>(st, P, gm, dbp, selp, out, nq, rows, kN, chunk_stride, wgs);    \
+        return hipGetLastError();                                                                                    \
+      }                                                                                                              \
+    }                                                                                                                \
+    if (gm.top4) return hipErrorInvalidValue;                                                                        \
+    launch_scan_mfma_variant<L_, KS_, NW_, false>(st, P, gm, dbp, selp, out, nq, rows, kN, chunk_stride, wgs);       \
+    return hipGetLastError();                                                                                        \
   }
   PIRGPU_MFMA_CASE(5, 1, 8) PIRGPU_MFMA_CASE(5, 2, 8) PIRGPU_MFMA_CASE(5, 3, 8)
   PIRGPU_MFMA_CASE(6, 1, 8) PIRGPU_MFMA_CASE(6, 2, 8) PIRGPU_MFMA_CASE(6, 3, 8)

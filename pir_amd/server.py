@@ -456,7 +456,8 @@ class PIRServer:
         info = (C.c_uint32 * 8)()
         self._check(self.lib.pirgpu_scan_info(self.db.handle, info))
         return {"mfma": bool(info[0]), "digits": info[1], "chunks": info[2], "ksteps": info[3],
-                "queries_per_pass": info[4], "rows": info[5], "cols": info[6], "single_query_mfma": bool(info[7])}
+                "queries_per_pass": info[4], "rows": info[5], "cols": info[6], "single_query_mfma": bool(info[7] & 1),
+                "top_digit_nibble": bool(info[7] & 2)}
 
     # -- test-visible helpers (server.h:66-131) -----------------------------------------
     def substitute_power_x_inplace(self, ct: np.ndarray, power: int) -> np.ndarray:

@@ -65,15 +65,18 @@ GEOMETRIES = [
 ]
 
 
+@pytest.mark.parametrize("top4", ["1", "0"], ids=["top digit nibble", "top digit byte"])
 @pytest.mark.parametrize("label,kw,digits,chunks,ksteps,wide", GEOMETRIES, ids=[g[0] for g in GEOMETRIES])
-def test_mfma_scan_geometries(label, kw, digits, chunks, ksteps, wide, monkeypatch):
+def test_mfma_scan_geometries(label, kw, digits, chunks, ksteps, wide, top4, monkeypatch):
     kw = dict(kw)
     if wide is not None:
         monkeypatch.setenv("PIRGPU_SCAN_MFMA_WIDE", wide)
+    monkeypatch.setenv("PIRGPU_SCAN_MFMA_TOP4", top4)
     s = setup_with_dims(kw.pop("dbsize"), kw.pop("elem"), kw.pop("dims"), **kw)
     db, srv = make(s)
     info = srv.scan_info()
     assert info["mfma"] and info["digits"] == digits and info["chunks"] == chunks and info["ksteps"] == ksteps, info
+    assert info["top_digit_nibble"] == (top4 == "1"), info      # 36-bit moduli: the nibble form is the default
     n = s.params.num_items
     check_queries(s, srv, [0, n // 2 + 1, n - 1])
     # the same through the batch pipeline (one group of 3)
@@ -304,8 +307,10 @@ def test_finalize_and_release_staging():
 
 def test_mfma_and_valu_scan_agree_on_boundary_selectors(monkeypatch):
     """Selection vectors made of the boundary residues of the centring / digit decomposition (0, 1, q-1, q/2,
-    q/2 +- 1, 0x7F / 0x80 byte patterns ...), injected in NTT form through pirgpu_batch_run_selectors: the
-    int8-MFMA scan and the 64-bit multiply-accumulate scan must produce identical replies."""
+    q/2 +- 1, 0x7F / 0x80 byte patterns, and the limits of the asymmetric centring that lets the top digit fit a nibble:
+    vmax = 7 * 256^4 + 127 (256^4 - 1) / 255 and its neighbours, 2^35 -+ ...), injected in NTT form through
+    pirgpu_batch_run_selectors: the int8-MFMA scan with the top digit as a nibble, the same with full bytes and the
+    64-bit multiply-accumulate scan must produce identical replies."""
     import torch
     s = setup_with_dims(1, 2048, [17, 19], N=4096, plain_bits=24)
     p = s.params
@@ -316,20 +321,26 @@ def test_mfma_and_valu_scan_agree_on_boundary_selectors(monkeypatch):
     for j in range(k):
         q = int(s.orc.moduli[j])
         half = q >> 1
+        vmax = 7 * 256 ** 4 + 127 * ((256 ** 4 - 1) // 255)      # largest value whose top digit is 7 (scan_mfma.hip)
         cases = np.array([0, 1, q - 1, q - 2, half, half + 1, half - 1, half + 2, 0x7F, 0x80, 0x81,
-                          0x7F7F7F7F7F % q, 0x8080808080 % q, 0x807F807F80 % q, q - 0x80, q - 0x8080], dtype=np.uint64)
+                          0x7F7F7F7F7F % q, 0x8080808080 % q, 0x807F807F80 % q, q - 0x80, q - 0x8080,
+                          vmax, vmax + 1, vmax + 2, vmax - 1, 2 ** 35, 2 ** 35 - 1, 2 ** 35 - 2155905152,
+                          2 ** 35 - 2155905153, 7 * 256 ** 4, 7 * 256 ** 4 - 1, 0x0F80808080 % q], dtype=np.uint64)
+        assert cases.max() < q
         pick = rng.integers(0, len(cases), size=(count, p.dim_sum, 2, N))
         sv[:, :, :, j, :] = cases[pick]
     sv_dev = torch.from_numpy(sv.view(np.int64)).cuda()
     replies = []
-    for mfma in ("1", "0"):
+    for mfma, top4 in (("1", "1"), ("1", "0"), ("0", "1")):
         monkeypatch.setenv("PIRGPU_SCAN_MFMA", mfma)
+        monkeypatch.setenv("PIRGPU_SCAN_MFMA_TOP4", top4)
         db, srv = make(s)
         assert srv.scan_info()["mfma"] == (mfma == "1")
+        assert srv.scan_info()["top_digit_nibble"] == (mfma == "1" and top4 == "1")
         srv.set_concurrency(8)
         srv.stage_batch(np.zeros((count, 1, 2, k, N), dtype=np.uint64))   # sizes the reply buffers
         srv.batch_run_selectors(sv_dev.data_ptr(), count)
         replies.append(srv.fetch_batch())
         db.close()
-    assert np.array_equal(replies[0], replies[1])
+    assert np.array_equal(replies[0], replies[1]) and np.array_equal(replies[0], replies[2])
     assert replies[0].any()

@@ -128,20 +128,23 @@ def scan_isa(tmp_path_factory):
     return out.read_text().split("\n")
 
 
-def _scan_descriptor(isa, L, KS, NW):
-    name = "_ZN6pirgpu16scan_mfma_kernelILi%dELi%dELi%dEEE" % (L, KS, NW)
+def _scan_descriptor(isa, L, KS, NW, top4=True):
+    name = "_ZN6pirgpu16scan_mfma_kernelILi%dELi%dELi%dELb%dEEE" % (L, KS, NW, 1 if top4 else 0)
     i = next(i for i, l in enumerate(isa) if ".amdhsa_kernel " + name in l)
     block = "\n".join(isa[i:i + 40])
     get = lambda key: int(re.search(r"\.amdhsa_%s (\d+)" % key, block).group(1))
     return get("next_free_vgpr"), get("accum_offset"), get("private_segment_fixed_size")
 
 
+@pytest.mark.parametrize("top4", [True, False])
 @pytest.mark.parametrize("L,KS", [(5, 1), (5, 2), (5, 3), (6, 1), (6, 2), (7, 1), (7, 2)])
-def test_eight_wave_scan_fits_two_waves_per_simd(scan_isa, L, KS):
+def test_eight_wave_scan_fits_two_waves_per_simd(scan_isa, L, KS, top4):
     """8-wave workgroups run two waves per SIMD: 256 registers per wave, no scratch (<6, 3, 8> is known to spill two
-    registers and is only used when the 4-wave kernel is forced off)."""
-    total, _, scratch = _scan_descriptor(scan_isa, L, KS, 8)
-    assert total <= 256 and scratch == 0, (L, KS, total, scratch)
+    registers and is only used when the 4-wave kernel is forced off).  top4: the top digit stored as nibbles (L <= 6)."""
+    if top4 and L == 7:
+        pytest.skip("the nibble form is not built for L = 7")
+    total, _, scratch = _scan_descriptor(scan_isa, L, KS, 8, top4)
+    assert total <= 256 and scratch == 0, (L, KS, top4, total, scratch)
 
 
 @pytest.mark.parametrize("L,KS", [(5, 7), (6, 4), (6, 7), (7, 5)])
@@ -149,6 +152,11 @@ def test_four_wave_scan_uses_the_unified_register_file_without_scratch(scan_isa,
     """4-wave workgroups run one wave per SIMD and may take the whole 512-entry VGPR + AGPR file: the selectors of up to
     7 k-steps live there (cfg 4: <6, 7, 4>).  More than 256 registers in use shows the AGPR half is really used; no
     scratch (<7, 6, 4>, cfg 5, is the one known exception: 20 spilled registers, still faster than two chunks)."""
-    total, accum_offset, scratch = _scan_descriptor(scan_isa, L, KS, 4)
-    assert scratch == 0, (L, KS, scratch)
+    for top4 in (True, False) if L <= 6 else (False,):
+        total, accum_offset, scratch = _scan_descriptor(scan_isa, L, KS, 4, top4)
+        # the nibble form of <6, 7, 4> (cfg 4) spills 13 registers to unpack into and is still 10 % faster than the
+        # byte form (4.6 against 5.1 ms: 8 % fewer bytes to stream)
+        assert scratch <= (64 if (L, KS, top4) == (6, 7, True) else 0), (L, KS, top4, scratch)
+        assert total <= 512, (L, KS, top4, total)
+    total, accum_offset, scratch = _scan_descriptor(scan_isa, L, KS, 4, False)
     assert total <= 512 and (KS < 5 or total > 256), (L, KS, total, accum_offset)

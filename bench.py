@@ -539,6 +539,42 @@ def main():
                                                    "with its own client's keys inside mixed groups of 8" % n_cl}
             except Exception as e:   # measurement extra only
                 out["multi_client_qps"] = {"error": repr(e)}
+            # the same through the WIRE: n_w clients' serialized pir.Request protos (keys + one query each) served by one
+            # pirgpu_process_requests call -- parsing, key fingerprint + byte compare against the resident sets, H2D of
+            # the queries, the batch pipeline, D2H and serialisation of the responses, all inside the timed region
+            try:
+                import seal_wire as W
+                mods = enc.coeff_modulus
+                n_w = 16
+                pid_k, pid_q = W.parms_id(N, mods, enc.plain_modulus), W.parms_id(N, mods[:-1], enc.plain_modulus)
+                reqs = []
+                for cidx in range(n_w):
+                    ck = {}
+                    for g, key in keys.items():
+                        kk = key.copy()
+                        for i in range(k + 1):
+                            kk[:, :, i, :] = (kk[:, :, i, :] + np.uint64(1000 + cidx)) % np.uint64(mods[i])
+                        ck[g] = kk
+                    reqs.append(W.save_request([queries[cidx]], W.save_galois_keys(ck, N, pid_k), pid_q))
+                first = srv.ProcessRequests(reqs)                 # installs the 16 key sets
+                for _ in range(2):
+                    srv.ProcessRequests(reqs)
+                w_steps = 10
+                t0 = time.perf_counter()
+                for _ in range(w_steps):
+                    res = srv.ProcessRequests(reqs)
+                dt = time.perf_counter() - t0
+                ok = all(st == 0 for st, _ in res) and all(st == 0 for st, _ in first)
+                same = ok and bool(np.array_equal(W.load_response(res[0][1])[0], W.load_response(first[0][1])[0]))
+                out["wire_multi_client_qps"] = {"value": w_steps * n_w / dt, "unit": "queries/s", "clients": n_w,
+                                                "ms_per_call": dt / w_steps * 1e3, "all_ok": ok,
+                                                "repeatable": same, "request_bytes_each": len(reqs[0]),
+                                                "note": "pirgpu_process_requests on %d clients' serialized requests per "
+                                                        "call (keys resident after the first call): wire parsing, key "
+                                                        "lookup + byte compare, PCIe both ways and response "
+                                                        "serialisation inside the timed region, one host thread" % n_w}
+            except Exception as e:   # measurement extra only
+                out["wire_multi_client_qps"] = {"error": repr(e)}
         if world == 1 and not use_dist and not args.no_cpu_baseline:
             out["batch_reply0_equals_single_query_reply"] = bool(np.array_equal(batch_replies[0], single_reply))
             out["cpu_baseline"] = cpu_baseline(pp, raw, keys, query, single_reply)

@@ -1409,6 +1409,15 @@ int pirgpu_keyset_verify(pirgpu_ctx* c, uint32_t slot, const uint8_t* blob, size
   return ks.blob.size() == len && memcmp(ks.blob.data(), blob, len) == 0 ? 1 : 0;
 }
 
+size_t pirgpu_keyset_blob(pirgpu_ctx* c, uint32_t slot, const uint8_t** blob) {
+  if (blob) *blob = nullptr;
+  if (!c || !blob) return 0;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  if (slot == 0 || slot >= c->keysets.size()) return 0;
+  *blob = c->keysets[slot].blob.data();
+  return c->keysets[slot].blob.size();
+}
+
 int pirgpu_keyset_claim(pirgpu_ctx* c, const uint8_t* blob, size_t len, uint32_t* slot) {
   return guarded(c, [&]() -> int {
     if (!slot || (!blob && len)) return fail(c, PIRGPU_INVALID_ARGUMENT, "null buffer");

@@ -13,13 +13,16 @@
 #include "wire_codec.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 #include <condition_variable>
 #include <deque>
+#include <chrono>
 #include <functional>
+#include <future>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -148,17 +151,52 @@ namespace {
 // pirgpu_process_request concurrently, or one pirgpu_process_requests call) are served TOGETHER: their queries go through
 // the batch pipeline as one batch -- grouped expansion with every query switched by its own client's Galois keys, one
 // database pass per group of 8 -- instead of one after the other at the single-query rate.
+// A response being assembled: ONE malloc'd buffer, sized up front, that finish() hands to the caller as it is (round 3
+// first built a std::string and copied it -- two passes over a megabyte of fresh pages per reply).
+struct OutBuf {
+  uint8_t* p = nullptr;
+  size_t n = 0, cap = 0;
+  OutBuf() = default;
+  OutBuf(const OutBuf&) = delete;
+  OutBuf& operator=(const OutBuf&) = delete;
+  ~OutBuf() { free(p); }
+  void reserve(size_t want) {
+    if (want <= cap) return;
+    const size_t grown = std::max(want, cap + cap / 2);
+    uint8_t* q = (uint8_t*)realloc(p, grown);
+    if (!q) throw std::bad_alloc();
+    p = q;
+    cap = grown;
+  }
+  void append(const void* src, size_t len) {
+    reserve(n + len);
+    memcpy(p + n, src, len);
+    n += len;
+  }
+  void clear() { n = 0; }
+  uint8_t* release(size_t* len) {   // never null: an empty response is a valid (zero-length) message
+    if (!p) reserve(1);
+    uint8_t* r = p;
+    *len = n;
+    p = nullptr;
+    n = cap = 0;
+    return r;
+  }
+};
+
 struct Job {
   const uint8_t* request = nullptr;
   size_t request_len = 0;
   int rc = 0;
   std::string err;
-  std::string out;            // serialized pir.Response
+  OutBuf out;                 // serialized pir.Response
   bool done = false;
   // filled while serving
   ParsedRequest pr;
   uint32_t slot = 0;          // resident key set of this client
   bool uniform = true;        // every query has the ciphertext count the dimensions call for (server.cpp:154)
+  bool unverified = false;    // the slot was taken on its fingerprint alone: the key bytes are compared under the GPU work
+  bool mismatch = false;      // ... and differed: install this client's keys and serve the request again
 };
 
 struct Server {               // what serving needs to know about a context
@@ -171,17 +209,21 @@ struct Server {               // what serving needs to know about a context
 };
 
 // Response.reply (payload.proto:39-42) for one query: n ciphertexts, written straight into the response buffer
-void append_reply(std::string& out, const Shape& sh, const uint64_t* cts_words, uint64_t n, size_t ctw) {
+void append_reply(OutBuf& out, const Shape& sh, const uint64_t* cts_words, uint64_t n, size_t ctw) {
   const size_t ct_size = saved_ciphertext_size(sh);
-  std::string len_prefix;
-  put_varint(len_prefix, ct_size);
-  const size_t per_ct = 1 + len_prefix.size() + ct_size;     // tag + length + object
-  out.push_back((char)((1 << 3) | 2));                        // Response.reply = 1, length-delimited
-  put_varint(out, n * per_ct);
+  std::string per_ct_head;                                    // Ciphertexts.ct = 1: tag + length + the object's prefix
+  per_ct_head.push_back((char)((1 << 3) | 2));
+  put_varint(per_ct_head, ct_size);
+  const size_t per_ct = per_ct_head.size() + ct_size;         // tag + length + object
+  append_ciphertext_prefix(per_ct_head, sh);
+  std::string reply_head;
+  reply_head.push_back((char)((1 << 3) | 2));                 // Response.reply = 1, length-delimited
+  put_varint(reply_head, n * per_ct);
+  out.reserve(out.n + reply_head.size() + n * per_ct);
+  out.append(reply_head.data(), reply_head.size());
   for (uint64_t i = 0; i < n; ++i) {
-    out.push_back((char)((1 << 3) | 2));                      // Ciphertexts.ct = 1
-    out.append(len_prefix);
-    append_ciphertext(out, sh, cts_words + i * ctw);
+    out.append(per_ct_head.data(), per_ct_head.size());
+    out.append(cts_words + i * ctw, ctw * 8);
   }
 }
 
@@ -251,8 +293,53 @@ void fail_job(Job& job, int code, const std::string& msg) {
   job.out.clear();
 }
 
+// Byte-for-byte compare of the key objects of the requests behind `items` with the resident sets they were matched
+// to by fingerprint -- once per request, on up to four worker threads (4.7 MB per client: 0.3-0.4 ms each on one
+// thread, which was most of a request's host time), while the GPU runs the chunk just queued.  The resident copies are
+// read without the context's lock: the request lock is held and the window's slots are pinned.
+template <typename Item>
+void verify_keys_of(const Server& sv, Item* items, uint32_t count) {
+  std::vector<Job*> todo;
+  for (uint32_t i = 0; i < count; ++i) {
+    Job* job = items[i].job;
+    if (job->unverified && std::find(todo.begin(), todo.end(), job) == todo.end()) todo.push_back(job);
+  }
+  if (todo.empty()) return;
+  // the resident copies are looked up HERE, on the serving thread: it holds the context's (recursive) lock for the whole
+  // window, a worker thread asking for it would wait for ever
+  std::vector<std::pair<const uint8_t*, size_t>> resident(todo.size());
+  for (size_t i = 0; i < todo.size(); ++i) resident[i].second = pirgpu_keyset_blob(sv.ctx, todo[i]->slot, &resident[i].first);
+  auto check_at = [&](size_t i) {
+    Job* job = todo[i];
+    const uint8_t* r = resident[i].first;
+    const size_t len = resident[i].second;
+    job->mismatch = !(r && len == job->pr.galois_keys_len && memcmp(r, job->pr.galois_keys, len) == 0);
+    job->unverified = false;
+  };
+  const size_t n_threads = std::min<size_t>(4, todo.size());
+  std::vector<std::future<void>> workers;
+  for (size_t t = 1; t < n_threads; ++t)
+    workers.push_back(std::async(std::launch::async, [&, t] {
+      for (size_t i = t; i < todo.size(); i += n_threads) check_at(i);
+    }));
+  for (size_t i = 0; i < todo.size(); i += n_threads) check_at(i);
+  for (auto& w : workers) w.get();
+}
+
+struct Trace {   // PIRGPU_WIRE_TRACE=1: host-side phase times of a window, to stderr
+  bool on = getenv("PIRGPU_WIRE_TRACE") != nullptr;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  void mark(const char* what) {
+    if (!on) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[wire] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
+
 // Serves a window of requests under the context's request lock.
 void serve_window(const Server& sv, Job* const* jobs, size_t n) {
+  Trace trace;
   // (1) parse, resolve keys, validate relin keys -- per request; a failing request does not affect the others
   uint32_t total_queries = 0;
   bool unverified = false;
@@ -262,9 +349,11 @@ void serve_window(const Server& sv, Job* const* jobs, size_t n) {
     if (job.rc) continue;
     try {
       job.pr = parse_request(job.request, job.request_len);
-      // a lone single-query request starts on a fingerprint match and verifies the key bytes under the GPU work
-      const bool spec = lone && job.pr.queries.size() == 1;
-      resolve_keys(sv, job, spec, spec ? &unverified : nullptr);
+      // every request starts on a fingerprint match; the key bytes (4.7 MB per client) are compared while the GPU works:
+      // by this thread for a lone single-query request, on worker threads for a window of requests
+      (void)lone;
+      resolve_keys(sv, job, true, &job.unverified);
+      unverified = unverified || job.unverified;
       // SEALDeserialize<RelinKeys> when present (server.cpp:53-58): only CT-multiplication mode uses them, but a
       // malformed non-empty field is InvalidArgument in the reference, so it is parsed and validated here too
       if (job.pr.relin_keys_len) load_kswitch_keys(sv.sh, job.pr.relin_keys, job.pr.relin_keys_len, nullptr);
@@ -275,6 +364,7 @@ void serve_window(const Server& sv, Job* const* jobs, size_t n) {
       fail_job(job, PIRGPU_INTERNAL, e.what());
     }
   }
+  trace.mark("parse + resolve keys");
   // (2) one query in the whole window: the single-query path
   if (total_queries == 1) {
     for (size_t i = 0; i < n; ++i) {
@@ -282,9 +372,8 @@ void serve_window(const Server& sv, Job* const* jobs, size_t n) {
       if (job.rc || job.pr.queries.empty()) continue;
       try {
         bool verified = true;
-        job.out.reserve(sv.n_reply * (saved_ciphertext_size(sv.sh) + 16) + 16);
         run_single(sv, job, job.pr.queries[0], [&]() {   // the byte-for-byte key compare runs under the GPU work
-          if (unverified) verified = pirgpu_keyset_verify(sv.ctx, job.slot, job.pr.galois_keys, job.pr.galois_keys_len) != 0;
+          if (job.unverified) verified = pirgpu_keyset_verify(sv.ctx, job.slot, job.pr.galois_keys, job.pr.galois_keys_len) != 0;
         });
         if (!verified) {
           // same fingerprint, different bytes: not this client's keys after all -- install them and run again
@@ -331,7 +420,7 @@ void serve_window(const Server& sv, Job* const* jobs, size_t n) {
     while (pos < items.size() && chunk.size() < room) {
       Item it = items[pos++];
       Job& job = *it.job;
-      if (job.rc || !job.uniform) continue;
+      if (job.rc || !job.uniform || job.mismatch) continue;
       try {
         if (!hq || !hr) throw Err{PIRGPU_INTERNAL, pirgpu_last_error(sv.ctx)};
         const auto& qm = job.pr.queries[it.qi];
@@ -351,7 +440,7 @@ void serve_window(const Server& sv, Job* const* jobs, size_t n) {
     // queries of requests that failed or turned non-uniform while the chunk was being filled are dropped from it
     size_t keep = 0;
     for (size_t i = 0; i < chunk.size(); ++i) {
-      if (chunk[i].job->rc || !chunk[i].job->uniform) continue;
+      if (chunk[i].job->rc || !chunk[i].job->uniform || chunk[i].job->mismatch) continue;
       if (keep != i) {
         memmove(hq + keep * qwords, hq + i * qwords, qwords * 8);
         chunk[keep] = chunk[i];
@@ -363,11 +452,16 @@ void serve_window(const Server& sv, Job* const* jobs, size_t n) {
     slots.resize(keep);
     if (chunk.empty()) continue;
     const uint32_t count = (uint32_t)chunk.size();
+    trace.mark("load queries");
     rc = pirgpu_batch_stage(sv.ctx, hq, sv.nq_expected, count);
     if (!rc) rc = pirgpu_batch_set_keysets(sv.ctx, slots.data(), count);
-    if (!rc) rc = pirgpu_batch_run(sv.ctx);
+    if (!rc) rc = pirgpu_batch_run(sv.ctx);      // asynchronous: the chunk's kernels are queued
+    trace.mark("stage + enqueue");
+    if (!rc) verify_keys_of(sv, chunk.data(), count);   // host work under the GPU's
+    trace.mark("verify keys");
     uint64_t got = 0;
     if (!rc) rc = pirgpu_batch_fetch(sv.ctx, hr, (uint64_t)count * sv.n_reply, &got);
+    trace.mark("wait + fetch");
     if (rc) {
       const std::string msg = pirgpu_last_error(sv.ctx);
       for (auto& it : chunk)
@@ -376,16 +470,49 @@ void serve_window(const Server& sv, Job* const* jobs, size_t n) {
     }
     // replies in request order: a request's queries are consecutive items, so appending in item order keeps
     // reply[i] answering query[i] (server.cpp:60-63)
-    for (uint32_t i = 0; i < count; ++i)
-      if (!chunk[i].job->rc && chunk[i].job->uniform) append_reply(chunk[i].job->out, sv.sh, hr + (size_t)i * rwords, sv.n_reply, sv.ctw);
+    // (a megabyte per reply, written into freshly mapped pages: on up to four threads, each taking whole requests)
+    std::vector<std::pair<uint32_t, uint32_t>> runs;          // [first, end) items of one request inside the chunk
+    for (uint32_t i = 0; i < count;) {
+      uint32_t e = i + 1;
+      while (e < count && chunk[e].job == chunk[i].job) ++e;
+      runs.emplace_back(i, e);
+      i = e;
+    }
+    auto serialise = [&](size_t r) {
+      Job& job = *chunk[runs[r].first].job;
+      if (job.rc || !job.uniform || job.mismatch) return;
+      try {
+        for (uint32_t i = runs[r].first; i < runs[r].second; ++i)
+          append_reply(job.out, sv.sh, hr + (size_t)i * rwords, sv.n_reply, sv.ctw);
+      } catch (const std::exception& e) {
+        fail_job(job, PIRGPU_INTERNAL, e.what());
+      }
+    };
+    const size_t n_threads = std::min<size_t>(4, runs.size());
+    std::vector<std::future<void>> workers;
+    for (size_t t = 1; t < n_threads; ++t)
+      workers.push_back(std::async(std::launch::async, [&, t] {
+        for (size_t r = t; r < runs.size(); r += n_threads) serialise(r);
+      }));
+    for (size_t r = 0; r < runs.size(); r += n_threads) serialise(r);
+    for (auto& w : workers) w.get();
+    trace.mark("serialise");
   }
   (void)pirgpu_set_concurrency(sv.ctx, before);
-  // sequential path for the requests with a wrong ciphertext count somewhere
+  // sequential path for the requests with a wrong ciphertext count somewhere, and for those whose key bytes turned out
+  // to differ from the resident set their fingerprint matched (another client's object: install theirs, serve again)
   for (size_t i = 0; i < n; ++i) {
     Job& job = *jobs[i];
-    if (job.rc || job.uniform) continue;
+    if (job.rc || (job.uniform && !job.mismatch)) continue;
     job.out.clear();
     try {
+      if (job.unverified && !job.mismatch &&
+          !pirgpu_keyset_verify(sv.ctx, job.slot, job.pr.galois_keys, job.pr.galois_keys_len))
+        job.mismatch = true;                       // (a request that never reached a batch chunk)
+      if (job.mismatch) {
+        resolve_keys(sv, job, false, nullptr);
+        job.unverified = job.mismatch = false;
+      }
       for (auto& qm : job.pr.queries) run_single(sv, job, qm);
     } catch (const Err& e) {
       fail_job(job, e.code, e.msg);
@@ -462,11 +589,11 @@ int finish(pirgpu_ctx* ctx, Job& job, uint8_t** response, size_t* response_len) 
     pirgpu_set_error(ctx, job.err.c_str());   // on the CALLING thread: pirgpu_last_error is per thread
     return job.rc;
   }
-  uint8_t* buf = (uint8_t*)malloc(job.out.size() ? job.out.size() : 1);
-  if (!buf) return PIRGPU_INTERNAL;
-  memcpy(buf, job.out.data(), job.out.size());
-  *response = buf;
-  *response_len = job.out.size();
+  try {
+    *response = job.out.release(response_len);   // the buffer the reply was serialised into: no copy
+  } catch (const std::bad_alloc&) {
+    return PIRGPU_INTERNAL;
+  }
   return PIRGPU_OK;
 }
 

@@ -25,6 +25,10 @@ int pirgpu_wire_validate_request(const struct pirgpu_params* params, const uint8
 struct pirgpu_ctx;
 void pirgpu_keyset_pin_begin(struct pirgpu_ctx* ctx);
 void pirgpu_keyset_pin_end(struct pirgpu_ctx* ctx);
+// The host copy of the key object resident key set `slot` was installed from (0 if the slot is empty).  The pointer stays
+// valid while the caller holds the request lock and the slot is pinned (no eviction, no reinstall): the wire layer
+// compares it with a request's bytes on worker threads without taking the context's lock.
+size_t pirgpu_keyset_blob(struct pirgpu_ctx* ctx, uint32_t slot, const uint8_t** blob);
 // Slot pirgpu_query_use_keyset last selected (the wire layer restores it after serving a request).
 uint32_t pirgpu_current_keyset(struct pirgpu_ctx* ctx);
 // Drops the wire layer's per-context state (called by pirgpu_destroy).

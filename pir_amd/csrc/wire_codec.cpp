@@ -319,6 +319,11 @@ size_t saved_ciphertext_size(const Shape& sh) {
 }
 
 void append_ciphertext(std::string& out, const Shape& sh, const uint64_t* ct) {
+  append_ciphertext_prefix(out, sh);
+  out.append(reinterpret_cast<const char*>(ct), 2ull * sh.k * sh.N * 8);
+}
+
+void append_ciphertext_prefix(std::string& out, const Shape& sh) {
   const uint64_t count = 2ull * sh.k * sh.N;
   put_header(out, saved_ciphertext_size(sh));
   for (int i = 0; i < 4; ++i) put_u64(out, sh.data_id[i]);
@@ -332,7 +337,6 @@ void append_ciphertext(std::string& out, const Shape& sh, const uint64_t* ct) {
   put_u64(out, sbits);
   put_header(out, kHeader + 8 + count * 8);
   put_u64(out, count);
-  out.append(reinterpret_cast<const char*>(ct), count * 8);
 }
 
 std::string save_public_key(const Shape& sh, const uint64_t* pk, const uint8_t* seed) {

@@ -138,6 +138,8 @@ void load_ciphertext_into(Cursor& c, const Shape& sh, bool key_level, uint64_t* 
 // Ciphertext::save of a data-level ciphertext appended to `out` (exactly saved_ciphertext_size bytes)
 size_t saved_ciphertext_size(const Shape& sh);
 void append_ciphertext(std::string& out, const Shape& sh, const uint64_t* ct);
+// Everything of that object before the 2 k N raw words (the same bytes for every data-level ciphertext of a context).
+void append_ciphertext_prefix(std::string& out, const Shape& sh);
 // Ciphertext::save of a size-2 ciphertext: data level (k primes, coefficient form) or, with
 // key_level, the (k+1)-prime NTT-form body of a PublicKey.
 std::string save_ciphertext(const Shape& sh, const uint64_t* ct, bool key_level = false,

@@ -191,6 +191,22 @@ def test_fingerprint_match_with_different_bytes_does_not_reuse_the_keys():
     assert got == want and got != good
     assert server.keyset_stats()["resident"] == 2            # the other object became its own key set
     assert server.ProcessRequest(req_a) == good              # and the first client's set is intact
+    # the same inside a WINDOW of requests (key bytes compared on worker threads under the batch's GPU work): on a fresh
+    # server client A's keys become resident first; one call then carries a two-query request with A's object, one with
+    # the look-alike and another with A's -- the look-alike must come back as its own client's replies, A's unchanged
+    server2 = pir_amd.PIRServer.Create(pir_amd.PIRDatabase.Create(pp, raw), pp)
+    assert server2.ProcessRequest(req_a) == good
+    req_a2 = W.save_request([query, c.create_query_for(77)], blob_a, data_pid)
+    res = server2.ProcessRequests([req_a2, req_b, req_a])
+    assert [st for st, _ in res] == [0, 0, 0]
+    assert res[1][1] == want and res[2][1] == good
+    assert c.ProcessResponse([123, 77], res[0][1]) == [raw[123].tobytes(), raw[77].tobytes()]
+    assert server2.keyset_stats()["resident"] == 2
+    # and with the look-alike FIRST in the window of a third server whose only resident set is A's
+    server3 = pir_amd.PIRServer.Create(pir_amd.PIRDatabase.Create(pp, raw), pp)
+    assert server3.ProcessRequest(req_a) == good
+    res = server3.ProcessRequests([req_b, req_a, req_b])
+    assert [st for st, _ in res] == [0, 0, 0] and res[0][1] == want and res[1][1] == good and res[2][1] == want
 
 
 def test_many_threads_many_clients_are_combined_correctly():

@@ -14,6 +14,7 @@ int pirgpu_batch_run(pirgpu_ctx*) { return 13; }
 int pirgpu_batch_fetch(pirgpu_ctx*, uint64_t*, uint64_t, uint64_t*) { return 13; }
 int pirgpu_keyset_lookup(pirgpu_ctx*, const uint8_t*, size_t, int, uint32_t*) { return 13; }
 int pirgpu_keyset_verify(pirgpu_ctx*, uint32_t, const uint8_t*, size_t) { return 0; }
+size_t pirgpu_keyset_blob(pirgpu_ctx*, uint32_t, const uint8_t** b) { if (b) *b = nullptr; return 0; }
 int pirgpu_keyset_claim(pirgpu_ctx*, const uint8_t*, size_t, uint32_t*) { return 13; }
 int pirgpu_keyset_release(pirgpu_ctx*, uint32_t) { return 13; }
 int pirgpu_keyset_set_key(pirgpu_ctx*, uint32_t, uint32_t, const uint64_t*) { return 13; }

@@ -27,6 +27,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/pirgpu.h"
@@ -293,8 +294,14 @@ void fail_job(Job& job, int code, const std::string& msg) {
   job.out.clear();
 }
 
+// Host threads a window may use next to the serving thread: at most `most`, never more than half the machine.
+size_t worker_threads(size_t most) {
+  const size_t hw = std::thread::hardware_concurrency();
+  return std::max<size_t>(1, std::min<size_t>(most, hw ? hw / 2 : 1));
+}
+
 // Byte-for-byte compare of the key objects of the requests behind `items` with the resident sets they were matched
-// to by fingerprint -- once per request, on up to four worker threads (4.7 MB per client: 0.3-0.4 ms each on one
+// to by fingerprint -- once per request, on up to 16 worker threads (4.7 MB per client: 0.3-0.4 ms each on one
 // thread, which was most of a request's host time), while the GPU runs the chunk just queued.  The resident copies are
 // read without the context's lock: the request lock is held and the window's slots are pinned.
 template <typename Item>
@@ -316,7 +323,8 @@ void verify_keys_of(const Server& sv, Item* items, uint32_t count) {
     job->mismatch = !(r && len == job->pr.galois_keys_len && memcmp(r, job->pr.galois_keys, len) == 0);
     job->unverified = false;
   };
-  const size_t n_threads = std::min<size_t>(4, todo.size());
+  // (64 clients' objects are 600 MB to read, more than the host's last-level cache: memory-bound, so many threads)
+  const size_t n_threads = std::min<size_t>(worker_threads(16), todo.size());
   std::vector<std::future<void>> workers;
   for (size_t t = 1; t < n_threads; ++t)
     workers.push_back(std::async(std::launch::async, [&, t] {
@@ -470,7 +478,7 @@ void serve_window(const Server& sv, Job* const* jobs, size_t n) {
     }
     // replies in request order: a request's queries are consecutive items, so appending in item order keeps
     // reply[i] answering query[i] (server.cpp:60-63)
-    // (a megabyte per reply, written into freshly mapped pages: on up to four threads, each taking whole requests)
+    // (a megabyte per reply, written into freshly mapped pages: on up to eight threads, each taking whole requests)
     std::vector<std::pair<uint32_t, uint32_t>> runs;          // [first, end) items of one request inside the chunk
     for (uint32_t i = 0; i < count;) {
       uint32_t e = i + 1;
@@ -488,7 +496,7 @@ void serve_window(const Server& sv, Job* const* jobs, size_t n) {
         fail_job(job, PIRGPU_INTERNAL, e.what());
       }
     };
-    const size_t n_threads = std::min<size_t>(4, runs.size());
+    const size_t n_threads = std::min<size_t>(worker_threads(8), runs.size());
     std::vector<std::future<void>> workers;
     for (size_t t = 1; t < n_threads; ++t)
       workers.push_back(std::async(std::launch::async, [&, t] {

@@ -185,6 +185,11 @@ int pirgpu_set_concurrency(pirgpu_ctx* ctx, uint32_t n_workers);
 int pirgpu_batch_stage(pirgpu_ctx* ctx, const uint64_t* queries, uint32_t nq, uint32_t count);
 int pirgpu_batch_run(pirgpu_ctx* ctx);
 int pirgpu_batch_fetch(pirgpu_ctx* ctx, uint64_t* replies, uint64_t reply_capacity, uint64_t* reply_count);
+/* Replies on their way to the host while the batch is still running: with a PINNED host buffer set here (capacity in
+ * ciphertexts; NULL switches it off), every group of a batch that fits it downloads its replies on its own stream as soon
+ * as they exist; pirgpu_batch_fetch into that same buffer then only waits.  (What the wire layer does with
+ * pirgpu_host_reply_buffer: 64 MB of replies per 64 queries no longer cross PCIe after the last kernel.) */
+int pirgpu_batch_set_host_replies(pirgpu_ctx* ctx, uint64_t* pinned_host, uint64_t capacity);
 /* Multi-GPU, query-parallel expansion (not in the reference).  batch_expand runs
  * only oblivious_expansion + the selector NTT for the staged queries [first, first+count) and writes
  * their selection vectors (count x dim_sum ciphertexts, NTT form, device order) to caller-owned DEVICE

@@ -164,6 +164,9 @@ struct pirgpu_ctx {
   // batch mode (pirgpu_batch_*): queries and replies of one batch, device resident
   uint64_t *d_bquery = nullptr, *d_breply = nullptr;
   uint64_t* ext_reply = nullptr;   // pirgpu_batch_set_reply_buffer: the caller's device buffer batches write replies to
+  uint64_t* host_reply = nullptr;  // pirgpu_batch_set_host_replies: pinned host memory every group downloads its replies to
+  uint64_t host_reply_cts = 0;     // ... its capacity in ciphertexts
+  bool host_reply_done = false;    // the batch that just ran queued those downloads: batch_fetch into it only waits
   uint64_t ext_reply_cts = 0;      // its capacity in ciphertexts
   uint32_t batch_cap = 0, batch_count = 0, n_active = 1;   // batch_count: replies the reply buffer holds
   uint32_t staged_count = 0;   // queries pirgpu_batch_stage left in d_bquery (0 again when the buffers are reallocated)
@@ -1631,6 +1634,16 @@ int pirgpu_batch_set_reply_buffer(pirgpu_ctx* c, uint64_t* device_buf, uint64_t 
   });
 }
 
+int pirgpu_batch_set_host_replies(pirgpu_ctx* c, uint64_t* pinned_host, uint64_t cap) {
+  return guarded(c, [&]() -> int {
+    if (c->in_batch) return fail(c, PIRGPU_FAILED_PRECONDITION, "a batch is being queued");
+    c->host_reply = pinned_host;
+    c->host_reply_cts = pinned_host ? cap : 0;
+    c->host_reply_done = false;
+    return PIRGPU_OK;
+  });
+}
+
 int pirgpu_fork(pirgpu_ctx* c) {
   return guarded(c, [&]() -> int {
     if (!c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -1962,6 +1975,9 @@ static void batch_run_mfma(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
     n_groups += (in_span + (pk ? (uint32_t)kMaxMfmaQueries : G) - 1) / (pk ? (uint32_t)kMaxMfmaQueries : G);
   }
   const bool share_chip = n_groups >= 2 && nl >= 2;
+  // pirgpu_batch_set_host_replies: every group downloads its replies as soon as they exist (on its lane's stream)
+  const bool host_dl = c->host_reply && (uint64_t)count * c->reply_cts <= c->host_reply_cts;
+  c->host_reply_done = host_dl;
   for (uint32_t rank0 = 0; rank0 < count; rank0 += span) {
     const uint32_t step = pk ? (uint32_t)kMaxMfmaQueries : G;
     const uint32_t in_span = std::min<uint32_t>(span, count - rank0);
@@ -2006,6 +2022,9 @@ static void batch_run_mfma(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
       if (!direct_reply)
         HIP_TRY(hipMemcpyAsync(reply_base(c) + (size_t)first * rwords, ln.lvl[0], (size_t)B * rwords * 8,
                                hipMemcpyDeviceToDevice, ln.stream));
+      if (host_dl)   // the group's replies start their way to the host while the next groups are computed
+        HIP_TRY(hipMemcpyAsync(c->host_reply + (size_t)first * rwords, reply_base(c) + (size_t)first * rwords,
+                               (size_t)B * rwords * 8, hipMemcpyDeviceToHost, ln.stream));
       for (uint32_t q = 0; q < B; ++q) {
         HIP_TRY(hipEventRecord(members[q]->ev_done, ln.stream));
         members[q]->reply_valid = false;  // the group's replies live in the lane / batch buffers, not in the worker
@@ -2294,7 +2313,8 @@ int pirgpu_batch_fetch(pirgpu_ctx* c, uint64_t* replies, uint64_t cap, uint64_t*
     const uint64_t total = (uint64_t)c->batch_count * c->reply_cts;
     if (!replies || cap < total) return fail(c, PIRGPU_INVALID_ARGUMENT, "reply buffer too small");
     sync_batch_streams(c);
-    HIP_TRY(hipMemcpy(replies, reply_base(c), total * c->ctw * 8, hipMemcpyDeviceToHost));
+    if (!(c->host_reply_done && replies == c->host_reply))   // else: the groups downloaded their replies themselves
+      HIP_TRY(hipMemcpy(replies, reply_base(c), total * c->ctw * 8, hipMemcpyDeviceToHost));
     if (count) *count = total;
     return PIRGPU_OK;
   });

@@ -463,12 +463,15 @@ void serve_window(const Server& sv, Job* const* jobs, size_t n) {
     trace.mark("load queries");
     rc = pirgpu_batch_stage(sv.ctx, hq, sv.nq_expected, count);
     if (!rc) rc = pirgpu_batch_set_keysets(sv.ctx, slots.data(), count);
+    // every group sends its replies to the pinned buffer as soon as they exist: the fetch below only waits
+    if (!rc) rc = pirgpu_batch_set_host_replies(sv.ctx, hr, (uint64_t)room * sv.n_reply);
     if (!rc) rc = pirgpu_batch_run(sv.ctx);      // asynchronous: the chunk's kernels are queued
     trace.mark("stage + enqueue");
     if (!rc) verify_keys_of(sv, chunk.data(), count);   // host work under the GPU's
     trace.mark("verify keys");
     uint64_t got = 0;
     if (!rc) rc = pirgpu_batch_fetch(sv.ctx, hr, (uint64_t)count * sv.n_reply, &got);
+    (void)pirgpu_batch_set_host_replies(sv.ctx, nullptr, 0);
     trace.mark("wait + fetch");
     if (rc) {
       const std::string msg = pirgpu_last_error(sv.ctx);

@@ -207,3 +207,46 @@ def test_batch_replies_into_a_caller_buffer():
     srv.run_batch()
     assert np.array_equal(srv.fetch_batch(), plain)
     db.close()
+
+
+def test_batch_replies_downloaded_group_by_group():
+    """pirgpu_batch_set_host_replies: every group of a batch sends its replies to the pinned host buffer on its own
+    stream as soon as they exist; pirgpu_batch_fetch into that buffer only waits.  Same replies as the plain fetch,
+    for a batch of two full groups and a ragged one; a batch larger than the buffer falls back to the plain download."""
+    import ctypes as C
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import pir_amd
+    from gpu_helpers import to_product_params
+    from pir_fixtures import PirSetup
+    s = PirSetup(10800, 288, 2, N=4096, plain_bits=24)
+    pp = to_product_params(s.params)
+    db = pir_amd.PIRDatabase.Create(pp, s.raw)
+    srv = pir_amd.PIRServer(db, pp)
+    srv.set_galois_keys(s.galois_keys)
+    srv.set_concurrency(16)
+    batch = 19
+    queries = [s.client.create_query_for(s.params, (11 + 523 * i) % 10800) for i in range(batch)]
+    srv.stage_batch(queries)
+    srv.run_batch()
+    plain = srv.fetch_batch()
+    n, words = db.reply_ct_count(), 2 * srv.k * srv.N
+    lib, h = srv.lib, db.handle
+    host = lib.pirgpu_host_reply_buffer(h, batch)
+    assert host
+    view = np.ctypeslib.as_array(C.cast(host, C.POINTER(C.c_uint64)), shape=(batch, n, 2, srv.k, srv.N))
+    for cap in (batch * n, batch * n - 1):          # fits / does not fit: group-wise download / plain download
+        view[:] = 0
+        assert lib.pirgpu_batch_set_host_replies(h, C.c_void_p(host), cap) == 0
+        srv.stage_batch(queries)
+        srv.run_batch()
+        cnt = C.c_uint64(0)
+        assert lib.pirgpu_batch_fetch(h, C.cast(host, C.POINTER(C.c_uint64)), batch * n, C.byref(cnt)) == 0
+        assert cnt.value == batch * n
+        assert np.array_equal(view, plain), cap
+    assert lib.pirgpu_batch_set_host_replies(h, None, 0) == 0
+    srv.stage_batch(queries)
+    srv.run_batch()
+    assert np.array_equal(srv.fetch_batch(), plain)
+    assert words == view.shape[2] * view.shape[3] * view.shape[4]
+    db.close()

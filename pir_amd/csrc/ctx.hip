@@ -2048,6 +2048,7 @@ static void batch_run_impl(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
   batch_run_impl_body(c, count, ext_sv);
 }
 static void batch_run_impl_body(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv) {
+  c->host_reply_done = false;   // set again by the path that queues per-group downloads (batch_run_mfma)
   const size_t rwords = (size_t)c->reply_cts * c->ctw;
   const size_t svwords = (size_t)c->dim_sum * c->ctw;
   const uint32_t W = std::max<uint32_t>(1, std::min<uint32_t>(c->n_active, (uint32_t)c->workers.size()));

@@ -190,6 +190,10 @@ int pirgpu_batch_fetch(pirgpu_ctx* ctx, uint64_t* replies, uint64_t reply_capaci
  * as they exist; pirgpu_batch_fetch into that same buffer then only waits.  (What the wire layer does with
  * pirgpu_host_reply_buffer: 64 MB of replies per 64 queries no longer cross PCIe after the last kernel.) */
 int pirgpu_batch_set_host_replies(pirgpu_ctx* ctx, uint64_t* pinned_host, uint64_t capacity);
+/* Blocks until the NEXT group of the batch just run has its replies in that host buffer and reports how many leading
+ * queries are complete (*ready; the batch's size once every group has been reported): the caller can serialise replies
+ * [previous ready, *ready) while the later groups are still being computed. */
+int pirgpu_batch_next_host_replies(pirgpu_ctx* ctx, uint32_t* ready);
 /* Multi-GPU, query-parallel expansion (not in the reference).  batch_expand runs
  * only oblivious_expansion + the selector NTT for the staged queries [first, first+count) and writes
  * their selection vectors (count x dim_sum ciphertexts, NTT form, device order) to caller-owned DEVICE

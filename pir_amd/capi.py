@@ -118,6 +118,7 @@ SIGNATURES = {
     "pirgpu_join": (C.c_int, [C.c_void_p]),
     "pirgpu_join_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pirgpu_batch_set_host_replies": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "pirgpu_batch_next_host_replies": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "pirgpu_batch_set_reply_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "pirgpu_fork": (C.c_int, [C.c_void_p]),
     "pirgpu_batch_expand_packed_async": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,

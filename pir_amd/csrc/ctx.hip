@@ -212,6 +212,11 @@ struct pirgpu_ctx {
   uint64_t groups_run = 0;
   hipEvent_t ev_fork = nullptr;             // pirgpu_fork: the main stream's position
   hipEvent_t ev_main_join = nullptr;        // pirgpu_join_stream onto a caller's stream: the main stream's position
+  // group-wise reply download (pirgpu_batch_set_host_replies): one event per group of the batch that just ran, recorded
+  // behind the group's device-to-host copy; dl_end[i] = one past the last query of group i, dl_next = next to report
+  std::vector<hipEvent_t> dl_events;
+  std::vector<uint32_t> dl_end;
+  size_t dl_next = 0;
   uint64_t *h_query = nullptr, *h_reply = nullptr;   // pinned host staging of the wire layer
   size_t h_query_words = 0, h_reply_words = 0;
 
@@ -1042,6 +1047,7 @@ void pirgpu_destroy(pirgpu_ctx* c) {
   }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_main_join) (void)hipEventDestroy(c->ev_main_join);
+  for (hipEvent_t e : c->dl_events) (void)hipEventDestroy(e);
   for (size_t i = 1; i < c->workers.size(); ++i)
     if (c->workers[i].stream) (void)hipStreamDestroy(c->workers[i].stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1644,6 +1650,28 @@ int pirgpu_batch_set_host_replies(pirgpu_ctx* c, uint64_t* pinned_host, uint64_t
   });
 }
 
+int pirgpu_batch_next_host_replies(pirgpu_ctx* c, uint32_t* ready) {
+  if (!c || !ready) return PIRGPU_INVALID_ARGUMENT;
+  // the wait itself happens WITHOUT the context's lock held by this call (the caller may hold it recursively anyway)
+  hipEvent_t ev = nullptr;
+  uint32_t end = 0;
+  int rc = guarded(c, [&]() -> int {
+    if (!c->host_reply_done) return fail(c, PIRGPU_FAILED_PRECONDITION, "the last batch did not download its replies group by group");
+    if (c->dl_next >= c->dl_end.size()) {
+      *ready = c->dl_end.empty() ? 0 : c->dl_end.back();
+      return PIRGPU_OK;
+    }
+    ev = c->dl_events[c->dl_next];
+    end = c->dl_end[c->dl_next];
+    ++c->dl_next;
+    return PIRGPU_OK;
+  });
+  if (rc || !ev) return rc;
+  if (hipEventSynchronize(ev) != hipSuccess) return fail(c, PIRGPU_INTERNAL, "waiting for a group's replies failed");
+  *ready = end;
+  return PIRGPU_OK;
+}
+
 int pirgpu_fork(pirgpu_ctx* c) {
   return guarded(c, [&]() -> int {
     if (!c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -1978,6 +2006,8 @@ static void batch_run_mfma(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
   // pirgpu_batch_set_host_replies: every group downloads its replies as soon as they exist (on its lane's stream)
   const bool host_dl = c->host_reply && (uint64_t)count * c->reply_cts <= c->host_reply_cts;
   c->host_reply_done = host_dl;
+  c->dl_end.clear();
+  c->dl_next = 0;
   for (uint32_t rank0 = 0; rank0 < count; rank0 += span) {
     const uint32_t step = pk ? (uint32_t)kMaxMfmaQueries : G;
     const uint32_t in_span = std::min<uint32_t>(span, count - rank0);
@@ -2022,9 +2052,18 @@ static void batch_run_mfma(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
       if (!direct_reply)
         HIP_TRY(hipMemcpyAsync(reply_base(c) + (size_t)first * rwords, ln.lvl[0], (size_t)B * rwords * 8,
                                hipMemcpyDeviceToDevice, ln.stream));
-      if (host_dl)   // the group's replies start their way to the host while the next groups are computed
+      if (host_dl) {   // the group's replies start their way to the host while the next groups are computed
         HIP_TRY(hipMemcpyAsync(c->host_reply + (size_t)first * rwords, reply_base(c) + (size_t)first * rwords,
                                (size_t)B * rwords * 8, hipMemcpyDeviceToHost, ln.stream));
+        const size_t gi = c->dl_end.size();
+        if (gi >= c->dl_events.size()) {
+          hipEvent_t e;
+          HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+          c->dl_events.push_back(e);
+        }
+        HIP_TRY(hipEventRecord(c->dl_events[gi], ln.stream));
+        c->dl_end.push_back(first + B);
+      }
       for (uint32_t q = 0; q < B; ++q) {
         HIP_TRY(hipEventRecord(members[q]->ev_done, ln.stream));
         members[q]->reply_valid = false;  // the group's replies live in the lane / batch buffers, not in the worker
@@ -2421,6 +2460,6 @@ int pirgpu_last_timings(pirgpu_ctx* c, float ms[6], uint32_t* runs) {
 
 uint32_t pirgpu_get_concurrency(pirgpu_ctx* c) { return c ? c->n_active : 0; }
 
-void pirgpu_free(void* p) { free(p); }
+// pirgpu_free: wire.cpp (response buffers are recycled)
 
 }  // extern "C"

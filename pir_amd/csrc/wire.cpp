@@ -152,22 +152,86 @@ namespace {
 // pirgpu_process_request concurrently, or one pirgpu_process_requests call) are served TOGETHER: their queries go through
 // the batch pipeline as one batch -- grouped expansion with every query switched by its own client's Galois keys, one
 // database pass per group of 8 -- instead of one after the other at the single-query rate.
-// A response being assembled: ONE malloc'd buffer, sized up front, that finish() hands to the caller as it is (round 3
-// first built a std::string and copied it -- two passes over a megabyte of fresh pages per reply).
+// Response buffers are RECYCLED: a buffer handed back with pirgpu_free goes to a process-wide pool (up to 256 MB) and
+// the next response of about that size is serialised into it.  A megabyte per reply from malloc is an mmap, 256 page
+// faults while it is filled and a munmap (with TLB shoot-downs across the process' threads) when the caller frees it:
+// 0.1 ms per response for the free alone, 6.4 ms of a 64-client window.  Every buffer carries a 64-byte header
+// (magic, capacity) in front of what the caller sees.
+struct PoolHdr {
+  uint64_t magic;
+  size_t cap;     // usable bytes behind the header
+};
+constexpr size_t kPoolHdr = 64;
+constexpr uint64_t kPoolMagic = 0x7069726770756221ull;
+constexpr size_t kPoolLimit = 256u << 20;
+std::mutex g_pool_mu;
+std::vector<uint8_t*> g_pool;     // headers of free buffers
+size_t g_pool_bytes = 0;
+
+uint8_t* pool_alloc(size_t want, size_t* cap) {   // -> user pointer
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    size_t best = g_pool.size();
+    for (size_t i = 0; i < g_pool.size(); ++i) {
+      const size_t c = reinterpret_cast<PoolHdr*>(g_pool[i])->cap;
+      if (c >= want && c <= 2 * want + 4096 && (best == g_pool.size() || c < reinterpret_cast<PoolHdr*>(g_pool[best])->cap))
+        best = i;
+    }
+    if (best != g_pool.size()) {
+      uint8_t* base = g_pool[best];
+      g_pool[best] = g_pool.back();
+      g_pool.pop_back();
+      g_pool_bytes -= reinterpret_cast<PoolHdr*>(base)->cap;
+      *cap = reinterpret_cast<PoolHdr*>(base)->cap;
+      return base + kPoolHdr;
+    }
+  }
+  uint8_t* base = (uint8_t*)malloc(want + kPoolHdr);
+  if (!base) throw std::bad_alloc();
+  PoolHdr* h = reinterpret_cast<PoolHdr*>(base);
+  h->magic = kPoolMagic;
+  h->cap = want;
+  *cap = want;
+  return base + kPoolHdr;
+}
+
+void pool_release(uint8_t* user) {
+  if (!user) return;
+  uint8_t* base = user - kPoolHdr;
+  PoolHdr* h = reinterpret_cast<PoolHdr*>(base);
+  if (h->magic != kPoolMagic) {   // not one of ours (cannot happen through the documented API)
+    free(user);
+    return;
+  }
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    if (h->cap >= 4096 && g_pool_bytes + h->cap <= kPoolLimit && g_pool.size() < 4096) {
+      g_pool.push_back(base);
+      g_pool_bytes += h->cap;
+      return;
+    }
+  }
+  h->magic = 0;
+  free(base);
+}
+
+// A response being assembled: ONE buffer, sized up front, that finish() hands to the caller as it is (round 3 first built
+// a std::string and copied it -- two passes over a megabyte of fresh pages per reply).
 struct OutBuf {
-  uint8_t* p = nullptr;
+  uint8_t* p = nullptr;   // user pointer (pool_alloc)
   size_t n = 0, cap = 0;
   OutBuf() = default;
   OutBuf(const OutBuf&) = delete;
   OutBuf& operator=(const OutBuf&) = delete;
-  ~OutBuf() { free(p); }
+  ~OutBuf() { pool_release(p); }
   void reserve(size_t want) {
     if (want <= cap) return;
-    const size_t grown = std::max(want, cap + cap / 2);
-    uint8_t* q = (uint8_t*)realloc(p, grown);
-    if (!q) throw std::bad_alloc();
+    size_t got = 0;
+    uint8_t* q = pool_alloc(std::max(want, cap + cap / 2), &got);
+    if (n) memcpy(q, p, n);
+    pool_release(p);
     p = q;
-    cap = grown;
+    cap = got;
   }
   void append(const void* src, size_t len) {
     reserve(n + len);
@@ -210,6 +274,9 @@ struct Server {               // what serving needs to know about a context
 };
 
 // Response.reply (payload.proto:39-42) for one query: n ciphertexts, written straight into the response buffer
+// Upper bound of what append_reply adds for a reply of n ciphertexts (tags and varint lengths: < 32 bytes each)
+size_t reply_bytes_bound(const Shape& sh, uint64_t n) { return 32 + n * (32 + saved_ciphertext_size(sh)); }
+
 void append_reply(OutBuf& out, const Shape& sh, const uint64_t* cts_words, uint64_t n, size_t ctw) {
   const size_t ct_size = saved_ciphertext_size(sh);
   std::string per_ct_head;                                    // Ciphertexts.ct = 1: tag + length + the object's prefix
@@ -460,6 +527,26 @@ void serve_window(const Server& sv, Job* const* jobs, size_t n) {
     slots.resize(keep);
     if (chunk.empty()) continue;
     const uint32_t count = (uint32_t)chunk.size();
+    // the response buffers are mapped NOW, before the GPU phase: the worker threads that fill them while the GPU runs
+    // then only touch pages -- an mmap / munmap in the middle of the GPU's work goes through the driver's MMU notifier
+    // and was measured to stretch a 64-client window from 15 to 25 ms
+    // replies in request order: a request's queries are consecutive items, so appending in item order keeps
+    // reply[i] answering query[i] (server.cpp:60-63)
+    std::vector<std::pair<uint32_t, uint32_t>> runs;          // [first, end) items of one request inside the chunk
+    for (uint32_t i = 0; i < count;) {
+      uint32_t e = i + 1;
+      while (e < count && chunk[e].job == chunk[i].job) ++e;
+      runs.emplace_back(i, e);
+      i = e;
+    }
+    for (auto& run : runs) {
+      Job& job = *chunk[run.first].job;
+      try {
+        job.out.reserve(job.out.n + (run.second - run.first) * reply_bytes_bound(sv.sh, sv.n_reply));
+      } catch (const std::exception& e) {
+        fail_job(job, PIRGPU_INTERNAL, e.what());
+      }
+    }
     trace.mark("load queries");
     rc = pirgpu_batch_stage(sv.ctx, hq, sv.nq_expected, count);
     if (!rc) rc = pirgpu_batch_set_keysets(sv.ctx, slots.data(), count);
@@ -469,26 +556,6 @@ void serve_window(const Server& sv, Job* const* jobs, size_t n) {
     trace.mark("stage + enqueue");
     if (!rc) verify_keys_of(sv, chunk.data(), count);   // host work under the GPU's
     trace.mark("verify keys");
-    uint64_t got = 0;
-    if (!rc) rc = pirgpu_batch_fetch(sv.ctx, hr, (uint64_t)count * sv.n_reply, &got);
-    (void)pirgpu_batch_set_host_replies(sv.ctx, nullptr, 0);
-    trace.mark("wait + fetch");
-    if (rc) {
-      const std::string msg = pirgpu_last_error(sv.ctx);
-      for (auto& it : chunk)
-        if (!it.job->rc) fail_job(*it.job, rc, msg);
-      continue;
-    }
-    // replies in request order: a request's queries are consecutive items, so appending in item order keeps
-    // reply[i] answering query[i] (server.cpp:60-63)
-    // (a megabyte per reply, written into freshly mapped pages: on up to eight threads, each taking whole requests)
-    std::vector<std::pair<uint32_t, uint32_t>> runs;          // [first, end) items of one request inside the chunk
-    for (uint32_t i = 0; i < count;) {
-      uint32_t e = i + 1;
-      while (e < count && chunk[e].job == chunk[i].job) ++e;
-      runs.emplace_back(i, e);
-      i = e;
-    }
     auto serialise = [&](size_t r) {
       Job& job = *chunk[runs[r].first].job;
       if (job.rc || !job.uniform || job.mismatch) return;
@@ -499,13 +566,47 @@ void serve_window(const Server& sv, Job* const* jobs, size_t n) {
         fail_job(job, PIRGPU_INTERNAL, e.what());
       }
     };
-    const size_t n_threads = std::min<size_t>(worker_threads(8), runs.size());
+    // While the GPU is still computing the later groups: as soon as a group's replies have landed in the pinned buffer,
+    // the requests they complete are serialised on a worker thread (a megabyte per reply, into freshly mapped pages)
     std::vector<std::future<void>> workers;
+    size_t next_run = 0;
+    static const bool stream_replies = !(getenv("PIRGPU_WIRE_STREAM") && getenv("PIRGPU_WIRE_STREAM")[0] == '0');
+    if (!rc && stream_replies) {
+      uint32_t ready = 0;
+      while (ready < count) {
+        uint32_t upto = 0;
+        if (pirgpu_batch_next_host_replies(sv.ctx, &upto) != 0 || upto <= ready) break;   // not group-wise: all below
+        ready = upto;
+        size_t e = next_run;
+        while (e < runs.size() && runs[e].second <= ready) ++e;
+        if (e > next_run) {
+          workers.push_back(std::async(std::launch::async, [&serialise, next_run, e] {
+            for (size_t r = next_run; r < e; ++r) serialise(r);
+          }));
+          next_run = e;
+        }
+      }
+    }
+    uint64_t got = 0;
+    if (!rc) rc = pirgpu_batch_fetch(sv.ctx, hr, (uint64_t)count * sv.n_reply, &got);   // everything has arrived
+    (void)pirgpu_batch_set_host_replies(sv.ctx, nullptr, 0);
+    for (auto& w : workers) w.get();
+    workers.clear();
+    trace.mark("wait + fetch");
+    if (rc) {
+      const std::string msg = pirgpu_last_error(sv.ctx);
+      for (auto& it : chunk)
+        if (!it.job->rc) fail_job(*it.job, rc, msg);
+      continue;
+    }
+    // what has not been serialised on the way (all of it without group-wise download): up to eight threads
+    const size_t left = runs.size() - next_run;
+    const size_t n_threads = std::min<size_t>(worker_threads(8), left);
     for (size_t t = 1; t < n_threads; ++t)
       workers.push_back(std::async(std::launch::async, [&, t] {
-        for (size_t r = t; r < runs.size(); r += n_threads) serialise(r);
+        for (size_t r = next_run + t; r < runs.size(); r += n_threads) serialise(r);
       }));
-    for (size_t r = 0; r < runs.size(); r += n_threads) serialise(r);
+    for (size_t r = next_run; r < runs.size(); r += std::max<size_t>(n_threads, 1)) serialise(r);
     for (auto& w : workers) w.get();
     trace.mark("serialise");
   }
@@ -631,6 +732,8 @@ std::shared_ptr<Combiner> combiner_for(pirgpu_ctx* ctx) {
 
 extern "C" {
 
+void pirgpu_free(void* p) { pool_release(static_cast<uint8_t*>(p)); }
+
 void pirgpu_wire_forget(pirgpu_ctx* ctx) {
   std::lock_guard<std::mutex> lock(g_combiners_mu);
   g_combiners.erase(ctx);
@@ -684,7 +787,9 @@ int pirgpu_process_requests(pirgpu_ctx* ctx, uint32_t n, const uint8_t* const* r
     ptrs[i] = &jobs[i];
     if (!requests[i] && request_lens[i]) fail_job(jobs[i], PIRGPU_INVALID_ARGUMENT, "null request");
   }
+  Trace trace;
   serve_guarded(ctx, ptrs.data(), n);
+  trace.mark("serve (whole call)");
   int worst = PIRGPU_OK;
   t_request_errors.assign(n, std::string());
   for (uint32_t i = 0; i < n; ++i) {
@@ -692,6 +797,7 @@ int pirgpu_process_requests(pirgpu_ctx* ctx, uint32_t n, const uint8_t* const* r
     if (status[i]) t_request_errors[i] = jobs[i].err;
     if (status[i] && !worst) worst = status[i];
   }
+  trace.mark("finish");
   return worst;
 }
 

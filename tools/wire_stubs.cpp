@@ -13,6 +13,7 @@ int pirgpu_batch_stage(pirgpu_ctx*, const uint64_t*, uint32_t, uint32_t) { retur
 int pirgpu_batch_run(pirgpu_ctx*) { return 13; }
 int pirgpu_batch_fetch(pirgpu_ctx*, uint64_t*, uint64_t, uint64_t*) { return 13; }
 int pirgpu_batch_set_host_replies(pirgpu_ctx*, uint64_t*, uint64_t) { return 13; }
+int pirgpu_batch_next_host_replies(pirgpu_ctx*, uint32_t*) { return 13; }
 int pirgpu_keyset_lookup(pirgpu_ctx*, const uint8_t*, size_t, int, uint32_t*) { return 13; }
 int pirgpu_keyset_verify(pirgpu_ctx*, uint32_t, const uint8_t*, size_t) { return 0; }
 size_t pirgpu_keyset_blob(pirgpu_ctx*, uint32_t, const uint8_t** b) { if (b) *b = nullptr; return 0; }

@@ -244,6 +244,22 @@ def test_batch_replies_downloaded_group_by_group():
         assert lib.pirgpu_batch_fetch(h, C.cast(host, C.POINTER(C.c_uint64)), batch * n, C.byref(cnt)) == 0
         assert cnt.value == batch * n
         assert np.array_equal(view, plain), cap
+    # pirgpu_batch_next_host_replies: the groups are reported in order as their replies land; what has been reported is
+    # complete in the host buffer before the batch as a whole is
+    view[:] = 0
+    assert lib.pirgpu_batch_set_host_replies(h, C.c_void_p(host), batch * n) == 0
+    srv.stage_batch(queries)
+    srv.run_batch()
+    seen, ready = [], C.c_uint32(0)
+    while not seen or seen[-1] < batch:
+        assert lib.pirgpu_batch_next_host_replies(h, C.byref(ready)) == 0
+        assert ready.value > (seen[-1] if seen else 0)
+        assert np.array_equal(view[:ready.value], plain[:ready.value])
+        seen.append(ready.value)
+    assert seen == [8, 16, 19]
+    assert lib.pirgpu_batch_next_host_replies(h, C.byref(ready)) == 0 and ready.value == batch   # nothing left: the total
+    cnt = C.c_uint64(0)
+    assert lib.pirgpu_batch_fetch(h, C.cast(host, C.POINTER(C.c_uint64)), batch * n, C.byref(cnt)) == 0
     assert lib.pirgpu_batch_set_host_replies(h, None, 0) == 0
     srv.stage_batch(queries)
     srv.run_batch()

@@ -302,6 +302,8 @@ int pirgpu_process_requests(pirgpu_ctx* ctx, uint32_t n, const uint8_t* const* r
 const char* pirgpu_request_error(uint32_t i);
 uint64_t* pirgpu_host_query_buffer(pirgpu_ctx* ctx, uint32_t queries);
 uint64_t* pirgpu_host_reply_buffer(pirgpu_ctx* ctx, uint32_t queries);
+/* Releases a response buffer.  The library keeps up to 256 MB of released buffers for later responses (a fresh megabyte
+ * per reply would cost an mmap, its page faults and a munmap every time); pass only pointers the library returned. */
 void pirgpu_free(void* p);
 
 /* Measurement: mean duration of the phases of the pirgpu_query_run calls made since

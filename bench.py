@@ -561,8 +561,8 @@ def main():
                 # a megabyte per response are the binding's cost, not the library's
                 import ctypes as C
                 lib, handle = srv.lib, srv.db.handle
-                bufs = [np.frombuffer(r, dtype=np.uint8) for r in reqs]
-                ptrs = (C.c_void_p * n_w)(*[b.ctypes.data for b in bufs])
+                req_views = [np.frombuffer(r, dtype=np.uint8) for r in reqs]
+                ptrs = (C.c_void_p * n_w)(*[b.ctypes.data for b in req_views])
                 lens = (C.c_size_t * n_w)(*[len(r) for r in reqs])
                 resp, rlen, status = (C.c_void_p * n_w)(), (C.c_size_t * n_w)(), (C.c_int * n_w)()
 

@@ -247,6 +247,13 @@ int pirgpu_batch_expand_packed_async(pirgpu_ctx* ctx, uint32_t first, uint32_t c
                                      uint64_t* device_rows, const uint32_t* row_cuts, uint32_t n_ranks);
 int pirgpu_batch_reply_copy_to_device_async(pirgpu_ctx* ctx, uint64_t* device_dst, uint64_t capacity);
 int pirgpu_reduce_fixup_device_async(pirgpu_ctx* ctx, uint64_t* device_ptr, uint64_t count, void* stream);
+/* Row selectors of the packed exchange in 5 bytes per residue instead of 8 (moduli below 2^40: pack40_supported = 1):
+ * `words` u64 residues (a multiple of 4) <-> words * 5 / 4 dwords in DEVICE memory, queued on `stream` (NULL: the main
+ * stream).  Every 4 words become 5 dwords, so the packed form of a buffer can be cut wherever the word form is cut at a
+ * multiple of 4 words -- e.g. into the per-rank pieces of an all-to-all. */
+int pirgpu_pack40_supported(pirgpu_ctx* ctx);
+int pirgpu_pack40_device_async(pirgpu_ctx* ctx, const uint64_t* words_in, uint32_t* packed, uint64_t words, void* stream);
+int pirgpu_unpack40_device_async(pirgpu_ctx* ctx, const uint32_t* packed, uint64_t* words_out, uint64_t words, void* stream);
 
 /* PIRServer::oblivious_expansion (reference server.cpp:105-146): one ciphertext
  * -> num_items ciphertexts, coefficient form. */

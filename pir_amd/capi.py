@@ -117,6 +117,9 @@ SIGNATURES = {
     "pirgpu_stream_handle": (C.c_void_p, [C.c_void_p]),
     "pirgpu_join": (C.c_int, [C.c_void_p]),
     "pirgpu_join_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pirgpu_pack40_supported": (C.c_int, [C.c_void_p]),
+    "pirgpu_pack40_device_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "pirgpu_unpack40_device_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "pirgpu_batch_set_host_replies": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "pirgpu_batch_next_host_replies": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "pirgpu_batch_set_reply_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),

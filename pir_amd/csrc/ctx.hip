@@ -2416,6 +2416,33 @@ int pirgpu_reduce_fixup_device_async(pirgpu_ctx* c, uint64_t* device_ptr, uint64
   });
 }
 
+// Row selectors of the multi-GPU exchange in 5 bytes per residue (moduli below 2^40): pack before the all-to-all,
+// unpack behind it.  words: multiple of 4; `packed` holds words * 5 / 4 dwords.  stream NULL: the main stream.
+static bool moduli_fit_40_bits(const pirgpu_ctx* c) {
+  for (uint32_t j = 0; j < c->k; ++j)
+    if (c->hp.mod[j].q >> 40) return false;
+  return true;
+}
+int pirgpu_pack40_supported(pirgpu_ctx* c) { return c && moduli_fit_40_bits(c) ? 1 : 0; }
+
+int pirgpu_pack40_device_async(pirgpu_ctx* c, const uint64_t* words_in, uint32_t* packed, uint64_t words, void* stream) {
+  return guarded(c, [&]() -> int {
+    if (!words_in || !packed || words % 4) return fail(c, PIRGPU_INVALID_ARGUMENT, "invalid buffers for the 5-byte form");
+    if (!moduli_fit_40_bits(c)) return fail(c, PIRGPU_FAILED_PRECONDITION, "the 5-byte form needs moduli below 2^40");
+    HIP_TRY(launch_pack40x4(stream ? (hipStream_t)stream : c->stream, words_in, packed, words));
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_unpack40_device_async(pirgpu_ctx* c, const uint32_t* packed, uint64_t* words_out, uint64_t words, void* stream) {
+  return guarded(c, [&]() -> int {
+    if (!words_out || !packed || words % 4) return fail(c, PIRGPU_INVALID_ARGUMENT, "invalid buffers for the 5-byte form");
+    if (!moduli_fit_40_bits(c)) return fail(c, PIRGPU_FAILED_PRECONDITION, "the 5-byte form needs moduli below 2^40");
+    HIP_TRY(launch_unpack40x4(stream ? (hipStream_t)stream : c->stream, packed, words_out, words));
+    return PIRGPU_OK;
+  });
+}
+
 int pirgpu_set_profiling(pirgpu_ctx* c, int enabled) {
   return guarded(c, [&]() -> int {
     HIP_TRY(hipStreamSynchronize(c->stream));

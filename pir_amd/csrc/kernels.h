@@ -86,6 +86,9 @@ const NttOps* ntt_ops_for(uint32_t N);  // nullptr for unsupported degrees
 
 hipError_t launch_ntt_reorder(hipStream_t st, uint32_t N, const uint64_t* in, uint64_t* out, uint64_t n_polys,
                               bool to_device, bool as_f64);
+// u64 residues < 2^40 <-> 5 bytes each (4 words <-> 5 dwords); words must be a multiple of 4
+hipError_t launch_pack40x4(hipStream_t st, const uint64_t* in, uint32_t* out, uint64_t words);
+hipError_t launch_unpack40x4(hipStream_t st, const uint32_t* in, uint64_t* out, uint64_t words);
 hipError_t launch_ks_combine(hipStream_t st, const DevParams* P, int mode, uint32_t N, uint32_t k,
                              const uint64_t* res_in, const uint64_t* prod, uint32_t galois_inv, uint32_t nodes,
                              uint32_t shift_pow, bool expand_step, uint32_t hi_limit, bool pack40, uint64_t* res_out);

@@ -782,6 +782,46 @@ hipError_t launch_ntt_reorder(hipStream_t st, uint32_t N, const uint64_t* in, ui
   return hipSuccess;
 }
 
+// Residues below 2^40 as 5 bytes for the multi-GPU exchange of row selectors: 4 words -> 5 dwords (the four low halves,
+// then the four high bytes in one dword), so every access is an aligned dword and the form does not depend on how the
+// buffer is cut into per-rank pieces (every piece is a multiple of 4 words).
+__global__ void pack40x4_kernel(const uint64_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t quads) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= quads) return;
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  const u64x2 a = reinterpret_cast<const u64x2*>(in)[2 * i], b = reinterpret_cast<const u64x2*>(in)[2 * i + 1];
+  uint32_t* o = out + 5 * i;
+  o[0] = (uint32_t)a[0];
+  o[1] = (uint32_t)a[1];
+  o[2] = (uint32_t)b[0];
+  o[3] = (uint32_t)b[1];
+  o[4] = (uint32_t)((a[0] >> 32) & 0xFF) | (uint32_t)((a[1] >> 32) & 0xFF) << 8 | (uint32_t)((b[0] >> 32) & 0xFF) << 16 |
+         (uint32_t)((b[1] >> 32) & 0xFF) << 24;
+}
+
+__global__ void unpack40x4_kernel(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t quads) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= quads) return;
+  const uint32_t* p = in + 5 * i;
+  const uint32_t hi = p[4];
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  reinterpret_cast<u64x2*>(out)[2 * i] = u64x2{p[0] | (uint64_t)(hi & 0xFF) << 32, p[1] | (uint64_t)((hi >> 8) & 0xFF) << 32};
+  reinterpret_cast<u64x2*>(out)[2 * i + 1] =
+      u64x2{p[2] | (uint64_t)((hi >> 16) & 0xFF) << 32, p[3] | (uint64_t)(hi >> 24) << 32};
+}
+
+hipError_t launch_pack40x4(hipStream_t st, const uint64_t* in, uint32_t* out, uint64_t words) {
+  const uint64_t quads = words / 4;
+  hipLaunchKernelGGL(pack40x4_kernel, dim3((uint32_t)((quads + 255) / 256)), dim3(256), 0, st, in, out, quads);
+  return hipGetLastError();
+}
+
+hipError_t launch_unpack40x4(hipStream_t st, const uint32_t* in, uint64_t* out, uint64_t words) {
+  const uint64_t quads = words / 4;
+  hipLaunchKernelGGL(unpack40x4_kernel, dim3((uint32_t)((quads + 255) / 256)), dim3(256), 0, st, in, out, quads);
+  return hipGetLastError();
+}
+
 hipError_t launch_ks_combine(hipStream_t st, const DevParams* P, int mode, uint32_t N, uint32_t k,
                              const uint64_t* res_in, const uint64_t* prod, uint32_t galois_inv, uint32_t nodes,
                              uint32_t shift_pow, bool expand_step, uint32_t hi_limit, bool pack40, uint64_t* res_out) {

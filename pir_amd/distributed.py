@@ -8,6 +8,7 @@ world-size-2 `gloo` tests -- stages them through host memory.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Tuple
 
 GROUP = 8          # queries per packed group = queries sharing one database pass (kMaxMfmaQueries)
@@ -255,10 +256,38 @@ class PackedBuffers:
         self.replies = torch.empty((self.per, reply_cts, 2, k, N), dtype=torch.int64, device=device)
         self.send_splits = [self.per * (self.cuts[s + 1] - self.cuts[s]) * self.ctw for s in range(world)]
         self.recv_splits = [self.per * self.my_rows * self.ctw] * world
+        # Row selectors cross the links in 5 bytes per residue where the moduli allow (below 2^40: cfg 2 / 3): every 4
+        # words are 5 dwords, so the per-rank pieces of the all-to-all are cut at the same places (x 5 / 4).  They are
+        # 15 % of a rank's ingest at 8 GPUs and 45 % at 2; PIRGPU_ROWS_PACK40=0 sends u64.
+        self.rows40 = (os.environ.get("PIRGPU_ROWS_PACK40", "1") != "0" and hasattr(server, "pack40_supported")
+                       and server.pack40_supported())
+        if self.rows40:
+            self.rows_send40 = torch.empty((self.rows_send.numel() * 5 // 4,), dtype=torch.int32, device=device)
+            self.rows_recv40 = torch.empty((self.rows_recv.numel() * 5 // 4,), dtype=torch.int32, device=device)
+            self.send_splits40 = [v * 5 // 4 for v in self.send_splits]
+            self.recv_splits40 = [v * 5 // 4 for v in self.recv_splits]
 
     def exchange_bytes_per_query(self, world: int) -> float:
         """Bytes a rank receives per query of the batch (packed column selectors from the other ranks + its rows)."""
-        return (world - 1) / world * (self.sel_bytes * self.groups / self.per + self.my_rows * self.ctw * 8)
+        return (world - 1) / world * (self.sel_bytes * self.groups / self.per
+                                      + self.my_rows * self.ctw * (5 if self.rows40 else 8))
+
+    # -- the rows part of the exchange, in whichever form this buffer set uses -------------------------------------
+    def pack_rows(self, server, stream: int = 0) -> None:
+        """After the expansion wrote rows_send: its 5-byte form (queued on `stream`; 0 = the library's main stream)."""
+        if self.rows40:
+            server.pack40_async(self.rows_send.data_ptr(), self.rows_send40.data_ptr(), self.rows_send.numel(), stream)
+
+    def exchange_rows(self, comm) -> None:
+        if self.rows40:
+            comm.all_to_all(self.rows_recv40, self.rows_send40, self.recv_splits40, self.send_splits40, units=self.per)
+        else:
+            comm.all_to_all(self.rows_recv, self.rows_send, self.recv_splits, self.send_splits, units=self.per)
+
+    def unpack_rows(self, server, stream: int = 0) -> None:
+        """Before the multiply reads rows_recv: back from the 5-byte form."""
+        if self.rows40:
+            server.unpack40_async(self.rows_recv40.data_ptr(), self.rows_recv.data_ptr(), self.rows_recv.numel(), stream)
 
 
 def packed_exchange_supported(server, dist, world: int, comm: Optional[Comm] = None, torch=None, device=None) -> bool:
@@ -289,10 +318,14 @@ def run_batch_rows_packed(server, bufs: PackedBuffers, dist, rank: int, world: i
     t = [time.perf_counter()]
     lo, hi = owned_queries(bufs.per * world, rank, world)
     server.batch_expand_packed(lo, bufs.per, bufs.packed[rank].data_ptr(), bufs.rows_send.data_ptr(), bufs.cuts)
+    bufs.pack_rows(server)
+    server.sync()
     t.append(time.perf_counter())
     comm.all_gather_inplace(bufs.packed, rank)
-    comm.all_to_all(bufs.rows_recv, bufs.rows_send, bufs.recv_splits, bufs.send_splits, units=bufs.per)
+    bufs.exchange_rows(comm)
     t.append(time.perf_counter())
+    bufs.unpack_rows(server)
+    server.fork()               # the lanes start behind the main stream's unpacking
     server.batch_run_packed(bufs.packed.data_ptr(), world, bufs.per, bufs.rows_recv.data_ptr())
     server.batch_reply_copy_to_device(bufs.partial.data_ptr())
     t.append(time.perf_counter())
@@ -395,6 +428,7 @@ class RowsPipeline:
         """Multiply + reduce of the step whose exchange went into set b."""
         srv, st, bufs = self.server, self.streams, self.sets[b]
         st.main_after_exchange(b)             # the main stream waits for X of that step ...
+        bufs.unpack_rows(srv)                 # (row selectors back from their 5-byte form, on the main stream)
         srv.fork()                            # ... and with it the lanes
         srv.batch_run_packed(bufs.packed.data_ptr(), self.world, bufs.per, bufs.rows_recv.data_ptr())
         srv.batch_reply_copy_to_device_async(bufs.partial.data_ptr())      # join + copy on the main stream
@@ -413,10 +447,11 @@ class RowsPipeline:
         srv.batch_expand_packed_async(first + self.rank * bufs.per, bufs.per, bufs.packed[self.rank].data_ptr(),
                                       bufs.rows_send.data_ptr(), bufs.cuts)
         srv.join()
+        bufs.pack_rows(srv)                   # on the main stream, behind the expansion it has just been joined to
         st.comm_after_main()
         with st.comm():
             self.comm.all_gather_inplace(bufs.packed, self.rank)
-            self.comm.all_to_all(bufs.rows_recv, bufs.rows_send, bufs.recv_splits, bufs.send_splits, units=bufs.per)
+            bufs.exchange_rows(self.comm)
             st.record_exchange(b)
         if self.pending is not None:
             self._finish(self.pending)

@@ -381,6 +381,18 @@ class PIRServer:
         self._check(self.lib.pirgpu_batch_reply_copy_to_device_async(self.db.handle, C.c_void_p(device_ptr),
                                                                      self._batch_count * self.db.reply_ct_count()))
 
+    def pack40_supported(self) -> bool:
+        """Row selectors may cross GPUs in 5 bytes per residue (every data modulus below 2^40)."""
+        return bool(self.lib.pirgpu_pack40_supported(self.db.handle))
+
+    def pack40_async(self, words_ptr: int, packed_ptr: int, words: int, stream: int = 0) -> None:
+        self._check(self.lib.pirgpu_pack40_device_async(self.db.handle, C.c_void_p(words_ptr), C.c_void_p(packed_ptr), words,
+                                                        C.c_void_p(stream)))
+
+    def unpack40_async(self, packed_ptr: int, words_ptr: int, words: int, stream: int = 0) -> None:
+        self._check(self.lib.pirgpu_unpack40_device_async(self.db.handle, C.c_void_p(packed_ptr), C.c_void_p(words_ptr),
+                                                          words, C.c_void_p(stream)))
+
     def reduce_fixup_device_async(self, device_ptr: int, n_cts: int, stream: int = 0) -> None:
         self._check(self.lib.pirgpu_reduce_fixup_device_async(self.db.handle, C.c_void_p(device_ptr), n_cts,
                                                               C.c_void_p(stream)))

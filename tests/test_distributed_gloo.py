@@ -50,6 +50,10 @@ def _view(ptr, n, dtype=np.uint64):
     return np.ctypeslib.as_array((ct * n).from_address(ptr))
 
 
+def _view32(ptr, n):
+    return np.ctypeslib.as_array((C.c_uint32 * n).from_address(ptr))
+
+
 class _Db:
     def __init__(self, n):
         self._n = n
@@ -164,6 +168,24 @@ class OracleShardServer:
     def join_stream(self, stream):
         pass
 
+    # -- row selectors in 5 bytes per residue (pirgpu_pack40_device_async / _unpack40_): 4 words <-> 5 dwords -----------
+    def pack40_supported(self):
+        return all(int(q) < 2 ** 40 for q in self.orc.moduli[: self.k])
+
+    def pack40_async(self, words_ptr, packed_ptr, words, stream=0):
+        w = _view(words_ptr, words).reshape(-1, 4)
+        out = _view32(packed_ptr, words * 5 // 4).reshape(-1, 5)
+        out[:, :4] = (w & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        hi = (w >> np.uint64(32)).astype(np.uint32)
+        assert (hi < 256).all()
+        out[:, 4] = hi[:, 0] | (hi[:, 1] << 8) | (hi[:, 2] << 16) | (hi[:, 3] << 24)
+
+    def unpack40_async(self, packed_ptr, words_ptr, words, stream=0):
+        p = _view32(packed_ptr, words * 5 // 4).reshape(-1, 5)
+        w = _view(words_ptr, words).reshape(-1, 4)
+        for i in range(4):
+            w[:, i] = p[:, i].astype(np.uint64) | (((p[:, 4] >> (8 * i)) & 0xFF).astype(np.uint64) << np.uint64(32))
+
     def sync(self):
         pass
 
@@ -230,11 +252,20 @@ def rows_step_check(rank, world, d, dbsize, elem, batch, zero_pt=None):
     if d == 2:
         assert D.packed_exchange_supported(srv, dist, world, comm, torch, "cpu")
         bufs = D.PackedBuffers(srv, batch, rank, world, torch, "cpu")
+        ok &= bufs.rows40                                      # 36-bit moduli: row selectors cross in 5 bytes
         D.run_batch_rows_packed(srv, bufs, dist, rank, world, comm)
         mine = bufs.replies.numpy().view(np.uint64)
         for i in range(lo, hi):                                # rank r ends with the replies of ITS queries
             ok &= bool(np.array_equal(mine[i - lo], full[i]))
             ok &= s.client.process_response(p, indexes[i], mine[i - lo]) == s.item(indexes[i])
+        os.environ["PIRGPU_ROWS_PACK40"] = "0"                 # ... and the same step with u64 row selectors
+        try:
+            bufs8 = D.PackedBuffers(srv, batch, rank, world, torch, "cpu")
+        finally:
+            del os.environ["PIRGPU_ROWS_PACK40"]
+        ok &= not bufs8.rows40 and bufs8.exchange_bytes_per_query(world) > bufs.exchange_bytes_per_query(world)
+        D.run_batch_rows_packed(srv, bufs8, dist, rank, world, comm)
+        ok &= bool(np.array_equal(bufs8.replies.numpy(), bufs.replies.numpy()))
         # the PIPELINED step (RowsPipeline): three consecutive steps over different queries -- step t serves the staged
         # queries [t * batch, (t + 1) * batch); the multiply + reduce of step t are queued by submit t + 1 (or flush),
         # the two buffer sets alternate, every rank checks the replies of ITS queries of every step

@@ -52,3 +52,56 @@ def test_launcher_environment_detection():
     assert launcher.launched_by_a_launcher({"RANK": "0", "WORLD_SIZE": "2"})
     assert not launcher.launched_by_a_launcher({"WORLD_SIZE": "2"})
     assert not launcher.launched_by_a_launcher({})
+
+
+def test_bench_output_stage_does_not_shadow_the_measurement_state():
+    """bench.py assembles its JSON line in a nested function that reads the measurement's variables of main() through
+    its closure.  An assignment to one of those names inside that function makes the name LOCAL to it and the line fails
+    with UnboundLocalError -- only in the runs that reach the affected branch (round 3: `bufs`, read only by multi-rank
+    runs with the packed exchange, i.e. never on the builder's one-GPU boxes).  Static check: the function assigns none
+    of the names main() assigns."""
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main")
+
+    def targets(node, skip_nested):
+        names = set()
+
+        class V(ast.NodeVisitor):
+            def visit_FunctionDef(self, n):
+                if not skip_nested:
+                    self.generic_visit(n)
+
+            def _add(self, t):
+                for x in ast.walk(t):
+                    if isinstance(x, ast.Name):
+                        names.add(x.id)
+
+            def visit_Assign(self, n):
+                for t in n.targets:
+                    self._add(t)
+                self.generic_visit(n)
+
+            def visit_AugAssign(self, n):
+                self._add(n.target)
+                self.generic_visit(n)
+
+            def visit_For(self, n):
+                self._add(n.target)
+                self.generic_visit(n)
+
+            def visit_With(self, n):
+                for it in n.items:
+                    if it.optional_vars is not None:
+                        self._add(it.optional_vars)
+                self.generic_visit(n)
+
+        v = V()
+        for child in node.body:
+            v.visit(child)
+        return names
+
+    emit_line = next(n for n in ast.walk(main) if isinstance(n, ast.FunctionDef) and n.name == "emit_line")
+    shadowed = targets(emit_line, skip_nested=False) & targets(main, skip_nested=True)
+    assert shadowed <= {"t0", "_"}, shadowed      # t0: a timer both use locally; _: loop dummies -- never read across

@@ -615,7 +615,9 @@ def main():
     deadline = [None]
 
     cut_off_note = ("what runs after the first complete headline measurement (second candidate form / reference legs) "
-                    "exceeded its time budget and was cut off; the headline above is complete")
+                    "exceeded its time budget and was cut off; the headline above is complete; every rank exits with "
+                    "code 3 (a collective that never completed is a failed job, whatever was measured before it)")
+    STALLED_EXIT = 3        # the watchdog's exit code: rank 0 prints its line first, then every rank leaves non-zero
 
     def past_deadline():
         return aborting.is_set() or (deadline[0] is not None and time.monotonic() > deadline[0])
@@ -625,7 +627,7 @@ def main():
         # main thread sat in a wait that holds the interpreter lock may get here before its own timer could run)
         if past_deadline():
             emit(cut_off_note)
-            os._exit(0)
+            os._exit(STALLED_EXIT)
 
     def arm_watchdog():
         if not (use_dist and world > 1) or watchdog:
@@ -637,7 +639,7 @@ def main():
             if rank == 0:
                 emit(cut_off_note)
                 time.sleep(6.0)   # the other ranks leave on their own timers (5 s later) while this one still answers
-            os._exit(0)
+            os._exit(STALLED_EXIT)
 
         deadline[0] = time.monotonic() + budget
         watchdog.append(threading.Timer(budget + (0.0 if rank == 0 else 5.0), _abort))   # rank 0 prints first
@@ -822,7 +824,7 @@ def main():
         w_.cancel()
     emit()
     if late:
-        os._exit(0)          # past the watchdog's deadline ranks may already have left: no final barrier
+        os._exit(STALLED_EXIT)   # past the watchdog's deadline ranks may already have left: no final barrier
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -64,6 +64,7 @@ class Comm:
     # and up wrong from the middle on); larger messages are cut into pieces at sub-block boundaries.  Real 8-GPU
     # steps stay far below (21 MB per peer at cfg 3); a forced single-rank run of the same step does not.
     MAX_MESSAGE_BYTES = 512 << 20
+    HARD_MESSAGE_BYTES = 1 << 30     # above this a single RCCL message is not trusted at all (all_to_all raises)
 
     def __init__(self, dist, world: int, host_sync: bool = True, group=None):
         """world: ranks taking part (the size of `group`, a torch.distributed process group; None = the default one)."""
@@ -115,9 +116,16 @@ class Comm:
         if self.device_native:
             limit = max(1, self.MAX_MESSAGE_BYTES // recv.element_size())
             biggest = max(max(recv_splits), max(send_splits))
-            pieces = min(max(1, units), -(-biggest // limit))
+            need = -(-biggest // limit)                      # pieces a per-peer block has to be cut into
+            pieces = min(max(1, units), need)
             if pieces > 1 and any(x % units for x in list(recv_splits) + list(send_splits)):
                 raise ValueError("all_to_all: split sizes must be multiples of `units` to be exchanged in pieces")
+            # a block can only be cut at sub-block boundaries: refuse a message that would still exceed what RCCL
+            # moves correctly (2.26.6 silently corrupts single messages above 1 GiB) instead of sending it
+            hard = max(1, self.HARD_MESSAGE_BYTES // recv.element_size())
+            if -(-biggest // max(1, units)) * -(-max(1, units) // pieces) > hard:
+                raise ValueError("all_to_all: a per-peer block of %d elements cannot be cut into pieces of at most %d "
+                                 "elements at its %d sub-block boundaries (HARD_MESSAGE_BYTES)" % (biggest, hard, max(1, units)))
             if pieces <= 1:
                 d.all_to_all_single(recv, send, list(recv_splits), list(send_splits), group=self.group)
             else:
@@ -407,7 +415,10 @@ class RowsPipeline:
     streams and the communication stream are ordered with events (pirgpu_join / pirgpu_fork on the library side,
     ExternalStream / wait_stream on ours); nothing in submit() blocks the host under RCCL.  Reply i of a step still
     answers query i (reference server.cpp:60-63): rank r ends with the replies of the queries it expanded, in
-    `replies(step)`, valid once the step has been flushed or two later steps have been submitted.
+    `replies(step)`.  submit() only QUEUES work (the reduce of a step runs on the communication stream, which the
+    caller's stream does not follow), and the reduce of step s + 2 overwrites the buffer of step s: the replies of a
+    step are valid -- and must be consumed -- after `flush()` and before the next-but-one submit; flush() is the only
+    safe point.
 
     submit(first) expands the staged queries [first + rank * per, first + (rank + 1) * per) -- with several batches
     staged back to back, consecutive steps can serve different queries."""

@@ -1,7 +1,7 @@
 """Self-launch of a one-process-per-GPU job on ONE node: `python bench.py --gpus N` (no launcher environment) starts
 N fresh rank processes itself instead of silently running one.
 
-The parent never touches a GPU (it only counts devices, which does not initialise HIP): every rank is a fresh child
+The parent never touches a GPU (devices are counted from sysfs, not through HIP): every rank is a fresh child
 process with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set the way `torch.distributed.run` sets them,
 so the same script runs unchanged under either launcher.  Rank 0's stdout is relayed (the single JSON line), every
 rank's stderr passes through, and the parent's exit code is non-zero as soon as any rank fails -- the surviving ranks
@@ -28,10 +28,46 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
-def visible_gpus() -> int:
-    """Devices this process could use; counting them does not initialise the GPU runtime."""
-    import torch
-    return int(torch.cuda.device_count())
+def _kfd_gpu_nodes(topology: str = "/sys/class/kfd/kfd/topology/nodes") -> Optional[int]:
+    """GPU agents the kernel driver exposes (KFD topology nodes with SIMDs), or None if there is no KFD sysfs tree."""
+    if not os.path.isdir(topology):
+        return None
+    gpus = 0
+    for node in os.listdir(topology):
+        try:
+            with open(os.path.join(topology, node, "properties")) as f:
+                props = dict(line.split(None, 1) for line in f if " " in line)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0").strip() or 0) > 0:
+            gpus += 1
+    return gpus
+
+
+def visible_gpus(environ=os.environ) -> int:
+    """Devices a rank of this job could use, counted WITHOUT a GPU runtime in this process: the KFD topology in sysfs
+    narrowed by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES (the runtime applies them in that
+    order); where sysfs has no KFD tree, a short-lived child process asks torch, so that the parent still never
+    initialises HIP next to its N rank children."""
+    have = _kfd_gpu_nodes()
+    if have is None:
+        try:
+            out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                                 capture_output=True, text=True, timeout=300, env=dict(environ))
+            return int(out.stdout.strip().splitlines()[-1])
+        except Exception:       # noqa: BLE001 -- no torch / no runtime: nothing usable
+            return 0
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if var in environ:
+            listed = [x for x in environ[var].split(",") if x.strip() != ""]
+            # an entry that is not a valid index / UUID ends the list (runtime semantics): count up to the first "-1"
+            usable = 0
+            for x in listed:
+                if x.strip() == "-1":
+                    break
+                usable += 1
+            have = min(have, usable)
+    return have
 
 
 def spawn_ranks(command: Sequence[str], n: int, *, check_devices: bool = True, stdout=None, stderr=None,

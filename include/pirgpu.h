@@ -142,7 +142,12 @@ int pirgpu_clear_galois_keys(pirgpu_ctx* ctx);
  *   keyset_release  empties a slot.
  *   query_use_keyset  slot for pirgpu_process_query / query_run / expand / substitute (default 0).
  *   batch_set_keysets one slot per staged query of the batch (after pirgpu_batch_stage, which resets them to 0).
- *   keyset_stats    [0] resident sets, [1] keys uploaded so far, [2] evictions, [3] capacity. */
+ *   keyset_stats    [0] resident sets, [1] keys uploaded so far, [2] evictions, [3] capacity.
+ * A `slot` is a HANDLE: slot index + the generation of the set living there (0 = the default set).  Once a set has been
+ * evicted or released, every entry point that is given its old handle fails with FailedPrecondition ("stale key set
+ * handle") instead of switching a query with whichever client's keys moved in -- claim it again.  keyset_claim never
+ * evicts a set that requests in flight are using, nor one that a staged batch (batch_set_keysets) or query_use_keyset
+ * still names: re-stage, pirgpu_batch_unstage or select another set first (FailedPrecondition when nothing is left). */
 int pirgpu_set_keyset_capacity(pirgpu_ctx* ctx, uint32_t capacity);
 int pirgpu_keyset_lookup(pirgpu_ctx* ctx, const uint8_t* id, size_t id_len, int verify, uint32_t* slot);
 int pirgpu_keyset_verify(pirgpu_ctx* ctx, uint32_t slot, const uint8_t* id, size_t id_len);
@@ -184,6 +189,18 @@ int pirgpu_sync(pirgpu_ctx* ctx);
 int pirgpu_set_concurrency(pirgpu_ctx* ctx, uint32_t n_workers);
 int pirgpu_batch_stage(pirgpu_ctx* ctx, const uint64_t* queries, uint32_t nq, uint32_t count);
 int pirgpu_batch_run(pirgpu_ctx* ctx);
+/* batch_stage without the wait: `pinned_queries` (pirgpu_host_query_buffer, or any pinned memory that stays untouched
+ * until the batch has run) goes up in pieces of 8 queries, and each group of a later pirgpu_batch_run waits -- on the
+ * device -- only for the pieces that hold its queries.  batch_unstage forgets the staged queries (and with them the
+ * references to key sets that pirgpu_batch_set_keysets left).
+ * A context has TWO independent sets of batch state (staged queries, replies, their key sets, the host-reply target and
+ * its group events, pinned staging): pirgpu_batch_select picks the set the CALLING THREAD's later pirgpu_batch_* /
+ * pirgpu_host_*_buffer calls work on (default 0).  Lanes and streams are shared, so batches run from the two sets
+ * execute back to back in the order they were queued: one can be parsed, staged and queued while the other is still on
+ * the GPU or on its way back to the host (what pirgpu_process_request(s) do with two request windows in flight). */
+int pirgpu_batch_stage_async(pirgpu_ctx* ctx, const uint64_t* pinned_queries, uint32_t nq, uint32_t count);
+int pirgpu_batch_unstage(pirgpu_ctx* ctx);
+int pirgpu_batch_select(pirgpu_ctx* ctx, uint32_t which);
 int pirgpu_batch_fetch(pirgpu_ctx* ctx, uint64_t* replies, uint64_t reply_capacity, uint64_t* reply_count);
 /* Replies on their way to the host while the batch is still running: with a PINNED host buffer set here (capacity in
  * ciphertexts; NULL switches it off), every group of a batch that fits it downloads its replies on its own stream as soon
@@ -300,9 +317,12 @@ int pirgpu_process_request(pirgpu_ctx* ctx, const uint8_t* request, size_t reque
  * among / installed into the resident key sets, all queries go through the batch pipeline as one batch (groups of 8
  * expanded together, each query with its own client's keys, one database pass per group), responses[i] answers
  * requests[i].  status[i] = what pirgpu_process_request would have returned for request i (a failing request does not
- * affect the others); the return value is the first non-zero status.  Threads that call pirgpu_process_request
- * concurrently on one context are combined the same way: requests that arrive while another is being served are
- * served together by the next thread that gets the context.  Host staging buffers the wire layer uses (pinned). */
+ * affect the others); the return value is the first non-zero status.  The requests are served in WINDOWS of at most 64
+ * queries and capacity / 2 clients (pirgpu_set_keyset_capacity), two windows in flight: the next one is parsed, staged
+ * and queued while the previous one's groups are still on the GPU and its replies are being downloaded and serialised.
+ * Threads that call pirgpu_process_request(s) concurrently on one context share those two slots: requests that arrive
+ * while both are taken are queued and served together by the next thread that gets one.  Host staging buffers the wire
+ * layer uses (pinned, one pair per batch set). */
 int pirgpu_process_requests(pirgpu_ctx* ctx, uint32_t n, const uint8_t* const* requests, const size_t* request_lens,
                             uint8_t** responses, size_t* response_lens, int* status);
 /* Message of request i of the calling thread's last pirgpu_process_requests call ("" if it succeeded). */

@@ -95,6 +95,9 @@ SIGNATURES = {
     "pirgpu_keyset_set_key": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, u64p]),
     "pirgpu_query_use_keyset": (C.c_int, [C.c_void_p, C.c_uint32]),
     "pirgpu_batch_set_keysets": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]),
+    "pirgpu_batch_stage_async": (C.c_int, [C.c_void_p, u64p, C.c_uint32, C.c_uint32]),
+    "pirgpu_batch_unstage": (C.c_int, [C.c_void_p]),
+    "pirgpu_batch_select": (C.c_int, [C.c_void_p, C.c_uint32]),
     "pirgpu_keyset_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "pirgpu_process_requests": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),

@@ -116,7 +116,46 @@ struct KeySet {
   std::vector<uint8_t> blob;            // wire layer: the serialized GaloisKeys object these keys came from
   uint64_t fingerprint = 0;             // sampled hash of `blob` (candidate selection before the full compare)
   uint64_t last_use = 0;
+  uint32_t gen = 0;                     // bumped whenever the slot is emptied: a handle of an earlier tenant goes stale
+  uint32_t pins = 0;                    // pirgpu_keyset_pin: requests in flight that use this set (never evicted meanwhile)
 };
+
+// What the ABI hands out for a key set: (generation << 12) | slot index.  Slot 0 (pirgpu_set_galois_key's set) has the
+// handle 0.  A handle whose generation no longer matches names a set that was evicted or released since -- every entry
+// point that takes one fails with FailedPrecondition instead of silently switching with another client's keys.
+constexpr uint32_t kSlotBits = 12;
+constexpr uint32_t kSlotMask = (1u << kSlotBits) - 1;
+
+// One set of batch state: the staged queries and the replies of one batch (device resident), where its replies go,
+// its per-query key sets and its pinned host staging.  A context has kBatchSets of them so that two request windows
+// can be in flight -- the next one parsed / staged / queued while the previous one's replies are still coming back
+// (wire.cpp); lanes, workers and streams are shared, their use is ordered by the streams themselves.
+constexpr int kBatchSets = 2;
+struct BatchSet {
+  uint64_t *d_bquery = nullptr, *d_breply = nullptr;
+  uint64_t* ext_reply = nullptr;   // pirgpu_batch_set_reply_buffer: the caller's device buffer batches write replies to
+  uint64_t ext_reply_cts = 0;      // its capacity in ciphertexts
+  uint64_t* host_reply = nullptr;  // pirgpu_batch_set_host_replies: pinned host memory every group downloads its replies to
+  uint64_t host_reply_cts = 0;     // ... its capacity in ciphertexts
+  bool host_reply_done = false;    // the batch that just ran queued those downloads: batch_fetch into it only waits
+  uint32_t batch_cap = 0, batch_count = 0;   // batch_count: replies the reply buffer holds
+  uint32_t staged_count = 0;   // queries pirgpu_batch_stage left in d_bquery (0 again when the buffers are reallocated)
+  bool batch_valid = false;
+  std::vector<uint32_t> batch_keysets;      // key set INDEX per staged query (all 0 unless pirgpu_batch_set_keysets)
+  // pirgpu_batch_stage_async: the queries arrive in pieces of kStagePiece queries on the main stream, one event each;
+  // a group waits for the pieces that hold its queries instead of the whole upload
+  std::vector<hipEvent_t> st_events;
+  uint32_t st_pieces = 0;          // 0: staged synchronously, nothing to wait for
+  // group-wise reply download (pirgpu_batch_set_host_replies): one event per group of the batch that just ran, recorded
+  // behind the group's device-to-host copy; dl_end[i] = one past the last query of group i, dl_next = next to report
+  std::vector<hipEvent_t> dl_events;
+  std::vector<uint32_t> dl_end;
+  size_t dl_next = 0;
+  uint64_t *h_query = nullptr, *h_reply = nullptr;   // pinned host staging of the wire layer
+  size_t h_query_words = 0, h_reply_words = 0;
+};
+constexpr uint32_t kStagePiece = 8;
+static thread_local int t_batch_set = 0;   // pirgpu_batch_select
 
 struct pirgpu_ctx {
   pirgpu_params prm{};
@@ -147,9 +186,7 @@ struct pirgpu_ctx {
   std::vector<KeySet> keysets{1};           // resident key sets; [0] = pirgpu_set_galois_key's
   uint32_t keyset_cap = 64;                 // client slots (pirgpu_set_keyset_capacity); 4.7 MB each at N = 4096, k = 2
   uint32_t cur_keyset = 0;                  // slot the single-query entry points use (pirgpu_query_use_keyset)
-  std::vector<uint32_t> batch_keysets;      // per staged query of the batch (all 0 unless pirgpu_batch_set_keysets)
   uint64_t keyset_clock = 0, key_uploads = 0, keyset_evictions = 0;
-  uint64_t keyset_pin = UINT64_MAX;         // sets touched after this clock value belong to the requests being processed
   std::vector<uint64_t*> key_pool;          // device key buffers of emptied sets, reused by the next upload (no hipMalloc)
   uint64_t* d_key_stage = nullptr;          // one key in SEAL order on its way to device order (allocated once)
   std::map<uint32_t, uint64_t*> xpow;       // shift -> NTT_j(x^(-shift)), [k][N] doubles (NTT-domain last expansion level)
@@ -161,16 +198,11 @@ struct pirgpu_ctx {
   std::vector<uint64_t> lvl_cts;   // ciphertexts per level result buffer
   uint64_t m_max = 1;              // expansion tree width (ciphertexts)
   uint64_t pt_words = 0;
-  // batch mode (pirgpu_batch_*): queries and replies of one batch, device resident
-  uint64_t *d_bquery = nullptr, *d_breply = nullptr;
-  uint64_t* ext_reply = nullptr;   // pirgpu_batch_set_reply_buffer: the caller's device buffer batches write replies to
-  uint64_t* host_reply = nullptr;  // pirgpu_batch_set_host_replies: pinned host memory every group downloads its replies to
-  uint64_t host_reply_cts = 0;     // ... its capacity in ciphertexts
-  bool host_reply_done = false;    // the batch that just ran queued those downloads: batch_fetch into it only waits
-  uint64_t ext_reply_cts = 0;      // its capacity in ciphertexts
-  uint32_t batch_cap = 0, batch_count = 0, n_active = 1;   // batch_count: replies the reply buffer holds
-  uint32_t staged_count = 0;   // queries pirgpu_batch_stage left in d_bquery (0 again when the buffers are reallocated)
-  bool batch_valid = false;
+  // batch mode (pirgpu_batch_*): kBatchSets independent sets of batch state (BatchSet above); the calling thread's
+  // pirgpu_batch_select picks the one its pirgpu_batch_* calls operate on (default 0)
+  BatchSet sets[kBatchSets];
+  BatchSet& bs();
+  uint32_t n_active = 1;
   uint32_t upper_blocks = 512;   // target workgroup count of upper_fused_kernel (PIRGPU_UPPER_BLOCKS)
   uint32_t upper_blocks_batch = 64;   // the same per query in batch mode, where other queries fill the chip too: fewer
                                       // chunks = fewer partial sums to write and fold (PIRGPU_UPPER_BLOCKS_BATCH)
@@ -212,13 +244,6 @@ struct pirgpu_ctx {
   uint64_t groups_run = 0;
   hipEvent_t ev_fork = nullptr;             // pirgpu_fork: the main stream's position
   hipEvent_t ev_main_join = nullptr;        // pirgpu_join_stream onto a caller's stream: the main stream's position
-  // group-wise reply download (pirgpu_batch_set_host_replies): one event per group of the batch that just ran, recorded
-  // behind the group's device-to-host copy; dl_end[i] = one past the last query of group i, dl_next = next to report
-  std::vector<hipEvent_t> dl_events;
-  std::vector<uint32_t> dl_end;
-  size_t dl_next = 0;
-  uint64_t *h_query = nullptr, *h_reply = nullptr;   // pinned host staging of the wire layer
-  size_t h_query_words = 0, h_reply_words = 0;
 
   bool prof = false;
   static constexpr int kMaxProfRuns = 256;
@@ -246,6 +271,8 @@ struct pirgpu_ctx {
   }
   void use_device() { HIP_TRY(hipSetDevice(device)); }
 };
+
+BatchSet& pirgpu_ctx::bs() { return sets[t_batch_set]; }
 
 namespace {
 
@@ -915,6 +942,9 @@ void run_staged(pirgpu_ctx* c, Worker& w, bool profile) {
   record(c, w, PH_COUNT);
   c->prof_cur = -1;
   w.reply_valid = true;
+  // a batch group that borrows this worker's selection vector next (on a lane's stream, possibly queued by another
+  // thread before this query has been fetched) waits for this point
+  HIP_TRY(hipEventRecord(w.ev_done, w.stream));
 }
 
 }  // namespace
@@ -1031,8 +1061,12 @@ void pirgpu_destroy(pirgpu_ctx* c) {
     for (auto& kv : ks.keys) (void)hipFree(kv.second);
   for (uint64_t* p : c->key_pool) (void)hipFree(p);
   for (void* p : c->allocs) (void)hipFree(p);
-  if (c->h_query) (void)hipHostFree(c->h_query);
-  if (c->h_reply) (void)hipHostFree(c->h_reply);
+  for (BatchSet& b : c->sets) {
+    if (b.h_query) (void)hipHostFree(b.h_query);
+    if (b.h_reply) (void)hipHostFree(b.h_reply);
+    for (hipEvent_t e : b.dl_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : b.st_events) (void)hipEventDestroy(e);
+  }
   for (auto& e : c->ev) (void)hipEventDestroy(e);
   for (Worker& w : c->workers) {
     if (w.ev_expanded) (void)hipEventDestroy(w.ev_expanded);
@@ -1047,7 +1081,6 @@ void pirgpu_destroy(pirgpu_ctx* c) {
   }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_main_join) (void)hipEventDestroy(c->ev_main_join);
-  for (hipEvent_t e : c->dl_events) (void)hipEventDestroy(e);
   for (size_t i = 1; i < c->workers.size(); ++i)
     if (c->workers[i].stream) (void)hipStreamDestroy(c->workers[i].stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1349,6 +1382,19 @@ static void clear_keyset(pirgpu_ctx* c, uint32_t slot) {
   }
   ks.blob.clear();
   ks.fingerprint = 0;
+  if (slot) ks.gen = (ks.gen + 1) & ((1u << (32 - kSlotBits)) - 1);   // handles of the previous tenant go stale
+}
+
+static uint32_t slot_handle(const pirgpu_ctx* c, uint32_t index) { return index ? (c->keysets[index].gen << kSlotBits) | index : 0; }
+
+// Handle -> slot index; FailedPrecondition for a handle whose set was evicted or released since it was handed out.
+static uint32_t resolve_slot(pirgpu_ctx* c, uint32_t handle) {
+  const uint32_t index = handle & kSlotMask;
+  if (index >= c->keysets.size()) throw Fail{PIRGPU_INVALID_ARGUMENT, "key set slot out of range"};
+  if (index && c->keysets[index].gen != handle >> kSlotBits)
+    throw Fail{PIRGPU_FAILED_PRECONDITION, "stale key set handle: the set was evicted or released (claim it again)"};
+  if (!index && handle) throw Fail{PIRGPU_INVALID_ARGUMENT, "key set slot out of range"};
+  return index;
 }
 
 // cheap candidate filter before the byte-for-byte compare: length + 64 words sampled across the blob
@@ -1383,10 +1429,16 @@ int pirgpu_clear_galois_keys(pirgpu_ctx* c) {
 int pirgpu_set_keyset_capacity(pirgpu_ctx* c, uint32_t slots) {
   return guarded(c, [&]() -> int {
     if (slots < 1 || slots > 1024) return fail(c, PIRGPU_INVALID_ARGUMENT, "key set capacity must be in [1, 1024]");
+    for (size_t i = (size_t)slots + 1; i < c->keysets.size(); ++i)
+      if (c->keysets[i].pins) return fail(c, PIRGPU_FAILED_PRECONDITION, "a key set beyond the new capacity is in use by requests in flight");
     while (c->keysets.size() > (size_t)slots + 1) {   // shrinking drops the highest slots
       clear_keyset(c, (uint32_t)c->keysets.size() - 1);
       c->keysets.pop_back();
     }
+    for (BatchSet& b : c->sets)                        // staged queries that named a dropped slot fall back to set 0
+      for (uint32_t& ix : b.batch_keysets)
+        if (ix >= c->keysets.size()) ix = 0;
+    if (c->cur_keyset >= c->keysets.size()) c->cur_keyset = 0;
     c->keyset_cap = slots;
     return PIRGPU_OK;
   });
@@ -1402,7 +1454,7 @@ int pirgpu_keyset_lookup(pirgpu_ctx* c, const uint8_t* blob, size_t len, int ver
       KeySet& ks = c->keysets[i];
       if (ks.fingerprint == fp && ks.blob.size() == len && (!verify || memcmp(ks.blob.data(), blob, len) == 0)) {
         ks.last_use = ++c->keyset_clock;
-        *slot = i;
+        *slot = slot_handle(c, i);
         break;
       }
     }
@@ -1413,8 +1465,9 @@ int pirgpu_keyset_lookup(pirgpu_ctx* c, const uint8_t* blob, size_t len, int ver
 int pirgpu_keyset_verify(pirgpu_ctx* c, uint32_t slot, const uint8_t* blob, size_t len) {
   if (!c || !blob) return 0;
   std::lock_guard<std::recursive_mutex> lock(c->mu);
-  if (slot == 0 || slot >= c->keysets.size()) return 0;
-  const KeySet& ks = c->keysets[slot];
+  const uint32_t index = slot & kSlotMask;
+  if (index == 0 || index >= c->keysets.size() || c->keysets[index].gen != slot >> kSlotBits) return 0;
+  const KeySet& ks = c->keysets[index];
   return ks.blob.size() == len && memcmp(ks.blob.data(), blob, len) == 0 ? 1 : 0;
 }
 
@@ -1422,9 +1475,18 @@ size_t pirgpu_keyset_blob(pirgpu_ctx* c, uint32_t slot, const uint8_t** blob) {
   if (blob) *blob = nullptr;
   if (!c || !blob) return 0;
   std::lock_guard<std::recursive_mutex> lock(c->mu);
-  if (slot == 0 || slot >= c->keysets.size()) return 0;
-  *blob = c->keysets[slot].blob.data();
-  return c->keysets[slot].blob.size();
+  const uint32_t index = slot & kSlotMask;
+  if (index == 0 || index >= c->keysets.size() || c->keysets[index].gen != slot >> kSlotBits) return 0;
+  *blob = c->keysets[index].blob.data();
+  return c->keysets[index].blob.size();
+}
+
+// A set some staged batch or the single-query selection still names must not change tenant under it.
+static bool slot_referenced(const pirgpu_ctx* c, uint32_t index) {
+  if (c->cur_keyset == index) return true;
+  for (const BatchSet& b : c->sets)
+    if (b.staged_count && std::find(b.batch_keysets.begin(), b.batch_keysets.end(), index) != b.batch_keysets.end()) return true;
+  return false;
 }
 
 int pirgpu_keyset_claim(pirgpu_ctx* c, const uint8_t* blob, size_t len, uint32_t* slot) {
@@ -1432,15 +1494,16 @@ int pirgpu_keyset_claim(pirgpu_ctx* c, const uint8_t* blob, size_t len, uint32_t
     if (!slot || (!blob && len)) return fail(c, PIRGPU_INVALID_ARGUMENT, "null buffer");
     uint32_t pick = 0;
     for (uint32_t i = 1; i < c->keysets.size() && !pick; ++i)
-      if (c->keysets[i].keys.empty() && c->keysets[i].blob.empty()) pick = i;
+      if (c->keysets[i].keys.empty() && c->keysets[i].blob.empty() && !c->keysets[i].pins) pick = i;
     if (!pick && c->keysets.size() < (size_t)c->keyset_cap + 1) {
       c->keysets.emplace_back();
       pick = (uint32_t)c->keysets.size() - 1;
     }
-    if (!pick) {   // least recently used, but never a set the requests being processed already refer to
+    if (!pick) {   // least recently used -- never a set that requests in flight are pinned to, nor one that a staged
+                   // batch or the single-query selection still refers to (the direct API: ADVICE round 3)
       uint64_t best = UINT64_MAX;
       for (uint32_t i = 1; i < c->keysets.size(); ++i)
-        if (c->keysets[i].last_use < best && c->keysets[i].last_use <= c->keyset_pin) {
+        if (c->keysets[i].last_use < best && !c->keysets[i].pins && !slot_referenced(c, i)) {
           best = c->keysets[i].last_use;
           pick = i;
         }
@@ -1456,46 +1519,71 @@ int pirgpu_keyset_claim(pirgpu_ctx* c, const uint8_t* blob, size_t len, uint32_t
       ks.fingerprint = blob_fingerprint(blob, len);
     }
     ks.last_use = ++c->keyset_clock;
-    *slot = pick;
+    *slot = slot_handle(c, pick);
     return PIRGPU_OK;
   });
 }
 
 int pirgpu_keyset_release(pirgpu_ctx* c, uint32_t slot) {
   return guarded(c, [&]() -> int {
-    if (slot == 0 || slot >= c->keysets.size()) return fail(c, PIRGPU_INVALID_ARGUMENT, "key set slot out of range");
-    clear_keyset(c, slot);
+    const uint32_t index = resolve_slot(c, slot);
+    if (index == 0) return fail(c, PIRGPU_INVALID_ARGUMENT, "key set slot out of range");
+    if (c->keysets[index].pins) return fail(c, PIRGPU_FAILED_PRECONDITION, "the key set is in use by requests in flight");
+    clear_keyset(c, index);
+    for (BatchSet& b : c->sets)                        // nothing staged may keep pointing at the emptied slot
+      for (uint32_t& ix : b.batch_keysets)
+        if (ix == index) ix = 0;
+    if (c->cur_keyset == index) c->cur_keyset = 0;
     return PIRGPU_OK;
   });
 }
 
 int pirgpu_keyset_set_key(pirgpu_ctx* c, uint32_t slot, uint32_t g, const uint64_t* key) {
   return guarded(c, [&]() -> int {
-    upload_key(c, slot, g, key);
+    upload_key(c, resolve_slot(c, slot), g, key);
     return PIRGPU_OK;
   });
+}
+
+int pirgpu_keyset_pin(pirgpu_ctx* c, uint32_t slot) {
+  return guarded(c, [&]() -> int {
+    const uint32_t index = resolve_slot(c, slot);
+    if (index) ++c->keysets[index].pins;
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_keyset_unpin(pirgpu_ctx* c, uint32_t slot) {
+  if (!c) return PIRGPU_INVALID_ARGUMENT;
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  const uint32_t index = slot & kSlotMask;   // a pinned set cannot have changed generation
+  if (index && index < c->keysets.size() && c->keysets[index].pins) --c->keysets[index].pins;
+  return PIRGPU_OK;
 }
 
 uint32_t pirgpu_current_keyset(pirgpu_ctx* c) {
   if (!c) return 0;
   std::lock_guard<std::recursive_mutex> lock(c->mu);
-  return c->cur_keyset;
+  return slot_handle(c, c->cur_keyset);
 }
 
 int pirgpu_query_use_keyset(pirgpu_ctx* c, uint32_t slot) {
   return guarded(c, [&]() -> int {
-    if (slot >= c->keysets.size()) return fail(c, PIRGPU_INVALID_ARGUMENT, "key set slot out of range");
-    c->cur_keyset = slot;
+    const uint32_t index = resolve_slot(c, slot);
+    c->cur_keyset = index;
+    c->keysets[index].last_use = ++c->keyset_clock;
     return PIRGPU_OK;
   });
 }
 
 int pirgpu_batch_set_keysets(pirgpu_ctx* c, const uint32_t* slots, uint32_t count) {
   return guarded(c, [&]() -> int {
-    if (!slots || count != c->staged_count) return fail(c, PIRGPU_INVALID_ARGUMENT, "one key set slot per staged query");
-    for (uint32_t i = 0; i < count; ++i)
-      if (slots[i] >= c->keysets.size()) return fail(c, PIRGPU_INVALID_ARGUMENT, "key set slot out of range");
-    c->batch_keysets.assign(slots, slots + count);
+    if (!slots || count != c->bs().staged_count) return fail(c, PIRGPU_INVALID_ARGUMENT, "one key set slot per staged query");
+    std::vector<uint32_t> idx(count);
+    for (uint32_t i = 0; i < count; ++i) idx[i] = resolve_slot(c, slots[i]);
+    ++c->keyset_clock;
+    for (uint32_t i = 0; i < count; ++i) c->keysets[idx[i]].last_use = c->keyset_clock;
+    c->bs().batch_keysets = std::move(idx);
     return PIRGPU_OK;
   });
 }
@@ -1513,15 +1601,10 @@ int pirgpu_keyset_stats(pirgpu_ctx* c, uint64_t stats[4]) {
   });
 }
 
-void pirgpu_keyset_pin_begin(pirgpu_ctx* c) {
-  if (!c) return;
-  std::lock_guard<std::recursive_mutex> lock(c->mu);
-  c->keyset_pin = c->keyset_clock;
-}
-void pirgpu_keyset_pin_end(pirgpu_ctx* c) {
-  if (!c) return;
-  std::lock_guard<std::recursive_mutex> lock(c->mu);
-  c->keyset_pin = UINT64_MAX;
+int pirgpu_batch_select(pirgpu_ctx* c, uint32_t which) {
+  if (!c || which >= (uint32_t)kBatchSets) return PIRGPU_INVALID_ARGUMENT;
+  t_batch_set = (int)which;
+  return PIRGPU_OK;
 }
 
 // Pinned host staging owned by the context (the wire layer parses queries straight into it and serialises replies
@@ -1543,7 +1626,7 @@ static uint64_t* host_buffer(pirgpu_ctx* c, uint64_t*& buf, size_t& cap, size_t 
 uint64_t* pirgpu_host_query_buffer(pirgpu_ctx* c, uint32_t count) {
   uint64_t* out = nullptr;
   (void)guarded(c, [&]() -> int {
-    out = host_buffer(c, c->h_query, c->h_query_words, (size_t)std::max<uint32_t>(count, 1) * (c->dim_sum / c->N + 1) * c->ctw);
+    out = host_buffer(c, c->bs().h_query, c->bs().h_query_words, (size_t)std::max<uint32_t>(count, 1) * (c->dim_sum / c->N + 1) * c->ctw);
     return PIRGPU_OK;
   });
   return out;
@@ -1552,7 +1635,7 @@ uint64_t* pirgpu_host_query_buffer(pirgpu_ctx* c, uint32_t count) {
 uint64_t* pirgpu_host_reply_buffer(pirgpu_ctx* c, uint32_t count) {
   uint64_t* out = nullptr;
   (void)guarded(c, [&]() -> int {
-    out = host_buffer(c, c->h_reply, c->h_reply_words, (size_t)std::max<uint32_t>(count, 1) * c->reply_cts * c->ctw);
+    out = host_buffer(c, c->bs().h_reply, c->bs().h_reply_words, (size_t)std::max<uint32_t>(count, 1) * c->reply_cts * c->ctw);
     return PIRGPU_OK;
   });
   return out;
@@ -1633,9 +1716,9 @@ int pirgpu_batch_set_reply_buffer(pirgpu_ctx* c, uint64_t* device_buf, uint64_t 
   return guarded(c, [&]() -> int {
     if (c->in_batch) return fail(c, PIRGPU_FAILED_PRECONDITION, "a batch is being queued");
     if (device_buf && cap == 0) return fail(c, PIRGPU_INVALID_ARGUMENT, "empty reply buffer");
-    c->ext_reply = device_buf;
-    c->ext_reply_cts = device_buf ? cap : 0;
-    c->batch_valid = false;   // replies of an earlier batch live in the other buffer
+    c->bs().ext_reply = device_buf;
+    c->bs().ext_reply_cts = device_buf ? cap : 0;
+    c->bs().batch_valid = false;   // replies of an earlier batch live in the other buffer
     return PIRGPU_OK;
   });
 }
@@ -1643,9 +1726,9 @@ int pirgpu_batch_set_reply_buffer(pirgpu_ctx* c, uint64_t* device_buf, uint64_t 
 int pirgpu_batch_set_host_replies(pirgpu_ctx* c, uint64_t* pinned_host, uint64_t cap) {
   return guarded(c, [&]() -> int {
     if (c->in_batch) return fail(c, PIRGPU_FAILED_PRECONDITION, "a batch is being queued");
-    c->host_reply = pinned_host;
-    c->host_reply_cts = pinned_host ? cap : 0;
-    c->host_reply_done = false;
+    c->bs().host_reply = pinned_host;
+    c->bs().host_reply_cts = pinned_host ? cap : 0;
+    c->bs().host_reply_done = false;
     return PIRGPU_OK;
   });
 }
@@ -1656,14 +1739,14 @@ int pirgpu_batch_next_host_replies(pirgpu_ctx* c, uint32_t* ready) {
   hipEvent_t ev = nullptr;
   uint32_t end = 0;
   int rc = guarded(c, [&]() -> int {
-    if (!c->host_reply_done) return fail(c, PIRGPU_FAILED_PRECONDITION, "the last batch did not download its replies group by group");
-    if (c->dl_next >= c->dl_end.size()) {
-      *ready = c->dl_end.empty() ? 0 : c->dl_end.back();
+    if (!c->bs().host_reply_done) return fail(c, PIRGPU_FAILED_PRECONDITION, "the last batch did not download its replies group by group");
+    if (c->bs().dl_next >= c->bs().dl_end.size()) {
+      *ready = c->bs().dl_end.empty() ? 0 : c->bs().dl_end.back();
       return PIRGPU_OK;
     }
-    ev = c->dl_events[c->dl_next];
-    end = c->dl_end[c->dl_next];
-    ++c->dl_next;
+    ev = c->bs().dl_events[c->bs().dl_next];
+    end = c->bs().dl_end[c->bs().dl_next];
+    ++c->bs().dl_next;
     return PIRGPU_OK;
   });
   if (rc || !ev) return rc;
@@ -1854,13 +1937,13 @@ int pirgpu_set_concurrency(pirgpu_ctx* c, uint32_t n_workers) {
 
 static void ensure_batch_capacity(pirgpu_ctx* c, uint32_t count);
 // Where a batch's replies are written and read: the context's own buffer, or the caller's (pirgpu_batch_set_reply_buffer).
-static inline uint64_t* reply_base(pirgpu_ctx* c) { return c->ext_reply ? c->ext_reply : c->d_breply; }
+static inline uint64_t* reply_base(pirgpu_ctx* c) { return c->bs().ext_reply ? c->bs().ext_reply : c->bs().d_breply; }
 static void check_reply_target(pirgpu_ctx* c, uint64_t count) {
-  if (c->ext_reply && count * c->reply_cts > c->ext_reply_cts)
+  if (c->bs().ext_reply && count * c->reply_cts > c->bs().ext_reply_cts)
     throw Fail{PIRGPU_INVALID_ARGUMENT, "the caller's reply buffer (pirgpu_batch_set_reply_buffer) is too small for this batch"};
 }
 
-int pirgpu_batch_stage(pirgpu_ctx* c, const uint64_t* queries, uint32_t nq, uint32_t count) {
+static int batch_stage_impl(pirgpu_ctx* c, const uint64_t* queries, uint32_t nq, uint32_t count, bool async) {
   return guarded(c, [&]() -> int {
     ensure_workspace(c);
     if (!queries || nq != c->dim_sum / c->N + 1)  // reference server.cpp:154-158
@@ -1868,44 +1951,90 @@ int pirgpu_batch_stage(pirgpu_ctx* c, const uint64_t* queries, uint32_t nq, uint
                   "Number of ciphertexts doesn't match number of items for oblivious expansion.");
     if (count == 0 || count > 4096) return fail(c, PIRGPU_INVALID_ARGUMENT, "batch size must be in [1, 4096]");
     ensure_batch_capacity(c, count);
-    HIP_TRY(hipMemcpyAsync(c->d_bquery, queries, (size_t)count * nq * c->ctw * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    c->batch_count = count;
-    c->staged_count = count;
-    c->batch_keysets.assign(count, 0);   // pirgpu_batch_set_keysets assigns other clients' key sets
-    c->batch_valid = false;
+    BatchSet& b = c->bs();
+    const size_t qwords = (size_t)nq * c->ctw;
+    if (async) {
+      // pieces of kStagePiece queries, one event each: the first group starts as soon as ITS queries are on the device
+      const uint32_t pieces = (count + kStagePiece - 1) / kStagePiece;
+      while (b.st_events.size() < pieces) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        b.st_events.push_back(e);
+      }
+      for (uint32_t p = 0; p < pieces; ++p) {
+        const uint32_t q0 = p * kStagePiece, n = std::min<uint32_t>(kStagePiece, count - q0);
+        HIP_TRY(hipMemcpyAsync(b.d_bquery + (size_t)q0 * qwords, queries + (size_t)q0 * qwords, (size_t)n * qwords * 8,
+                               hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipEventRecord(b.st_events[p], c->stream));
+      }
+      b.st_pieces = pieces;
+    } else {
+      HIP_TRY(hipMemcpyAsync(b.d_bquery, queries, (size_t)count * qwords * 8, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      b.st_pieces = 0;
+    }
+    b.batch_count = count;
+    b.staged_count = count;
+    b.batch_keysets.assign(count, 0);   // pirgpu_batch_set_keysets assigns other clients' key sets
+    b.batch_valid = false;
     return PIRGPU_OK;
   });
+}
+
+int pirgpu_batch_stage(pirgpu_ctx* c, const uint64_t* queries, uint32_t nq, uint32_t count) {
+  return batch_stage_impl(c, queries, nq, count, false);
+}
+
+int pirgpu_batch_stage_async(pirgpu_ctx* c, const uint64_t* pinned_queries, uint32_t nq, uint32_t count) {
+  return batch_stage_impl(c, pinned_queries, nq, count, true);
+}
+
+int pirgpu_batch_unstage(pirgpu_ctx* c) {
+  return guarded(c, [&]() -> int {
+    BatchSet& b = c->bs();
+    b.staged_count = 0;
+    b.batch_keysets.clear();
+    b.st_pieces = 0;
+    return PIRGPU_OK;
+  });
+}
+
+// `stream` waits for the upload of the staged queries [first, first + n) (asynchronously staged batches only)
+static void wait_staged(pirgpu_ctx* c, hipStream_t stream, uint32_t first, uint32_t n) {
+  BatchSet& b = c->bs();
+  if (!b.st_pieces || !n) return;
+  const uint32_t p0 = first / kStagePiece, p1 = std::min<uint32_t>(b.st_pieces - 1, (first + n - 1) / kStagePiece);
+  for (uint32_t p = p0; p <= p1; ++p) HIP_TRY(hipStreamWaitEvent(stream, b.st_events[p], 0));
 }
 
 // Batch staging (queries + replies, device resident) for at least `count` queries.  Growth frees the old pair
 // (after every stream that may still touch it has drained) and at least doubles, so a peer that sends ever
 // larger requests cannot accumulate stale buffers.
 static void ensure_batch_capacity(pirgpu_ctx* c, uint32_t count) {
-  if (count <= c->batch_cap) return;
+  if (count <= c->bs().batch_cap) return;
   const uint32_t nq = c->dim_sum / c->N + 1;
-  const uint32_t old_cap = c->batch_cap;
-  if (c->d_bquery || c->d_breply) {
+  const uint32_t old_cap = c->bs().batch_cap;
+  if (c->bs().d_bquery || c->bs().d_breply) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (BatchLane& ln : c->lanes)
       if (ln.stream) HIP_TRY(hipStreamSynchronize(ln.stream));
     for (Worker& w : c->workers)
       if (w.stream) HIP_TRY(hipStreamSynchronize(w.stream));
-    for (uint64_t* p : {c->d_bquery, c->d_breply}) {
+    for (uint64_t* p : {c->bs().d_bquery, c->bs().d_breply}) {
       if (!p) continue;
       auto it = std::find(c->allocs.begin(), c->allocs.end(), (void*)p);
       if (it != c->allocs.end()) c->allocs.erase(it);
       HIP_TRY(hipFree(p));
     }
-    c->d_bquery = c->d_breply = nullptr;
-    c->batch_cap = 0;
-    c->batch_valid = false;
-    c->staged_count = 0;   // the staged queries went with the old buffer
+    c->bs().d_bquery = c->bs().d_breply = nullptr;
+    c->bs().batch_cap = 0;
+    c->bs().batch_valid = false;
+    c->bs().staged_count = 0;   // the staged queries went with the old buffer
   }
   const uint32_t cap = std::max<uint32_t>(count, std::min<uint32_t>(4096, 2 * old_cap));
-  c->d_bquery = c->dalloc<uint64_t>((size_t)cap * nq * c->ctw);
-  c->d_breply = c->dalloc<uint64_t>((size_t)cap * c->reply_cts * c->ctw);
-  c->batch_cap = cap;
+  c->bs().d_bquery = c->dalloc<uint64_t>((size_t)cap * nq * c->ctw);
+  c->bs().d_breply = c->dalloc<uint64_t>((size_t)cap * c->reply_cts * c->ctw);
+  c->bs().batch_cap = cap;
 }
 
 // Lanes (stream + expansion buffers for up to 8 interleaved queries), created on the first batch.
@@ -1948,17 +2077,18 @@ static void expand_group_on_lane(pirgpu_ctx* c, BatchLane& ln, Worker* const* me
   const uint32_t nq = c->dim_sum / N + 1;
   const size_t ctw = c->ctw, qwords = (size_t)nq * ctw;
   uint64_t remaining = c->dim_sum, produced = 0;
+  wait_staged(c, ln.stream, first, B);
   for (uint32_t qc = 0; qc < nq && remaining; ++qc) {
     const uint32_t slots = (uint32_t)std::min<uint64_t>(remaining, N);
     // the B query ciphertexts, gathered side by side out of the staged batch, become the roots of the B interleaved
     // trees (one strided import launch: no separate 2-D copy)
-    HIP_TRY(launch_tree_convert(ln.stream, c->dp, c->mode, c->d_bquery + (size_t)first * qwords + (size_t)qc * ctw, ln.res_a,
+    HIP_TRY(launch_tree_convert(ln.stream, c->dp, c->mode, c->bs().d_bquery + (size_t)first * qwords + (size_t)qc * ctw, ln.res_a,
                                 (uint64_t)B * ctw, true, ctw, qwords));
     MfmaPtrs dst{};
     uint32_t ksets[kMaxMfmaQueries];   // every query of the group is switched with its own client's keys
     for (uint32_t q = 0; q < B; ++q) {
       dst.p[q] = members[q]->sv_ntt + produced * ctw;
-      ksets[q] = first + q < c->batch_keysets.size() ? c->batch_keysets[first + q] : 0;
+      ksets[q] = first + q < c->bs().batch_keysets.size() ? c->bs().batch_keysets[first + q] : 0;
     }
     uint64_t* res = expand_core(c, ln.stream, ln.res_a, ln.res_b, ln.dig, ln.prod, slots, B, &dst, sel_f64, ksets);
     if (res) HIP_TRY(c->ops->ct_ntt_fwd_split(ln.stream, c->mode, c->dp, k, res, dst, B, (uint64_t)slots * B));
@@ -2004,10 +2134,10 @@ static void batch_run_mfma(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
   }
   const bool share_chip = n_groups >= 2 && nl >= 2;
   // pirgpu_batch_set_host_replies: every group downloads its replies as soon as they exist (on its lane's stream)
-  const bool host_dl = c->host_reply && (uint64_t)count * c->reply_cts <= c->host_reply_cts;
-  c->host_reply_done = host_dl;
-  c->dl_end.clear();
-  c->dl_next = 0;
+  const bool host_dl = c->bs().host_reply && (uint64_t)count * c->reply_cts <= c->bs().host_reply_cts;
+  c->bs().host_reply_done = host_dl;
+  c->bs().dl_end.clear();
+  c->bs().dl_next = 0;
   for (uint32_t rank0 = 0; rank0 < count; rank0 += span) {
     const uint32_t step = pk ? (uint32_t)kMaxMfmaQueries : G;
     const uint32_t in_span = std::min<uint32_t>(span, count - rank0);
@@ -2053,16 +2183,16 @@ static void batch_run_mfma(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
         HIP_TRY(hipMemcpyAsync(reply_base(c) + (size_t)first * rwords, ln.lvl[0], (size_t)B * rwords * 8,
                                hipMemcpyDeviceToDevice, ln.stream));
       if (host_dl) {   // the group's replies start their way to the host while the next groups are computed
-        HIP_TRY(hipMemcpyAsync(c->host_reply + (size_t)first * rwords, reply_base(c) + (size_t)first * rwords,
+        HIP_TRY(hipMemcpyAsync(c->bs().host_reply + (size_t)first * rwords, reply_base(c) + (size_t)first * rwords,
                                (size_t)B * rwords * 8, hipMemcpyDeviceToHost, ln.stream));
-        const size_t gi = c->dl_end.size();
-        if (gi >= c->dl_events.size()) {
+        const size_t gi = c->bs().dl_end.size();
+        if (gi >= c->bs().dl_events.size()) {
           hipEvent_t e;
           HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-          c->dl_events.push_back(e);
+          c->bs().dl_events.push_back(e);
         }
-        HIP_TRY(hipEventRecord(c->dl_events[gi], ln.stream));
-        c->dl_end.push_back(first + B);
+        HIP_TRY(hipEventRecord(c->bs().dl_events[gi], ln.stream));
+        c->bs().dl_end.push_back(first + B);
       }
       for (uint32_t q = 0; q < B; ++q) {
         HIP_TRY(hipEventRecord(members[q]->ev_done, ln.stream));
@@ -2087,7 +2217,7 @@ static void batch_run_impl(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
   batch_run_impl_body(c, count, ext_sv);
 }
 static void batch_run_impl_body(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv) {
-  c->host_reply_done = false;   // set again by the path that queues per-group downloads (batch_run_mfma)
+  c->bs().host_reply_done = false;   // set again by the path that queues per-group downloads (batch_run_mfma)
   const size_t rwords = (size_t)c->reply_cts * c->ctw;
   const size_t svwords = (size_t)c->dim_sum * c->ctw;
   const uint32_t W = std::max<uint32_t>(1, std::min<uint32_t>(c->n_active, (uint32_t)c->workers.size()));
@@ -2100,7 +2230,7 @@ static void batch_run_impl_body(pirgpu_ctx* c, uint32_t count, const uint64_t* e
   c->prof_cur = -1;
   if (c->mfma_on) {
     batch_run_mfma(c, count, ext_sv);
-    c->batch_valid = true;
+    c->bs().batch_valid = true;
     return;
   }
   if (!ext_sv) ensure_lanes(c, true);
@@ -2164,14 +2294,14 @@ static void batch_run_impl_body(pirgpu_ctx* c, uint32_t count, const uint64_t* e
       w.reply_valid = true;
     }
   }
-  c->batch_valid = true;
+  c->bs().batch_valid = true;
 }
 
 int pirgpu_batch_run(pirgpu_ctx* c) {
   return guarded(c, [&]() -> int {
-    if (!c->staged_count) return fail(c, PIRGPU_FAILED_PRECONDITION, "no batch has been staged");
-    batch_run_impl(c, c->staged_count, nullptr);
-    c->batch_count = c->staged_count;
+    if (!c->bs().staged_count) return fail(c, PIRGPU_FAILED_PRECONDITION, "no batch has been staged");
+    batch_run_impl(c, c->bs().staged_count, nullptr);
+    c->bs().batch_count = c->bs().staged_count;
     return PIRGPU_OK;
   });
 }
@@ -2180,7 +2310,7 @@ int pirgpu_batch_run(pirgpu_ctx* c) {
 
 int pirgpu_batch_expand(pirgpu_ctx* c, uint32_t first, uint32_t count, uint64_t* device_dst) {
   return guarded(c, [&]() -> int {
-    if (!c->staged_count || (uint64_t)first + count > c->staged_count)
+    if (!c->bs().staged_count || (uint64_t)first + count > c->bs().staged_count)
       return fail(c, PIRGPU_INVALID_ARGUMENT, "query range outside the staged batch");
     if (!device_dst && count) return fail(c, PIRGPU_INVALID_ARGUMENT, "null buffer");
     const uint32_t nq = c->dim_sum / c->N + 1;
@@ -2190,10 +2320,11 @@ int pirgpu_batch_expand(pirgpu_ctx* c, uint32_t first, uint32_t count, uint64_t*
     for (uint32_t i = 0; i < count; ++i) {
       Worker& w = c->workers[i % W];
       HIP_TRY(hipStreamWaitEvent(w.stream, w.ev_done, 0));   // a lane's group may still be reading its buffers
-      HIP_TRY(hipMemcpyAsync(w.d_query, c->d_bquery + (size_t)(first + i) * qwords, qwords * 8,
+      wait_staged(c, w.stream, first + i, 1);
+      HIP_TRY(hipMemcpyAsync(w.d_query, c->bs().d_bquery + (size_t)(first + i) * qwords, qwords * 8,
                              hipMemcpyDeviceToDevice, w.stream));
       w.staged_nq = nq;
-      w.keyset = first + i < c->batch_keysets.size() ? c->batch_keysets[first + i] : 0;
+      w.keyset = first + i < c->bs().batch_keysets.size() ? c->bs().batch_keysets[first + i] : 0;
       expand_query_to_sv(c, w, w.d_query, nq);
       HIP_TRY(hipMemcpyAsync(device_dst + (size_t)i * svwords, w.sv_ntt, svwords * 8, hipMemcpyDeviceToDevice,
                              w.stream));
@@ -2209,7 +2340,7 @@ int pirgpu_batch_run_selectors(pirgpu_ctx* c, const uint64_t* device_sv, uint32_
     if (!device_sv || count == 0 || count > 4096) return fail(c, PIRGPU_INVALID_ARGUMENT, "invalid batch");
     ensure_batch_capacity(c, count);
     batch_run_impl(c, count, device_sv);
-    c->batch_count = count;
+    c->bs().batch_count = count;
     return PIRGPU_OK;
   });
 }
@@ -2233,7 +2364,7 @@ static int batch_expand_packed_impl(pirgpu_ctx* c, uint32_t first_query, uint32_
     ensure_workspace(c);
     if (c->d != 2 || !c->mfma_on)
       return fail(c, PIRGPU_FAILED_PRECONDITION, "packed selector exchange needs d = 2 and the int8-MFMA scan");
-    if (!c->staged_count || (uint64_t)first_query + count > c->staged_count)
+    if (!c->bs().staged_count || (uint64_t)first_query + count > c->bs().staged_count)
       return fail(c, PIRGPU_INVALID_ARGUMENT, "query range outside the staged batch");
     if (!device_packed || !device_rows || !row_cuts || n_ranks == 0 || row_cuts[0] != 0 || row_cuts[n_ranks] != c->dims[0])
       return fail(c, PIRGPU_INVALID_ARGUMENT, "invalid packed-exchange buffers or row cuts");
@@ -2315,16 +2446,16 @@ int pirgpu_batch_run_packed(pirgpu_ctx* c, const uint8_t* device_packed, uint32_
       throw;
     }
     c->in_batch = false;
-    c->batch_count = (uint32_t)count;
-    c->batch_valid = true;
+    c->bs().batch_count = (uint32_t)count;
+    c->bs().batch_valid = true;
     return PIRGPU_OK;
   });
 }
 
 int pirgpu_batch_reply_copy_to_device(pirgpu_ctx* c, uint64_t* dst, uint64_t cap) {
   return guarded(c, [&]() -> int {
-    if (!c->batch_valid) return fail(c, PIRGPU_FAILED_PRECONDITION, "no batch has been run");
-    const uint64_t total = (uint64_t)c->batch_count * c->reply_cts;
+    if (!c->bs().batch_valid) return fail(c, PIRGPU_FAILED_PRECONDITION, "no batch has been run");
+    const uint64_t total = (uint64_t)c->bs().batch_count * c->reply_cts;
     if (!dst || cap < total) return fail(c, PIRGPU_INVALID_ARGUMENT, "reply buffer too small");
     sync_batch_streams(c);
     // a device-to-device hipMemcpy on the null stream may return before the copy has run, and the context's
@@ -2339,8 +2470,8 @@ int pirgpu_batch_reply_copy_to_device_async(pirgpu_ctx* c, uint64_t* dst, uint64
   int rc = pirgpu_join(c);   // the main stream now follows every lane: the copy below sees the finished batch
   if (rc) return rc;
   return guarded(c, [&]() -> int {
-    if (!c->batch_valid) return fail(c, PIRGPU_FAILED_PRECONDITION, "no batch has been run");
-    const uint64_t total = (uint64_t)c->batch_count * c->reply_cts;
+    if (!c->bs().batch_valid) return fail(c, PIRGPU_FAILED_PRECONDITION, "no batch has been run");
+    const uint64_t total = (uint64_t)c->bs().batch_count * c->reply_cts;
     if (!dst || cap < total) return fail(c, PIRGPU_INVALID_ARGUMENT, "reply buffer too small");
     HIP_TRY(hipMemcpyAsync(dst, reply_base(c), total * c->ctw * 8, hipMemcpyDeviceToDevice, c->stream));
     return PIRGPU_OK;
@@ -2349,11 +2480,11 @@ int pirgpu_batch_reply_copy_to_device_async(pirgpu_ctx* c, uint64_t* dst, uint64
 
 int pirgpu_batch_fetch(pirgpu_ctx* c, uint64_t* replies, uint64_t cap, uint64_t* count) {
   return guarded(c, [&]() -> int {
-    if (!c->batch_valid) return fail(c, PIRGPU_FAILED_PRECONDITION, "no batch has been run");
-    const uint64_t total = (uint64_t)c->batch_count * c->reply_cts;
+    if (!c->bs().batch_valid) return fail(c, PIRGPU_FAILED_PRECONDITION, "no batch has been run");
+    const uint64_t total = (uint64_t)c->bs().batch_count * c->reply_cts;
     if (!replies || cap < total) return fail(c, PIRGPU_INVALID_ARGUMENT, "reply buffer too small");
     sync_batch_streams(c);
-    if (!(c->host_reply_done && replies == c->host_reply))   // else: the groups downloaded their replies themselves
+    if (!(c->bs().host_reply_done && replies == c->bs().host_reply))   // else: the groups downloaded their replies themselves
       HIP_TRY(hipMemcpy(replies, reply_base(c), total * c->ctw * 8, hipMemcpyDeviceToHost));
     if (count) *count = total;
     return PIRGPU_OK;

@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <chrono>
@@ -262,6 +263,8 @@ struct Job {
   bool uniform = true;        // every query has the ciphertext count the dimensions call for (server.cpp:154)
   bool unverified = false;    // the slot was taken on its fingerprint alone: the key bytes are compared under the GPU work
   bool mismatch = false;      // ... and differed: install this client's keys and serve the request again
+  int pins = 0;               // times `slot` is pinned for this request (pirgpu_keyset_pin; once per window in flight
+                              // that holds queries of it): unpinned as the windows finish
 };
 
 struct Server {               // what serving needs to know about a context
@@ -295,46 +298,179 @@ void append_reply(OutBuf& out, const Shape& sh, const uint64_t* cts_words, uint6
   }
 }
 
+// ---------------------------------------------------------------------------------------------- worker pool
+//
+// Host threads the wire layer uses next to the serving thread (key compare, query parsing, seed expansion, response
+// serialisation): created once per process, on first use, and kept -- round 3 started fresh std::async threads in every
+// window (three places), a thread creation + join per task on the request path.  The singleton is never destroyed
+// (its threads sleep on a condition variable; the process ends under them).
+class Pool {
+ public:
+  static Pool& get() {
+    static Pool* p = new Pool();
+    return *p;
+  }
+  size_t size() const { return threads_.size(); }
+
+  // A set of tasks somebody waits for.
+  struct Group {
+    std::mutex m;
+    std::condition_variable cv;
+    size_t pending = 0;
+    void wait() {
+      std::unique_lock<std::mutex> lk(m);
+      cv.wait(lk, [&] { return pending == 0; });
+    }
+  };
+
+  void submit(Group& g, std::function<void()> fn) {
+    {
+      std::lock_guard<std::mutex> lk(g.m);
+      ++g.pending;
+    }
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      q_.push_back(Task{&g, std::move(fn)});
+    }
+    cv_.notify_one();
+  }
+
+  // fn(i) for every i < n on up to max_threads threads, the caller among them; returns when all are done.
+  // fn must not throw.
+  void parallel_for(size_t n, size_t max_threads, const std::function<void(size_t)>& fn) {
+    if (n == 0) return;
+    const size_t helpers = std::min(std::min(max_threads, n) - 1, size());
+    std::atomic<size_t> next{0};
+    auto loop = [&] {
+      for (size_t i; (i = next.fetch_add(1)) < n;) fn(i);
+    };
+    Group g;
+    for (size_t t = 0; t < helpers; ++t) submit(g, loop);
+    loop();
+    g.wait();
+  }
+
+ private:
+  struct Task {
+    Group* g;
+    std::function<void()> fn;
+  };
+  Pool() {
+    const size_t hw = std::thread::hardware_concurrency();
+    size_t n = std::max<size_t>(1, std::min<size_t>(16, hw ? hw / 2 : 1));   // never more than half the machine
+    if (const char* v = getenv("PIRGPU_WIRE_THREADS")) n = std::max<size_t>(1, std::min<size_t>(64, (size_t)atoi(v)));
+    for (size_t i = 0; i < n; ++i) {
+      threads_.emplace_back([this] { run(); });
+      threads_.back().detach();
+    }
+  }
+  void run() {
+    for (;;) {
+      Task t;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return !q_.empty(); });
+        t = std::move(q_.front());
+        q_.pop_front();
+      }
+      try {
+        t.fn();
+      } catch (...) {   // tasks report through their own state; nothing may unwind a pool thread
+      }
+      {
+        std::lock_guard<std::mutex> lk(t.g->m);
+        if (--t.g->pending == 0) t.g->cv.notify_all();
+      }
+    }
+  }
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::deque<Task> q_;
+  std::vector<std::thread> threads_;
+};
+
+struct Trace {   // PIRGPU_WIRE_TRACE=1: host-side phase times of a window, to stderr
+  bool on = getenv("PIRGPU_WIRE_TRACE") != nullptr;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  void mark(const char* what, int window = -1) {
+    if (!on) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[wire w%-2d] %-22s %8.3f ms\n", window, what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
+
+void fail_job(Job& job, int code, const std::string& msg) {
+  job.rc = code;
+  job.err = msg;
+  job.out.clear();
+}
+
+// RAII for the request-level critical section of the context (recursive with the per-call lock of the ABI entry points)
+struct CtxLock {
+  pirgpu_ctx* c;
+  explicit CtxLock(pirgpu_ctx* ctx) : c(ctx) { pirgpu_request_lock(c); }
+  ~CtxLock() { pirgpu_request_unlock(c); }
+  CtxLock(const CtxLock&) = delete;
+  CtxLock& operator=(const CtxLock&) = delete;
+};
+
 // SEALDeserialize<GaloisKeys> (server.cpp:46-48) with the device-resident key cache: a client that
-// repeats its (multi-MB) key object byte for byte finds its keys resident; a new client's keys are parsed, validated
-// as a whole (a malformed object must not leave half-installed keys behind) and uploaded into a free or the least
-// recently used slot.  `speculative`: accept a resident set on its fingerprint alone -- the caller verifies the bytes
-// (pirgpu_keyset_verify) while the GPU already works and discards the result on a mismatch.
+// repeats its (multi-MB) key object byte for byte finds its keys resident; a new client's keys are parsed -- the
+// objects of a seed-compressed Serializable<GaloisKeys>, what the reference client sends (client.cpp:47-54), are
+// re-expanded on the pool's threads --, validated as a whole (a malformed object must not leave half-installed keys
+// behind) and uploaded into a free or the least recently used slot.  `speculative`: accept a resident set on its
+// fingerprint alone -- the caller verifies the bytes while the GPU already works and discards the result on a
+// mismatch.  The slot comes back PINNED (pirgpu_keyset_pin): it cannot be evicted until the caller unpins it.
 void resolve_keys(const Server& sv, Job& job, bool speculative, bool* unverified) {
   if (unverified) *unverified = false;
   uint32_t slot = 0;
   int rc = 0;
+  CtxLock lock(sv.ctx);   // lookup + pin (or claim + upload + pin) are one step with respect to other windows
   if (job.pr.galois_keys_len) {
     rc = pirgpu_keyset_lookup(sv.ctx, job.pr.galois_keys, job.pr.galois_keys_len, speculative ? 0 : 1, &slot);
     if (rc) throw Err{rc, pirgpu_last_error(sv.ctx)};
   }
   if (slot) {
+    rc = pirgpu_keyset_pin(sv.ctx, slot);
+    if (rc) throw Err{rc, pirgpu_last_error(sv.ctx)};
     if (unverified) *unverified = speculative;
     job.slot = slot;
+    job.pins = 1;
     return;
   }
   // empty bytes -> load throws -> InvalidArgument, like the reference
-  std::vector<std::pair<uint32_t, std::vector<uint64_t>>> parsed;
-  const size_t key_words = (size_t)sv.sh.k * 2 * (sv.sh.k + 1) * sv.sh.N;
-  load_kswitch_keys(sv.sh, job.pr.galois_keys, job.pr.galois_keys_len, [&](uint64_t index, const uint64_t* key) {
-    parsed.emplace_back((uint32_t)(2 * index + 1), std::vector<uint64_t>(key, key + key_words));
-  });
+  std::vector<std::pair<uint64_t, std::vector<uint64_t>>> parsed;
+  load_kswitch_keys_parallel(sv.sh, job.pr.galois_keys, job.pr.galois_keys_len,
+                             [](size_t n, const std::function<void(size_t)>& fn) { Pool::get().parallel_for(n, 16, fn); },
+                             parsed);
   rc = pirgpu_keyset_claim(sv.ctx, job.pr.galois_keys, job.pr.galois_keys_len, &slot);
   if (rc) throw Err{rc, pirgpu_last_error(sv.ctx)};
   for (auto& kv : parsed) {
-    rc = pirgpu_keyset_set_key(sv.ctx, slot, kv.first, kv.second.data());
+    rc = pirgpu_keyset_set_key(sv.ctx, slot, (uint32_t)(2 * kv.first + 1), kv.second.data());
     if (rc) {
       const std::string msg = pirgpu_last_error(sv.ctx);
       (void)pirgpu_keyset_release(sv.ctx, slot);
       throw Err{rc, msg};
     }
   }
+  rc = pirgpu_keyset_pin(sv.ctx, slot);
+  if (rc) throw Err{rc, pirgpu_last_error(sv.ctx)};
   job.slot = slot;
+  job.pins = 1;
+}
+
+void unpin_job(const Server& sv, Job& job) {
+  if (job.pins > 0) {
+    (void)pirgpu_keyset_unpin(sv.ctx, job.slot);
+    --job.pins;
+  }
 }
 
 // One query through the single-query path (lowest latency; also reports a wrong ciphertext count at the offending
 // query like the reference, server.cpp:154-158).  Query parsed into pinned staging, reply serialised out of it.
 // `while_running` (optional) is host work done between enqueueing the kernels and waiting for the reply.
+// The caller holds the context's request lock: worker 0 and the single-query selection are context state.
 void run_single(const Server& sv, Job& job, const std::pair<const uint8_t*, size_t>& qm,
                 const std::function<void()>& while_running = nullptr) {
   uint64_t* hq = pirgpu_host_query_buffer(sv.ctx, 1);
@@ -355,288 +491,242 @@ void run_single(const Server& sv, Job& job, const std::pair<const uint8_t*, size
   append_reply(job.out, sv.sh, hr, got, sv.ctw);
 }
 
-void fail_job(Job& job, int code, const std::string& msg) {
-  job.rc = code;
-  job.err = msg;
-  job.out.clear();
-}
+// One WINDOW of requests on its way through the batch pipeline: up to kMaxRequestBatch queries of at most
+// `max_clients` requests, staged in one of the context's batch sets.  begin() does everything up to "the window's
+// kernels are queued"; finish() everything from there to "its responses are serialised".  Two windows can be in flight
+// on one context -- the next one parsed, staged and queued (by the same serving thread or by another one) while the
+// previous one's groups are still being computed and its replies are on their way back -- so the GPU's queues do not
+// run dry between windows: a window of 64 clients was 15.3 ms of which the GPU was busy 12 (round 3).
+struct Item {
+  Job* job;
+  uint32_t qi;
+};
 
-// Host threads a window may use next to the serving thread: at most `most`, never more than half the machine.
-size_t worker_threads(size_t most) {
-  const size_t hw = std::thread::hardware_concurrency();
-  return std::max<size_t>(1, std::min<size_t>(most, hw ? hw / 2 : 1));
-}
+struct Window {
+  int set = 0;                       // batch set of the context (pirgpu_batch_select)
+  int home = 0;                      // the serving thread's own set, selected again when begin / finish return
+  int id = 0;                        // for the trace
+  std::vector<Job*> jobs;            // requests with queries in this window (a request's queries never span windows
+                                     // unless it has more than kMaxRequestBatch of them)
+  std::vector<Item> chunk;           // the queries queued, in reply order
+  std::vector<std::pair<uint32_t, uint32_t>> runs;   // [first, end) items of one request
+  std::vector<uint32_t> slots;
+  uint64_t *hq = nullptr, *hr = nullptr;
+  uint32_t room = 0;
+  bool queued = false;               // the batch pipeline holds this window's work
+  int rc = 0;
+  std::string err;
+};
 
-// Byte-for-byte compare of the key objects of the requests behind `items` with the resident sets they were matched
-// to by fingerprint -- once per request, on up to 16 worker threads (4.7 MB per client: 0.3-0.4 ms each on one
-// thread, which was most of a request's host time), while the GPU runs the chunk just queued.  The resident copies are
-// read without the context's lock: the request lock is held and the window's slots are pinned.
-template <typename Item>
-void verify_keys_of(const Server& sv, Item* items, uint32_t count) {
+template <typename F>
+struct Finally {
+  F f;
+  ~Finally() { f(); }
+};
+template <typename F>
+Finally<F> finally(F f) { return Finally<F>{std::move(f)}; }
+
+// Byte-for-byte compare of the key objects of the window's requests with the resident sets they were matched to by
+// fingerprint -- once per request, on the pool's threads (4.7 MB per client: 0.3-0.4 ms each on one thread, which was
+// most of a request's host time), while the GPU runs the window just queued.  The resident copies are read without the
+// context's lock: the slots are pinned (no eviction, no reinstall).
+void verify_keys_of(const Server& sv, Window& w) {
   std::vector<Job*> todo;
-  for (uint32_t i = 0; i < count; ++i) {
-    Job* job = items[i].job;
-    if (job->unverified && std::find(todo.begin(), todo.end(), job) == todo.end()) todo.push_back(job);
-  }
+  for (const Item& it : w.chunk)
+    if (it.job->unverified && std::find(todo.begin(), todo.end(), it.job) == todo.end()) todo.push_back(it.job);
   if (todo.empty()) return;
-  // the resident copies are looked up HERE, on the serving thread: it holds the context's (recursive) lock for the whole
-  // window, a worker thread asking for it would wait for ever
   std::vector<std::pair<const uint8_t*, size_t>> resident(todo.size());
   for (size_t i = 0; i < todo.size(); ++i) resident[i].second = pirgpu_keyset_blob(sv.ctx, todo[i]->slot, &resident[i].first);
-  auto check_at = [&](size_t i) {
+  // (64 clients' objects are 600 MB to read, more than the host's last-level cache: memory-bound, so many threads)
+  Pool::get().parallel_for(todo.size(), 16, [&](size_t i) {
     Job* job = todo[i];
     const uint8_t* r = resident[i].first;
     const size_t len = resident[i].second;
     job->mismatch = !(r && len == job->pr.galois_keys_len && memcmp(r, job->pr.galois_keys, len) == 0);
     job->unverified = false;
-  };
-  // (64 clients' objects are 600 MB to read, more than the host's last-level cache: memory-bound, so many threads)
-  const size_t n_threads = std::min<size_t>(worker_threads(16), todo.size());
-  std::vector<std::future<void>> workers;
-  for (size_t t = 1; t < n_threads; ++t)
-    workers.push_back(std::async(std::launch::async, [&, t] {
-      for (size_t i = t; i < todo.size(); i += n_threads) check_at(i);
-    }));
-  for (size_t i = 0; i < todo.size(); i += n_threads) check_at(i);
-  for (auto& w : workers) w.get();
+  });
 }
 
-struct Trace {   // PIRGPU_WIRE_TRACE=1: host-side phase times of a window, to stderr
-  bool on = getenv("PIRGPU_WIRE_TRACE") != nullptr;
-  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-  void mark(const char* what) {
-    if (!on) return;
-    const auto t1 = std::chrono::steady_clock::now();
-    fprintf(stderr, "[wire] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
-    t0 = t1;
+// Parses the queries of `items` into the window's pinned staging (on the pool's threads: 128 KiB + a range check per
+// ciphertext), drops what failed, maps the response buffers, stages the queries asynchronously and queues the window.
+void begin_window(const Server& sv, Window& w, const std::vector<Item>& items, Trace& trace) {
+  const size_t qwords = (size_t)sv.nq_expected * sv.ctw;
+  (void)pirgpu_batch_select(sv.ctx, (uint32_t)w.set);
+  auto unselect = finally([&] { (void)pirgpu_batch_select(sv.ctx, (uint32_t)w.home); });
+  w.room = (uint32_t)items.size();
+  {
+    CtxLock lock(sv.ctx);      // (re)allocation of pinned memory is context state
+    w.hq = pirgpu_host_query_buffer(sv.ctx, w.room);
+    w.hr = pirgpu_host_reply_buffer(sv.ctx, w.room);
+  }
+  if (!w.hq || !w.hr) {
+    const std::string msg = pirgpu_last_error(sv.ctx);
+    for (const Item& it : items)
+      if (!it.job->rc) fail_job(*it.job, PIRGPU_INTERNAL, msg);
+    return;
+  }
+  // (1) queries -> pinned staging, in parallel; per-item outcome applied afterwards on this thread
+  struct Outcome {
+    uint32_t nq = 0;
+    int code = 0;
+    std::string msg;
+  };
+  std::vector<Outcome> res(items.size());
+  Pool::get().parallel_for(items.size(), 8, [&](size_t i) {
+    const Job& job = *items[i].job;
+    if (job.rc) return;
+    try {
+      const auto& qm = job.pr.queries[items[i].qi];
+      res[i].nq = load_query_into(sv.sh, qm.first, qm.second, w.hq + i * qwords, sv.nq_expected);
+    } catch (const Err& e) {
+      res[i].code = e.code;
+      res[i].msg = e.msg;
+    } catch (const std::exception& e) {
+      res[i].code = PIRGPU_INTERNAL;
+      res[i].msg = e.what();
+    }
+  });
+  for (size_t i = 0; i < items.size(); ++i) {
+    Job& job = *items[i].job;
+    if (job.rc) continue;
+    if (res[i].code) fail_job(job, res[i].code, res[i].msg);          // the first failing query of the request, in order
+    else if (res[i].nq != sv.nq_expected) job.uniform = false;         // sequential path (reports it like the reference)
+  }
+  // queries of requests that failed or turned non-uniform are dropped from the window
+  w.chunk.clear();
+  w.slots.clear();
+  for (size_t i = 0; i < items.size(); ++i) {
+    const Job& job = *items[i].job;
+    if (job.rc || !job.uniform || job.mismatch) continue;
+    const size_t keep = w.chunk.size();
+    if (keep != i) memmove(w.hq + keep * qwords, w.hq + i * qwords, qwords * 8);
+    w.chunk.push_back(items[i]);
+    w.slots.push_back(job.slot);
+  }
+  trace.mark("load queries", w.id);
+  if (w.chunk.empty()) return;
+  const uint32_t count = (uint32_t)w.chunk.size();
+  // the response buffers are mapped NOW, before the GPU phase: the threads that fill them while the GPU runs then only
+  // touch pages -- an mmap / munmap in the middle of the GPU's work goes through the driver's MMU notifier and was
+  // measured to stretch a 64-client window from 15 to 25 ms.  Replies in request order: a request's queries are
+  // consecutive items, so appending in item order keeps reply[i] answering query[i] (server.cpp:60-63)
+  w.runs.clear();
+  for (uint32_t i = 0; i < count;) {
+    uint32_t e = i + 1;
+    while (e < count && w.chunk[e].job == w.chunk[i].job) ++e;
+    w.runs.emplace_back(i, e);
+    i = e;
+  }
+  for (auto& run : w.runs) {
+    Job& job = *w.chunk[run.first].job;
+    try {
+      job.out.reserve(job.out.n + (run.second - run.first) * reply_bytes_bound(sv.sh, sv.n_reply));
+    } catch (const std::exception& e) {
+      fail_job(job, PIRGPU_INTERNAL, e.what());
+    }
+  }
+  // (2) stage + queue: the only part of a window that holds the context (lanes, workers and streams are shared between
+  // the windows in flight; what is queued here runs behind the previous window's work in stream order)
+  {
+    CtxLock lock(sv.ctx);
+    const uint32_t before = pirgpu_get_concurrency(sv.ctx);
+    int rc = pirgpu_set_concurrency(sv.ctx, std::max<uint32_t>(before, 16));
+    if (!rc) rc = pirgpu_batch_stage_async(sv.ctx, w.hq, sv.nq_expected, count);   // piecewise: group 0 starts after 1 MB
+    if (!rc) rc = pirgpu_batch_set_keysets(sv.ctx, w.slots.data(), count);
+    // every group sends its replies to the pinned buffer as soon as they exist: finish_window only waits
+    if (!rc) rc = pirgpu_batch_set_host_replies(sv.ctx, w.hr, (uint64_t)w.room * sv.n_reply);
+    if (!rc) rc = pirgpu_batch_run(sv.ctx);      // asynchronous: the window's kernels are queued
+    if (rc) w.err = pirgpu_last_error(sv.ctx);
+    w.rc = rc;
+    (void)pirgpu_set_concurrency(sv.ctx, before);
+  }
+  w.queued = w.rc == 0;
+  trace.mark("stage + enqueue", w.id);
+}
+
+// Everything after "queued": key compare under the GPU's work, the replies group by group as they land in pinned
+// memory, serialisation on the pool's threads while the later groups are still being computed.
+void finish_window(const Server& sv, Window& w, Trace& trace) {
+  (void)pirgpu_batch_select(sv.ctx, (uint32_t)w.set);
+  auto cleanup = finally([&] {
+    (void)pirgpu_batch_set_host_replies(sv.ctx, nullptr, 0);
+    (void)pirgpu_batch_unstage(sv.ctx);            // nothing staged keeps referring to the window's key sets
+    (void)pirgpu_batch_select(sv.ctx, (uint32_t)w.home);
+    for (Job* job : w.jobs) unpin_job(sv, *job);
+  });
+  if (w.chunk.empty()) return;
+  const uint32_t count = (uint32_t)w.chunk.size();
+  const size_t rwords = (size_t)sv.n_reply * sv.ctw;
+  if (w.rc) {
+    for (const Item& it : w.chunk)
+      if (!it.job->rc) fail_job(*it.job, w.rc, w.err);
+    return;
+  }
+  verify_keys_of(sv, w);   // host work under the GPU's
+  trace.mark("verify keys", w.id);
+  auto serialise = [&](size_t r) {
+    Job& job = *w.chunk[w.runs[r].first].job;
+    if (job.rc || !job.uniform || job.mismatch) return;
+    try {
+      for (uint32_t i = w.runs[r].first; i < w.runs[r].second; ++i)
+        append_reply(job.out, sv.sh, w.hr + (size_t)i * rwords, sv.n_reply, sv.ctw);
+    } catch (const std::exception& e) {
+      fail_job(job, PIRGPU_INTERNAL, e.what());
+    }
+  };
+  Pool::Group g;
+  size_t next_run = 0;
+  uint32_t ready = 0;
+  int rc = 0;
+  while (ready < count) {
+    uint32_t upto = 0;
+    rc = pirgpu_batch_next_host_replies(sv.ctx, &upto);   // waits for the next group's download, not for the device
+    if (rc || upto <= ready) break;                        // not downloaded group-wise: everything below
+    ready = upto;
+    while (next_run < w.runs.size() && w.runs[next_run].second <= ready) {
+      const size_t r = next_run++;
+      Pool::get().submit(g, [&serialise, r] { serialise(r); });   // one request per task: a megabyte per reply
+    }
+  }
+  if (ready < count) {
+    // d = 1 / 64-bit scan contexts do not download group by group: wait for the batch (this also waits for whatever
+    // another window has queued behind it) and serialise everything here
+    uint64_t got = 0;
+    rc = pirgpu_batch_fetch(sv.ctx, w.hr, (uint64_t)count * sv.n_reply, &got);
+    if (!rc)
+      while (next_run < w.runs.size()) {
+        const size_t r = next_run++;
+        Pool::get().submit(g, [&serialise, r] { serialise(r); });
+      }
+  }
+  g.wait();
+  trace.mark("wait + serialise", w.id);
+  if (rc) {
+    const std::string msg = pirgpu_last_error(sv.ctx);
+    for (const Item& it : w.chunk)
+      if (!it.job->rc) fail_job(*it.job, rc, msg);
+  }
+}
+
+// Which batch sets of a context are taken by windows in flight (any thread); a serving thread owns the sets it took.
+struct Combiner {
+  std::mutex m;
+  std::condition_variable cv;
+  std::deque<Job*> pending;
+  bool set_busy[2] = {false, false};
+  int take_set() {   // call with m held; -1: none free
+    for (int i = 0; i < 2; ++i)
+      if (!set_busy[i]) {
+        set_busy[i] = true;
+        return i;
+      }
+    return -1;
   }
 };
 
-// Serves a window of requests under the context's request lock.
-void serve_window(const Server& sv, Job* const* jobs, size_t n) {
-  Trace trace;
-  // (1) parse, resolve keys, validate relin keys -- per request; a failing request does not affect the others
-  uint32_t total_queries = 0;
-  bool unverified = false;
-  const bool lone = n == 1;
-  for (size_t i = 0; i < n; ++i) {
-    Job& job = *jobs[i];
-    if (job.rc) continue;
-    try {
-      job.pr = parse_request(job.request, job.request_len);
-      // every request starts on a fingerprint match; the key bytes (4.7 MB per client) are compared while the GPU works:
-      // by this thread for a lone single-query request, on worker threads for a window of requests
-      (void)lone;
-      resolve_keys(sv, job, true, &job.unverified);
-      unverified = unverified || job.unverified;
-      // SEALDeserialize<RelinKeys> when present (server.cpp:53-58): only CT-multiplication mode uses them, but a
-      // malformed non-empty field is InvalidArgument in the reference, so it is parsed and validated here too
-      if (job.pr.relin_keys_len) load_kswitch_keys(sv.sh, job.pr.relin_keys, job.pr.relin_keys_len, nullptr);
-      total_queries += (uint32_t)job.pr.queries.size();
-    } catch (const Err& e) {
-      fail_job(job, e.code, e.msg);
-    } catch (const std::exception& e) {
-      fail_job(job, PIRGPU_INTERNAL, e.what());
-    }
-  }
-  trace.mark("parse + resolve keys");
-  // (2) one query in the whole window: the single-query path
-  if (total_queries == 1) {
-    for (size_t i = 0; i < n; ++i) {
-      Job& job = *jobs[i];
-      if (job.rc || job.pr.queries.empty()) continue;
-      try {
-        bool verified = true;
-        run_single(sv, job, job.pr.queries[0], [&]() {   // the byte-for-byte key compare runs under the GPU work
-          if (job.unverified) verified = pirgpu_keyset_verify(sv.ctx, job.slot, job.pr.galois_keys, job.pr.galois_keys_len) != 0;
-        });
-        if (!verified) {
-          // same fingerprint, different bytes: not this client's keys after all -- install them and run again
-          job.out.clear();
-          resolve_keys(sv, job, false, nullptr);
-          run_single(sv, job, job.pr.queries[0]);
-        }
-      } catch (const Err& e) {
-        fail_job(job, e.code, e.msg);
-      } catch (const std::exception& e) {
-        fail_job(job, PIRGPU_INTERNAL, e.what());
-      }
-    }
-    return;
-  }
-  // (3) several queries: the batch pipeline in chunks of <= kMaxRequestBatch, every query with its client's key set.
-  // Requests whose queries do not all have the expected ciphertext count take the sequential path, which reports the
-  // error at the offending query like the reference does (nothing of theirs has run on the device at that point).
-  struct Item { Job* job; uint32_t qi; };
-  std::vector<Item> items;
-  for (size_t i = 0; i < n; ++i) {
-    Job& job = *jobs[i];
-    if (job.rc) continue;
-    for (uint32_t q = 0; q < job.pr.queries.size(); ++q) items.push_back({&job, q});
-  }
-  const uint32_t before = pirgpu_get_concurrency(sv.ctx);
-  int rc = pirgpu_set_concurrency(sv.ctx, std::max<uint32_t>(before, std::min<uint32_t>((uint32_t)items.size(), 16)));
-  if (rc) {
-    const std::string msg = pirgpu_last_error(sv.ctx);
-    for (size_t i = 0; i < n; ++i)
-      if (!jobs[i]->rc) fail_job(*jobs[i], rc, msg);
-    return;
-  }
-  const size_t qwords = (size_t)sv.nq_expected * sv.ctw, rwords = (size_t)sv.n_reply * sv.ctw;
-  size_t pos = 0;
-  std::vector<uint32_t> slots;
-  while (pos < items.size()) {
-    // pinned staging for this chunk only (a reply is (2 ER)^(d-1) ciphertexts: 24 MiB per query at N = 16384, k = 4)
-    const uint32_t room = (uint32_t)std::min<size_t>(kMaxRequestBatch, items.size() - pos);
-    uint64_t* hq = pirgpu_host_query_buffer(sv.ctx, room);
-    uint64_t* hr = pirgpu_host_reply_buffer(sv.ctx, room);
-    std::vector<Item> chunk;
-    slots.clear();
-    while (pos < items.size() && chunk.size() < room) {
-      Item it = items[pos++];
-      Job& job = *it.job;
-      if (job.rc || !job.uniform || job.mismatch) continue;
-      try {
-        if (!hq || !hr) throw Err{PIRGPU_INTERNAL, pirgpu_last_error(sv.ctx)};
-        const auto& qm = job.pr.queries[it.qi];
-        const uint32_t nq = load_query_into(sv.sh, qm.first, qm.second, hq + chunk.size() * qwords, sv.nq_expected);
-        if (nq != sv.nq_expected) {
-          job.uniform = false;     // sequential path below (its earlier queries are recomputed there: error path only)
-          continue;
-        }
-        chunk.push_back(it);
-        slots.push_back(job.slot);
-      } catch (const Err& e) {
-        fail_job(job, e.code, e.msg);
-      } catch (const std::exception& e) {
-        fail_job(job, PIRGPU_INTERNAL, e.what());
-      }
-    }
-    // queries of requests that failed or turned non-uniform while the chunk was being filled are dropped from it
-    size_t keep = 0;
-    for (size_t i = 0; i < chunk.size(); ++i) {
-      if (chunk[i].job->rc || !chunk[i].job->uniform || chunk[i].job->mismatch) continue;
-      if (keep != i) {
-        memmove(hq + keep * qwords, hq + i * qwords, qwords * 8);
-        chunk[keep] = chunk[i];
-        slots[keep] = slots[i];
-      }
-      ++keep;
-    }
-    chunk.resize(keep);
-    slots.resize(keep);
-    if (chunk.empty()) continue;
-    const uint32_t count = (uint32_t)chunk.size();
-    // the response buffers are mapped NOW, before the GPU phase: the worker threads that fill them while the GPU runs
-    // then only touch pages -- an mmap / munmap in the middle of the GPU's work goes through the driver's MMU notifier
-    // and was measured to stretch a 64-client window from 15 to 25 ms
-    // replies in request order: a request's queries are consecutive items, so appending in item order keeps
-    // reply[i] answering query[i] (server.cpp:60-63)
-    std::vector<std::pair<uint32_t, uint32_t>> runs;          // [first, end) items of one request inside the chunk
-    for (uint32_t i = 0; i < count;) {
-      uint32_t e = i + 1;
-      while (e < count && chunk[e].job == chunk[i].job) ++e;
-      runs.emplace_back(i, e);
-      i = e;
-    }
-    for (auto& run : runs) {
-      Job& job = *chunk[run.first].job;
-      try {
-        job.out.reserve(job.out.n + (run.second - run.first) * reply_bytes_bound(sv.sh, sv.n_reply));
-      } catch (const std::exception& e) {
-        fail_job(job, PIRGPU_INTERNAL, e.what());
-      }
-    }
-    trace.mark("load queries");
-    rc = pirgpu_batch_stage(sv.ctx, hq, sv.nq_expected, count);
-    if (!rc) rc = pirgpu_batch_set_keysets(sv.ctx, slots.data(), count);
-    // every group sends its replies to the pinned buffer as soon as they exist: the fetch below only waits
-    if (!rc) rc = pirgpu_batch_set_host_replies(sv.ctx, hr, (uint64_t)room * sv.n_reply);
-    if (!rc) rc = pirgpu_batch_run(sv.ctx);      // asynchronous: the chunk's kernels are queued
-    trace.mark("stage + enqueue");
-    if (!rc) verify_keys_of(sv, chunk.data(), count);   // host work under the GPU's
-    trace.mark("verify keys");
-    auto serialise = [&](size_t r) {
-      Job& job = *chunk[runs[r].first].job;
-      if (job.rc || !job.uniform || job.mismatch) return;
-      try {
-        for (uint32_t i = runs[r].first; i < runs[r].second; ++i)
-          append_reply(job.out, sv.sh, hr + (size_t)i * rwords, sv.n_reply, sv.ctw);
-      } catch (const std::exception& e) {
-        fail_job(job, PIRGPU_INTERNAL, e.what());
-      }
-    };
-    // While the GPU is still computing the later groups: as soon as a group's replies have landed in the pinned buffer,
-    // the requests they complete are serialised on a worker thread (a megabyte per reply, into freshly mapped pages)
-    std::vector<std::future<void>> workers;
-    size_t next_run = 0;
-    static const bool stream_replies = !(getenv("PIRGPU_WIRE_STREAM") && getenv("PIRGPU_WIRE_STREAM")[0] == '0');
-    if (!rc && stream_replies) {
-      uint32_t ready = 0;
-      while (ready < count) {
-        uint32_t upto = 0;
-        if (pirgpu_batch_next_host_replies(sv.ctx, &upto) != 0 || upto <= ready) break;   // not group-wise: all below
-        ready = upto;
-        size_t e = next_run;
-        while (e < runs.size() && runs[e].second <= ready) ++e;
-        if (e > next_run) {
-          workers.push_back(std::async(std::launch::async, [&serialise, next_run, e] {
-            for (size_t r = next_run; r < e; ++r) serialise(r);
-          }));
-          next_run = e;
-        }
-      }
-    }
-    uint64_t got = 0;
-    if (!rc) rc = pirgpu_batch_fetch(sv.ctx, hr, (uint64_t)count * sv.n_reply, &got);   // everything has arrived
-    (void)pirgpu_batch_set_host_replies(sv.ctx, nullptr, 0);
-    for (auto& w : workers) w.get();
-    workers.clear();
-    trace.mark("wait + fetch");
-    if (rc) {
-      const std::string msg = pirgpu_last_error(sv.ctx);
-      for (auto& it : chunk)
-        if (!it.job->rc) fail_job(*it.job, rc, msg);
-      continue;
-    }
-    // what has not been serialised on the way (all of it without group-wise download): up to eight threads
-    const size_t left = runs.size() - next_run;
-    const size_t n_threads = std::min<size_t>(worker_threads(8), left);
-    for (size_t t = 1; t < n_threads; ++t)
-      workers.push_back(std::async(std::launch::async, [&, t] {
-        for (size_t r = next_run + t; r < runs.size(); r += n_threads) serialise(r);
-      }));
-    for (size_t r = next_run; r < runs.size(); r += std::max<size_t>(n_threads, 1)) serialise(r);
-    for (auto& w : workers) w.get();
-    trace.mark("serialise");
-  }
-  (void)pirgpu_set_concurrency(sv.ctx, before);
-  // sequential path for the requests with a wrong ciphertext count somewhere, and for those whose key bytes turned out
-  // to differ from the resident set their fingerprint matched (another client's object: install theirs, serve again)
-  for (size_t i = 0; i < n; ++i) {
-    Job& job = *jobs[i];
-    if (job.rc || (job.uniform && !job.mismatch)) continue;
-    job.out.clear();
-    try {
-      if (job.unverified && !job.mismatch &&
-          !pirgpu_keyset_verify(sv.ctx, job.slot, job.pr.galois_keys, job.pr.galois_keys_len))
-        job.mismatch = true;                       // (a request that never reached a batch chunk)
-      if (job.mismatch) {
-        resolve_keys(sv, job, false, nullptr);
-        job.unverified = job.mismatch = false;
-      }
-      for (auto& qm : job.pr.queries) run_single(sv, job, qm);
-    } catch (const Err& e) {
-      fail_job(job, e.code, e.msg);
-    } catch (const std::exception& e) {
-      fail_job(job, PIRGPU_INTERNAL, e.what());
-    }
-  }
-}
-
-// Serves `n` requests: windows of at most `capacity` clients (so that every client's key set of a window can be
-// resident at once) and kMaxRequestBatch queries' worth of requests.
-void serve(pirgpu_ctx* ctx, Job* const* jobs, size_t n) {
+// Serves `n` requests on batch set `first_set` (which the caller owns) and, when it is free, the other one: windows of
+// at most kMaxRequestBatch queries / half the key-set capacity in clients, two in flight.
+void serve(pirgpu_ctx* ctx, Combiner& cb, int first_set, Job* const* jobs, size_t n) {
   Server sv{};
   sv.ctx = ctx;
   if (pirgpu_get_params(ctx, &sv.prm)) {
@@ -649,33 +739,194 @@ void serve(pirgpu_ctx* ctx, Job* const* jobs, size_t n) {
   uint64_t dim_sum = 0;
   for (uint32_t l = 0; l < sv.prm.num_dimensions; ++l) dim_sum += sv.prm.dimensions[l];
   sv.nq_expected = (uint32_t)(dim_sum / sv.sh.N + 1);  // server.cpp:154
-  // One window = one critical section on the context (the batch staging, the lanes and the key set slots are
-  // context state); PIRServer::ProcessRequest is const and re-entrant in the reference because everything is local.
-  pirgpu_request_lock(ctx);
-  struct Unlock {
-    pirgpu_ctx* c;
-    ~Unlock() {
-      pirgpu_keyset_pin_end(c);
-      pirgpu_request_unlock(c);
-    }
-  } unlock{ctx};
+  Trace trace;
+  // this thread's pinned staging and batch state are those of the set it owns (the lone-query and the sequential paths
+  // use them too); the calling thread's default selection (0) is restored when the call returns
+  (void)pirgpu_batch_select(ctx, (uint32_t)first_set);
+  auto reselect = finally([&] { (void)pirgpu_batch_select(ctx, 0); });
   uint64_t stats[4] = {0, 0, 0, 16};
   (void)pirgpu_keyset_stats(ctx, stats);
-  const size_t window = std::max<size_t>(1, std::min<size_t>(stats[3], kMaxRequestBatch));
-  for (size_t first = 0; first < n; first += window) {
-    pirgpu_keyset_pin_begin(ctx);   // key sets touched from here on are not evicted until the window is done
-    serve_window(sv, jobs + first, std::min(window, n - first));
+  // every window pins its clients' key sets until it is finished, and two windows can be in flight (this thread's or
+  // another serving thread's): half the slots each, so that a new client's claim always finds an unpinned set
+  const size_t max_clients = std::max<size_t>(1, std::min<size_t>(stats[3] >= 2 ? stats[3] / 2 : 1, kMaxRequestBatch));
+  const bool may_overlap = stats[3] >= 2;
+
+  // (1) parse every request; RelinKeys validated when present (server.cpp:53-58: only CT-multiplication mode uses them,
+  // but a malformed non-empty field is InvalidArgument in the reference)
+  uint64_t total_queries = 0;
+  for (size_t i = 0; i < n; ++i) {
+    Job& job = *jobs[i];
+    if (job.rc) continue;
+    try {
+      job.pr = parse_request(job.request, job.request_len);
+      total_queries += job.pr.queries.size();
+    } catch (const Err& e) {
+      fail_job(job, e.code, e.msg);
+    } catch (const std::exception& e) {
+      fail_job(job, PIRGPU_INTERNAL, e.what());
+    }
+  }
+  trace.mark("parse");
+
+  // keys of one request: a fingerprint match first (the 4.7 MB compare runs under the GPU's work), else parse + upload
+  auto keys_for_job = [&](Job& job) {
+    if (job.rc) return;
+    if (job.pins > 0) {     // a request cut over several windows: one more pin on the set it already resolved to
+      if (pirgpu_keyset_pin(sv.ctx, job.slot) == 0) ++job.pins;
+      else fail_job(job, PIRGPU_INTERNAL, pirgpu_last_error(sv.ctx));
+      return;
+    }
+    try {
+      resolve_keys(sv, job, true, &job.unverified);
+      if (job.pr.relin_keys_len) load_kswitch_keys(sv.sh, job.pr.relin_keys, job.pr.relin_keys_len, nullptr);
+    } catch (const Err& e) {
+      unpin_job(sv, job);
+      fail_job(job, e.code, e.msg);
+    } catch (const std::exception& e) {
+      unpin_job(sv, job);
+      fail_job(job, PIRGPU_INTERNAL, e.what());
+    }
+  };
+
+  // (2) one query in the whole call: the single-query path (lowest latency), under the context's request lock
+  if (total_queries == 1) {
+    CtxLock lock(ctx);
+    for (size_t i = 0; i < n; ++i) {
+      Job& job = *jobs[i];
+      if (job.rc) continue;
+      keys_for_job(job);
+      if (job.rc || job.pr.queries.empty()) {
+        unpin_job(sv, job);
+        continue;
+      }
+      try {
+        bool verified = true;
+        run_single(sv, job, job.pr.queries[0], [&]() {   // the byte-for-byte key compare runs under the GPU work
+          if (job.unverified) verified = pirgpu_keyset_verify(sv.ctx, job.slot, job.pr.galois_keys, job.pr.galois_keys_len) != 0;
+        });
+        if (!verified) {
+          // same fingerprint, different bytes: not this client's keys after all -- install them and run again
+          job.out.clear();
+          unpin_job(sv, job);
+          resolve_keys(sv, job, false, nullptr);
+          run_single(sv, job, job.pr.queries[0]);
+        }
+      } catch (const Err& e) {
+        fail_job(job, e.code, e.msg);
+      } catch (const std::exception& e) {
+        fail_job(job, PIRGPU_INTERNAL, e.what());
+      }
+      unpin_job(sv, job);
+    }
+    return;
+  }
+
+  // (3) several queries: windows through the batch pipeline, every query with its client's key set.  Requests whose
+  // queries do not all have the expected ciphertext count, and those whose key bytes turn out to differ from the
+  // resident set their fingerprint matched, take the sequential path at the end.
+  int sets[2] = {first_set, -1};
+  auto release_second = finally([&] {
+    if (sets[1] >= 0) {
+      std::lock_guard<std::mutex> lk(cb.m);
+      cb.set_busy[sets[1]] = false;
+      cb.cv.notify_all();
+    }
+  });
+  Window win[2];
+  bool open[2] = {false, false};
+  std::deque<int> order;     // open windows, oldest first
+  int wid = 0;
+  auto finish_oldest = [&] {
+    const int slot = order.front();
+    order.pop_front();
+    finish_window(sv, win[slot], trace);
+    open[slot] = false;
+    win[slot] = Window();
+    return slot;
+  };
+  size_t ji = 0;        // next request
+  uint32_t qi = 0;      // its next query
+  while (ji < n) {
+    // the next window's items: whole requests while they fit (a request with more than kMaxRequestBatch queries is cut)
+    std::vector<Item> items;
+    std::vector<Job*> wjobs;
+    while (ji < n && items.size() < kMaxRequestBatch && wjobs.size() < max_clients) {
+      Job& job = *jobs[ji];
+      const uint32_t left = job.rc ? 0 : (uint32_t)job.pr.queries.size() - qi;
+      if (!left) {
+        if (!job.rc && job.pr.queries.empty()) {   // no query: the keys are still deserialised (server.cpp:46-48)
+          keys_for_job(job);
+          unpin_job(sv, job);
+        }
+        ++ji;
+        qi = 0;
+        continue;
+      }
+      if (left > kMaxRequestBatch - items.size() && !items.empty() && left <= kMaxRequestBatch) break;   // next window
+      wjobs.push_back(&job);
+      const uint32_t take = (uint32_t)std::min<size_t>(left, kMaxRequestBatch - items.size());
+      for (uint32_t q = 0; q < take; ++q) items.push_back({&job, qi + q});
+      qi += take;
+      if (qi == job.pr.queries.size()) {
+        ++ji;
+        qi = 0;
+      }
+    }
+    if (items.empty()) break;
+    // a free slot for it: the second batch set is taken when nobody else has it; otherwise finish the window in flight
+    int slot = -1;
+    for (int s2 = 0; s2 < 2 && slot < 0; ++s2)
+      if (!open[s2] && sets[s2] >= 0) slot = s2;
+    if (slot < 0 && sets[1] < 0 && may_overlap) {
+      std::lock_guard<std::mutex> lk(cb.m);
+      const int got = cb.take_set();
+      if (got >= 0) {
+        sets[1] = got;
+        slot = 1;
+      }
+    }
+    if (slot < 0) slot = finish_oldest();
+    Window& w = win[slot];
+    w.set = sets[slot];
+    w.home = first_set;
+    w.id = wid++;
+    w.jobs = wjobs;
+    for (Job* job : wjobs) keys_for_job(*job);      // pins the window's key sets
+    trace.mark("resolve keys", w.id);
+    begin_window(sv, w, items, trace);
+    open[slot] = true;
+    order.push_back(slot);
+  }
+  while (!order.empty()) (void)finish_oldest();
+
+  // sequential path for the requests with a wrong ciphertext count somewhere, and for those whose key bytes turned out
+  // to differ from the resident set their fingerprint matched (another client's object: install theirs, serve again)
+  for (size_t i = 0; i < n; ++i) {
+    Job& job = *jobs[i];
+    if (job.rc || (job.uniform && !job.mismatch)) continue;
+    job.out.clear();
+    CtxLock lock(ctx);
+    try {
+      resolve_keys(sv, job, false, nullptr);      // verified lookup, or this client's own keys installed
+      job.unverified = job.mismatch = false;
+      for (auto& qm : job.pr.queries) run_single(sv, job, qm);
+    } catch (const Err& e) {
+      fail_job(job, e.code, e.msg);
+    } catch (const std::exception& e) {
+      fail_job(job, PIRGPU_INTERNAL, e.what());
+    }
+    unpin_job(sv, job);
   }
 }
 
 // serve() catches what a request can cause per request; anything that still escapes (out of memory while queueing, ...)
-// must not leave the combiner without a leader or cross the C ABI: every request of the call fails with Internal.
-void serve_guarded(pirgpu_ctx* ctx, Job* const* jobs, size_t n) noexcept {
+// must not leave the combiner without its batch set or cross the C ABI: every request of the call fails with Internal.
+void serve_guarded(pirgpu_ctx* ctx, Combiner& cb, int set, Job* const* jobs, size_t n) noexcept {
   const char* what = nullptr;
   std::string msg;
   int code = PIRGPU_INTERNAL;
   try {
-    serve(ctx, jobs, n);
+    serve(ctx, cb, set, jobs, n);
     return;
   } catch (const Err& e) {
     code = e.code;
@@ -688,6 +939,7 @@ void serve_guarded(pirgpu_ctx* ctx, Job* const* jobs, size_t n) noexcept {
     what = "unexpected failure while serving";
   }
   for (size_t i = 0; i < n; ++i) {
+    for (; jobs[i]->pins > 0; --jobs[i]->pins) (void)pirgpu_keyset_unpin(ctx, jobs[i]->slot);
     try {
       fail_job(*jobs[i], code, what);
     } catch (...) {
@@ -709,14 +961,9 @@ int finish(pirgpu_ctx* ctx, Job& job, uint8_t** response, size_t* response_len) 
   return PIRGPU_OK;
 }
 
-// Requests that arrive while another thread is serving are queued and served together by whichever thread gets the
-// context next (flat combining): no extra latency when the server is idle, cross-client batching under load.
-struct Combiner {
-  std::mutex m;
-  std::condition_variable cv;
-  std::deque<Job*> pending;
-  bool leader = false;
-};
+// Requests that arrive while every batch set is taken are queued and served together by whichever thread gets a set
+// next (flat combining): no extra latency when the server is idle, cross-client batching under load -- and with two
+// batch sets per context the next window is parsed, staged and queued while the previous one is still on the GPU.
 thread_local std::vector<std::string> t_request_errors;   // per request of this thread's last pirgpu_process_requests
 std::mutex g_combiners_mu;
 std::map<pirgpu_ctx*, std::shared_ptr<Combiner>> g_combiners;
@@ -752,22 +999,23 @@ int pirgpu_process_request(pirgpu_ctx* ctx, const uint8_t* request, size_t reque
     std::unique_lock<std::mutex> lk(cb->m);
     cb->pending.push_back(&job);
     while (!job.done) {
-      if (cb->leader) {
+      // (nothing pending: this thread's request is being served by another leader -- wait for it)
+      const int set = cb->pending.empty() ? -1 : cb->take_set();
+      if (set < 0) {
         cb->cv.wait(lk);
         continue;
       }
-      // lead: serve what is queued (this thread's own request is in there) and hand over
-      cb->leader = true;
+      // lead: serve what is queued (this thread's own request is in there unless another leader took it) and hand over
       std::vector<Job*> batch;
       while (!cb->pending.empty() && batch.size() < kMaxRequestBatch) {
         batch.push_back(cb->pending.front());
         cb->pending.pop_front();
       }
       lk.unlock();
-      serve_guarded(ctx, batch.data(), batch.size());
+      if (!batch.empty()) serve_guarded(ctx, *cb, set, batch.data(), batch.size());
       lk.lock();
       for (Job* j : batch) j->done = true;
-      cb->leader = false;
+      cb->set_busy[set] = false;
       cb->cv.notify_all();
     }
   }
@@ -788,7 +1036,18 @@ int pirgpu_process_requests(pirgpu_ctx* ctx, uint32_t n, const uint8_t* const* r
     if (!requests[i] && request_lens[i]) fail_job(jobs[i], PIRGPU_INVALID_ARGUMENT, "null request");
   }
   Trace trace;
-  serve_guarded(ctx, ptrs.data(), n);
+  std::shared_ptr<Combiner> cb = combiner_for(ctx);
+  int set;
+  {
+    std::unique_lock<std::mutex> lk(cb->m);
+    while ((set = cb->take_set()) < 0) cb->cv.wait(lk);
+  }
+  serve_guarded(ctx, *cb, set, ptrs.data(), n);
+  {
+    std::lock_guard<std::mutex> lk(cb->m);
+    cb->set_busy[set] = false;
+    cb->cv.notify_all();
+  }
   trace.mark("serve (whole call)");
   int worst = PIRGPU_OK;
   t_request_errors.assign(n, std::string());

@@ -20,21 +20,21 @@ int pirgpu_wire_load_kswitch_key(const struct pirgpu_params* params, const uint8
 struct pirgpu_params;
 int pirgpu_wire_validate_request(const struct pirgpu_params* params, const uint8_t* request, size_t request_len,
                                  uint32_t* n_queries);
-// Key sets touched between pin_begin and pin_end belong to the requests being processed together: pirgpu_keyset_claim
-// does not evict them.
+// A pinned key set is never evicted or released (one pin per request in flight that uses it; slot handles as handed out
+// by pirgpu_keyset_lookup / _claim).
 struct pirgpu_ctx;
-void pirgpu_keyset_pin_begin(struct pirgpu_ctx* ctx);
-void pirgpu_keyset_pin_end(struct pirgpu_ctx* ctx);
+int pirgpu_keyset_pin(struct pirgpu_ctx* ctx, uint32_t slot);
+int pirgpu_keyset_unpin(struct pirgpu_ctx* ctx, uint32_t slot);
 // The host copy of the key object resident key set `slot` was installed from (0 if the slot is empty).  The pointer stays
-// valid while the caller holds the request lock and the slot is pinned (no eviction, no reinstall): the wire layer
+// valid while the slot is pinned (no eviction, no reinstall): the wire layer
 // compares it with a request's bytes on worker threads without taking the context's lock.
 size_t pirgpu_keyset_blob(struct pirgpu_ctx* ctx, uint32_t slot, const uint8_t** blob);
 // Slot pirgpu_query_use_keyset last selected (the wire layer restores it after serving a request).
 uint32_t pirgpu_current_keyset(struct pirgpu_ctx* ctx);
 // Drops the wire layer's per-context state (called by pirgpu_destroy).
 void pirgpu_wire_forget(struct pirgpu_ctx* ctx);
-// Request-level critical section (recursive with the per-call lock of the ABI entry points): held by
-// pirgpu_process_request for its whole body so that concurrent requests on one context cannot interleave.
+// Request-level critical section (recursive with the per-call lock of the ABI entry points): the wire layer holds it
+// while it stages + queues a window, installs a client's keys, or serves a lone query; NOT while a queued window runs.
 void pirgpu_request_lock(struct pirgpu_ctx* ctx);
 void pirgpu_request_unlock(struct pirgpu_ctx* ctx);
 // Queries in flight as last set with pirgpu_set_concurrency (1 by default).

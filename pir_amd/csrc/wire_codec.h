@@ -6,6 +6,7 @@
 
 #include <functional>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/pirgpu.h"
@@ -149,6 +150,11 @@ std::string save_public_key(const Shape& sh, const uint64_t* pk, const uint8_t* 
 // KSwitchKeys::load (GaloisKeys / RelinKeys): calls sink(index, key [k][2][k+1][N]) per present entry.
 void load_kswitch_keys(const Shape& sh, const uint8_t* data, size_t len,
                        const std::function<void(uint64_t, const uint64_t*)>& sink);
+// The same with the objects parsed (and their seeded halves expanded) through `pf` (n, fn): fn(i) for every i < n, on
+// whatever threads pf has; nullptr = sequentially.  keys[e] = (index, key) in object order.
+using ParallelFor = std::function<void(size_t, const std::function<void(size_t)>&)>;
+void load_kswitch_keys_parallel(const Shape& sh, const uint8_t* data, size_t len, const ParallelFor& pf,
+                                std::vector<std::pair<uint64_t, std::vector<uint64_t>>>& keys);
 // KSwitchKeys::save: entries[i] = key [k][2][k+1][N] or nullptr (absent), i < dim1.
 // seeds (optional): per entry k * kSeedBytes bytes -> the seed-compressed Serializable<> form (c1 halves omitted).
 std::string save_kswitch_keys(const Shape& sh, const std::vector<const uint64_t*>& entries,

@@ -29,8 +29,11 @@ int pirgpu_query_run(pirgpu_ctx*) { return 13; }
 int pirgpu_query_fetch(pirgpu_ctx*, uint64_t*, uint64_t, uint64_t*) { return 13; }
 uint64_t* pirgpu_host_query_buffer(pirgpu_ctx*, uint32_t) { return nullptr; }
 uint64_t* pirgpu_host_reply_buffer(pirgpu_ctx*, uint32_t) { return nullptr; }
-void pirgpu_keyset_pin_begin(pirgpu_ctx*) {}
-void pirgpu_keyset_pin_end(pirgpu_ctx*) {}
+int pirgpu_keyset_pin(pirgpu_ctx*, uint32_t) { return 13; }
+int pirgpu_keyset_unpin(pirgpu_ctx*, uint32_t) { return 13; }
+int pirgpu_batch_stage_async(pirgpu_ctx*, const uint64_t*, uint32_t, uint32_t) { return 13; }
+int pirgpu_batch_unstage(pirgpu_ctx*) { return 13; }
+int pirgpu_batch_select(pirgpu_ctx*, uint32_t) { return 13; }
 void pirgpu_request_lock(pirgpu_ctx*) {}
 void pirgpu_request_unlock(pirgpu_ctx*) {}
 uint32_t pirgpu_get_concurrency(pirgpu_ctx*) { return 1; }

@@ -160,21 +160,66 @@ def build_workload(args, pir_amd):
     return enc, pp, item_bytes
 
 
-def timed_steps(step, barrier, steps, warmup, dist, use_dist, torch, dev):
-    """The bench contract: W untimed steps, then exactly K steps between barrier + synchronise, MAX over ranks."""
+BLOCK_LOG = []           # per measurement: the per-block elapsed seconds behind the reported median
+
+
+def timed_steps(step, barrier, steps, warmup, dist, use_dist, torch, dev, min_seconds=1.0, max_blocks=9):
+    """The bench contract: W untimed steps, then exactly K steps between barrier + synchronise, MAX over ranks.
+    When that timed block is shorter than `min_seconds` (the driver's --steps 20 is 0.24 s at the headline config, and the
+    same kernel measures 0.195 / 0.207 ms in consecutive runs), the block of K steps is REPEATED -- every block
+    bracketed the same way -- and the median block is reported; the block count follows from the first block's
+    all-reduced time, so every rank runs the same number."""
+    def block():
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        el = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([el], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
     for _ in range(warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    return elapsed
+    times = [block()]
+    want = 1 if times[0] >= min_seconds else min(max_blocks, int(np.ceil(min_seconds / max(times[0], 1e-6))))
+    if want > 1 and want % 2 == 0:
+        want += 1                      # odd: the median is a measured block
+    while len(times) < want:
+        times.append(block())
+    BLOCK_LOG.append([round(t, 6) for t in times])
+    return float(np.median(times))
+
+
+def scan_source_sha16():
+    """What the PMC traffic file is stamped with (tools/pmc_scan_traffic.sh): the scan kernel's source as it was profiled."""
+    import hashlib
+    with open(os.path.join(ROOT, "pir_amd", "csrc", "scan_mfma.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def recorded_traffic(config, log_items, world, single_query_mfma):
+    """roofline.traffic: HBM bytes per single-query scan launch as RECORDED by the newest committed PMC passes of this
+    workload (rocprofv3 --pmc cannot run inside the bench); `stale` says whether the scan kernel's source has changed
+    since those passes (True), is the one that was profiled (False), or cannot be told (None: no stamp in the file)."""
+    import glob
+    try:
+        pmf = sorted(glob.glob(os.path.join(ROOT, "profiles", PMC_GLOB)))[-1]
+        pm = json.load(open(pmf))
+        ent = pm["configs"].get("cfg%d" % config)
+        default_shape = log_items == {2: 16, 3: 20, 4: 22, 5: 24}[config]
+        if not (ent and "traffic_bytes_per_launch" in ent and default_shape and world == 1 and single_query_mfma):
+            return None, None, None
+        stamp = pm.get("scan_source_sha16")
+        stale = None if not stamp else stamp != scan_source_sha16()
+        src = "RECORDED, not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (gfx950 x2 correction " \
+              "on FETCH_SIZE) of this workload at commit %s, profiles/%s" % (pm.get("commit"), os.path.basename(pmf))
+        return ent["traffic_bytes_per_launch"], src, stale
+    except Exception:
+        return None, None, None
 
 
 def main():
@@ -364,19 +409,7 @@ def main():
         scan_ms = timings["scan_ms"]
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         import glob
-        traffic, traffic_src = None, None
-        try:   # HBM bytes per single-query scan launch: RECORDED by the newest committed PMC passes, same workload only
-            pmf = sorted(glob.glob(os.path.join(ROOT, "profiles", PMC_GLOB)))[-1]
-            pm = json.load(open(pmf))
-            ent = pm["configs"].get("cfg%d" % args.config)
-            default_shape = args.log_items == {2: 16, 3: 20, 4: 22, 5: 24}[args.config]
-            if ent and "traffic_bytes_per_launch" in ent and default_shape and world == 1 and info["single_query_mfma"]:
-                traffic = ent["traffic_bytes_per_launch"]
-                traffic_src = "RECORDED, not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes " \
-                              "(gfx950 x2 correction on FETCH_SIZE) of this workload at commit %s, profiles/%s" \
-                              % (pm.get("commit"), os.path.basename(pmf))
-        except Exception:
-            pass
+        traffic, traffic_src, traffic_stale = recorded_traffic(args.config, args.log_items, world, info["single_query_mfma"])
         compute = None
         try:   # VALU-issue roofline of the transform kernels (recorded: tools/valu_roofline.py over PMC passes)
             compute = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", VALU_GLOB)))[-1]))
@@ -399,6 +432,8 @@ def main():
             "rccl_ranks": (dist.get_world_size() if dist.get_backend() == "nccl" else 0) if use_dist else None,
             **({"backend": "gloo (ranks share one GPU: test facility, not a multi-GPU measurement)"} if share_gpu else {}),
             "steps": args.steps, "warmup": args.warmup,
+            # blocks of K timed steps behind ms_per_step (median block; one block when K steps last >= 1 s)
+            "timed_blocks": len(headline_blocks), "timed_block_seconds": headline_blocks,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": "N=%d, %d RNS data primes (%s bit | special %d bit), t=24 bit, DB=2^%d x %dB, "
@@ -417,6 +452,9 @@ def main():
                          "frac_definition": "bytes the kernel must read (packed operand layout) / HIP-event duration / 8 TB/s",
                          "traffic": traffic,
                          "traffic_source": traffic_src,
+                         # true: scan_mfma.hip has changed since the PMC passes were taken -- the figure describes an
+                         # older kernel; null: the PMC file carries no source stamp
+                         "traffic_stale": traffic_stale,
                          "kernel": ("scan_mfma_kernel<%d digits, %d k-steps> (int8 MFMA digit products, 1 query; "
                                     "the same pass serves up to 8)" % (info["digits"], info["ksteps"])) if info["single_query_mfma"]
                          else ("scan_mq_kernel<4 rows/wave, 1 query>" if args.dims > 1
@@ -466,33 +504,61 @@ def main():
                                         "step s-1 and the expansion of step s+1, no host waits): ms_per_step"}
         if world == 1 and not use_dist and args.config == 3:
             # wire-level ProcessRequest (what benchmark.cpp:71-79 times): serialized pir.Request in host
-            # memory -> serialized pir.Response, incl. parsing, H2D of keys + query, D2H, serialisation
+            # memory -> serialized pir.Response, incl. parsing, H2D of keys + query, D2H, serialisation.  The requests
+            # come from the product client library (pir_amd.PIRClient, CPU): real keys, a real query ciphertext.
             try:
-                sys.path.insert(0, os.path.join(ROOT, "tests"))
-                import seal_wire as W
-                mods = enc.coeff_modulus
-                gk = W.save_galois_keys(keys, N, W.parms_id(N, mods, enc.plain_modulus))
-                req = W.save_request([query], gk, W.parms_id(N, mods[:-1], enc.plain_modulus))
+                cl = pir_amd.PIRClient.Create(pp, seed=b"bench-wire-client-0")
+                q_ct = cl.create_query_for(123457 % pp.num_items)
+                cl.set_seeded_keys(False)                 # expanded key objects (4.9 MB), as server_test.cpp builds them
+                req = cl.SaveRequest([q_ct])
                 srv.set_concurrency(1)
                 wt = []
                 for _ in range(25):
                     t0 = time.perf_counter()
                     resp = srv.ProcessRequest(req)
                     wt.append((time.perf_counter() - t0) * 1e3)
-                same = bool(np.array_equal(W.load_response(resp)[0], single_reply))
-                # a SECOND client's first request on the warm context (its 4.7 MB of keys parsed, validated, uploaded)
-                k2 = {g: (kk + np.uint64(1)) % np.array(mods, dtype=np.uint64)[None, None, :, None] for g, kk in keys.items()}
-                req2 = W.save_request([query], W.save_galois_keys(k2, N, W.parms_id(N, mods, enc.plain_modulus)),
-                                      W.parms_id(N, mods[:-1], enc.plain_modulus))
-                t0 = time.perf_counter()
-                srv.ProcessRequest(req2)
-                new_client_ms = (time.perf_counter() - t0) * 1e3
+                # the same ciphertext through the residue-level entry point with the same client's keys
+                slot = srv.install_keyset(b"bench-wire-client-0-residues", cl.galois_keys())
+                srv.use_keyset(slot)
+                same = bool(np.array_equal(cl.LoadResponse(resp)[0], srv.process_query(q_ct)))
+                srv.use_keyset(0)
+                srv.release_keyset(slot)
+                # the reference client's DEFAULT request: seed-compressed Serializable<GaloisKeys> (client.cpp:47-54),
+                # every key's uniform half re-sampled on the server (BLAKE2Xb + rejection sampling, on the pool's threads)
+                cl.set_seeded_keys(True)
+                req_s = cl.SaveRequest([q_ct])
+                ws = []
+                for _ in range(13):
+                    t0 = time.perf_counter()
+                    resp_s = srv.ProcessRequest(req_s)
+                    ws.append((time.perf_counter() - t0) * 1e3)
+                same_s = resp_s == resp                   # same keys, same query: the same bytes come back
+                # NEW clients' first requests on the warm context (keys parsed / re-sampled, validated, uploaded)
+                new_exp, new_seed = [], []
+                for i in range(3):
+                    c2 = pir_amd.PIRClient.Create(pp, seed=b"bench-wire-new-%d" % i)
+                    q2 = c2.create_query_for((1000003 * (i + 1)) % pp.num_items)
+                    for seeded, acc in ((False, new_exp), (True, new_seed)):
+                        c3 = pir_amd.PIRClient.Create(pp, seed=b"bench-wire-new-%d-%d" % (i, seeded))
+                        c3.set_seeded_keys(seeded)
+                        r3 = c3.SaveRequest([q2])
+                        t0 = time.perf_counter()
+                        srv.ProcessRequest(r3)
+                        acc.append((time.perf_counter() - t0) * 1e3)
                 out["wire_process_request_ms"] = {"first_request_with_key_upload": round(wt[0], 3),
-                                                  "new_client_first_request_on_warm_context": round(new_client_ms, 3),
+                                                  "new_client_first_request_on_warm_context": round(float(np.median(new_exp)), 3),
+                                                  "new_client_seeded_keys_ms": round(float(np.median(new_seed)), 3),
+                                                  "repeat": round(float(np.median(wt[1:])), 3),
                                                   "repeat_client_keys_cached_median_of_24": round(float(np.median(wt[1:])), 3),
                                                   "repeat_min": round(float(np.min(wt[1:])), 3),
-                                                  "request_bytes": len(req), "response_bytes": len(resp),
-                                                  "response_equals_residue_path": same}
+                                                  "repeat_seeded_keys_median_of_12": round(float(np.median(ws[1:])), 3),
+                                                  "request_bytes": len(req), "request_bytes_seeded_keys": len(req_s),
+                                                  "response_bytes": len(resp),
+                                                  "response_equals_residue_path": same,
+                                                  "seeded_response_equals_expanded_response": same_s,
+                                                  "requests_from": "pir_amd.PIRClient (product client library): expanded "
+                                                                   "key objects for the first block, seed-compressed ones "
+                                                                   "(the reference client's default) for the seeded figures"}
             except Exception as e:   # measurement extra only
                 out["wire_process_request_ms"] = {"error": repr(e)}
         if world == 1 and not use_dist and args.config == 3:
@@ -539,23 +605,20 @@ def main():
                                                    "with its own client's keys inside mixed groups of 8" % n_cl}
             except Exception as e:   # measurement extra only
                 out["multi_client_qps"] = {"error": repr(e)}
-            # the same through the WIRE: n_w clients' serialized pir.Request protos (keys + one query each) served by one
-            # pirgpu_process_requests call -- parsing, key fingerprint + byte compare against the resident sets, H2D of
-            # the queries, the batch pipeline, D2H and serialisation of the responses, all inside the timed region
+            # the same through the WIRE: n_w clients' serialized pir.Request protos (the product client's CreateRequest:
+            # seed-compressed keys + one query each) served by pirgpu_process_requests -- parsing, key fingerprint + byte
+            # compare against the resident sets, H2D of the queries, the batch pipeline, D2H and serialisation of the
+            # responses, all inside the timed region.  `value` = the server under sustained load: `callers` threads, each
+            # sending its n_w clients' requests in a loop (two request windows in flight on the context, so parsing /
+            # staging of one window and the download / serialisation of another run beside the GPU's work on a third);
+            # `single_caller` = one thread, one call after the other (every call fills and drains the pipeline alone).
             try:
-                import seal_wire as W
-                mods = enc.coeff_modulus
+                srv.unstage_batch()       # the device-resident leg's staged batch no longer holds on to its 64 key sets
                 n_w = int(os.environ.get("PIRGPU_BENCH_WIRE_CLIENTS", "64"))
-                pid_k, pid_q = W.parms_id(N, mods, enc.plain_modulus), W.parms_id(N, mods[:-1], enc.plain_modulus)
-                reqs = []
-                for cidx in range(n_w):
-                    ck = {}
-                    for g, key in keys.items():
-                        kk = key.copy()
-                        for i in range(k + 1):
-                            kk[:, :, i, :] = (kk[:, :, i, :] + np.uint64(1000 + cidx)) % np.uint64(mods[i])
-                        ck[g] = kk
-                    reqs.append(W.save_request([queries[cidx]], W.save_galois_keys(ck, N, pid_k), pid_q))
+                callers = max(1, int(os.environ.get("PIRGPU_BENCH_WIRE_CALLERS", "2")))
+                srv.set_keyset_capacity(int(os.environ.get("PIRGPU_BENCH_WIRE_CAPACITY", str(max(64, 2 * n_w)))))
+                wcl = [pir_amd.PIRClient.Create(pp, seed=b"bench-wire-mc-%d" % i) for i in range(n_w)]
+                reqs = [c.CreateRequest([(7919 * i + 13) % pp.num_items]) for i, c in enumerate(wcl)]
                 first = srv.ProcessRequests(reqs)                 # installs the key sets
                 # timed through the C ABI itself (ctypes call, responses freed unread): the Python mirror's copies of
                 # a megabyte per response are the binding's cost, not the library's
@@ -564,9 +627,12 @@ def main():
                 req_views = [np.frombuffer(r, dtype=np.uint8) for r in reqs]
                 ptrs = (C.c_void_p * n_w)(*[b.ctypes.data for b in req_views])
                 lens = (C.c_size_t * n_w)(*[len(r) for r in reqs])
-                resp, rlen, status = (C.c_void_p * n_w)(), (C.c_size_t * n_w)(), (C.c_int * n_w)()
 
-                def one_call(keep=False):
+                def call_state():
+                    return (C.c_void_p * n_w)(), (C.c_size_t * n_w)(), (C.c_int * n_w)()
+
+                def one_call(state, keep=False):
+                    resp, rlen, status = state
                     lib.pirgpu_process_requests(handle, n_w, ptrs, lens, resp, rlen, status)
                     good = all(status[i] == 0 for i in range(n_w))
                     kept = C.string_at(resp[0], rlen[0]) if keep and good else None
@@ -575,25 +641,53 @@ def main():
                             lib.pirgpu_free(resp[i])
                     return good, kept
 
+                st0 = call_state()
                 for _ in range(2):
-                    one_call()
-                w_steps = 10
+                    one_call(st0)
+                w_steps = 20
                 ok = True
                 t0 = time.perf_counter()
                 for _ in range(w_steps):
-                    ok = one_call()[0] and ok
-                dt = time.perf_counter() - t0
-                good, kept = one_call(keep=True)
-                ok = ok and good and all(st == 0 for st, _ in first)
-                same = ok and bool(np.array_equal(W.load_response(kept)[0], W.load_response(first[0][1])[0]))
-                out["wire_multi_client_qps"] = {"value": w_steps * n_w / dt, "unit": "queries/s", "clients": n_w,
-                                                "ms_per_call": dt / w_steps * 1e3, "all_ok": ok,
-                                                "repeatable": same, "request_bytes_each": len(reqs[0]),
+                    ok = one_call(st0)[0] and ok
+                dt1 = time.perf_counter() - t0
+                # sustained load: `callers` threads (ctypes releases the interpreter lock for the duration of a call)
+                oks = [True] * callers
+                gate = threading.Barrier(callers + 1)
+
+                def caller(ci):
+                    st = call_state()
+                    one_call(st)
+                    gate.wait()
+                    for _ in range(w_steps):
+                        oks[ci] = one_call(st)[0] and oks[ci]
+                    gate.wait()
+
+                ths = [threading.Thread(target=caller, args=(ci,)) for ci in range(callers)]
+                for th in ths:
+                    th.start()
+                gate.wait()
+                t0 = time.perf_counter()
+                gate.wait()
+                dtn = time.perf_counter() - t0
+                for th in ths:
+                    th.join()
+                good, kept = one_call(st0, keep=True)
+                ok = ok and good and all(oks) and all(st == 0 for st, _ in first)
+                same = ok and kept == first[0][1]
+                out["wire_multi_client_qps"] = {"value": callers * w_steps * n_w / dtn, "unit": "queries/s", "clients": n_w,
+                                                "callers": callers, "calls_per_caller": w_steps,
+                                                "ms_per_call": dtn / w_steps * 1e3,
+                                                "single_caller": {"value": w_steps * n_w / dt1, "unit": "queries/s",
+                                                                  "ms_per_call": dt1 / w_steps * 1e3},
+                                                "all_ok": ok, "repeatable": same, "request_bytes_each": len(reqs[0]),
+                                                "keys": "seed-compressed (product client default)",
+                                                "keysets": srv.keyset_stats(),
                                                 "note": "pirgpu_process_requests on %d clients' serialized requests per "
                                                         "call (keys resident after the first call): wire parsing, key "
                                                         "lookup + byte compare, PCIe both ways and response "
-                                                        "serialisation inside the timed region; one calling thread, "
-                                                        "timed at the C ABI" % n_w}
+                                                        "serialisation inside the timed region, timed at the C ABI; value = "
+                                                        "%d calling threads in a loop (sustained load, two request windows "
+                                                        "in flight), single_caller = one thread, call after call" % (n_w, callers)}
             except Exception as e:   # measurement extra only
                 out["wire_multi_client_qps"] = {"error": repr(e)}
         if world == 1 and not use_dist and not args.no_cpu_baseline:
@@ -715,6 +809,7 @@ def main():
         exchange = "replicated"
         el_r = measure("replicated")
         elapsed, qps = el_r, args.steps * batch / el_r
+        headline_blocks = BLOCK_LOG[-1]
         arm_watchdog()
         el_p = measure("packed")
         tune = {"ms_per_step": {"replicated": round(el_r / args.steps * 1e3, 4), "packed": round(el_p / args.steps * 1e3, 4)},
@@ -724,6 +819,7 @@ def main():
         if el_p < el_r:
             exchange = "packed"
             elapsed, qps = el_p, args.steps * batch / el_p
+            headline_blocks = BLOCK_LOG[-1]
         else:
             tune["packed_details"] = {"exchange_bytes_received_per_query_per_gpu": bufs.exchange_bytes_per_query(world),
                                       "phases_ms_serial": serial_phases}
@@ -733,6 +829,7 @@ def main():
     else:
         elapsed = measure(exchange)
         qps = args.steps * batch / elapsed
+        headline_blocks = BLOCK_LOG[-1]
     if use_dist and world == 1:   # forced single-rank run: the reduced replies must equal the plain ones
         got = ((pipe.replies(pipe.step - 1) if pipe is not None else bufs.replies) if exchange == "packed"
                else (rpipe.replies(rpipe.step - 1) if rpipe is not None else redb)).cpu().numpy().view(np.uint64)

@@ -53,6 +53,15 @@ int pirclient_process_response(pirclient* c, const uint64_t* indexes, size_t n_i
 int pirclient_process_response_integer(pirclient* c, const uint8_t* response, size_t response_len, int64_t* out,
                                        size_t out_cap, size_t* n_out);
 void pirclient_free(void* p);
+/* SaveRequest(queries, galois_keys, relin_keys, request) -- serialization.cpp:44-73 -- with this client's keys: a
+ * serialized pir.Request around n_queries caller-supplied query ciphertext sets (residues [n_queries][query_ct_count]
+ * [2][k][N], e.g. from pirclient_create_query), so that the SAME ciphertexts can go through the residue-level and the
+ * wire-level server entry points.  *request is malloc'd; release with pirclient_free. */
+int pirclient_save_request(pirclient* c, const uint64_t* queries, size_t n_queries, uint8_t** request, size_t* request_len);
+/* LoadCiphertexts over every Response.reply -- serialization.cpp:32-42: serialized pir.Response -> residues
+ * [n_replies][reply_ct_count][2][k][N] (cap_replies = room in replies_out, in replies). */
+int pirclient_load_response(pirclient* c, const uint8_t* response, size_t response_len, uint64_t* replies_out,
+                            size_t cap_replies, size_t* n_replies);
 /* Key fields of the requests: seed-compressed (default; what SEAL 3.5.6's Serializable<GaloisKeys> /
  * Serializable<RelinKeys> of PIRClient::initialize produce, client.cpp:47-54: every key sample carries c0 and the
  * 64-byte seed its uniform half is re-sampled from) or, with enabled == 0, fully expanded objects. */

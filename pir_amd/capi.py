@@ -189,6 +189,8 @@ CLIENT_SIGNATURES = {
                                                       C.POINTER(C.c_size_t)]),
     "pirclient_free": (None, [C.c_void_p]),
     "pirclient_set_seeded_keys": (C.c_int, [C.c_void_p, C.c_int]),
+    "pirclient_save_request": (C.c_int, [C.c_void_p, u64p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "pirclient_load_response": (C.c_int, [C.c_void_p, u8p, C.c_size_t, u64p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "pirclient_query_ct_count": (C.c_uint32, [C.c_void_p]),
     "pirclient_create_query": (C.c_int, [C.c_void_p, C.c_uint64, u64p, C.c_size_t, C.POINTER(C.c_uint32)]),
     "pirclient_galois_key": (C.c_int, [C.c_void_p, C.c_uint32, u64p]),

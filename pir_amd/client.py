@@ -81,6 +81,30 @@ class PIRClient:
         finally:
             self.lib.pirclient_free(out)
 
+    def SaveRequest(self, queries: Sequence[np.ndarray]) -> bytes:
+        """serialization.cpp:44-73 with this client's keys: a serialized pir.Request around caller-supplied query
+        ciphertexts (each [query_ct_count, 2, k, N], e.g. from create_query_for) -- the same ciphertexts can then go
+        through the residue-level and the wire-level server entry points."""
+        q = _u64(np.stack([_u64(x).reshape(self.query_ct_count, 2, self.k, self.N) for x in queries])) if len(queries) \
+            else np.zeros((0,), dtype=np.uint64)
+        out, n = C.c_void_p(), C.c_size_t()
+        self._check(self.lib.pirclient_save_request(self._h, _ptr(q), len(queries), C.byref(out), C.byref(n)))
+        try:
+            return C.string_at(out, n.value)
+        finally:
+            self.lib.pirclient_free(out)
+
+    def LoadResponse(self, response: bytes, max_replies: int = 4096) -> np.ndarray:
+        """serialization.cpp:32-42 over every Response.reply -> [n_replies, reply_ct_count, 2, k, N] uint64."""
+        buf = (C.c_uint8 * max(1, len(response))).from_buffer_copy(response or b"\0")
+        # a reply is at least one ciphertext object: bound the output by the response's size
+        per = self.reply_ct_count * 2 * self.k * self.N
+        cap = max(1, min(max_replies, len(response) // (per * 8) + 1))
+        out = np.empty((cap, self.reply_ct_count, 2, self.k, self.N), dtype=np.uint64)
+        n = C.c_size_t()
+        self._check(self.lib.pirclient_load_response(self._h, buf, len(response), _ptr(out), cap, C.byref(n)))
+        return out[:n.value]
+
     def ProcessResponse(self, indexes: Sequence[int], response: bytes) -> List[bytes]:
         """client.cpp:160-185: serialized pir.Response -> one item per index."""
         idx = _u64(list(indexes))

@@ -708,19 +708,25 @@ struct pirclient {
   }
 
   // ---------------------------------------------------------------- wire level
-  std::string create_request(const uint64_t* indexes, size_t n) {  // client.cpp:80-90 + serialization.cpp:44-73
+  // SaveRequest (serialization.cpp:44-73): one Ciphertexts per query, then this client's GaloisKeys and RelinKeys
+  std::string save_request(const uint64_t* queries, size_t n) const {
     std::string out;
     const uint32_t nq = query_ct_count();
-    std::vector<uint64_t> q((size_t)nq * ct_words());
     for (size_t i = 0; i < n; ++i) {
-      create_query(indexes[i], q.data());
+      const uint64_t* q = queries + i * nq * ct_words();
       std::string cts;
-      for (uint32_t c = 0; c < nq; ++c) wire::put_bytes_field(cts, 1, wire::save_ciphertext(sh, q.data() + c * ct_words()));
+      for (uint32_t c = 0; c < nq; ++c) wire::put_bytes_field(cts, 1, wire::save_ciphertext(sh, q + c * ct_words()));
       wire::put_bytes_field(out, 1, cts);
     }
     wire::put_bytes_field(out, 2, seeded_keys ? galois_blob_seeded : galois_blob);
     wire::put_bytes_field(out, 3, seeded_keys ? relin_blob_seeded : relin_blob);
     return out;
+  }
+  std::string create_request(const uint64_t* indexes, size_t n) {  // client.cpp:80-90
+    const uint32_t nq = query_ct_count();
+    std::vector<uint64_t> q(n * (size_t)nq * ct_words());
+    for (size_t i = 0; i < n; ++i) create_query(indexes[i], q.data() + i * nq * ct_words());
+    return save_request(q.data(), n);
   }
   // pir.Response (payload.proto:39-42): the Ciphertexts sub-messages
   static std::vector<std::pair<const uint8_t*, size_t>> parse_response(const uint8_t* data, size_t len) {
@@ -817,6 +823,37 @@ int pirclient_create_request(pirclient* c, const uint64_t* indexes, size_t n_ind
     memcpy(buf, s.data(), s.size());
     *request = buf;
     *request_len = s.size();
+  });
+}
+
+int pirclient_save_request(pirclient* c, const uint64_t* queries, size_t n_queries, uint8_t** request, size_t* request_len) {
+  if (!c || (!queries && n_queries) || !request || !request_len) return PIRGPU_INVALID_ARGUMENT;
+  *request = nullptr;
+  *request_len = 0;
+  return guarded(c, [&] {
+    const std::string s = c->save_request(queries, n_queries);
+    uint8_t* buf = (uint8_t*)malloc(s.size() ? s.size() : 1);
+    if (!buf) throw Err{PIRGPU_INTERNAL, "out of memory"};
+    memcpy(buf, s.data(), s.size());
+    *request = buf;
+    *request_len = s.size();
+  });
+}
+
+int pirclient_load_response(pirclient* c, const uint8_t* response, size_t response_len, uint64_t* replies_out,
+                            size_t cap_replies, size_t* n_replies) {
+  if (!c || (!response && response_len) || !n_replies) return PIRGPU_INVALID_ARGUMENT;
+  return guarded(c, [&] {
+    const auto replies = pirclient::parse_response(response, response_len);
+    if (cap_replies < replies.size() || (!replies_out && !replies.empty())) throw Err{PIRGPU_INVALID_ARGUMENT, "replies_out too small"};
+    const size_t per = (size_t)c->reply_ct_count() * c->ct_words();
+    std::vector<uint64_t> cts;
+    for (size_t i = 0; i < replies.size(); ++i) {
+      const uint32_t n = wire::load_query(c->sh, replies[i].first, replies[i].second, cts);
+      if (n != c->reply_ct_count()) throw Err{PIRGPU_INVALID_ARGUMENT, "Number of ciphertexts in reply does not match expected"};
+      memcpy(replies_out + i * per, cts.data(), per * 8);
+    }
+    *n_replies = replies.size();
   });
 }
 

@@ -322,6 +322,11 @@ class PIRServer:
     def run_batch(self) -> None:
         self._check(self.lib.pirgpu_batch_run(self.db.handle))
 
+    def unstage_batch(self) -> None:
+        """Forgets the staged queries -- and with them the references to key sets set_batch_keysets left, which keep
+        those sets from being evicted for new clients."""
+        self._check(self.lib.pirgpu_batch_unstage(self.db.handle))
+
     def fetch_batch(self) -> np.ndarray:
         n = self.db.reply_ct_count()
         out = np.empty((self._batch_count, n, 2, self.k, self.N), dtype=np.uint64)

@@ -1,6 +1,7 @@
 """Rank process for tests/test_launcher.py, started by pir_amd.launcher.spawn_ranks (environment as torch.distributed.run
 sets it).  Modes: `rows` = the row-sharded step over gloo with the oracle-backed server (tests/test_distributed_gloo.py),
-rank 0 prints ONE JSON line; `fail` = rank 1 exits 3 at once while rank 0 would block for a minute."""
+rank 0 prints ONE JSON line; `rows8` = the same at whatever world size was spawned with the uneven 13-row shards of
+tests/test_distributed_world8.py; `fail` = rank 1 exits 3 at once while rank 0 would block for a minute."""
 import json
 import os
 import sys
@@ -26,8 +27,12 @@ def main():
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from test_distributed_gloo import rows_step_check
-        ok = rows_step_check(rank, world, 2, 300, 288, 2)
+        if mode == "rows8":
+            from test_distributed_world8 import world8_check
+            ok = world8_check(rank, world, 13, 1, "packed")
+        else:
+            from test_distributed_gloo import rows_step_check
+            ok = rows_step_check(rank, world, 2, 300, 288, 2)
         import torch
         t = torch.tensor([1 if ok else 0])
         dist.all_reduce(t)

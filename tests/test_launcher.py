@@ -25,6 +25,17 @@ def test_spawn_two_ranks_relays_rank0_json(tmp_path):
     assert j == {"n_gpus": 2, "ranks": 2, "backend": "gloo", "all_ranks_ok": True}
 
 
+def test_spawn_eight_ranks(tmp_path):
+    """The launch shape of `bench.py --gpus 8`: eight rank processes, rank 0's single line relayed."""
+    out = tmp_path / "out.txt"
+    with open(out, "w") as fo:
+        rc = launcher.spawn_ranks([sys.executable, CHILD, "rows8"], 8, check_devices=False, stdout=fo, timeout_s=900)
+    assert rc == 0
+    lines = [l for l in open(out).read().splitlines() if l.strip()]
+    assert len(lines) == 1
+    assert json.loads(lines[0]) == {"n_gpus": 8, "ranks": 8, "backend": "gloo", "all_ranks_ok": True}
+
+
 def test_failing_rank_fails_the_job_and_stops_the_others(tmp_path):
     out = tmp_path / "out.txt"
     t0 = time.monotonic()

@@ -19,13 +19,16 @@ for cfg in $CFGS; do
   done
 done
 python3 - "$OUT" "$COMMIT" $CFGS <<'PY'
-import csv, glob, json, collections, sys
+import csv, glob, hashlib, json, collections, sys
 out_path, commit, cfgs = sys.argv[1], sys.argv[2], sys.argv[3:]
+# the scan kernel's source as profiled: bench.py compares it with the source it runs and flags roofline.traffic as stale
+# when they differ; tools/check_pmc_fresh.py refuses a file whose stamp is not the committed source
+src_sha = hashlib.sha256(open("pir_amd/csrc/scan_mfma.hip", "rb").read()).hexdigest()[:16]
 out = {"collection": "bash tools/pmc_scan_traffic.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes with "
                      "--kernel-trace over `bench.py --config C --batch 8 --steps 1 --latency-runs 4`; the single-query "
                      "launches are the ones with the smallest WRITE_SIZE",
        "correction": "FETCH_SIZE x2 on gfx950 for 16 B/lane coalesced streaming reads (MI355X_MICROARCH.md, HBM "
-                     "section); WRITE_SIZE as reported; both in KB", "commit": commit, "configs": {}}
+                     "section); WRITE_SIZE as reported; both in KB", "commit": commit, "scan_source_sha16": src_sha, "configs": {}}
 for cfg in cfgs:
     per = {}
     for name in ("fetch", "write"):

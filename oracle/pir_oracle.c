@@ -544,11 +544,15 @@ uint32_t orc_expansion_ratio(const orc_ctx* c) {
   return er;
 }
 
-/* reference ct_reencoder.cpp:40-71 (ct.size() == 2).  The mask `(1 << b) - 1`
- * is int arithmetic there; identical for b < 31. */
+/* reference ct_reencoder.cpp:40-71 (ct.size() == 2).  The mask `(1 << b) - 1` is `int` arithmetic there (:45):
+ * identical to the 64-bit expression for b < 31, UNDEFINED BEHAVIOUR for b >= 31 (a shift by the width of int or more;
+ * gcc on x86-64 happens to emit a shift by b mod 32, i.e. a mask of 9 bits at b = 41).  The reference's own tests
+ * reach such b only with CT multiplication switched on (correctness_test.cpp:99: 42-bit t), where the re-encoder is
+ * not used.  For b >= 31 the restatement therefore takes the mathematically intended mask 2^b - 1 -- the only choice
+ * under which Decode (:73-112) inverts Encode -- instead of reproducing one compiler's treatment of the UB. */
 void orc_reencode(const orc_ctx* c, const uint64_t* ct, uint64_t* pts) {
   const uint32_t N = c->N, k = c->k, b = orc_bits_per_coeff(c->t);
-  const uint64_t mask = (uint64_t)((1 << b) - 1);
+  const uint64_t mask = b >= 31 ? ((uint64_t)1 << b) - 1 : (uint64_t)((1 << b) - 1);
   uint64_t* dst = pts;
   for (uint32_t p = 0; p < 2; ++p)
     for (uint32_t j = 0; j < k; ++j) {

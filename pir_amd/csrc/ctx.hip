@@ -149,6 +149,7 @@ struct BatchSet {
   // group-wise reply download (pirgpu_batch_set_host_replies): one event per group of the batch that just ran, recorded
   // behind the group's device-to-host copy; dl_end[i] = one past the last query of group i, dl_next = next to report
   std::vector<hipEvent_t> dl_events;
+  std::vector<hipEvent_t> rd_events;   // "this group's replies are final" on the lane's stream: what the copy stream waits for
   std::vector<uint32_t> dl_end;
   size_t dl_next = 0;
   uint64_t *h_query = nullptr, *h_reply = nullptr;   // pinned host staging of the wire layer
@@ -242,6 +243,8 @@ struct pirgpu_ctx {
   bool staging_released = false;            // pirgpu_db_finalize(release): only the operand-layout copy is left
   std::vector<BatchLane> lanes;             // created on the first batch
   uint64_t groups_run = 0;
+  hipStream_t copy_stream = nullptr;        // device-to-host downloads of finished groups (pirgpu_batch_set_host_replies):
+                                            // a lane that downloaded its own replies sat idle for 8 MB of PCIe per group
   hipEvent_t ev_fork = nullptr;             // pirgpu_fork: the main stream's position
   hipEvent_t ev_main_join = nullptr;        // pirgpu_join_stream onto a caller's stream: the main stream's position
 
@@ -420,6 +423,7 @@ int64_t option(const pirgpu_ctx* c, const char* name, int64_t dflt, bool* presen
 void sync_batch_streams(pirgpu_ctx* c) {
   for (BatchLane& ln : c->lanes)
     if (ln.stream) HIP_TRY(hipStreamSynchronize(ln.stream));
+  if (c->copy_stream) HIP_TRY(hipStreamSynchronize(c->copy_stream));   // reply downloads queued behind the lanes
   for (Worker& w : c->workers)
     if (w.stream) HIP_TRY(hipStreamSynchronize(w.stream));
 }
@@ -694,7 +698,7 @@ uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* 
       const bool next_last = j + 2 == logm;
       const bool next_reads40 = next_last ? (fuse_last && c->last_level_ntt && ks_digit_takes_c0(next_nodes))
                                           : (next_nodes >= fuse_from);
-      const bool out40 = c->tree40 && c->pack40 && j + 1 < logm && next_reads40 && (1u << j) < N / 16;
+      const bool out40 = c->tree40 && c->pack40 && j + 1 < logm && next_reads40 && (1u << j) < (N >> ntt_log_ept((int)c->logN));
       HIP_TRY(c->ops->ks_mac_intt(st, c->mode, c->dp, k, dig, key, nodes, prod, c->pack40, k, 1));
       HIP_TRY(c->ops->ks_mac_combine(st, c->mode, c->dp, k, dig, key, prod, cur, g, nodes, 1u << j, nxt, c->pack40, cur40,
                                      out40));
@@ -1065,6 +1069,7 @@ void pirgpu_destroy(pirgpu_ctx* c) {
     if (b.h_query) (void)hipHostFree(b.h_query);
     if (b.h_reply) (void)hipHostFree(b.h_reply);
     for (hipEvent_t e : b.dl_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : b.rd_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : b.st_events) (void)hipEventDestroy(e);
   }
   for (auto& e : c->ev) (void)hipEventDestroy(e);
@@ -1078,6 +1083,10 @@ void pirgpu_destroy(pirgpu_ctx* c) {
     if (ln.ev_scanned) (void)hipEventDestroy(ln.ev_scanned);
     if (ln.ev_join) (void)hipEventDestroy(ln.ev_join);
     if (ln.stream) (void)hipStreamDestroy(ln.stream);
+  }
+  if (c->copy_stream) {
+    (void)hipStreamSynchronize(c->copy_stream);
+    (void)hipStreamDestroy(c->copy_stream);
   }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_main_join) (void)hipEventDestroy(c->ev_main_join);
@@ -1671,6 +1680,7 @@ int pirgpu_sync(pirgpu_ctx* c) {
       if (ln.stream) HIP_TRY(hipStreamSynchronize(ln.stream));
     for (Worker& w : c->workers)
       if (w.stream) HIP_TRY(hipStreamSynchronize(w.stream));
+    if (c->copy_stream) HIP_TRY(hipStreamSynchronize(c->copy_stream));
     return PIRGPU_OK;
   });
 }
@@ -2182,17 +2192,26 @@ static void batch_run_mfma(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
       if (!direct_reply)
         HIP_TRY(hipMemcpyAsync(reply_base(c) + (size_t)first * rwords, ln.lvl[0], (size_t)B * rwords * 8,
                                hipMemcpyDeviceToDevice, ln.stream));
-      if (host_dl) {   // the group's replies start their way to the host while the next groups are computed
-        HIP_TRY(hipMemcpyAsync(c->bs().host_reply + (size_t)first * rwords, reply_base(c) + (size_t)first * rwords,
-                               (size_t)B * rwords * 8, hipMemcpyDeviceToHost, ln.stream));
-        const size_t gi = c->bs().dl_end.size();
-        if (gi >= c->bs().dl_events.size()) {
+      if (host_dl) {
+        // the group's replies start their way to the host while the next groups are computed -- on the context's COPY
+        // stream, behind an event of the lane: the lane itself goes straight on to its next group (round 3 queued the
+        // copy on the lane, which then idled for 8 MB of PCIe per group: 5-6 % of a lane's time at cfg 3)
+        BatchSet& b = c->bs();
+        const size_t gi = b.dl_end.size();
+        while (gi >= b.dl_events.size()) {
           hipEvent_t e;
           HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-          c->bs().dl_events.push_back(e);
+          b.dl_events.push_back(e);
+          HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+          b.rd_events.push_back(e);
         }
-        HIP_TRY(hipEventRecord(c->bs().dl_events[gi], ln.stream));
-        c->bs().dl_end.push_back(first + B);
+        if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventRecord(b.rd_events[gi], ln.stream));
+        HIP_TRY(hipStreamWaitEvent(c->copy_stream, b.rd_events[gi], 0));
+        HIP_TRY(hipMemcpyAsync(b.host_reply + (size_t)first * rwords, reply_base(c) + (size_t)first * rwords,
+                               (size_t)B * rwords * 8, hipMemcpyDeviceToHost, c->copy_stream));
+        HIP_TRY(hipEventRecord(b.dl_events[gi], c->copy_stream));
+        b.dl_end.push_back(first + B);
       }
       for (uint32_t q = 0; q < B; ++q) {
         HIP_TRY(hipEventRecord(members[q]->ev_done, ln.stream));

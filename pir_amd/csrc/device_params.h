@@ -8,7 +8,17 @@ constexpr int kMaxPrimes = 8;            // data primes
 constexpr int kMaxMod = kMaxPrimes + 1;  // + special prime
 constexpr int kMaxEnc = 64;              // max 2 * ExpansionRatio
 constexpr int kMaxScanQueries = 4;       // queries sharing one database pass in batch mode
-constexpr int kNttElemsPerThread = 16;   // NTT workgroup = N / 16 threads, 16 residues per thread
+// NTT workgroup = N / EPT threads, EPT = 2^ntt_log_ept residues per thread in registers.  This also defines the DEVICE
+// ORDER of NTT-form data: SEAL position EPT * t + e lives at slot e * (N / EPT) + t.  16 residues per thread for every
+// degree; the kernels are written for any power of two, and N = 16384 was measured with 32 (512-thread workgroups whose
+// waves get 256 VGPRs: twiddle prefetch on, three passes instead of four) against 16 (1024-thread workgroups, 128
+// VGPRs) on one box, round 4: 104.4 against 112.7 queries/s at cfg 5, single query 19.1 against 18.1 ms -- with one
+// workgroup per CU either way (a 16384-point polynomial fills the LDS), sixteen waves hide more latency than eight with
+// twice the registers (-DPIRGPU_LOG_EPT14=5 rebuilds the other organisation, tools/r04_ab_ept.sh).
+#ifndef PIRGPU_LOG_EPT14
+#define PIRGPU_LOG_EPT14 4
+#endif
+constexpr int ntt_log_ept(int logN) { return logN >= 14 ? PIRGPU_LOG_EPT14 : 4; }
 
 // One RNS modulus with the Barrett ratio floor(2^128 / q) (SEAL Modulus::const_ratio).
 struct ModConst {

@@ -29,17 +29,17 @@
 namespace pirgpu {
 
 // SEAL NTT order <-> device NTT order for npolys polynomials (boundary only:
-// Galois-key upload and the test hooks).  to_device: out[e*NT + t] = in[16 t + e].
+// Galois-key upload and the test hooks).  to_device: out[e*NT + t] = in[EPT t + e], EPT = 2^ntt_log_ept(logN).
 // as_f64: the device-order side holds the residues as exact doubles (fp64 NTT flavours).
 __global__ void ntt_reorder_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint32_t logN,
                                    uint64_t npolys, int to_device, int as_f64) {
   const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t N = 1u << logN, NT = N >> 4;
+  const uint32_t N = 1u << logN, le = (uint32_t)ntt_log_ept((int)logN), NT = N >> le;
   if (gid >= npolys << logN) return;
   const uint64_t poly = gid >> logN;
   const uint32_t i = (uint32_t)(gid & (N - 1));  // device slot
   const uint32_t e = i / NT, t = i % NT;
-  const uint32_t seal = (t << 4) | e;
+  const uint32_t seal = (t << le) | e;
   if (to_device) {
     uint64_t v = in[(poly << logN) + seal];
     if (as_f64) v = (uint64_t)__double_as_longlong(f64_from_u64(v));
@@ -158,8 +158,9 @@ __global__ void ks_combine_f64_kernel(const DevParams* __restrict__ P, const dou
       const uint8_t* pr = reinterpret_cast<const uint8_t*>(prod) + ((size_t)node * 2 + comp) * km * 5 * N;
       const uint8_t* ps = pr + (size_t)k * 5 * N;
       const uint8_t* pj = pr + (size_t)j * 5 * N;
-      // high bytes thread-major (ntt_kernels.hip store40f): element e * (N/16) + t at 4 N + 16 t + e
-      const size_t hi_at = 4 * (size_t)N + 16 * (size_t)(i & (N / 16 - 1)) + (i >> (P->logN - 4));
+      // high bytes thread-major (ntt_kernels.hip store40f): element e * (N/EPT) + t at 4 N + EPT t + e
+      const uint32_t le = (uint32_t)ntt_log_ept((int)P->logN);
+      const size_t hi_at = 4 * (size_t)N + ((size_t)(i & ((N >> le) - 1)) << le) + (i >> (P->logN - le));
       sp = f64_unpack40(reinterpret_cast<const uint32_t*>(ps)[i], ps[hi_at], f64_pack_magic(pf));
       dj = f64_unpack40(reinterpret_cast<const uint32_t*>(pj)[i], pj[hi_at], f64_pack_magic(mj.q));
     } else {

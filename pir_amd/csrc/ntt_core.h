@@ -1,15 +1,18 @@
 // ntt_core.h -- register-resident negacyclic NTT for one workgroup per polynomial.
 //
-// One workgroup of N/16 threads transforms one polynomial; every thread keeps 16
-// residues in registers and runs up to four butterfly stages per pass, so a
-// 4096-point transform is 3 register passes with 2 LDS exchanges.  A pass with
-// window LB owns, per thread, the 16 residues
-//     idx = (outer << (LB+4)) | (e << LB) | inner,      tid = (outer << LB) | inner.
+// One workgroup of N/EPT threads transforms one polynomial; every thread keeps EPT = 2^R
+// residues in registers and runs up to R butterfly stages per pass: EPT = 16 (R = 4) up to
+// N = 8192 -- a 4096-point transform is 3 register passes with 2 LDS exchanges -- and
+// EPT = 32 (R = 5) at N = 16384 (round 4): 512 threads instead of 1024, so a workgroup's waves
+// get 256 VGPRs each instead of 128 (twiddle prefetch and the fused kernels fit again), and
+// 14 = 5 + 5 + 4 stages are 3 passes with 2 exchanges instead of 4 with 3.  A pass with
+// window LB owns, per thread, the EPT residues
+//     idx = (outer << (LB+R)) | (e << LB) | inner,      tid = (outer << LB) | inner.
 //
-//  * LDS is padded by one word per 16 (lds_idx), which makes all three access
-//    patterns (stride N/16, stride 16, contiguous 16) bank-conflict free;
+//  * LDS is padded by one word per EPT (lds_idx), which makes all three access
+//    patterns (stride N/EPT, stride EPT, contiguous EPT) bank-conflict free;
 //  * NTT-domain data lives in HBM in "device order": SEAL's bit-reversed position
-//    pos = 16*tid + e is stored at slot e*(N/16) + tid.  Every dyadic operation is
+//    pos = EPT*tid + e is stored at slot e*(N/EPT) + tid.  Every dyadic operation is
 //    order-agnostic, both transforms read and write global memory fully
 //    coalesced, and the register layout on the NTT side is exactly that order --
 //    key-switch products are formed between a forward and an inverse transform
@@ -27,11 +30,15 @@ namespace pirgpu {
 template <int LOGN>
 struct Plan {
   static constexpr int N = 1 << LOGN;
-  static constexpr int NT = N / kNttElemsPerThread;
-  static constexpr int LDS_WORDS = N + N / 16;
+  static constexpr int R = ntt_log_ept(LOGN);   // butterfly stages per register pass
+  static constexpr int EPT = 1 << R;            // residues per thread
+  static constexpr int NT = N / EPT;
+  static constexpr int LDS_WORDS = N + N / EPT;
 };
 
-__device__ __forceinline__ uint32_t lds_idx(uint32_t i) { return i + (i >> 4); }
+// padded LDS position of element i (one pad word per 2^R)
+template <int R>
+__device__ __forceinline__ uint32_t lds_idx(uint32_t i) { return i + (i >> R); }
 
 // Twiddle tables are reached through pointers stored in DevParams; typing them as global
 // (address space 1) makes hipcc emit global_load instead of flat_load for them.
@@ -142,45 +149,45 @@ struct Arith<kNttF64Wide> : ArithF64<kNttF64Wide> {};
 
 // ------------------------------------------------------------------ passes
 
-// Padded LDS position of the 16 residues a thread owns in a pass with window LB: lds_idx(base | (e << LB)) is
-// lds_base16<LB>(tid) + lds_off16<LB>(e) with a compile-time second term, so the 16 accesses of a pass are one
-// address computation plus immediate offsets (written as `idx + (idx >> 4)` per element the compiler spends
+// Padded LDS position of the EPT = 2^R residues a thread owns in a pass with window LB: lds_idx(base | (e << LB)) is
+// lds_base<LB, R>(tid) + lds_off<LB, R>(e) with a compile-time second term, so the accesses of a pass are one
+// address computation plus immediate offsets (written as `idx + (idx >> R)` per element the compiler spends
 // four VALU instructions on every access).
-//   LB >= 4: (idx >> 4) = (base >> 4) | (e << (LB - 4)), the two terms occupy disjoint bits;
-//   LB <  4: (idx >> 4) = (outer << LB) | (e >> (4 - LB)), since (e << LB) | inner < 2^(LB + 4).
-template <int LB>
-__device__ __forceinline__ uint32_t lds_base16(uint32_t tid) {
+//   LB >= R: (idx >> R) = (base >> R) | (e << (LB - R)), the two terms occupy disjoint bits;
+//   LB <  R: (idx >> R) = (outer << LB) | (e >> (R - LB)), since (e << LB) | inner < 2^(LB + R).
+template <int LB, int R>
+__device__ __forceinline__ uint32_t lds_base(uint32_t tid) {
   const uint32_t inner = tid & ((1u << LB) - 1u), outer = tid >> LB;
-  const uint32_t base = (outer << (LB + 4)) | inner;
-  if constexpr (LB >= 4) return base + (base >> 4);
+  const uint32_t base = (outer << (LB + R)) | inner;
+  if constexpr (LB >= R) return base + (base >> R);
   else return base + (outer << LB);
 }
-template <int LB>
-__device__ __forceinline__ constexpr uint32_t lds_off16(int e) {
-  if constexpr (LB >= 4) return (uint32_t)e * ((1u << LB) + (1u << (LB - 4)));
-  else return ((uint32_t)e << LB) + ((uint32_t)e >> (4 - LB));
+template <int LB, int R>
+__device__ __forceinline__ constexpr uint32_t lds_off(int e) {
+  if constexpr (LB >= R) return (uint32_t)e * ((1u << LB) + (1u << (LB - R)));
+  else return ((uint32_t)e << LB) + ((uint32_t)e >> (R - LB));
 }
 
-template <int LB, typename T>
-__device__ __forceinline__ void lds_store16(T* s, const T (&x)[16], uint32_t tid) {
-  T* p = s + lds_base16<LB>(tid);
+template <int LB, int R, typename T>
+__device__ __forceinline__ void lds_store_pass(T* s, const T (&x)[1 << R], uint32_t tid) {
+  T* p = s + lds_base<LB, R>(tid);
 #pragma unroll
-  for (int e = 0; e < 16; ++e) p[lds_off16<LB>(e)] = x[e];
+  for (int e = 0; e < (1 << R); ++e) p[lds_off<LB, R>(e)] = x[e];
 }
 
-template <int LB, typename T>
-__device__ __forceinline__ void lds_load16(const T* s, T (&x)[16], uint32_t tid) {
-  const T* p = s + lds_base16<LB>(tid);
+template <int LB, int R, typename T>
+__device__ __forceinline__ void lds_load_pass(const T* s, T (&x)[1 << R], uint32_t tid) {
+  const T* p = s + lds_base<LB, R>(tid);
 #pragma unroll
-  for (int e = 0; e < 16; ++e) x[e] = p[lds_off16<LB>(e)];
+  for (int e = 0; e < (1 << R); ++e) x[e] = p[lds_off<LB, R>(e)];
 }
 
-// Padded LDS position of element e * NT + tid (the layout a thread's 16 residues have in global memory), NT a
-// multiple of 16: tid + (tid >> 4) + e * (NT + NT / 16).
-template <int NT_>
-__device__ __forceinline__ uint32_t lds_lin_base(uint32_t tid) { return tid + (tid >> 4); }
-template <int NT_>
-__device__ __forceinline__ constexpr uint32_t lds_lin_off(int e) { return (uint32_t)e * (NT_ + NT_ / 16); }
+// Padded LDS position of element e * NT + tid (the layout a thread's residues have in global memory), NT a
+// multiple of EPT: tid + (tid >> R) + e * (NT + NT / EPT).
+template <int NT_, int R>
+__device__ __forceinline__ uint32_t lds_lin_base(uint32_t tid) { return tid + (tid >> R); }
+template <int NT_, int R>
+__device__ __forceinline__ constexpr uint32_t lds_lin_off(int e) { return (uint32_t)e * (NT_ + (NT_ >> R)); }
 
 // A forward twiddle table copied to LDS (upper_fused_kernel: a transform free of vector memory instructions lets
 // loads issued before it complete under it -- vmcnt is in order).  Stored pass by pass, slot-major: the twiddle of
@@ -217,14 +224,16 @@ struct LdsTw {
   const double* p;
 };
 
-// twiddle of (window LB, relative bit rb, g, outer): table index 2^(LOGN-1-(LB+rb)) + (outer << (3 - rb)) + g
+// twiddle of (window LB, relative bit rb, g, outer): table index 2^(LOGN-1-(LB+rb)) + (outer << (R-1-rb)) + g
 template <typename A, int LOGN, int LB, typename TP>
 __device__ __forceinline__ typename A::TW tw_at(TP tw, int rb, int g, uint32_t outer) {
+  constexpr int R = Plan<LOGN>::R;
   const uint32_t mm = 1u << (LOGN - 1 - (LB + rb));
-  return A::load_tw(tw, mm + (outer << (3 - rb)) + g);
+  return A::load_tw(tw, mm + (outer << (R - 1 - rb)) + g);
 }
 template <typename A, int LOGN, int LB>
 __device__ __forceinline__ typename A::TW tw_at(LdsTw tw, int rb, int g, uint32_t outer) {
+  static_assert(Plan<LOGN>::R == 4, "the LDS twiddle table is laid out for 16 residues per thread");
   using S = TwSoA<LOGN>;
   return tw.p[S::offset(LB) + ((8 >> rb) - 1 + g - S::w0(LB)) * (S::NT >> LB) + outer];
 }
@@ -250,30 +259,32 @@ __device__ __forceinline__ void lds_twiddles_fill(double* dst, SRC src, uint32_t
   lds_twiddles_fill_pass<LOGN, LOGN - 4>(dst, src, tid);
 }
 
-// The 15 twiddles of one 4-stage pass, in the order the stages consume them: relative bit rb
-// (3..0) owns slots (8 >> rb) - 1 ... ; loaded one pass AHEAD of their use so that their L2
+// The EPT - 1 twiddles of one R-stage pass, in the order the stages consume them: relative bit rb
+// (R-1..0) owns slots (EPT/2 >> rb) - 1 ... ; loaded one pass AHEAD of their use so that their L2
 // latency hides under the previous pass's butterflies and LDS exchange.
 template <typename A, int LOGN, int LB, int RHI, int RLO, typename TP>
-__device__ __forceinline__ void load_twiddles(typename A::TW (&W)[15], TP tw, uint32_t outer) {
+__device__ __forceinline__ void load_twiddles(typename A::TW (&W)[Plan<LOGN>::EPT - 1], TP tw, uint32_t outer) {
+  constexpr int H = Plan<LOGN>::EPT / 2;
 #pragma unroll
   for (int rb = RHI; rb >= RLO; --rb) {
 #pragma unroll
-    for (int g = 0; g < (8 >> rb); ++g) W[(8 >> rb) - 1 + g] = tw_at<A, LOGN, LB>(tw, rb, g, outer);
+    for (int g = 0; g < (H >> rb); ++g) W[(H >> rb) - 1 + g] = tw_at<A, LOGN, LB>(tw, rb, g, outer);
   }
 }
 
-// Cooley-Tukey stages on window LB for relative bits RHI..RLO (high to low).
-template <typename A, int RHI, int RLO>
-__device__ __forceinline__ void fwd_stages(typename A::T (&x)[16], const typename A::TW (&W)[15],
+// Cooley-Tukey stages on one window for relative bits RHI..RLO (high to low) over EPT = 2^R residues.
+template <typename A, int R, int RHI, int RLO>
+__device__ __forceinline__ void fwd_stages(typename A::T (&x)[1 << R], const typename A::TW (&W)[(1 << R) - 1],
                                            const typename A::Mod& m) {
+  constexpr int H = 1 << (R - 1);
 #pragma unroll
   for (int rb = RHI; rb >= RLO; --rb) {
 #pragma unroll
-    for (int g = 0; g < (8 >> rb); ++g) {
+    for (int g = 0; g < (H >> rb); ++g) {
 #pragma unroll
       for (int l = 0; l < (1 << rb); ++l) {
         const int e0 = (g << (rb + 1)) | l, e1 = e0 | (1 << rb);
-        A::fwd(x[e0], x[e1], W[(8 >> rb) - 1 + g], m);
+        A::fwd(x[e0], x[e1], W[(H >> rb) - 1 + g], m);
       }
     }
   }
@@ -283,127 +294,132 @@ __device__ __forceinline__ void fwd_stages(typename A::T (&x)[16], const typenam
 // PF: load the next pass's twiddles before this pass's butterflies (hides their L2 latency, costs
 // 30-60 registers); without PF they are loaded at the start of their own pass.
 template <typename A, int LOGN, int LB, int RHI, bool PF, typename TP>
-__device__ __forceinline__ void fwd_chain(typename A::T (&x)[16], typename A::T* s, TP tw, const typename A::Mod& m,
-                                          uint32_t tid, const typename A::TW (&Wcur)[15]) {
+__device__ __forceinline__ void fwd_chain(typename A::T (&x)[Plan<LOGN>::EPT], typename A::T* s, TP tw,
+                                          const typename A::Mod& m, uint32_t tid,
+                                          const typename A::TW (&Wcur)[Plan<LOGN>::EPT - 1]) {
+  constexpr int R = Plan<LOGN>::R;
   if constexpr (LB > 0) {
-    constexpr int NLB = LB >= 4 ? LB - 4 : 0;
-    constexpr int NRHI = LB >= 4 ? 3 : LB - 1;
-    typename A::TW Wnext[15];
+    constexpr int NLB = LB >= R ? LB - R : 0;
+    constexpr int NRHI = LB >= R ? R - 1 : LB - 1;
+    typename A::TW Wnext[Plan<LOGN>::EPT - 1];
     if constexpr (PF) {
       load_twiddles<A, LOGN, NLB, NRHI, 0>(Wnext, tw, tid >> NLB);
       __builtin_amdgcn_sched_barrier(0);
     }
-    fwd_stages<A, RHI, 0>(x, Wcur, m);
-    lds_store16<LB>(s, x, tid);
+    fwd_stages<A, R, RHI, 0>(x, Wcur, m);
+    lds_store_pass<LB, R>(s, x, tid);
     __syncthreads();
     if constexpr (!PF) load_twiddles<A, LOGN, NLB, NRHI, 0>(Wnext, tw, tid >> NLB);
-    lds_load16<NLB>(s, x, tid);
+    lds_load_pass<NLB, R>(s, x, tid);
     fwd_chain<A, LOGN, NLB, NRHI, PF>(x, s, tw, m, tid, Wnext);
   } else {
-    fwd_stages<A, RHI, 0>(x, Wcur, m);
+    fwd_stages<A, R, RHI, 0>(x, Wcur, m);
   }
 }
 
 // Forward NTT.  In: x[e] = coefficient e*NT + tid (A::in of a canonical residue).
-// Out: x[e] = SEAL NTT position 16*tid + e == device-order slot e*NT + tid, canonical
+// Out: x[e] = SEAL NTT position EPT*tid + e == device-order slot e*NT + tid, canonical
 // representative (A::out gives the residue).  The caller guarantees nobody still reads
 // `s` (barrier) when this is entered.
 // CANON = false (fp64 flavours only): leave signed representatives |x| <= (1/2 + eps) q instead of canonical ones.
 // `tw`: the forward twiddle table of modulus mi, in global memory (A::tw) or copied to LDS by the caller.
 template <int MODE, int LOGN, bool PF, bool CANON, typename TP>
-__device__ __forceinline__ void ntt_forward_tw(typename Arith<MODE>::T (&x)[16], void* lds, const DevParams* P, int mi,
-                                               uint32_t tid, TP tw) {
+__device__ __forceinline__ void ntt_forward_tw(typename Arith<MODE>::T (&x)[Plan<LOGN>::EPT], void* lds, const DevParams* P,
+                                               int mi, uint32_t tid, TP tw) {
   using A = Arith<MODE>;
+  constexpr int R = Plan<LOGN>::R;
   typename A::T* s = reinterpret_cast<typename A::T*>(lds);
   const typename A::Mod m = A::mod(P, mi);
-  typename A::TW W0[15];
-  load_twiddles<A, LOGN, LOGN - 4, 3, 0>(W0, tw, 0u);
-  fwd_chain<A, LOGN, LOGN - 4, 3, PF>(x, s, tw, m, tid, W0);
+  typename A::TW W0[Plan<LOGN>::EPT - 1];
+  load_twiddles<A, LOGN, LOGN - R, R - 1, 0>(W0, tw, 0u);
+  fwd_chain<A, LOGN, LOGN - R, R - 1, PF>(x, s, tw, m, tid, W0);
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
+  for (int e = 0; e < Plan<LOGN>::EPT; ++e) {
     if constexpr (CANON) x[e] = A::canon_fwd(x[e], m);
     else x[e] = A::signed_fwd(x[e], m);
   }
 }
 
 template <int MODE, int LOGN, bool PF = true, bool CANON = true>
-__device__ __forceinline__ void ntt_forward(typename Arith<MODE>::T (&x)[16], void* lds, const DevParams* P, int mi,
-                                            uint32_t tid) {
+__device__ __forceinline__ void ntt_forward(typename Arith<MODE>::T (&x)[Plan<LOGN>::EPT], void* lds, const DevParams* P,
+                                            int mi, uint32_t tid) {
   ntt_forward_tw<MODE, LOGN, PF, CANON>(x, lds, P, mi, tid, Arith<MODE>::tw(P, mi));
 }
 
-// Gentleman-Sande stages for relative bits RLO..3 (low to high) with preloaded twiddles; with
+// Gentleman-Sande stages for relative bits RLO..R-1 (low to high) with preloaded twiddles; with
 // LAST the final stage multiplies by N^-1 (folded into both outputs, its own twiddle unused).
-template <typename A, int RLO, bool LAST>
-__device__ __forceinline__ void inv_stages(typename A::T (&x)[16], const typename A::TW (&W)[15],
+template <typename A, int R, int RLO, bool LAST>
+__device__ __forceinline__ void inv_stages(typename A::T (&x)[1 << R], const typename A::TW (&W)[(1 << R) - 1],
                                            const typename A::TW& ninv, const typename A::TW& iw1n,
                                            const typename A::Mod& m) {
+  constexpr int H = 1 << (R - 1);
 #pragma unroll
-  for (int rb = RLO; rb <= 3; ++rb) {
-    if (LAST && rb == 3) {
+  for (int rb = RLO; rb <= R - 1; ++rb) {
+    if (LAST && rb == R - 1) {
 #pragma unroll
-      for (int l = 0; l < 8; ++l) A::inv_last(x[l], x[l | 8], ninv, iw1n, m);
+      for (int l = 0; l < H; ++l) A::inv_last(x[l], x[l | H], ninv, iw1n, m);
     } else {
 #pragma unroll
-      for (int g = 0; g < (8 >> rb); ++g) {
+      for (int g = 0; g < (H >> rb); ++g) {
 #pragma unroll
         for (int l = 0; l < (1 << rb); ++l) {
           const int e0 = (g << (rb + 1)) | l, e1 = e0 | (1 << rb);
-          A::inv(x[e0], x[e1], W[(8 >> rb) - 1 + g], m);
+          A::inv(x[e0], x[e1], W[(H >> rb) - 1 + g], m);
         }
       }
     }
   }
 }
 
-// Runs the pass on window LB (relative bits RLO..3) whose twiddles are in Wcur; D = index bits
+// Runs the pass on window LB (relative bits RLO..R-1) whose twiddles are in Wcur; D = index bits
 // done once this pass completes.
 template <typename A, int LOGN, int LB, int RLO, bool PF>
-__device__ __forceinline__ void inv_chain(typename A::T (&x)[16], typename A::T* s,
+__device__ __forceinline__ void inv_chain(typename A::T (&x)[Plan<LOGN>::EPT], typename A::T* s,
                                           typename A::TWPtr itw, const typename A::TW& ninv,
                                           const typename A::TW& iw1n, const typename A::Mod& m, uint32_t tid,
-                                          const typename A::TW (&Wcur)[15]) {
-  constexpr int D = LB + 4;
+                                          const typename A::TW (&Wcur)[Plan<LOGN>::EPT - 1]) {
+  constexpr int R = Plan<LOGN>::R;
+  constexpr int D = LB + R;
   constexpr bool LAST = (D == LOGN);
   if constexpr (!LAST) {
-    constexpr int NLB = (LOGN - D >= 4) ? D : LOGN - 4;
+    constexpr int NLB = (LOGN - D >= R) ? D : LOGN - R;
     constexpr int NRLO = D - NLB;
-    typename A::TW Wnext[15];
+    typename A::TW Wnext[Plan<LOGN>::EPT - 1];
     if constexpr (PF) {  // one pass ahead
-      load_twiddles<A, LOGN, NLB, 3, NRLO>(Wnext, itw, tid >> NLB);
+      load_twiddles<A, LOGN, NLB, R - 1, NRLO>(Wnext, itw, tid >> NLB);
       __builtin_amdgcn_sched_barrier(0);
     }
-    inv_stages<A, RLO, false>(x, Wcur, ninv, iw1n, m);
+    inv_stages<A, R, RLO, false>(x, Wcur, ninv, iw1n, m);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) x[e] = A::pass_norm(x[e], m);
-    lds_store16<LB>(s, x, tid);
+    for (int e = 0; e < Plan<LOGN>::EPT; ++e) x[e] = A::pass_norm(x[e], m);
+    lds_store_pass<LB, R>(s, x, tid);
     __syncthreads();
-    if constexpr (!PF) load_twiddles<A, LOGN, NLB, 3, NRLO>(Wnext, itw, tid >> NLB);
-    lds_load16<NLB>(s, x, tid);
+    if constexpr (!PF) load_twiddles<A, LOGN, NLB, R - 1, NRLO>(Wnext, itw, tid >> NLB);
+    lds_load_pass<NLB, R>(s, x, tid);
     inv_chain<A, LOGN, NLB, NRLO, PF>(x, s, itw, ninv, iw1n, m, tid, Wnext);
   } else {
-    inv_stages<A, RLO, true>(x, Wcur, ninv, iw1n, m);
+    inv_stages<A, R, RLO, true>(x, Wcur, ninv, iw1n, m);
   }
 }
 
-// Inverse NTT.  In: x[e] = NTT position 16*tid + e (any representative the flavour
+// Inverse NTT.  In: x[e] = NTT position EPT*tid + e (any representative the flavour
 // accepts: < 2q for integers, |v| <= 4q for fp64).  Out: x[e] = coefficient e*NT + tid,
 // canonical, scaled by N^-1.
 template <int MODE, int LOGN, bool PF = true, bool CANON = true>
-__device__ __forceinline__ void ntt_inverse(typename Arith<MODE>::T (&x)[16], void* lds, const DevParams* P, int mi,
-                                            uint32_t tid) {
+__device__ __forceinline__ void ntt_inverse(typename Arith<MODE>::T (&x)[Plan<LOGN>::EPT], void* lds, const DevParams* P,
+                                            int mi, uint32_t tid) {
   static_assert(LOGN >= 8, "at least two passes expected");
   using A = Arith<MODE>;
   typename A::T* s = reinterpret_cast<typename A::T*>(lds);
   const typename A::Mod m = A::mod(P, mi);
   const typename A::TWPtr itw = A::itw(P, mi);
   const typename A::TW ninv = A::ninv(P, mi), iw1n = A::iw1n(P, mi);
-  typename A::TW W0[15];
-  load_twiddles<A, LOGN, 0, 3, 0>(W0, itw, tid);
+  typename A::TW W0[Plan<LOGN>::EPT - 1];
+  load_twiddles<A, LOGN, 0, Plan<LOGN>::R - 1, 0>(W0, itw, tid);
   inv_chain<A, LOGN, 0, 0, PF>(x, s, itw, ninv, iw1n, m, tid, W0);
   if constexpr (CANON) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) x[e] = A::canon_inv(x[e], m);
+    for (int e = 0; e < Plan<LOGN>::EPT; ++e) x[e] = A::canon_inv(x[e], m);
   }  // else: the last stage's products already are signed representatives
 }
 

@@ -37,10 +37,16 @@ namespace PIRGPU_DEG_NS {
 constexpr int LOGN = PIRGPU_LOGN;
 constexpr int NT = Plan<LOGN>::NT;
 constexpr int N = Plan<LOGN>::N;
+constexpr int R_ = Plan<LOGN>::R;        // butterfly stages per register pass
+constexpr int EPT = Plan<LOGN>::EPT;     // residues per thread: 16, or 32 at N = 16384 (512-thread workgroups, 256 VGPRs)
 constexpr size_t kLdsBytes = (size_t)Plan<LOGN>::LDS_WORDS * 8;
-// twiddle prefetch one pass ahead costs ~30 VGPRs: not affordable under the 128-VGPR cap of the 1024-thread
-// workgroups of N = 16384 (it spills)
-constexpr bool kPF = LOGN < 14;
+// twiddle prefetch one pass ahead costs 30 (EPT = 16) / 62 (EPT = 32) VGPRs.  Round 4: N = 16384 runs 32 residues per
+// thread in 512-thread workgroups, whose waves have 256 VGPRs -- the prefetch is on for every degree again (rounds 1-3:
+// 1024-thread workgroups under a 128-VGPR cap, prefetch off, four passes instead of three)
+#ifndef PIRGPU_PF14
+#define PIRGPU_PF14 1
+#endif
+constexpr bool kPF = LOGN < 14 || (EPT == 32 && PIRGPU_PF14 != 0);   // 1024-thread workgroups (EPT = 16 at N = 16384): 128 VGPRs, no room
 // upper_fused_kernel with the twiddle table in LDS (exchange buffer + N doubles of LDS per workgroup, ~245 VGPRs).
 // N = 8192 spills there (four passes, more temporaries: 256 VGPRs + 76 bytes of scratch, cfg 4 363 -> 352 queries/s)
 // and N = 16384 runs the split upper level anyway.
@@ -63,16 +69,21 @@ __device__ __forceinline__ void store40(uint8_t* poly, uint32_t i, uint64_t v) {
 
 // fp64 flavours: signed representative <-> offset 40-bit storage (arith.h f64_pack40).  The kernels below all hold
 // element e * NT + tid in register e of thread tid, so the high bytes are stored THREAD-MAJOR: byte e of thread tid
-// at 4 N + 16 tid + e.  A thread then moves its 16 high bytes with one 16-byte access (a wave: 1 KiB contiguous)
-// instead of 16 single-byte ones -- 17 memory instructions per polynomial instead of 32, and no partial-line
+// at 4 N + EPT tid + e.  A thread then moves its EPT high bytes with one 16-byte access (a wave: 1 KiB contiguous)
+// (two at EPT = 32) instead of EPT single-byte ones -- 17 memory instructions per polynomial instead of 32, and no partial-line
 // byte stores.  (The integer flavour keeps the element-major load40/store40 layout above; buffers are never shared
 // between flavours.)
-struct Hi16 {
-  uint32_t w[4];
+struct Hi16 {               // the EPT high bytes of a thread (EPT / 4 words)
+  uint32_t w[EPT / 4];
 };
 __device__ __forceinline__ Hi16 load40f_hi(const uint8_t* poly, uint32_t tid) {
-  const uint4 v = *reinterpret_cast<const uint4*>(poly + 4 * N + 16 * tid);
-  return Hi16{{v.x, v.y, v.z, v.w}};
+  Hi16 h;
+#pragma unroll
+  for (int g = 0; g < EPT / 16; ++g) {
+    const uint4 v = *reinterpret_cast<const uint4*>(poly + 4 * N + EPT * tid + 16 * g);
+    h.w[4 * g] = v.x, h.w[4 * g + 1] = v.y, h.w[4 * g + 2] = v.z, h.w[4 * g + 3] = v.w;
+  }
+  return h;
 }
 // element e * NT + tid
 __device__ __forceinline__ double load40f(const uint8_t* poly, const Hi16& h, int e, uint32_t tid, double magic) {
@@ -81,38 +92,47 @@ __device__ __forceinline__ double load40f(const uint8_t* poly, const Hi16& h, in
   const uint32_t hi = __builtin_amdgcn_perm(0x43300000u, h.w[e >> 2], 0x07060c00u | (uint32_t)(e & 3));
   return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo)) - magic;
 }
-__device__ __forceinline__ void store40f(uint8_t* poly, uint32_t tid, const double (&x)[16], double magic) {
-  uint32_t hb[16];
+// four high words' low bytes -> one word, for the EPT / 4 words of a thread
+__device__ __forceinline__ void pack_hi_bytes(const uint32_t (&hb)[EPT], uint32_t (&w)[EPT / 4]) {
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    uint32_t lo;
-    f64_pack40(x[e], magic, lo, hb[e]);
-    reinterpret_cast<uint32_t*>(poly)[e * NT + tid] = lo;
-  }
-  uint32_t w[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {   // low bytes of four words -> one word
+  for (int g = 0; g < EPT / 4; ++g) {
     const uint32_t ab = __builtin_amdgcn_perm(hb[4 * g + 1], hb[4 * g], 0x0c0c0400u);
     const uint32_t cd = __builtin_amdgcn_perm(hb[4 * g + 3], hb[4 * g + 2], 0x0c0c0400u);
     w[g] = __builtin_amdgcn_perm(cd, ab, 0x05040100u);
   }
-  *reinterpret_cast<uint4*>(poly + 4 * N + 16 * tid) = uint4{w[0], w[1], w[2], w[3]};
+}
+__device__ __forceinline__ void store_hi_words(uint8_t* poly, uint32_t tid, const uint32_t (&w)[EPT / 4]) {
+#pragma unroll
+  for (int g = 0; g < EPT / 16; ++g)
+    *reinterpret_cast<uint4*>(poly + 4 * N + EPT * tid + 16 * g) = uint4{w[4 * g], w[4 * g + 1], w[4 * g + 2], w[4 * g + 3]};
+}
+__device__ __forceinline__ void store40f(uint8_t* poly, uint32_t tid, const double (&x)[EPT], double magic) {
+  uint32_t hb[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    uint32_t lo;
+    f64_pack40(x[e], magic, lo, hb[e]);
+    reinterpret_cast<uint32_t*>(poly)[e * NT + tid] = lo;
+  }
+  uint32_t w[EPT / 4];
+  pack_hi_bytes(hb, w);
+  store_hi_words(poly, tid, w);
 }
 
 // Polynomial `poly` (index in units of polynomials) of an expansion-tree buffer, this thread's 16 elements: doubles, or
 // (T40, wide levels of the fused expansion, every modulus < 2^39) the 5-byte offset form with modulus q.
 template <bool T40>
-__device__ __forceinline__ void tree_load(const uint64_t* tree_raw, size_t poly, uint32_t tid, double q, double (&out)[16]) {
+__device__ __forceinline__ void tree_load(const uint64_t* tree_raw, size_t poly, uint32_t tid, double q, double (&out)[EPT]) {
   if constexpr (T40) {
     const uint8_t* pp = reinterpret_cast<const uint8_t*>(tree_raw) + poly * kPoly40;
     const Hi16 h = load40f_hi(pp, tid);
     const double magic = f64_pack_magic(q);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) out[e] = load40f(pp, h, e, tid, magic);
+    for (int e = 0; e < EPT; ++e) out[e] = load40f(pp, h, e, tid, magic);
   } else {
     const double* pp = reinterpret_cast<const double*>(tree_raw) + poly * N;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) out[e] = pp[e * NT + tid];
+    for (int e = 0; e < EPT; ++e) out[e] = pp[e * NT + tid];
   }
 }
 
@@ -143,15 +163,15 @@ ntt_batch_kernel(const DevParams* __restrict__ P, uint64_t* __restrict__ data, u
   const int mi = mod_base + (blockIdx.x % mod_period);
   const typename A::Mod m = A::mod(P, mi);
   uint64_t* poly = data + (size_t)blockIdx.x * N;
-  typename A::T x[16];
+  typename A::T x[EPT];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) x[e] = A::in(poly[e * NT + tid], m);
+  for (int e = 0; e < EPT; ++e) x[e] = A::in(poly[e * NT + tid], m);
   if constexpr (INVERSE)
     ntt_inverse<MODE, LOGN, kPF>(x, smem_raw, P, mi, tid);
   else
     ntt_forward<MODE, LOGN, kPF>(x, smem_raw, P, mi, tid);
 #pragma unroll
-  for (int e = 0; e < 16; ++e) poly[e * NT + tid] = A::out(x[e], m);
+  for (int e = 0; e < EPT; ++e) poly[e * NT + tid] = A::out(x[e], m);
 }
 
 // Out-of-place forward NTT of ciphertexts: src[ct][2][k][N] (coefficient form)
@@ -166,15 +186,15 @@ ct_ntt_fwd_oop_kernel(const DevParams* __restrict__ P, const uint64_t* __restric
   const typename A::Mod m = A::mod(P, mi);
   const uint64_t* in = src + (size_t)blockIdx.x * N;
   uint64_t* out = dst + (size_t)blockIdx.x * N;
-  typename A::T x[16];
+  typename A::T x[EPT];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
+  for (int e = 0; e < EPT; ++e) {
     if constexpr (SRC_TREE) x[e] = reinterpret_cast<const typename A::T*>(in)[e * NT + tid];
     else x[e] = A::in(in[e * NT + tid], m);
   }
   ntt_forward<MODE, LOGN, kPF>(x, smem_raw, P, mi, tid);
 #pragma unroll
-  for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
+  for (int e = 0; e < EPT; ++e) out[e * NT + tid] = A::out(x[e], m);
 }
 
 // The same transform for B queries expanded together: source ciphertext index = slot * B + query
@@ -191,12 +211,12 @@ ct_ntt_fwd_split_kernel(const DevParams* __restrict__ P, const uint64_t* __restr
   const uint32_t slot = ct / B, q = ct % B;
   const typename A::T* in = reinterpret_cast<const typename A::T*>(src) + (size_t)blockIdx.x * N;  // the expansion tree
   uint64_t* out = (uint64_t*)dst.p[q] + ((size_t)slot * k2 + rem) * N;
-  typename A::T x[16];
+  typename A::T x[EPT];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) x[e] = in[e * NT + tid];
+  for (int e = 0; e < EPT; ++e) x[e] = in[e * NT + tid];
   ntt_forward<MODE, LOGN, kPF>(x, smem_raw, P, mi, tid);
 #pragma unroll
-  for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
+  for (int e = 0; e < EPT; ++e) out[e * NT + tid] = A::out(x[e], m);
 }
 
 // grid = (n_pt, k).  Source is either pre-encoded coefficients (coeffs != null)
@@ -222,9 +242,9 @@ db_encode_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ c
     L = start >= total_bytes ? 0 : (total_bytes - start < bytes_per_pt ? total_bytes - start : bytes_per_pt);
     src = bytes + start;
   }
-  typename A::T x[16];
+  typename A::T x[EPT];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
+  for (int e = 0; e < EPT; ++e) {
     const uint32_t c = e * NT + tid;
     uint64_t v;
     if (coeffs) {
@@ -253,7 +273,7 @@ db_encode_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ c
   ntt_forward<MODE, LOGN, kPF>(x, smem_raw, P, j, tid);
   uint64_t* out = db + (pt * k + j) * N;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
+  for (int e = 0; e < EPT; ++e) out[e * NT + tid] = A::out(x[e], m);
 }
 
 // A_0[n][j] = NTT_j(a_0 mod q_j) of tree ciphertext n (NTT-domain last expansion level, see ks_last_ntt_kernel),
@@ -267,7 +287,7 @@ __device__ __forceinline__ void tree_c0_ntt_body(const DevParams* __restrict__ P
   static_assert(MODE != kNttInt, "fp64 flavours only");
   const uint32_t k = P->k, km = k + 1;
   const typename A::Mod m = A::mod(P, j);
-  double x[16];
+  double x[EPT];
   tree_load<T40>(tree_raw, (size_t)node * 2 * k + j, tid, m.q, x);
   ntt_forward<MODE, LOGN, kPF, /*CANON=*/false>(x, smem_raw, P, j, tid);
   const size_t opoly = (size_t)node * 2 * km + j;
@@ -277,7 +297,7 @@ __device__ __forceinline__ void tree_c0_ntt_body(const DevParams* __restrict__ P
   } else {
     double* out = reinterpret_cast<double*>(prod) + opoly * N;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) out[e * NT + tid] = x[e];
+    for (int e = 0; e < EPT; ++e) out[e * NT + tid] = x[e];
   }
 }
 
@@ -320,20 +340,20 @@ ks_digit_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ re
   const typename A::Mod m = A::mod(P, I);
   [[maybe_unused]] const uint64_t qJ = P->mod[J].q;
   [[maybe_unused]] const uint64_t* src = res_in + (((size_t)node * 2 + 1) * k + J) * N;  // poly 1, residue J (u64 / doubles)
-  typename A::T x[16];
+  typename A::T x[EPT];
   if constexpr (MODE == kNttInt) {
     // sigma_g in coefficient form (SEAL GaloisTool::apply_galois), then reduce mod m_I
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
+    for (int e = 0; e < EPT; ++e) {
       const uint32_t i = e * NT + tid;
       const uint32_t raw = i * galois_elt;
       uint64_t v = src[i];
       if ((raw >> LOGN) & 1) v = neg_mod(v, qJ);
-      s[lds_idx(raw & (N - 1))] = reduce64(v, mI);
+      s[lds_idx<R_>(raw & (N - 1))] = reduce64(v, mI);
     }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 16; ++e) x[e] = A::in(s[lds_lin_base<NT>(tid) + lds_lin_off<NT>(e)], m);
+    for (int e = 0; e < EPT; ++e) x[e] = A::in(s[lds_lin_base<NT, R_>(tid) + lds_lin_off<NT, R_>(e)], m);
   } else {
     // fp64 flavours: the tree holds doubles (signed representatives, |v| <= (1/2 + eps) q_J); sigma_g's sign
     // is the double's sign bit.  The RNS digit is the CANONICAL residue in [0, q_J) read as an integer and
@@ -344,20 +364,20 @@ ks_digit_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ re
     const bool norm_in = MODE == kNttF64Wide && I != J;
     const double qJd = P->tab[J].qd;
     const uint32_t raw0 = tid * galois_elt, rstep = (uint32_t)NT * galois_elt;
-    double c1[16];
+    double c1[EPT];
     tree_load<T40>(res_in, ((size_t)node * 2 + 1) * k + J, tid, qJd, c1);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
+    for (int e = 0; e < EPT; ++e) {
       const uint32_t raw = raw0 + (uint32_t)e * rstep;
       const uint64_t sign = (uint64_t)((raw << (31 - LOGN)) & 0x80000000u) << 32;
       double v = __longlong_as_double((long long)((uint64_t)__double_as_longlong(c1[e]) ^ sign));
       v = v < 0.0 ? v + qJd : v;  // -0.0 stays 0
       if (norm_in) v = f64_norm(v, m);
-      sd[lds_idx(raw & (N - 1))] = v;
+      sd[lds_idx<R_>(raw & (N - 1))] = v;
     }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 16; ++e) x[e] = sd[lds_lin_base<NT>(tid) + lds_lin_off<NT>(e)];
+    for (int e = 0; e < EPT; ++e) x[e] = sd[lds_lin_base<NT, R_>(tid) + lds_lin_off<NT, R_>(e)];
   }
   __syncthreads();  // the transform reuses the same LDS words with its own element type
   const size_t poly = ((size_t)node * (k + 1) + I) * k + J;
@@ -370,11 +390,11 @@ ks_digit_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ re
     if constexpr (P40) {
       uint8_t* out = reinterpret_cast<uint8_t*>(dig) + poly * kPoly40;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) store40(out, e * NT + tid, A::out(x[e], m));
+      for (int e = 0; e < EPT; ++e) store40(out, e * NT + tid, A::out(x[e], m));
     } else {
       typename A::T* out = reinterpret_cast<typename A::T*>(dig) + poly * N;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) out[e * NT + tid] = x[e];
+      for (int e = 0; e < EPT; ++e) out[e * NT + tid] = x[e];
     }
   }
 }
@@ -386,7 +406,7 @@ ks_digit_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ re
 template <int MODE, bool P40>
 __device__ __forceinline__ void ks_mac_core(const DevParams* __restrict__ P, const uint64_t* __restrict__ dig_raw,
                                             const uint64_t* __restrict__ key_raw, uint32_t node, uint32_t I,
-                                            uint32_t comp, uint32_t tid, typename Arith<MODE>::T (&x)[16]) {
+                                            uint32_t comp, uint32_t tid, typename Arith<MODE>::T (&x)[EPT]) {
   using A = Arith<MODE>;
   using T = typename A::T;
   const uint32_t k = P->k, km = k + 1;
@@ -402,35 +422,35 @@ __device__ __forceinline__ void ks_mac_core(const DevParams* __restrict__ P, con
       if constexpr (P40) return A::in(load40(d40 + (size_t)J * kPoly40, i), m);
       else return d0[(size_t)J * N + i];
     };
-    u128 acc[16];
+    u128 acc[EPT];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0;
+    for (int e = 0; e < EPT; ++e) acc[e] = 0;
     for (uint32_t J = 0; J < k; ++J) {  // k <= 8 products of two residues < 2^61 fit 128 bits
       const T* kj = key + (((size_t)J * 2 + comp) * km + I) * N;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[e] += (u128)digit(J, e * NT + tid) * kj[e * NT + tid];
+      for (int e = 0; e < EPT; ++e) acc[e] += (u128)digit(J, e * NT + tid) * kj[e * NT + tid];
     }
 #pragma unroll
-    for (int e = 0; e < 16; ++e) x[e] = reduce128((uint64_t)acc[e], (uint64_t)(acc[e] >> 64), mI);
+    for (int e = 0; e < EPT; ++e) x[e] = reduce128((uint64_t)acc[e], (uint64_t)(acc[e] >> 64), mI);
     ntt_inverse<MODE, LOGN, kPF>(x, smem_raw, P, I, tid);
   } else {
     const double magic = f64_pack_magic(m.q);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) x[e] = 0.0;
+    for (int e = 0; e < EPT; ++e) x[e] = 0.0;
     for (uint32_t J = 0; J < k; ++J) {
       const T* kj = key + (((size_t)J * 2 + comp) * km + I) * N;
       if constexpr (P40) {
         const uint8_t* dj = d40 + (size_t)J * kPoly40;
         const Hi16 h = load40f_hi(dj, tid);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) x[e] += f64_mulmod(load40f(dj, h, e, tid, magic), kj[e * NT + tid], m);
+        for (int e = 0; e < EPT; ++e) x[e] += f64_mulmod(load40f(dj, h, e, tid, magic), kj[e * NT + tid], m);
       } else {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) x[e] += f64_mulmod(d0[(size_t)J * N + e * NT + tid], kj[e * NT + tid], m);
+        for (int e = 0; e < EPT; ++e) x[e] += f64_mulmod(d0[(size_t)J * N + e * NT + tid], kj[e * NT + tid], m);
       }
     }
 #pragma unroll
-    for (int e = 0; e < 16; ++e) x[e] = f64_norm(x[e], m);
+    for (int e = 0; e < EPT; ++e) x[e] = f64_norm(x[e], m);
     ntt_inverse<MODE, LOGN, kPF, /*CANON=*/false>(x, smem_raw, P, I, tid);
   }
 }
@@ -459,7 +479,7 @@ ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
   }
   I += I_base;
   const typename A::Mod m = A::mod(P, I);
-  T x[16];
+  T x[EPT];
   ks_mac_core<MODE, P40>(P, dig_raw, keys.p[node % keys.B], node, I, comp, tid, x);   // the key of this node's query
   const size_t opoly = ((size_t)node * 2 + comp) * km + I;
   if constexpr (P40 && MODE != kNttInt) {
@@ -468,15 +488,15 @@ ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
   } else if constexpr (MODE != kNttInt) {  // plain doubles (moduli >= 2^39): signed representatives as they are
     T* out = reinterpret_cast<T*>(prod) + opoly * N;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) out[e * NT + tid] = x[e];
+    for (int e = 0; e < EPT; ++e) out[e * NT + tid] = x[e];
   } else if constexpr (P40) {
     uint8_t* out = reinterpret_cast<uint8_t*>(prod) + opoly * kPoly40;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) store40(out, e * NT + tid, A::out(x[e], m));
+    for (int e = 0; e < EPT; ++e) store40(out, e * NT + tid, A::out(x[e], m));
   } else {
     uint64_t* out = prod + opoly * N;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
+    for (int e = 0; e < EPT; ++e) out[e * NT + tid] = A::out(x[e], m);
   }
 }
 
@@ -507,7 +527,7 @@ ks_mac_combine_kernel(const DevParams* __restrict__ P, const uint64_t* __restric
     node = (u / k) * 8 + xcd;
   }
   const typename A::Mod m = A::mod(P, j);
-  double g[16];
+  double g[EPT];
   ks_mac_core<MODE, P40>(P, dig_raw, keys.p[node % keys.B], node, j, comp, tid, g);
   {
     const double pf = P->p_f, half = P->p_half_f, pinv = P->p_inv_f[j];
@@ -515,7 +535,7 @@ ks_mac_combine_kernel(const DevParams* __restrict__ P, const uint64_t* __restric
     [[maybe_unused]] Hi16 hs{};
     if constexpr (P40) hs = load40f_hi(reinterpret_cast<const uint8_t*>(prod) + spoly * kPoly40, tid);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
+    for (int e = 0; e < EPT; ++e) {
       double sp;
       if constexpr (P40) {
         sp = load40f(reinterpret_cast<const uint8_t*>(prod) + spoly * kPoly40, hs, e, tid, f64_pack_magic(pf));
@@ -529,63 +549,58 @@ ks_mac_combine_kernel(const DevParams* __restrict__ P, const uint64_t* __restric
   }
   if (comp == 0) {  // + sigma_g(c0)
     const uint32_t raw0 = tid * galois_elt, rstep = (uint32_t)NT * galois_elt;
-    double c0[16];
+    double c0[EPT];
     tree_load<TIN40>(tree_in_raw, (size_t)node * 2 * k + j, tid, m.q, c0);
     __syncthreads();  // the inverse transform is done with the LDS words
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
+    for (int e = 0; e < EPT; ++e) {
       const uint32_t raw = raw0 + (uint32_t)e * rstep;
       const uint64_t sign = (uint64_t)((raw << (31 - LOGN)) & 0x80000000u) << 32;
-      sd[lds_idx(raw & (N - 1))] = __longlong_as_double((long long)((uint64_t)__double_as_longlong(c0[e]) ^ sign));
+      sd[lds_idx<R_>(raw & (N - 1))] = __longlong_as_double((long long)((uint64_t)__double_as_longlong(c0[e]) ^ sign));
     }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 16; ++e) g[e] += sd[lds_lin_base<NT>(tid) + lds_lin_off<NT>(e)];
+    for (int e = 0; e < EPT; ++e) g[e] += sd[lds_lin_base<NT, R_>(tid) + lds_lin_off<NT, R_>(e)];
   }
   const size_t opoly = (size_t)comp * k + j;
-  double a[16];
+  double a[EPT];
   tree_load<TIN40>(tree_in_raw, (size_t)node * 2 * k + opoly, tid, m.q, a);
   if constexpr (TOUT40) {
     // 5-byte tree out (shift_pow < NT, checked by the host): lo keeps its index; hi = x^(-shift) (a - g) moves element
     // e NT + tid to (e NT + tid - shift) mod N, i.e. to thread tid' = (tid - shift) mod NT, same e -- or, for the
-    // threads tid < shift, e - 1 with element 0 wrapping to 15 negated.  All 16 values of a thread land in ONE
-    // destination thread, so its 16 high bytes are still one 16-byte store (rotated by a byte when borrowing).
+    // threads tid < shift, e - 1 with element 0 wrapping to EPT - 1 negated.  All EPT values of a thread land in ONE
+    // destination thread, so its EPT high bytes are still one contiguous store (rotated by a byte when borrowing).
     const double magic = f64_pack_magic(m.q);
     uint8_t* plo = reinterpret_cast<uint8_t*>(tree_out_raw) + ((size_t)node * 2 * k + opoly) * kPoly40;
     uint8_t* phi = reinterpret_cast<uint8_t*>(tree_out_raw) + (((size_t)node + nodes) * 2 * k + opoly) * kPoly40;
-    double lo[16];
+    double lo[EPT];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) lo[e] = f64_norm(a[e] + g[e], m);
+    for (int e = 0; e < EPT; ++e) lo[e] = f64_norm(a[e] + g[e], m);
     store40f(plo, tid, lo, magic);
     const bool borrow = tid < shift_pow;
     const uint32_t tid_d = (tid - shift_pow) & (NT - 1);
-    uint32_t hb[16];
+    uint32_t hb[EPT];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
+    for (int e = 0; e < EPT; ++e) {
       double d = f64_norm(a[e] - g[e], m);
       if (e == 0) d = borrow ? -d : d;
       uint32_t l32;
       f64_pack40(d, magic, l32, hb[e]);
       reinterpret_cast<uint32_t*>(phi)[(e * NT + tid - shift_pow) & (N - 1)] = l32;
     }
-    uint32_t w[4];
+    uint32_t w[EPT / 4];
+    pack_hi_bytes(hb, w);
+    uint32_t o[EPT / 4];
 #pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) {
-      const uint32_t ab = __builtin_amdgcn_perm(hb[4 * q4 + 1], hb[4 * q4], 0x0c0c0400u);
-      const uint32_t cd = __builtin_amdgcn_perm(hb[4 * q4 + 3], hb[4 * q4 + 2], 0x0c0c0400u);
-      w[q4] = __builtin_amdgcn_perm(cd, ab, 0x05040100u);
-    }
-    uint32_t o[4];
-#pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4)   // borrowing threads: destination byte e' holds source byte e' + 1 (mod 16)
-      o[q4] = borrow ? __builtin_amdgcn_alignbyte(w[(q4 + 1) & 3], w[q4], 1) : w[q4];
-    *reinterpret_cast<uint4*>(phi + 4 * N + 16 * tid_d) = uint4{o[0], o[1], o[2], o[3]};
+    for (int q4 = 0; q4 < EPT / 4; ++q4)   // borrowing threads: destination byte e' holds source byte e' + 1 (mod EPT)
+      o[q4] = borrow ? __builtin_amdgcn_alignbyte(w[(q4 + 1) % (EPT / 4)], w[q4], 1) : w[q4];
+    store_hi_words(phi, tid_d, o);
   } else {
     const size_t off = opoly * N;
     double* tree_lo = reinterpret_cast<double*>(tree_out_raw) + (size_t)node * 2 * k * N + off;
     double* tree_hi = reinterpret_cast<double*>(tree_out_raw) + ((size_t)node + nodes) * 2 * k * N + off;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
+    for (int e = 0; e < EPT; ++e) {
       const uint32_t i = e * NT + tid;
       tree_lo[i] = f64_norm(a[e] + g[e], m);
       const double d = f64_norm(a[e] - g[e], m);
@@ -622,7 +637,7 @@ ks_last_level_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict
   const double pf = P->p_f, half = P->p_half_f, pinv = P->p_inv_f[j];
   const double* tree = reinterpret_cast<const double*>(tree_raw) + (size_t)ct * 2 * k * N;
   // g = round(S / p) mod q_j, signed representative (ks_combine_f64_kernel)
-  double g[16];
+  double g[EPT];
   [[maybe_unused]] Hi16 hs{}, hj{};
   if constexpr (P40) {
     const uint8_t* pr = reinterpret_cast<const uint8_t*>(prod) + ((size_t)ct * 2 + comp) * km * kPoly40;
@@ -630,7 +645,7 @@ ks_last_level_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict
     hj = load40f_hi(pr + (size_t)j * kPoly40, tid);
   }
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
+  for (int e = 0; e < EPT; ++e) {
     [[maybe_unused]] const uint32_t i = e * NT + tid;
     double sp, dj;
     if constexpr (P40) {
@@ -650,39 +665,39 @@ ks_last_level_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict
     const double* c0 = tree + (size_t)j * N;
     const uint32_t raw0 = tid * galois_elt, rstep = (uint32_t)NT * galois_elt;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
+    for (int e = 0; e < EPT; ++e) {
       const uint32_t raw = raw0 + (uint32_t)e * rstep;
       const uint64_t sign = (uint64_t)((raw << (31 - LOGN)) & 0x80000000u) << 32;
-      sd[lds_idx(raw & (N - 1))] =
+      sd[lds_idx<R_>(raw & (N - 1))] =
           __longlong_as_double((long long)((uint64_t)__double_as_longlong(c0[e * NT + tid]) ^ sign));
     }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 16; ++e) g[e] += sd[lds_lin_base<NT>(tid) + lds_lin_off<NT>(e)];
+    for (int e = 0; e < EPT; ++e) g[e] += sd[lds_lin_base<NT, R_>(tid) + lds_lin_off<NT, R_>(e)];
     __syncthreads();
   }
   const double* a = tree + ((size_t)comp * k + j) * N;
-  typename A::T x[16];
+  typename A::T x[EPT];
   if (!half_id) {  // lo = a + g -> selector `slot`
 #pragma unroll
-    for (int e = 0; e < 16; ++e) x[e] = f64_norm(a[e * NT + tid] + g[e], m);
+    for (int e = 0; e < EPT; ++e) x[e] = f64_norm(a[e * NT + tid] + g[e], m);
   } else {         // hi = x^(-2^j) (a - g): negacyclic rotation by 2N - 2^j through LDS -> selector `slot + 2^j`
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
+    for (int e = 0; e < EPT; ++e) {
       const uint32_t i = e * NT + tid;
       const double d = f64_norm(a[i] - g[e], m);
       const uint32_t sraw = i + (2 * N - shift_pow);
-      sd[lds_idx(sraw & (N - 1))] = (sraw & N) ? -d : d;
+      sd[lds_idx<R_>(sraw & (N - 1))] = (sraw & N) ? -d : d;
     }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 16; ++e) x[e] = sd[lds_lin_base<NT>(tid) + lds_lin_off<NT>(e)];
+    for (int e = 0; e < EPT; ++e) x[e] = sd[lds_lin_base<NT, R_>(tid) + lds_lin_off<NT, R_>(e)];
     __syncthreads();
   }
   ntt_forward<MODE, LOGN, kPF>(x, smem_raw, P, j, tid);
   uint64_t* out = (uint64_t*)dst.p[q] + ((size_t)out_slot * 2 * k + comp * k + j) * N;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) out[e * NT + tid] = A::out(x[e], m);
+  for (int e = 0; e < EPT; ++e) out[e * NT + tid] = A::out(x[e], m);
 }
 
 // ---- last expansion level in the NTT domain (fp64 flavours) ----
@@ -706,7 +721,7 @@ __device__ __forceinline__ uint32_t galois_ntt_slot(uint32_t P, uint32_t g) {
   const uint32_t r = __brev(P) >> (32 - LOGN);
   const uint32_t ex = ((2 * r + 1) * g) & (2 * N - 1);
   const uint32_t Pin = __brev(ex >> 1) >> (32 - LOGN);
-  return (Pin & 15u) * NT + (Pin >> 4);
+  return (Pin & (uint32_t)(EPT - 1)) * NT + (Pin >> R_);
 }
 
 // One workgroup per (tree ciphertext, data modulus j, component): one forward transform (of the lifted special
@@ -734,14 +749,14 @@ ks_last_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
   const typename A::Mod m = A::mod(P, j);
   const uint32_t slot = node / B, q = node % B;
   // t = NTT_j(lift(s))
-  double x[16];
+  double x[EPT];
   {
     const double pf = P->p_f, half = P->p_half_f;
     const size_t spoly = ((size_t)node * 2 + comp) * km + k;
     [[maybe_unused]] Hi16 hs{};
     if constexpr (P40) hs = load40f_hi(reinterpret_cast<const uint8_t*>(prod) + spoly * kPoly40, tid);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
+    for (int e = 0; e < EPT; ++e) {
       double sp;
       if constexpr (P40)
         sp = load40f(reinterpret_cast<const uint8_t*>(prod) + spoly * kPoly40, hs, e, tid, f64_pack_magic(pf));
@@ -757,33 +772,33 @@ ks_last_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
   const size_t dpoly0 = ((size_t)node * km + j) * k;
   const double magic = f64_pack_magic(m.q);
   // polynomial `poly` of a 5-byte / double buffer, this thread's 16 elements
-  auto load_poly = [&](const uint64_t* base, size_t poly, double (&out)[16], uint32_t t) {
+  auto load_poly = [&](const uint64_t* base, size_t poly, double (&out)[EPT], uint32_t t) {
     if constexpr (P40) {
       const uint8_t* pp = reinterpret_cast<const uint8_t*>(base) + poly * kPoly40;
       const Hi16 h = load40f_hi(pp, t);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) out[e] = load40f(pp, h, e, t, magic);
+      for (int e = 0; e < EPT; ++e) out[e] = load40f(pp, h, e, t, magic);
     } else {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) out[e] = reinterpret_cast<const double*>(base)[poly * N + e * NT + t];
+      for (int e = 0; e < EPT; ++e) out[e] = reinterpret_cast<const double*>(base)[poly * N + e * NT + t];
     }
   };
   {
     // the products accumulate onto -t in place: a second accumulator array next to x leaves too few registers for
     // the digit and key loads of one J to be in flight together (the MAC then costs more than the transform)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) x[e] = -x[e];
+    for (int e = 0; e < EPT; ++e) x[e] = -x[e];
     const double* key = reinterpret_cast<const double*>(keys.p[node % keys.B]);   // the key of this node's query
     for (uint32_t J = 0; J < k; ++J) {
       const double* kj = key + (((size_t)J * 2 + comp) * km + j) * N;
-      double d[16];
+      double d[EPT];
       load_poly(dig_raw, dpoly0 + J, d, tid);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) x[e] += f64_mulmod(d[e], kj[e * NT + tid], m);
+      for (int e = 0; e < EPT; ++e) x[e] += f64_mulmod(d[e], kj[e * NT + tid], m);
     }
     const double pinv = P->p_inv_f[j];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) x[e] = f64_mulmod(f64_norm(x[e], m), pinv, m);
+    for (int e = 0; e < EPT; ++e) x[e] = f64_mulmod(f64_norm(x[e], m), pinv, m);
   }
   // Everything below is indexed through an opaque copy of the thread index: the compiler otherwise computes the
   // epilogue's 16 permuted LDS addresses and its global addresses BEFORE the product loop, and with those ~40
@@ -792,19 +807,19 @@ ks_last_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
   uint32_t tid_e = tid;
   asm volatile("" : "+v"(tid_e));
   // A (and, for component 0, A_0 o pi_g) through an LDS permutation
-  double a[16];
+  double a[EPT];
   {
-    double v[16];
+    double v[EPT];
     if (comp == 0) load_poly(prod, (size_t)node * 2 * km + j, v, tid_e);
     else load_poly(dig_raw, dpoly0 + j, v, tid_e);
     __syncthreads();  // the transform's last exchange is done with the LDS words
 #pragma unroll
-    for (int e = 0; e < 16; ++e) sd[lds_lin_base<NT>(tid_e) + lds_lin_off<NT>(e)] = v[e];
+    for (int e = 0; e < EPT; ++e) sd[lds_lin_base<NT, R_>(tid_e) + lds_lin_off<NT, R_>(e)] = v[e];
     __syncthreads();
     const uint32_t gel = comp == 0 ? galois_elt : galois_inv;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const double w = sd[lds_idx(galois_ntt_slot(16 * tid_e + e, gel))];
+    for (int e = 0; e < EPT; ++e) {
+      const double w = sd[lds_idx<R_>(galois_ntt_slot(EPT * tid_e + e, gel))];
       if (comp == 0) {
         a[e] = v[e];
         x[e] += w;
@@ -816,7 +831,7 @@ ks_last_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
   const size_t opoly = (size_t)comp * k + j;
   uint64_t* lo = (uint64_t*)dst.p[q] + ((size_t)slot * 2 * k + opoly) * N;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
+  for (int e = 0; e < EPT; ++e) {
     const double r = f64_canon(f64_norm(a[e] + x[e], m), m);
     if constexpr (OUTF64) reinterpret_cast<double*>(lo)[e * NT + tid_e] = r;   // lane-internal selectors: exact doubles
     else lo[e * NT + tid_e] = A::out(r, m);
@@ -825,7 +840,7 @@ ks_last_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
     uint64_t* hi = (uint64_t*)dst.p[q] + ((size_t)(slot + shift_pow) * 2 * k + opoly) * N;
     const double* X = xpow + (size_t)j * N;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
+    for (int e = 0; e < EPT; ++e) {
       const double r = f64_canon(f64_mulmod(f64_norm(a[e] - x[e], m), X[e * NT + tid_e], m), m);
       if constexpr (OUTF64) reinterpret_cast<double*>(hi)[e * NT + tid_e] = r;
       else hi[e * NT + tid_e] = A::out(r, m);
@@ -875,10 +890,10 @@ upper_fused_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
 
   // lazy accumulators: fp64 sums of signed representatives (|term| <= 0.7 q, renormalised
   // every 8 terms) or exact 128-bit integer sums (folded every lazy_limit terms)
-  T acc0[16], acc1[16];
-  u128 wide0[MODE == kNttInt ? 16 : 1], wide1[MODE == kNttInt ? 16 : 1];
+  T acc0[EPT], acc1[EPT];
+  u128 wide0[MODE == kNttInt ? EPT : 1], wide1[MODE == kNttInt ? EPT : 1];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
+  for (int e = 0; e < EPT; ++e) {
     acc0[e] = 0;
     acc1[e] = 0;
     if constexpr (MODE == kNttInt) wide0[e] = wide1[e] = 0;
@@ -901,36 +916,36 @@ upper_fused_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
     static_assert(MODE != kNttInt, "fp64 flavours only");
     double* ltw = reinterpret_cast<double*>(smem_raw + kLdsBytes);
     lds_twiddles_fill<LOGN>(ltw, A::tw(P, jt), tid);
-    uint64_t in_raw[16];
+    uint64_t in_raw[EPT];
     auto load_in = [&](uint32_t ii) {
       const __amdgpu_buffer_rsrc_t in = poly_rsrc(src + ((((size_t)(child0 + ii) * C + cc) * 2 + sp) * k + sj) * N);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) in_raw[e] = poly_load_u64(in, tid, e);
+      for (int e = 0; e < EPT; ++e) in_raw[e] = poly_load_u64(in, tid, e);
     };
     if (ii0 < ii1) load_in(ii0);
     for (uint32_t ii = ii0; ii < ii1; ++ii) {
       const __amdgpu_buffer_rsrc_t s0 = poly_rsrc(sv + (((size_t)(sv_first + ii) * 2 + 0) * k + jt) * N);
       const __amdgpu_buffer_rsrc_t s1 = poly_rsrc(sv + (((size_t)(sv_first + ii) * 2 + 1) * k + jt) * N);
-      T x[16];
+      T x[EPT];
       if (fast_lift) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
+        for (int e = 0; e < EPT; ++e) {
           const uint32_t v = (uint32_t)(in_raw[e] >> sh) & mask32;
           const double d = (double)v;
           x[e] = v >= thr32 ? d - td : d;  // m >= (t+1)/2 -> m + q - t == m - t (mod q): SURVEY App. A.5
         }
       } else {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
+        for (int e = 0; e < EPT; ++e) {
           uint64_t v = (in_raw[e] >> sh) & mask;
           uint64_t rr = reduce64(v, mc);
           if (v >= thr) rr = add_mod(rr, inc, mc.q);
           x[e] = A::in(rr, m);
         }
       }
-      uint64_t s0r[16], s1r[16];
+      uint64_t s0r[EPT], s1r[EPT];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
+      for (int e = 0; e < EPT; ++e) {
         s0r[e] = poly_load_u64(s0, tid, e);
         s1r[e] = poly_load_u64(s1, tid, e);
       }
@@ -939,7 +954,7 @@ upper_fused_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
       __syncthreads();  // previous iteration's transform may still be reading LDS (and, first time, the table copy)
       ntt_forward_tw<MODE, LOGN, false, /*CANON=*/false>(x, smem_raw, P, jt, tid, LdsTw{ltw});
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
+      for (int e = 0; e < EPT; ++e) {
         // SELF64: the group's selectors were written as exact doubles by ks_last_ntt_kernel (no conversion)
         acc0[e] += f64_mulmod(x[e], SELF64 ? __longlong_as_double((long long)s0r[e]) : f64_from_u64(s0r[e]), m);
         acc1[e] += f64_mulmod(x[e], SELF64 ? __longlong_as_double((long long)s1r[e]) : f64_from_u64(s1r[e]), m);
@@ -947,7 +962,7 @@ upper_fused_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
       if (++since == 8) {
         since = 0;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
+        for (int e = 0; e < EPT; ++e) {
           acc0[e] = f64_norm(acc0[e], m);
           acc1[e] = f64_norm(acc1[e], m);
         }
@@ -956,18 +971,18 @@ upper_fused_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
   } else
   for (uint32_t ii = ii0; ii < ii1; ++ii) {
     const uint64_t* in = src + ((((size_t)(child0 + ii) * C + cc) * 2 + sp) * k + sj) * N;
-    T x[16];
+    T x[EPT];
     if constexpr (MODE != kNttInt) {
       if (fast_lift) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
+        for (int e = 0; e < EPT; ++e) {
           const uint32_t v = (uint32_t)(in[e * NT + tid] >> sh) & mask32;
           const double d = (double)v;
           x[e] = v >= thr32 ? d - td : d;  // m >= (t+1)/2 -> m + q - t == m - t (mod q): SURVEY App. A.5
         }
       } else {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
+        for (int e = 0; e < EPT; ++e) {
           uint64_t v = (in[e * NT + tid] >> sh) & mask;
           uint64_t rr = reduce64(v, mc);
           if (v >= thr) rr = add_mod(rr, inc, mc.q);
@@ -976,7 +991,7 @@ upper_fused_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
+      for (int e = 0; e < EPT; ++e) {
         uint64_t v = (in[e * NT + tid] >> sh) & mask;
         uint64_t rr = reduce64(v, mc);
         if (v >= thr) rr = add_mod(rr, inc, mc.q);
@@ -990,21 +1005,21 @@ upper_fused_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
     const uint64_t* s1 = sv + (((size_t)(sv_first + ii) * 2 + 1) * k + jt) * N;
     if constexpr (MODE == kNttInt) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
+      for (int e = 0; e < EPT; ++e) {
         wide0[e] += (u128)x[e] * s0[e * NT + tid];
         wide1[e] += (u128)x[e] * s1[e * NT + tid];
       }
       if (++since == P->lazy_limit) {
         since = 0;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
+        for (int e = 0; e < EPT; ++e) {
           wide0[e] = reduce128((uint64_t)wide0[e], (uint64_t)(wide0[e] >> 64), mc);
           wide1[e] = reduce128((uint64_t)wide1[e], (uint64_t)(wide1[e] >> 64), mc);
         }
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
+      for (int e = 0; e < EPT; ++e) {
         const uint64_t w0 = s0[e * NT + tid], w1 = s1[e * NT + tid];
         acc0[e] += f64_mulmod(x[e], SELF64 ? __longlong_as_double((long long)w0) : f64_from_u64(w0), m);
         acc1[e] += f64_mulmod(x[e], SELF64 ? __longlong_as_double((long long)w1) : f64_from_u64(w1), m);
@@ -1012,7 +1027,7 @@ upper_fused_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
       if (++since == 8) {
         since = 0;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
+        for (int e = 0; e < EPT; ++e) {
           acc0[e] = f64_norm(acc0[e], m);
           acc1[e] = f64_norm(acc1[e], m);
         }
@@ -1023,7 +1038,7 @@ upper_fused_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
   uint64_t* o0 = part + ((slot * 2 + 0) * k + jt) * N;
   uint64_t* o1 = part + ((slot * 2 + 1) * k + jt) * N;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
+  for (int e = 0; e < EPT; ++e) {
     if constexpr (MODE == kNttInt) {
       o0[e * NT + tid] = reduce128((uint64_t)wide0[e], (uint64_t)(wide0[e] >> 64), mc);
       o1[e * NT + tid] = reduce128((uint64_t)wide1[e], (uint64_t)(wide1[e] >> 64), mc);
@@ -1059,10 +1074,10 @@ upper_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ s
   uint32_t nchild = n_children_total > child0 ? n_children_total - child0 : 0;
   if (nchild > n_dim) nchild = n_dim;
   double* out = scratch + (((((size_t)qi * n_rows + r) * C + cc) * blk + iib) * E + e_idx) * k * N + (size_t)jt * N;
-  typename A::T x[16];
+  typename A::T x[EPT];
   if (ii >= nchild) {  // beyond the database: contributes nothing (uniform per workgroup)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) out[e * NT + tid] = 0.0;
+    for (int e = 0; e < EPT; ++e) out[e * NT + tid] = 0.0;
     return;
   }
   const ModConst mc = P->mod[jt];
@@ -1077,14 +1092,14 @@ upper_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ s
   const uint64_t* in = src_all + (size_t)qi * src_qstride + ((((size_t)(child0 + ii) * C + cc) * 2 + sp) * k + sj) * N;
   if (fast_lift) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
+    for (int e = 0; e < EPT; ++e) {
       const uint32_t v = (uint32_t)(in[e * NT + tid] >> sh) & mask32;
       const double d = (double)v;
       x[e] = v >= thr32 ? d - td : d;
     }
   } else {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
+    for (int e = 0; e < EPT; ++e) {
       uint64_t v = (in[e * NT + tid] >> sh) & mask;
       uint64_t rr = reduce64(v, mc);
       if (v >= thr) rr = add_mod(rr, inc, mc.q);
@@ -1093,7 +1108,7 @@ upper_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ s
   }
   ntt_forward<MODE, LOGN, kPF, /*CANON=*/false>(x, smem_raw, P, jt, tid);
 #pragma unroll
-  for (int e = 0; e < 16; ++e) out[e * NT + tid] = x[e];
+  for (int e = 0; e < EPT; ++e) out[e * NT + tid] = x[e];
 }
 
 // ------------------------------------------------------------------ host side

@@ -250,6 +250,7 @@ struct OutBuf {
   }
 };
 
+struct RelinCache;
 struct Job {
   const uint8_t* request = nullptr;
   size_t request_len = 0;
@@ -263,6 +264,7 @@ struct Job {
   bool uniform = true;        // every query has the ciphertext count the dimensions call for (server.cpp:154)
   bool unverified = false;    // the slot was taken on its fingerprint alone: the key bytes are compared under the GPU work
   bool mismatch = false;      // ... and differed: install this client's keys and serve the request again
+  bool relin_checked = false; // the RelinKeys field (if any) has been validated
   int pins = 0;               // times `slot` is pinned for this request (pirgpu_keyset_pin; once per window in flight
                               // that holds queries of it): unpinned as the windows finish
 };
@@ -274,6 +276,8 @@ struct Server {               // what serving needs to know about a context
   size_t ctw;
   uint64_t n_reply;
   uint32_t nq_expected;
+  struct RelinCache* relin = nullptr;   // per context (Combiner)
+  size_t relin_keep = 256;
 };
 
 // Response.reply (payload.proto:39-42) for one query: n ciphertexts, written straight into the response buffer
@@ -389,6 +393,33 @@ class Pool {
   std::vector<std::thread> threads_;
 };
 
+// SEALDeserialize<RelinKeys> (server.cpp:53-58): only CT-multiplication mode uses the keys, but a malformed non-empty
+// field is InvalidArgument in the reference, so the object is parsed and validated here too.  The reference client sends
+// its RelinKeys with EVERY request (client.cpp:80-90) -- seed-compressed, i.e. 0.2-0.4 ms of BLAKE2Xb re-sampling per
+// request at N = 4096 -- so the verdict is remembered per resident key set: a request whose relin bytes equal the ones
+// already validated for its client's set skips the parse (a memcmp of 0.2 MB instead).  Keyed by the key set HANDLE
+// (slot + generation): an evicted set's entry can never be hit by the next tenant.
+struct RelinCache {
+  std::mutex m;
+  std::map<uint32_t, std::shared_ptr<const std::vector<uint8_t>>> ok;   // handle -> validated bytes
+  bool known_good(uint32_t slot, const uint8_t* p, size_t n) {
+    std::shared_ptr<const std::vector<uint8_t>> have;
+    {
+      std::lock_guard<std::mutex> lk(m);
+      auto it = ok.find(slot);
+      if (it == ok.end()) return false;
+      have = it->second;
+    }
+    return have->size() == n && memcmp(have->data(), p, n) == 0;
+  }
+  void remember(uint32_t slot, const uint8_t* p, size_t n, size_t keep) {
+    auto copy = std::make_shared<const std::vector<uint8_t>>(p, p + n);
+    std::lock_guard<std::mutex> lk(m);
+    if (ok.size() >= keep) ok.clear();   // bounded: at most a few entries per key set slot
+    ok[slot] = std::move(copy);
+  }
+};
+
 struct Trace {   // PIRGPU_WIRE_TRACE=1: host-side phase times of a window, to stderr
   bool on = getenv("PIRGPU_WIRE_TRACE") != nullptr;
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
@@ -458,6 +489,15 @@ void resolve_keys(const Server& sv, Job& job, bool speculative, bool* unverified
   if (rc) throw Err{rc, pirgpu_last_error(sv.ctx)};
   job.slot = slot;
   job.pins = 1;
+}
+
+// The request's RelinKeys field, if any: validated (or recognised as already validated for this client's key set).
+// Throws Err like the loader.  Runs on pool threads / under the GPU's work: only the job's status depends on it.
+void check_relin_keys(const Server& sv, const Job& job) {
+  if (!job.pr.relin_keys_len) return;   // empty = absent (server.cpp:53)
+  if (sv.relin && job.slot && sv.relin->known_good(job.slot, job.pr.relin_keys, job.pr.relin_keys_len)) return;
+  load_kswitch_keys(sv.sh, job.pr.relin_keys, job.pr.relin_keys_len, nullptr);
+  if (sv.relin && job.slot) sv.relin->remember(job.slot, job.pr.relin_keys, job.pr.relin_keys_len, sv.relin_keep);
 }
 
 void unpin_job(const Server& sv, Job& job) {
@@ -533,18 +573,36 @@ Finally<F> finally(F f) { return Finally<F>{std::move(f)}; }
 void verify_keys_of(const Server& sv, Window& w) {
   std::vector<Job*> todo;
   for (const Item& it : w.chunk)
-    if (it.job->unverified && std::find(todo.begin(), todo.end(), it.job) == todo.end()) todo.push_back(it.job);
+    if ((it.job->unverified || (it.job->pr.relin_keys_len && !it.job->relin_checked)) &&
+        std::find(todo.begin(), todo.end(), it.job) == todo.end())
+      todo.push_back(it.job);
   if (todo.empty()) return;
   std::vector<std::pair<const uint8_t*, size_t>> resident(todo.size());
-  for (size_t i = 0; i < todo.size(); ++i) resident[i].second = pirgpu_keyset_blob(sv.ctx, todo[i]->slot, &resident[i].first);
+  for (size_t i = 0; i < todo.size(); ++i)
+    if (todo[i]->unverified) resident[i].second = pirgpu_keyset_blob(sv.ctx, todo[i]->slot, &resident[i].first);
   // (64 clients' objects are 600 MB to read, more than the host's last-level cache: memory-bound, so many threads)
+  std::vector<Err> relin_err(todo.size(), Err{0, ""});
   Pool::get().parallel_for(todo.size(), 16, [&](size_t i) {
     Job* job = todo[i];
-    const uint8_t* r = resident[i].first;
-    const size_t len = resident[i].second;
-    job->mismatch = !(r && len == job->pr.galois_keys_len && memcmp(r, job->pr.galois_keys, len) == 0);
-    job->unverified = false;
+    if (job->unverified) {
+      const uint8_t* r = resident[i].first;
+      const size_t len = resident[i].second;
+      job->mismatch = !(r && len == job->pr.galois_keys_len && memcmp(r, job->pr.galois_keys, len) == 0);
+      job->unverified = false;
+    }
+    if (job->pr.relin_keys_len && !job->relin_checked && !job->mismatch) {
+      try {
+        check_relin_keys(sv, *job);
+        job->relin_checked = true;
+      } catch (const Err& e) {
+        relin_err[i] = e;
+      } catch (const std::exception& e) {
+        relin_err[i] = Err{PIRGPU_INTERNAL, e.what()};
+      }
+    }
   });
+  for (size_t i = 0; i < todo.size(); ++i)
+    if (relin_err[i].code && !todo[i]->rc) fail_job(*todo[i], relin_err[i].code, relin_err[i].msg);   // its replies are dropped
 }
 
 // Parses the queries of `items` into the window's pinned staging (on the pool's threads: 128 KiB + a range check per
@@ -714,6 +772,7 @@ struct Combiner {
   std::condition_variable cv;
   std::deque<Job*> pending;
   bool set_busy[2] = {false, false};
+  RelinCache relin;
   int take_set() {   // call with m held; -1: none free
     for (int i = 0; i < 2; ++i)
       if (!set_busy[i]) {
@@ -739,6 +798,7 @@ void serve(pirgpu_ctx* ctx, Combiner& cb, int first_set, Job* const* jobs, size_
   uint64_t dim_sum = 0;
   for (uint32_t l = 0; l < sv.prm.num_dimensions; ++l) dim_sum += sv.prm.dimensions[l];
   sv.nq_expected = (uint32_t)(dim_sum / sv.sh.N + 1);  // server.cpp:154
+  sv.relin = &cb.relin;
   Trace trace;
   // this thread's pinned staging and batch state are those of the set it owns (the lone-query and the sequential paths
   // use them too); the calling thread's default selection (0) is restored when the call returns
@@ -750,6 +810,7 @@ void serve(pirgpu_ctx* ctx, Combiner& cb, int first_set, Job* const* jobs, size_
   // another serving thread's): half the slots each, so that a new client's claim always finds an unpinned set
   const size_t max_clients = std::max<size_t>(1, std::min<size_t>(stats[3] >= 2 ? stats[3] / 2 : 1, kMaxRequestBatch));
   const bool may_overlap = stats[3] >= 2;
+  sv.relin_keep = 4 * (size_t)stats[3] + 16;
 
   // (1) parse every request; RelinKeys validated when present (server.cpp:53-58: only CT-multiplication mode uses them,
   // but a malformed non-empty field is InvalidArgument in the reference)
@@ -778,7 +839,6 @@ void serve(pirgpu_ctx* ctx, Combiner& cb, int first_set, Job* const* jobs, size_
     }
     try {
       resolve_keys(sv, job, true, &job.unverified);
-      if (job.pr.relin_keys_len) load_kswitch_keys(sv.sh, job.pr.relin_keys, job.pr.relin_keys_len, nullptr);
     } catch (const Err& e) {
       unpin_job(sv, job);
       fail_job(job, e.code, e.msg);
@@ -795,6 +855,13 @@ void serve(pirgpu_ctx* ctx, Combiner& cb, int first_set, Job* const* jobs, size_
       Job& job = *jobs[i];
       if (job.rc) continue;
       keys_for_job(job);
+      if (!job.rc && job.pr.queries.empty()) {
+        try {
+          check_relin_keys(sv, job);
+        } catch (const Err& e) {
+          fail_job(job, e.code, e.msg);
+        }
+      }
       if (job.rc || job.pr.queries.empty()) {
         unpin_job(sv, job);
         continue;
@@ -803,12 +870,14 @@ void serve(pirgpu_ctx* ctx, Combiner& cb, int first_set, Job* const* jobs, size_
         bool verified = true;
         run_single(sv, job, job.pr.queries[0], [&]() {   // the byte-for-byte key compare runs under the GPU work
           if (job.unverified) verified = pirgpu_keyset_verify(sv.ctx, job.slot, job.pr.galois_keys, job.pr.galois_keys_len) != 0;
+          if (verified) check_relin_keys(sv, job);       // ... and so does the RelinKeys validation (throws -> the job fails)
         });
         if (!verified) {
           // same fingerprint, different bytes: not this client's keys after all -- install them and run again
           job.out.clear();
           unpin_job(sv, job);
           resolve_keys(sv, job, false, nullptr);
+          check_relin_keys(sv, job);
           run_single(sv, job, job.pr.queries[0]);
         }
       } catch (const Err& e) {
@@ -854,8 +923,13 @@ void serve(pirgpu_ctx* ctx, Combiner& cb, int first_set, Job* const* jobs, size_
       Job& job = *jobs[ji];
       const uint32_t left = job.rc ? 0 : (uint32_t)job.pr.queries.size() - qi;
       if (!left) {
-        if (!job.rc && job.pr.queries.empty()) {   // no query: the keys are still deserialised (server.cpp:46-48)
+        if (!job.rc && job.pr.queries.empty()) {   // no query: the keys are still deserialised (server.cpp:46-58)
           keys_for_job(job);
+          try {
+            if (!job.rc) check_relin_keys(sv, job);
+          } catch (const Err& e) {
+            fail_job(job, e.code, e.msg);
+          }
           unpin_job(sv, job);
         }
         ++ji;
@@ -909,6 +983,7 @@ void serve(pirgpu_ctx* ctx, Combiner& cb, int first_set, Job* const* jobs, size_
     try {
       resolve_keys(sv, job, false, nullptr);      // verified lookup, or this client's own keys installed
       job.unverified = job.mismatch = false;
+      if (!job.relin_checked) check_relin_keys(sv, job);
       for (auto& qm : job.pr.queries) run_single(sv, job, qm);
     } catch (const Err& e) {
       fail_job(job, e.code, e.msg);

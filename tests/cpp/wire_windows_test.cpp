@@ -442,6 +442,7 @@ namespace {
 
 struct Client {
   std::string keys_blob;
+  std::string relin_blob;   // RelinKeys: validated by the server (server.cpp:53-58), otherwise unused in this mode
   uint64_t keysum = 0;
 };
 
@@ -481,6 +482,8 @@ Client make_client(uint32_t seed, bool seeded) {
     for (uint64_t w : keys[e]) c.keysum += w;
   }
   c.keys_blob = save_kswitch_keys(g_sh, entries, seeded ? &seed_ptrs : nullptr);
+  // RelinKeys = a KSwitchKeys object with one entry; every second client sends one (seeded like its Galois keys)
+  if (seed % 2 == 0) c.relin_blob = save_kswitch_keys(g_sh, {entries[0]}, seeded ? new std::vector<const uint8_t*>{seed_ptrs[0]} : nullptr);
   return c;
 }
 
@@ -499,6 +502,7 @@ std::string make_request(const Client& c, const std::vector<std::vector<uint64_t
     put_bytes_field(req, 1, cts);
   }
   put_bytes_field(req, 2, c.keys_blob);
+  if (!c.relin_blob.empty()) put_bytes_field(req, 3, c.relin_blob);
   return req;
 }
 
@@ -649,6 +653,19 @@ int main() {
     pirgpu_free(resps[0]);
     pirgpu_free(resps[3]);
     no_pins_left(&ctx);
+    {   // a malformed RelinKeys object fails ITS request with InvalidArgument -- in a window and alone -- nobody else's
+      Client bad = clients[2];
+      bad.relin_blob = clients[0].relin_blob.substr(0, clients[0].relin_blob.size() - 11);
+      CHECK(!clients[0].relin_blob.empty());
+      many_requests(&ctx, {&clients[0], &bad, &clients[3]}, {{make_query(21)}, {make_query(22)}, {make_query(23)}},
+                    {0, PIRGPU_INVALID_ARGUMENT, 0});
+      const std::string req = make_request(bad, {make_query(24)});
+      uint8_t* resp = nullptr;
+      size_t len = 0;
+      CHECK(pirgpu_process_request(&ctx, (const uint8_t*)req.data(), req.size(), &resp, &len) == PIRGPU_INVALID_ARGUMENT);
+      one_request(&ctx, clients[2], {make_query(25)});
+      no_pins_left(&ctx);
+    }
     ctx.fail_next_run = true;   // the whole window fails with the backend's status, nothing is left pinned or in flight
     many_requests(&ctx, {&clients[0], &clients[3]}, {{make_query(7)}, {make_query(8)}}, {PIRGPU_INTERNAL, PIRGPU_INTERNAL});
     no_pins_left(&ctx);

@@ -283,3 +283,57 @@ def test_more_queries_than_one_batch_chunk():
         assert st == 0
         assert cl.ProcessResponse(w, resp) == [raw[i].tobytes() for i in w]
     assert server.ProcessRequest(requests[1]) == out[1][1]
+
+
+def test_stale_key_set_handles_are_refused_not_reused():
+    """slots handed out by the direct API are HANDLES (slot index + generation).  A set that a staged
+    batch or the single-query selection still names is not evicted; once a set HAS been evicted, its old handle fails
+    with FailedPrecondition everywhere instead of silently switching a query with the new tenant's keys."""
+    s = PirSetup(3000, 288, 2, N=4096, plain_bits=24)
+    p = s.params
+    db, srv = _server(s)
+    srv.set_keyset_capacity(2)
+    clients = [Client(s.orc, seed=4000 + i) for i in range(3)]
+    keys = [c.galois_keys() for c in clients]
+    a = srv.install_keyset(b"client-a", keys[0])
+    b = srv.install_keyset(b"client-b", keys[1])
+    queries = np.stack([clients[i].create_query_for(p, 100 + i) for i in range(2)])
+    srv.set_concurrency(8)
+    srv.stage_batch(queries)
+    srv.set_batch_keysets([a, b])
+    # both slots are named by the staged batch: a third client cannot push either of them out
+    with pytest.raises(pir_amd.PirGpuError) as e:
+        srv.install_keyset(b"client-c", keys[2])
+    assert e.value.code == pir_amd.StatusCode.FAILED_PRECONDITION
+    srv.run_batch()
+    got = srv.fetch_batch()
+    for i in range(2):
+        rc, exp = s.orc.process_query(s.db_ntt, p.dimensions, queries[i], keys[i])
+        assert rc == 0 and np.array_equal(got[i], exp)
+    srv.unstage_batch()                          # nothing staged refers to a or b any more
+    c = srv.install_keyset(b"client-c", keys[2])                 # evicts the least recently used set: client a's
+    assert srv.keyset_stats()["evictions"] == 1
+    assert (c & 0xFFF) == (a & 0xFFF) and c != a                 # same slot, next generation
+    for stale_use in (lambda: srv.use_keyset(a),
+                      lambda: (srv.stage_batch(queries), srv.set_batch_keysets([a, b])),
+                      lambda: srv.release_keyset(a)):
+        with pytest.raises(pir_amd.PirGpuError) as e:
+            stale_use()
+        assert e.value.code == pir_amd.StatusCode.FAILED_PRECONDITION and "stale" in e.value.message
+    # the live handles keep working: client c in the slot client a had, client b untouched
+    q2 = np.stack([clients[2].create_query_for(p, 777), clients[1].create_query_for(p, 778)])
+    srv.stage_batch(q2)
+    srv.set_batch_keysets([c, b])
+    srv.run_batch()
+    got = srv.fetch_batch()
+    for qi, ki in ((0, 2), (1, 1)):
+        rc, exp = s.orc.process_query(s.db_ntt, p.dimensions, q2[qi], keys[ki])
+        assert rc == 0 and np.array_equal(got[qi], exp)
+    # the single-query selection protects its set the same way
+    srv.unstage_batch()
+    srv.use_keyset(c)
+    srv.use_keyset(b)                                            # b is current, c is the least recently used
+    d2 = srv.install_keyset(b"client-a-again", keys[0])          # evicts c, never the selected b
+    assert (d2 & 0xFFF) == (c & 0xFFF)
+    assert np.array_equal(srv.process_query(q2[1]), got[1])
+    db.close()

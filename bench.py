@@ -403,6 +403,8 @@ def main():
                 emitted[0] = True
                 emit_line(note)
 
+    skip_wire = os.environ.get("PIRGPU_BENCH_SKIP_WIRE", "") == "1"     # A/B sweeps of the device path only
+
     def emit_line(note):
         ms_per_step = elapsed / args.steps * 1e3
         u64_bytes = pp.num_pt * k * N * 8          # B_q = num_pt * k * N * 8
@@ -502,7 +504,7 @@ def main():
                                         "reduce (reduce-scatter + mod q) of one step with a host wait after every phase; "
                                         "the timed steps run them pipelined (exchange of step s under the multiply of "
                                         "step s-1 and the expansion of step s+1, no host waits): ms_per_step"}
-        if world == 1 and not use_dist and args.config == 3:
+        if world == 1 and not use_dist and args.config == 3 and not skip_wire:
             # wire-level ProcessRequest (what benchmark.cpp:71-79 times): serialized pir.Request in host
             # memory -> serialized pir.Response, incl. parsing, H2D of keys + query, D2H, serialisation.  The requests
             # come from the product client library (pir_amd.PIRClient, CPU): real keys, a real query ciphertext.
@@ -561,7 +563,7 @@ def main():
                                                                    "(the reference client's default) for the seeded figures"}
             except Exception as e:   # measurement extra only
                 out["wire_process_request_ms"] = {"error": repr(e)}
-        if world == 1 and not use_dist and args.config == 3:
+        if world == 1 and not use_dist and args.config == 3 and not skip_wire:
             # several CLIENTS at once (the reference's keys are per request, server.cpp:46-48): `batch` clients with
             # different Galois keys, one query each, through the same batch pipeline -- every group of 8 holds 8
             # different clients' queries, each switched with its own client's resident key set

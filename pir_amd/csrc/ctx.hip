@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -80,8 +81,23 @@ struct Worker {
 // expansion kernels run over nodes x queries, ciphertext index = node * B + query), scanned in one
 // database pass, and finished per query on the workers' own streams.  Two lanes alternate so that the
 // bandwidth-bound scan of one group overlaps the compute-bound expansion of the next.
+// The first few levels of a group's expansion tree are a chain of small, latency-bound launches (8-128 tree ciphertexts:
+// three dependent launches per level, 5-7 us each on their own, ~20 us each while the other lane's big kernels own the
+// chip).  On the lane they cost 0.2-0.35 ms of a group's ~3 ms although they need almost no CU time.  Round 4: they run
+// AHEAD on the context's head stream, in small buffers of their own (a ring of two per lane), and the lane picks the
+// tree up at level `head_levels` behind an event: the chain is off the lanes' critical path, its few workgroups slip in
+// beside the lanes' kernels.
+struct HeadSlot {
+  uint64_t *res_a = nullptr, *res_b = nullptr, *dig = nullptr, *prod = nullptr;
+  hipEvent_t ev_ready = nullptr;    // head stream: the slot holds the tree of its group at level head_levels
+  hipEvent_t ev_free = nullptr;     // lane stream: the lane's first level has consumed it
+  bool in_use = false;              // ev_free has been recorded at least once
+};
+
 struct BatchLane {
   hipStream_t stream = nullptr;
+  HeadSlot head[2];
+  uint32_t head_next = 0;
   uint64_t *res_a = nullptr, *res_b = nullptr, *prod = nullptr, *dig = nullptr;
   uint8_t* selp = nullptr;
   hipEvent_t ev_scanned = nullptr;
@@ -243,6 +259,9 @@ struct pirgpu_ctx {
   bool staging_released = false;            // pirgpu_db_finalize(release): only the operand-layout copy is left
   std::vector<BatchLane> lanes;             // created on the first batch
   uint64_t groups_run = 0;
+  hipStream_t head_stream = nullptr;        // the narrow first levels of every group's expansion (HeadSlot)
+  uint32_t head_levels = 5;                 // levels 0 .. head_levels - 1 run there (option HEAD_LEVELS; 0: all on the lane)
+  hipEvent_t ev_head_tail = nullptr;        // the head stream's position (an upload into a batch set waits for it)
   hipStream_t copy_stream = nullptr;        // device-to-host downloads of finished groups (pirgpu_batch_set_host_replies):
                                             // a lane that downloaded its own replies sat idle for 8 MB of PCIe per group
   hipEvent_t ev_fork = nullptr;             // pirgpu_fork: the main stream's position
@@ -423,6 +442,7 @@ int64_t option(const pirgpu_ctx* c, const char* name, int64_t dflt, bool* presen
 void sync_batch_streams(pirgpu_ctx* c) {
   for (BatchLane& ln : c->lanes)
     if (ln.stream) HIP_TRY(hipStreamSynchronize(ln.stream));
+  if (c->head_stream) HIP_TRY(hipStreamSynchronize(c->head_stream));
   if (c->copy_stream) HIP_TRY(hipStreamSynchronize(c->copy_stream));   // reply downloads queued behind the lanes
   for (Worker& w : c->workers)
     if (w.stream) HIP_TRY(hipStreamSynchronize(w.stream));
@@ -536,6 +556,8 @@ void ensure_workspace(pirgpu_ctx* c) {
     c->want_sel_f64 = env_u32("PIRGPU_SEL_F64", 1) != 0;
     c->tree40 = env_u32("PIRGPU_TREE40", 1) != 0;
     c->fuse_mac_nodes = env_u32("PIRGPU_FUSE_MAC_NODES", 128);
+    //   PIRGPU_HEAD_LEVELS  expansion levels of a batch group that run ahead on the head stream (0: none)
+    c->head_levels = std::min<uint32_t>(env_u32("PIRGPU_HEAD_LEVELS", c->head_levels), 8);
     c->split_upper = env_u32("PIRGPU_SPLIT_UPPER", c->logN >= 14 ? 1 : 0) != 0 && c->mode != kNttInt;
     c->split_upper_words = (uint64_t)env_u32("PIRGPU_SPLIT_UPPER_MB", 3072) * (1ull << 20) / 8;
     c->pack40 = env_u32("PIRGPU_PACK40", 1) != 0;
@@ -669,9 +691,21 @@ const uint64_t* xpow_table(pirgpu_ctx* c, hipStream_t st, uint32_t shift) {
 // transform any more.  sel_f64: selectors written as exact doubles (a batch lane's own consumers only).
 // Levels: narrow ones digit -> products of all moduli -> combine; wide ones digit -> special-prime product -> data
 // products + combine in one kernel, the tree between two such levels in 5-byte polynomials (cur40).
+// A tree in the middle of its expansion: handed from the head stream's levels to the lane's (HeadSlot).
+struct TreeState {
+  uint64_t* cur = nullptr;   // buffer holding the current level's ciphertexts
+  bool cur40 = false;        // ... as 5-byte polynomials (between fused levels) instead of doubles
+};
+
+// Levels [j_begin, j_end) of the tree (j_end clamped to the tree's depth).  `from` (j_begin > 0): where the earlier levels
+// left the tree -- that buffer is only READ; the first level here writes res_a, later ones ping-pong res_a / res_b.
+// `to` (j_end < depth): receives the state after level j_end - 1 instead of the function running to the leaves.
+// after_first: called when the first level's launches are queued (the `from` buffer may be recycled behind them).
 uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* res_b, uint64_t* dig, uint64_t* prod,
                       uint32_t n, uint32_t B, const MfmaPtrs* sel_dst = nullptr, bool sel_f64 = false,
-                      const uint32_t* ksets = nullptr) {
+                      const uint32_t* ksets = nullptr, uint32_t j_begin = 0, uint32_t j_end = UINT32_MAX,
+                      const TreeState* from = nullptr, TreeState* to = nullptr,
+                      const std::function<void()>& after_first = nullptr) {
   const uint32_t N = c->N, k = c->k;
   if (n > N) throw Fail{PIRGPU_INVALID_ARGUMENT, "Cannot expand more items from a CT than poly modulus degree"};
   const uint32_t logm = hm::ceil_log2(n);
@@ -679,7 +713,20 @@ uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* 
   if (sel_f64 && !(fuse_last && c->last_level_ntt && n >= 2)) throw Fail{PIRGPU_INTERNAL, "double-form selectors need the NTT-domain last level"};
   uint64_t *cur = res_a, *nxt = res_b;
   bool cur40 = false;   // `cur` holds 5-byte polynomials (between fused levels) instead of doubles
-  for (uint32_t j = 0; j < logm; ++j) {
+  if (from) {
+    cur = from->cur;
+    cur40 = from->cur40;
+    nxt = res_a;
+  }
+  const uint32_t j_stop = std::min(j_end, logm);
+  for (uint32_t j = j_begin; j < j_stop; ++j) {
+    // (picking a tree up from another buffer: after its first level here the ping-pong is res_a <-> res_b)
+    auto level_done = [&]() {
+      if (from && j == j_begin) {
+        nxt = res_b;
+        if (after_first) after_first();
+      }
+    };
     const uint32_t g = (N >> j) + 1;
     const KeyPtrs key = keys_for(c, g, ksets, B);   // per query of the group: its own client's key
     const uint32_t nodes = (1u << j) * B;
@@ -704,6 +751,7 @@ uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* 
                                      out40));
       cur40 = out40;
       std::swap(cur, nxt);
+      level_done();
       continue;
     }
     if (cur40 && !last_ntt) throw Fail{PIRGPU_INTERNAL, "5-byte tree reached an unfused level"};
@@ -725,6 +773,11 @@ uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* 
     HIP_TRY(launch_ks_combine(st, c->dp, c->mode, N, k, cur, prod, galois_inverse(g, N), nodes, 1u << j, true, hi_limit,
                               c->pack40, nxt));
     std::swap(cur, nxt);
+    level_done();
+  }
+  if (to) {
+    to->cur = cur;
+    to->cur40 = cur40;
   }
   return cur;
 }
@@ -1084,6 +1137,16 @@ void pirgpu_destroy(pirgpu_ctx* c) {
     if (ln.ev_join) (void)hipEventDestroy(ln.ev_join);
     if (ln.stream) (void)hipStreamDestroy(ln.stream);
   }
+  if (c->head_stream) {
+    (void)hipStreamSynchronize(c->head_stream);
+    (void)hipStreamDestroy(c->head_stream);
+  }
+  if (c->ev_head_tail) (void)hipEventDestroy(c->ev_head_tail);
+  for (BatchLane& ln : c->lanes)
+    for (HeadSlot& hs : ln.head) {
+      if (hs.ev_ready) (void)hipEventDestroy(hs.ev_ready);
+      if (hs.ev_free) (void)hipEventDestroy(hs.ev_free);
+    }
   if (c->copy_stream) {
     (void)hipStreamSynchronize(c->copy_stream);
     (void)hipStreamDestroy(c->copy_stream);
@@ -1127,7 +1190,7 @@ static const struct { const char* name; bool early; } kOptions[] = {
     {"SCAN_MQ_SINGLE_LIMB", true}, {"SCAN_ROWS", true}, {"SCAN_BLOCK", true}, {"SCAN_NSPLIT", true},
     {"FUSE_LAST", true}, {"FUSE_MAC_COMBINE", true}, {"LAST_NTT", true}, {"SEL_F64", true}, {"TREE40", true},
     {"FUSE_MAC_NODES", true}, {"SPLIT_UPPER", true}, {"SPLIT_UPPER_MB", true}, {"PACK40", true},
-    {"SCAN_MFMA", true}, {"SCAN_MFMA_WIDE", true}, {"SCAN_MFMA_TOP4", true}, {"SCAN_MFMA_NQ", true}, {"SCAN_MFMA_SINGLE", true}, {"LANES", true},
+    {"SCAN_MFMA", true}, {"SCAN_MFMA_WIDE", true}, {"SCAN_MFMA_TOP4", true}, {"SCAN_MFMA_NQ", true}, {"SCAN_MFMA_SINGLE", true}, {"LANES", true}, {"HEAD_LEVELS", true},
 };
 
 int pirgpu_set_option(pirgpu_ctx* c, const char* name, int64_t value) {
@@ -1771,6 +1834,7 @@ int pirgpu_fork(pirgpu_ctx* c) {
     HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
     for (BatchLane& ln : c->lanes)
       if (ln.stream) HIP_TRY(hipStreamWaitEvent(ln.stream, c->ev_fork, 0));
+    if (c->head_stream) HIP_TRY(hipStreamWaitEvent(c->head_stream, c->ev_fork, 0));
     for (Worker& w : c->workers)
       if (w.stream && w.stream != c->stream) HIP_TRY(hipStreamWaitEvent(w.stream, c->ev_fork, 0));
     return PIRGPU_OK;
@@ -1963,6 +2027,8 @@ static int batch_stage_impl(pirgpu_ctx* c, const uint64_t* queries, uint32_t nq,
     ensure_batch_capacity(c, count);
     BatchSet& b = c->bs();
     const size_t qwords = (size_t)nq * c->ctw;
+    // head-stream work queued earlier may still import queries of this set's previous batch: uploads go behind it
+    if (c->ev_head_tail) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_head_tail, 0));
     if (async) {
       // pieces of kStagePiece queries, one event each: the first group starts as soon as ITS queries are on the device
       const uint32_t pieces = (count + kStagePiece - 1) / kStagePiece;
@@ -2081,26 +2147,66 @@ static void ensure_lanes(pirgpu_ctx* c, bool with_expansion_buffers) {
 
 // Batched oblivious expansion of the staged queries first .. first+B-1 on lane `ln`, B queries interleaved
 // (ciphertext index = node * B + query), into the members' own selection vectors (NTT form).
+static void ensure_head_slot(pirgpu_ctx* c, HeadSlot& hs) {
+  if (hs.res_a) return;
+  const uint32_t N = c->N, k = c->k;
+  const uint64_t cts = ((uint64_t)1 << c->head_levels) * kMaxMfmaQueries;   // tree ciphertexts after the last head level
+  hs.res_a = c->dalloc<uint64_t>(cts * c->ctw);
+  hs.res_b = c->dalloc<uint64_t>(cts * c->ctw);
+  hs.prod = c->dalloc<uint64_t>(std::max<uint64_t>(cts / 2, 1) * 2 * (k + 1) * N);
+  hs.dig = c->dalloc<uint64_t>(std::max<uint64_t>(cts / 2, 1) * (k + 1) * k * N);
+  HIP_TRY(hipEventCreateWithFlags(&hs.ev_ready, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&hs.ev_free, hipEventDisableTiming));
+  if (!c->head_stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&c->head_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_head_tail, hipEventDisableTiming));
+  }
+}
+
 static void expand_group_on_lane(pirgpu_ctx* c, BatchLane& ln, Worker* const* members, uint32_t B, uint32_t first,
                                  bool sel_f64 = false) {
   const uint32_t N = c->N, k = c->k;
   const uint32_t nq = c->dim_sum / N + 1;
   const size_t ctw = c->ctw, qwords = (size_t)nq * ctw;
   uint64_t remaining = c->dim_sum, produced = 0;
-  wait_staged(c, ln.stream, first, B);
+  // the narrow first levels on the head stream (HeadSlot): one query ciphertext per query (the usual case), a real group,
+  // and at least two levels left for the lane
+  const bool use_head = nq == 1 && B > 1 && c->head_levels > 0 &&
+                        hm::ceil_log2((uint32_t)std::min<uint64_t>(c->dim_sum, N)) >= c->head_levels + 2;
+  if (!use_head) wait_staged(c, ln.stream, first, B);
   for (uint32_t qc = 0; qc < nq && remaining; ++qc) {
     const uint32_t slots = (uint32_t)std::min<uint64_t>(remaining, N);
-    // the B query ciphertexts, gathered side by side out of the staged batch, become the roots of the B interleaved
-    // trees (one strided import launch: no separate 2-D copy)
-    HIP_TRY(launch_tree_convert(ln.stream, c->dp, c->mode, c->bs().d_bquery + (size_t)first * qwords + (size_t)qc * ctw, ln.res_a,
-                                (uint64_t)B * ctw, true, ctw, qwords));
     MfmaPtrs dst{};
     uint32_t ksets[kMaxMfmaQueries];   // every query of the group is switched with its own client's keys
     for (uint32_t q = 0; q < B; ++q) {
       dst.p[q] = members[q]->sv_ntt + produced * ctw;
       ksets[q] = first + q < c->bs().batch_keysets.size() ? c->bs().batch_keysets[first + q] : 0;
     }
-    uint64_t* res = expand_core(c, ln.stream, ln.res_a, ln.res_b, ln.dig, ln.prod, slots, B, &dst, sel_f64, ksets);
+    const uint64_t* roots = c->bs().d_bquery + (size_t)first * qwords + (size_t)qc * ctw;
+    uint64_t* res;
+    if (use_head) {
+      HeadSlot& hs = ln.head[ln.head_next++ & 1];
+      ensure_head_slot(c, hs);
+      hipStream_t hst = c->head_stream;
+      if (hs.in_use) HIP_TRY(hipStreamWaitEvent(hst, hs.ev_free, 0));   // the lane is done with the slot's previous tree
+      wait_staged(c, hst, first, B);
+      HIP_TRY(launch_tree_convert(hst, c->dp, c->mode, roots, hs.res_a, (uint64_t)B * ctw, true, ctw, qwords));
+      TreeState at;
+      (void)expand_core(c, hst, hs.res_a, hs.res_b, hs.dig, hs.prod, slots, B, &dst, sel_f64, ksets, 0, c->head_levels, nullptr, &at);
+      HIP_TRY(hipEventRecord(hs.ev_ready, hst));
+      HIP_TRY(hipEventRecord(c->ev_head_tail, hst));
+      HIP_TRY(hipStreamWaitEvent(ln.stream, hs.ev_ready, 0));
+      res = expand_core(c, ln.stream, ln.res_a, ln.res_b, ln.dig, ln.prod, slots, B, &dst, sel_f64, ksets, c->head_levels,
+                        UINT32_MAX, &at, nullptr, [&]() {
+                          HIP_TRY(hipEventRecord(hs.ev_free, ln.stream));
+                          hs.in_use = true;
+                        });
+    } else {
+      // the B query ciphertexts, gathered side by side out of the staged batch, become the roots of the B interleaved
+      // trees (one strided import launch: no separate 2-D copy)
+      HIP_TRY(launch_tree_convert(ln.stream, c->dp, c->mode, roots, ln.res_a, (uint64_t)B * ctw, true, ctw, qwords));
+      res = expand_core(c, ln.stream, ln.res_a, ln.res_b, ln.dig, ln.prod, slots, B, &dst, sel_f64, ksets);
+    }
     if (res) HIP_TRY(c->ops->ct_ntt_fwd_split(ln.stream, c->mode, c->dp, k, res, dst, B, (uint64_t)slots * B));
     produced += slots;
     remaining -= slots;

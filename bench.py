@@ -615,7 +615,7 @@ def main():
             # staging of one window and the download / serialisation of another run beside the GPU's work on a third);
             # `single_caller` = one thread, one call after the other (every call fills and drains the pipeline alone).
             try:
-                srv.unstage_batch()       # the device-resident leg's staged batch no longer holds on to its 64 key sets
+                srv.unstage_batch()       # (the device-resident leg's staged batch is not run again)
                 n_w = int(os.environ.get("PIRGPU_BENCH_WIRE_CLIENTS", "64"))
                 callers = max(1, int(os.environ.get("PIRGPU_BENCH_WIRE_CALLERS", "2")))
                 srv.set_keyset_capacity(int(os.environ.get("PIRGPU_BENCH_WIRE_CAPACITY", str(max(64, 2 * n_w)))))

@@ -145,9 +145,10 @@ int pirgpu_clear_galois_keys(pirgpu_ctx* ctx);
  *   keyset_stats    [0] resident sets, [1] keys uploaded so far, [2] evictions, [3] capacity.
  * A `slot` is a HANDLE: slot index + the generation of the set living there (0 = the default set).  Once a set has been
  * evicted or released, every entry point that is given its old handle fails with FailedPrecondition ("stale key set
- * handle") instead of switching a query with whichever client's keys moved in -- claim it again.  keyset_claim never
- * evicts a set that requests in flight are using, nor one that a staged batch (batch_set_keysets) or query_use_keyset
- * still names: re-stage, pirgpu_batch_unstage or select another set first (FailedPrecondition when nothing is left). */
+ * handle") instead of switching a query with whichever client's keys moved in -- claim it again.  The same holds for
+ * handles the context REMEMBERS: a staged batch (batch_set_keysets) or the query_use_keyset selection whose set has been
+ * evicted since fails its next run / expansion with FailedPrecondition.  keyset_claim never evicts a set that requests
+ * in flight are pinned to (the wire layer's windows). */
 int pirgpu_set_keyset_capacity(pirgpu_ctx* ctx, uint32_t capacity);
 int pirgpu_keyset_lookup(pirgpu_ctx* ctx, const uint8_t* id, size_t id_len, int verify, uint32_t* slot);
 int pirgpu_keyset_verify(pirgpu_ctx* ctx, uint32_t slot, const uint8_t* id, size_t id_len);
@@ -172,6 +173,9 @@ uint32_t pirgpu_expansion_ratio(const pirgpu_ctx* ctx);
  * stage = H2D of the query, run = every kernel of the path (asynchronous on the
  * context's stream), fetch = D2H of the reply, sync = wait for the stream. */
 int pirgpu_query_stage(pirgpu_ctx* ctx, const uint64_t* query, uint32_t nq);
+/* query_stage without the wait: the upload is queued on the context's stream in front of query_run's kernels;
+ * `pinned_query` (pirgpu_host_query_buffer or other pinned memory) must stay untouched until query_fetch returns. */
+int pirgpu_query_stage_async(pirgpu_ctx* ctx, const uint64_t* pinned_query, uint32_t nq);
 int pirgpu_query_run(pirgpu_ctx* ctx);
 int pirgpu_query_fetch(pirgpu_ctx* ctx, uint64_t* reply, uint64_t reply_capacity, uint64_t* reply_count);
 int pirgpu_sync(pirgpu_ctx* ctx);

@@ -108,6 +108,7 @@ SIGNATURES = {
     "pirgpu_reply_ct_count": (C.c_uint64, [C.c_void_p]),
     "pirgpu_expansion_ratio": (C.c_uint32, [C.c_void_p]),
     "pirgpu_query_stage": (C.c_int, [C.c_void_p, u64p, C.c_uint32]),
+    "pirgpu_query_stage_async": (C.c_int, [C.c_void_p, u64p, C.c_uint32]),
     "pirgpu_query_run": (C.c_int, [C.c_void_p]),
     "pirgpu_query_fetch": (C.c_int, [C.c_void_p, u64p, C.c_uint64, u64p]),
     "pirgpu_sync": (C.c_int, [C.c_void_p]),

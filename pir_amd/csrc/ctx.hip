@@ -157,7 +157,8 @@ struct BatchSet {
   uint32_t batch_cap = 0, batch_count = 0;   // batch_count: replies the reply buffer holds
   uint32_t staged_count = 0;   // queries pirgpu_batch_stage left in d_bquery (0 again when the buffers are reallocated)
   bool batch_valid = false;
-  std::vector<uint32_t> batch_keysets;      // key set INDEX per staged query (all 0 unless pirgpu_batch_set_keysets)
+  std::vector<uint32_t> batch_keysets;      // key set INDEX per staged query (all 0 unless pirgpu_batch_set_keysets) ...
+  std::vector<uint32_t> batch_keyset_gens;  // ... and the generation it had then: checked again when the batch is run
   // pirgpu_batch_stage_async: the queries arrive in pieces of kStagePiece queries on the main stream, one event each;
   // a group waits for the pieces that hold its queries instead of the whole upload
   std::vector<hipEvent_t> st_events;
@@ -202,7 +203,8 @@ struct pirgpu_ctx {
   uint64_t n_loaded = 0;
   std::vector<KeySet> keysets{1};           // resident key sets; [0] = pirgpu_set_galois_key's
   uint32_t keyset_cap = 64;                 // client slots (pirgpu_set_keyset_capacity); 4.7 MB each at N = 4096, k = 2
-  uint32_t cur_keyset = 0;                  // slot the single-query entry points use (pirgpu_query_use_keyset)
+  uint32_t cur_keyset = 0;                  // slot the single-query entry points use (pirgpu_query_use_keyset) ...
+  uint32_t cur_keyset_gen = 0;              // ... and its generation at that time
   uint64_t keyset_clock = 0, key_uploads = 0, keyset_evictions = 0;
   std::vector<uint64_t*> key_pool;          // device key buffers of emptied sets, reused by the next upload (no hipMalloc)
   uint64_t* d_key_stage = nullptr;          // one key in SEAL order on its way to device order (allocated once)
@@ -261,6 +263,7 @@ struct pirgpu_ctx {
   uint64_t groups_run = 0;
   hipStream_t head_stream = nullptr;        // the narrow first levels of every group's expansion (HeadSlot)
   uint32_t head_levels = 5;                 // levels 0 .. head_levels - 1 run there (option HEAD_LEVELS; 0: all on the lane)
+  uint32_t head_mode = 1;                   // option HEAD_MODE: 0 never, 1 batches staged with pirgpu_batch_stage_async, 2 always
   hipEvent_t ev_head_tail = nullptr;        // the head stream's position (an upload into a batch set waits for it)
   hipStream_t copy_stream = nullptr;        // device-to-host downloads of finished groups (pirgpu_batch_set_host_replies):
                                             // a lane that downloaded its own replies sat idle for 8 MB of PCIe per group
@@ -558,6 +561,7 @@ void ensure_workspace(pirgpu_ctx* c) {
     c->fuse_mac_nodes = env_u32("PIRGPU_FUSE_MAC_NODES", 128);
     //   PIRGPU_HEAD_LEVELS  expansion levels of a batch group that run ahead on the head stream (0: none)
     c->head_levels = std::min<uint32_t>(env_u32("PIRGPU_HEAD_LEVELS", c->head_levels), 8);
+    c->head_mode = std::min<uint32_t>(env_u32("PIRGPU_HEAD_MODE", c->head_mode), 2);
     c->split_upper = env_u32("PIRGPU_SPLIT_UPPER", c->logN >= 14 ? 1 : 0) != 0 && c->mode != kNttInt;
     c->split_upper_words = (uint64_t)env_u32("PIRGPU_SPLIT_UPPER_MB", 3072) * (1ull << 20) / 8;
     c->pack40 = env_u32("PIRGPU_PACK40", 1) != 0;
@@ -628,6 +632,25 @@ uint32_t galois_inverse(uint32_t g, uint32_t N) {
   return (uint32_t)r;
 }
 
+// The key sets a staged batch / the single-query selection name must still be the ones that were named: a set that was
+// evicted or released since (its generation moved on) fails the run with FailedPrecondition instead of switching the
+// query with the next tenant's keys.
+uint32_t current_keyset(pirgpu_ctx* c) {
+  const uint32_t i = c->cur_keyset;
+  if (i >= c->keysets.size() || (i && c->keysets[i].gen != c->cur_keyset_gen))
+    throw Fail{PIRGPU_FAILED_PRECONDITION, "stale key set handle: the selected set was evicted or released (claim it again)"};
+  return i;
+}
+void check_staged_keysets(pirgpu_ctx* c) {
+  BatchSet& b = c->bs();
+  for (size_t q = 0; q < b.batch_keysets.size(); ++q) {
+    const uint32_t i = b.batch_keysets[q];
+    if (i >= c->keysets.size() || (i && q < b.batch_keyset_gens.size() && c->keysets[i].gen != b.batch_keyset_gens[q]))
+      throw Fail{PIRGPU_FAILED_PRECONDITION,
+                 "stale key set handle: a key set of the staged batch was evicted or released (pirgpu_batch_set_keysets again)"};
+  }
+}
+
 const uint64_t* find_key(pirgpu_ctx* c, uint32_t slot, uint32_t g) {
   if (slot >= c->keysets.size()) throw Fail{PIRGPU_INVALID_ARGUMENT, "key set slot out of range"};
   auto& keys = c->keysets[slot].keys;
@@ -643,7 +666,7 @@ KeyPtrs keys_for(pirgpu_ctx* c, uint32_t g, const uint32_t* ksets, uint32_t B) {
   KeyPtrs kp{};
   bool same = true;
   for (uint32_t q = 0; q < B; ++q) {
-    kp.p[q] = find_key(c, ksets ? ksets[q] : c->cur_keyset, g);
+    kp.p[q] = find_key(c, ksets ? ksets[q] : current_keyset(c), g);
     same = same && kp.p[q] == kp.p[0];
   }
   kp.B = same ? 1 : B;
@@ -985,7 +1008,7 @@ void run_staged(pirgpu_ctx* c, Worker& w, bool profile) {
     throw Fail{PIRGPU_INVALID_ARGUMENT,
                "Number of ciphertexts doesn't match number of items for oblivious expansion."};
   c->prof_cur = -1;
-  w.keyset = c->cur_keyset;
+  w.keyset = current_keyset(c);
   // a batch group that borrowed this worker's selection vector (its multiply runs on a lane stream) must be done
   HIP_TRY(hipStreamWaitEvent(w.stream, w.ev_done, 0));
   if (profile) begin_profiled_run(c);
@@ -1190,7 +1213,7 @@ static const struct { const char* name; bool early; } kOptions[] = {
     {"SCAN_MQ_SINGLE_LIMB", true}, {"SCAN_ROWS", true}, {"SCAN_BLOCK", true}, {"SCAN_NSPLIT", true},
     {"FUSE_LAST", true}, {"FUSE_MAC_COMBINE", true}, {"LAST_NTT", true}, {"SEL_F64", true}, {"TREE40", true},
     {"FUSE_MAC_NODES", true}, {"SPLIT_UPPER", true}, {"SPLIT_UPPER_MB", true}, {"PACK40", true},
-    {"SCAN_MFMA", true}, {"SCAN_MFMA_WIDE", true}, {"SCAN_MFMA_TOP4", true}, {"SCAN_MFMA_NQ", true}, {"SCAN_MFMA_SINGLE", true}, {"LANES", true}, {"HEAD_LEVELS", true},
+    {"SCAN_MFMA", true}, {"SCAN_MFMA_WIDE", true}, {"SCAN_MFMA_TOP4", true}, {"SCAN_MFMA_NQ", true}, {"SCAN_MFMA_SINGLE", true}, {"LANES", true}, {"HEAD_LEVELS", true}, {"HEAD_MODE", true},
 };
 
 int pirgpu_set_option(pirgpu_ctx* c, const char* name, int64_t value) {
@@ -1507,11 +1530,7 @@ int pirgpu_set_keyset_capacity(pirgpu_ctx* c, uint32_t slots) {
       clear_keyset(c, (uint32_t)c->keysets.size() - 1);
       c->keysets.pop_back();
     }
-    for (BatchSet& b : c->sets)                        // staged queries that named a dropped slot fall back to set 0
-      for (uint32_t& ix : b.batch_keysets)
-        if (ix >= c->keysets.size()) ix = 0;
-    if (c->cur_keyset >= c->keysets.size()) c->cur_keyset = 0;
-    c->keyset_cap = slots;
+    c->keyset_cap = slots;   // (a staged batch / selection that named a dropped slot fails its next run: stale handle)
     return PIRGPU_OK;
   });
 }
@@ -1553,14 +1572,6 @@ size_t pirgpu_keyset_blob(pirgpu_ctx* c, uint32_t slot, const uint8_t** blob) {
   return c->keysets[index].blob.size();
 }
 
-// A set some staged batch or the single-query selection still names must not change tenant under it.
-static bool slot_referenced(const pirgpu_ctx* c, uint32_t index) {
-  if (c->cur_keyset == index) return true;
-  for (const BatchSet& b : c->sets)
-    if (b.staged_count && std::find(b.batch_keysets.begin(), b.batch_keysets.end(), index) != b.batch_keysets.end()) return true;
-  return false;
-}
-
 int pirgpu_keyset_claim(pirgpu_ctx* c, const uint8_t* blob, size_t len, uint32_t* slot) {
   return guarded(c, [&]() -> int {
     if (!slot || (!blob && len)) return fail(c, PIRGPU_INVALID_ARGUMENT, "null buffer");
@@ -1571,11 +1582,11 @@ int pirgpu_keyset_claim(pirgpu_ctx* c, const uint8_t* blob, size_t len, uint32_t
       c->keysets.emplace_back();
       pick = (uint32_t)c->keysets.size() - 1;
     }
-    if (!pick) {   // least recently used -- never a set that requests in flight are pinned to, nor one that a staged
-                   // batch or the single-query selection still refers to (the direct API: ADVICE round 3)
+    if (!pick) {   // least recently used -- never a set that requests in flight are pinned to.  (A staged batch or the
+                   // single-query selection that still names the evicted set notices at its next run: its handle is stale.)
       uint64_t best = UINT64_MAX;
       for (uint32_t i = 1; i < c->keysets.size(); ++i)
-        if (c->keysets[i].last_use < best && !c->keysets[i].pins && !slot_referenced(c, i)) {
+        if (c->keysets[i].last_use < best && !c->keysets[i].pins) {
           best = c->keysets[i].last_use;
           pick = i;
         }
@@ -1602,10 +1613,6 @@ int pirgpu_keyset_release(pirgpu_ctx* c, uint32_t slot) {
     if (index == 0) return fail(c, PIRGPU_INVALID_ARGUMENT, "key set slot out of range");
     if (c->keysets[index].pins) return fail(c, PIRGPU_FAILED_PRECONDITION, "the key set is in use by requests in flight");
     clear_keyset(c, index);
-    for (BatchSet& b : c->sets)                        // nothing staged may keep pointing at the emptied slot
-      for (uint32_t& ix : b.batch_keysets)
-        if (ix == index) ix = 0;
-    if (c->cur_keyset == index) c->cur_keyset = 0;
     return PIRGPU_OK;
   });
 }
@@ -1643,6 +1650,7 @@ int pirgpu_query_use_keyset(pirgpu_ctx* c, uint32_t slot) {
   return guarded(c, [&]() -> int {
     const uint32_t index = resolve_slot(c, slot);
     c->cur_keyset = index;
+    c->cur_keyset_gen = c->keysets[index].gen;
     c->keysets[index].last_use = ++c->keyset_clock;
     return PIRGPU_OK;
   });
@@ -1654,8 +1662,13 @@ int pirgpu_batch_set_keysets(pirgpu_ctx* c, const uint32_t* slots, uint32_t coun
     std::vector<uint32_t> idx(count);
     for (uint32_t i = 0; i < count; ++i) idx[i] = resolve_slot(c, slots[i]);
     ++c->keyset_clock;
-    for (uint32_t i = 0; i < count; ++i) c->keysets[idx[i]].last_use = c->keyset_clock;
+    std::vector<uint32_t> gens(count);
+    for (uint32_t i = 0; i < count; ++i) {
+      c->keysets[idx[i]].last_use = c->keyset_clock;
+      gens[i] = c->keysets[idx[i]].gen;
+    }
     c->bs().batch_keysets = std::move(idx);
+    c->bs().batch_keyset_gens = std::move(gens);
     return PIRGPU_OK;
   });
 }
@@ -1713,7 +1726,7 @@ uint64_t* pirgpu_host_reply_buffer(pirgpu_ctx* c, uint32_t count) {
   return out;
 }
 
-int pirgpu_query_stage(pirgpu_ctx* c, const uint64_t* query, uint32_t nq) {
+static int query_stage_impl(pirgpu_ctx* c, const uint64_t* query, uint32_t nq, bool wait) {
   return guarded(c, [&]() -> int {
     ensure_workspace(c);
     Worker& w = c->workers[0];
@@ -1722,10 +1735,16 @@ int pirgpu_query_stage(pirgpu_ctx* c, const uint64_t* query, uint32_t nq) {
                   "Number of ciphertexts doesn't match number of items for oblivious expansion.");
     HIP_TRY(hipStreamWaitEvent(c->stream, w.ev_done, 0));
     HIP_TRY(hipMemcpyAsync(w.d_query, query, (size_t)nq * c->ctw * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (wait) HIP_TRY(hipStreamSynchronize(c->stream));   // the caller may reuse `query` at once
     w.staged_nq = nq;
     return PIRGPU_OK;
   });
+}
+
+int pirgpu_query_stage(pirgpu_ctx* c, const uint64_t* query, uint32_t nq) { return query_stage_impl(c, query, nq, true); }
+
+int pirgpu_query_stage_async(pirgpu_ctx* c, const uint64_t* pinned_query, uint32_t nq) {
+  return query_stage_impl(c, pinned_query, nq, false);
 }
 
 int pirgpu_query_run(pirgpu_ctx* c) {
@@ -1888,7 +1907,7 @@ int pirgpu_expand(pirgpu_ctx* c, const uint64_t* ct, uint32_t num_items, uint64_
     const uint64_t m_max = std::min<uint64_t>(c->N, hm::next_power_two(std::max<uint32_t>(c->dim_sum, 1)));
     if (hm::next_power_two(num_items) > m_max)
       return fail(c, PIRGPU_INVALID_ARGUMENT, "num_items exceeds this context's expansion workspace");
-    w.keyset = c->cur_keyset;
+    w.keyset = current_keyset(c);
     HIP_TRY(hipMemcpyAsync(w.res_b, ct, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(launch_tree_convert(c->stream, c->dp, c->mode, w.res_b, w.res_a, c->ctw, true));
     uint64_t* res = expand_on_device(c, w, num_items);
@@ -1911,7 +1930,7 @@ int pirgpu_expand_multi(pirgpu_ctx* c, const uint64_t* cts, uint32_t num_cts, ui
                   "Number of ciphertexts doesn't match number of items for oblivious expansion.");
     const uint64_t m_max = std::min<uint64_t>(c->N, hm::next_power_two(std::max<uint32_t>(c->dim_sum, 1)));
     uint64_t remaining = total_items, produced = 0;
-    w.keyset = c->cur_keyset;
+    w.keyset = current_keyset(c);
     for (uint32_t q = 0; q < num_cts && remaining; ++q) {
       uint32_t n = (uint32_t)std::min<uint64_t>(remaining, c->N);
       if (hm::next_power_two(n) > m_max)
@@ -1937,7 +1956,7 @@ int pirgpu_substitute_power_x(pirgpu_ctx* c, uint64_t* ct, uint32_t power) {
     if (!(power & 1) || power >= 2 * c->N)  // SEAL: "Galois element is not valid" -> InternalError
       return fail(c, PIRGPU_INTERNAL, "Galois element is not valid");
     KeyPtrs key{};
-    key.p[0] = find_key(c, c->cur_keyset, power);
+    key.p[0] = find_key(c, current_keyset(c), power);
     key.B = 1;
     HIP_TRY(hipMemcpyAsync(w.res_b, ct, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(launch_tree_convert(c->stream, c->dp, c->mode, w.res_b, w.res_a, c->ctw, true));
@@ -2052,6 +2071,7 @@ static int batch_stage_impl(pirgpu_ctx* c, const uint64_t* queries, uint32_t nq,
     b.batch_count = count;
     b.staged_count = count;
     b.batch_keysets.assign(count, 0);   // pirgpu_batch_set_keysets assigns other clients' key sets
+    b.batch_keyset_gens.assign(count, 0);
     b.batch_valid = false;
     return PIRGPU_OK;
   });
@@ -2070,6 +2090,7 @@ int pirgpu_batch_unstage(pirgpu_ctx* c) {
     BatchSet& b = c->bs();
     b.staged_count = 0;
     b.batch_keysets.clear();
+    b.batch_keyset_gens.clear();
     b.st_pieces = 0;
     return PIRGPU_OK;
   });
@@ -2171,7 +2192,10 @@ static void expand_group_on_lane(pirgpu_ctx* c, BatchLane& ln, Worker* const* me
   uint64_t remaining = c->dim_sum, produced = 0;
   // the narrow first levels on the head stream (HeadSlot): one query ciphertext per query (the usual case), a real group,
   // and at least two levels left for the lane
-  const bool use_head = nq == 1 && B > 1 && c->head_levels > 0 &&
+  // -- for batches that were staged asynchronously (request windows queued behind one another: +6 % through the wire,
+  // 12.0 against 12.9 ms per window of 64 with two callers) or always (head_mode 2); a back-to-back loop over one staged
+  // batch gains nothing from it (5 325-5 408 against 5 379-5 433 queries/s, same box) and keeps the plain path
+  const bool use_head = nq == 1 && B > 1 && c->head_levels > 0 && (c->head_mode == 2 || (c->head_mode == 1 && c->bs().st_pieces > 0)) &&
                         hm::ceil_log2((uint32_t)std::min<uint64_t>(c->dim_sum, N)) >= c->head_levels + 2;
   if (!use_head) wait_staged(c, ln.stream, first, B);
   for (uint32_t qc = 0; qc < nq && remaining; ++qc) {
@@ -2351,6 +2375,7 @@ static void batch_run_impl_body(pirgpu_ctx* c, uint32_t count, const uint64_t* e
     throw Fail{PIRGPU_FAILED_PRECONDITION, "database not fully loaded"};
   check_transparent(c);
   check_reply_target(c, count);
+  if (!ext_sv) check_staged_keysets(c);
   ensure_packed(c);
   c->prof_cur = -1;
   if (c->mfma_on) {
@@ -2442,6 +2467,7 @@ int pirgpu_batch_expand(pirgpu_ctx* c, uint32_t first, uint32_t count, uint64_t*
     const size_t qwords = (size_t)nq * c->ctw, svwords = (size_t)c->dim_sum * c->ctw;
     const uint32_t W = std::max<uint32_t>(1, std::min<uint32_t>(c->n_active, (uint32_t)c->workers.size()));
     c->prof_cur = -1;
+    check_staged_keysets(c);
     for (uint32_t i = 0; i < count; ++i) {
       Worker& w = c->workers[i % W];
       HIP_TRY(hipStreamWaitEvent(w.stream, w.ev_done, 0));   // a lane's group may still be reading its buffers
@@ -2500,6 +2526,7 @@ static int batch_expand_packed_impl(pirgpu_ctx* c, uint32_t first_query, uint32_
       return fail(c, PIRGPU_FAILED_PRECONDITION, "packed groups need min(count, 8) workers (pirgpu_set_concurrency)");
     ensure_lanes(c, true);
     c->prof_cur = -1;
+    check_staged_keysets(c);
     const size_t ctw = c->ctw;
     const uint32_t kN = c->k * c->N;
     const uint32_t first = first_query;

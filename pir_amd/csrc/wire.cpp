@@ -520,7 +520,7 @@ void run_single(const Server& sv, Job& job, const std::pair<const uint8_t*, size
   const uint32_t callers_slot = pirgpu_current_keyset(sv.ctx);   // the direct API's selection survives a request
   int rc = pirgpu_query_use_keyset(sv.ctx, job.slot);
   uint64_t got = 0;
-  if (!rc) rc = pirgpu_query_stage(sv.ctx, hq, nq);
+  if (!rc) rc = pirgpu_query_stage_async(sv.ctx, hq, nq);   // pinned staging, untouched until the fetch below returns
   if (!rc) rc = pirgpu_query_run(sv.ctx);      // asynchronous: every kernel of the path is queued
   const std::string msg = rc ? pirgpu_last_error(sv.ctx) : "";
   (void)pirgpu_query_use_keyset(sv.ctx, callers_slot);

@@ -414,6 +414,7 @@ int pirgpu_query_stage(pirgpu_ctx* c, const uint64_t* q, uint32_t nq) {
   c->w0_query.assign(q, q + kCtw);
   return 0;
 }
+int pirgpu_query_stage_async(pirgpu_ctx* c, const uint64_t* q, uint32_t nq) { return pirgpu_query_stage(c, q, nq); }
 int pirgpu_query_run(pirgpu_ctx* c) {
   std::lock_guard<std::recursive_mutex> lk(c->mu);
   c->w0_slot = c->cur;

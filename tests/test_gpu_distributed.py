@@ -266,3 +266,32 @@ def test_batch_replies_downloaded_group_by_group():
     assert np.array_equal(srv.fetch_batch(), plain)
     assert words == view.shape[2] * view.shape[3] * view.shape[4]
     db.close()
+
+
+def test_bench_eight_ranks_sharing_one_gpu():
+    """`bench.py --gpus 8` end to end at world size 8 on ONE GPU (PIRGPU_BENCH_SHARE_GPU=1: all ranks use device 0, the
+    collectives go over gloo): the launcher, eight row shards of 10 / 11 rows of an 81 x 81 matrix (uneven, n0 % 8 != 0),
+    one full group of 8 queries per rank, both forms of the row-sharded step timed and the faster one reported, the
+    replica and hybrid 2 x 4 reference legs.  Not a multi-GPU measurement (the line says so) -- a rehearsal of every
+    line of the driver's 8-GPU run except the RCCL calls themselves."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["PIRGPU_BENCH_SHARE_GPU"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--log-items", "18", "--steps", "2",
+                        "--warmup", "1", "--latency-runs", "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                       timeout=1200)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1                                   # exactly rank 0's line
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["rccl_ranks"] == 0 and "gloo" in j["backend"]
+    assert j["config"]["queries_per_step"] == 64 and j["config"]["queries_per_step_per_gpu"] == 8
+    assert j["value"] > 0 and j["scaling"] == "strong"
+    tune = j["exchange_autotune"]
+    assert set(tune["ms_per_step"]) == {"replicated", "packed"} and tune["chosen"] == j["config"]["exchange"]
+    assert j["replicas_reference"]["value"] > 0
+    assert j["hybrid_rows_reference"]["value"] > 0 and j["hybrid_rows_reference"]["row_shards_per_group"] == 4
+    assert "extras_aborted" not in j

@@ -286,9 +286,9 @@ def test_more_queries_than_one_batch_chunk():
 
 
 def test_stale_key_set_handles_are_refused_not_reused():
-    """slots handed out by the direct API are HANDLES (slot index + generation).  A set that a staged
-    batch or the single-query selection still names is not evicted; once a set HAS been evicted, its old handle fails
-    with FailedPrecondition everywhere instead of silently switching a query with the new tenant's keys."""
+    """slots handed out by the direct API are HANDLES (slot index + generation).  Once a set has been
+    evicted, its old handle fails with FailedPrecondition everywhere -- also where the context REMEMBERS it (a staged
+    batch, the single-query selection) -- instead of silently switching a query with the new tenant's keys."""
     s = PirSetup(3000, 288, 2, N=4096, plain_bits=24)
     p = s.params
     db, srv = _server(s)
@@ -301,19 +301,18 @@ def test_stale_key_set_handles_are_refused_not_reused():
     srv.set_concurrency(8)
     srv.stage_batch(queries)
     srv.set_batch_keysets([a, b])
-    # both slots are named by the staged batch: a third client cannot push either of them out
-    with pytest.raises(pir_amd.PirGpuError) as e:
-        srv.install_keyset(b"client-c", keys[2])
-    assert e.value.code == pir_amd.StatusCode.FAILED_PRECONDITION
     srv.run_batch()
     got = srv.fetch_batch()
     for i in range(2):
         rc, exp = s.orc.process_query(s.db_ntt, p.dimensions, queries[i], keys[i])
         assert rc == 0 and np.array_equal(got[i], exp)
-    srv.unstage_batch()                          # nothing staged refers to a or b any more
-    c = srv.install_keyset(b"client-c", keys[2])                 # evicts the least recently used set: client a's
+    # a third client pushes the least recently used set (client a's) out while the batch that names it is still staged
+    c = srv.install_keyset(b"client-c", keys[2])
     assert srv.keyset_stats()["evictions"] == 1
     assert (c & 0xFFF) == (a & 0xFFF) and c != a                 # same slot, next generation
+    with pytest.raises(pir_amd.PirGpuError) as e:                # the staged batch remembers a's handle: refused, not
+        srv.run_batch()                                          # run with client c's keys
+    assert e.value.code == pir_amd.StatusCode.FAILED_PRECONDITION and "stale" in e.value.message
     for stale_use in (lambda: srv.use_keyset(a),
                       lambda: (srv.stage_batch(queries), srv.set_batch_keysets([a, b])),
                       lambda: srv.release_keyset(a)):
@@ -329,11 +328,19 @@ def test_stale_key_set_handles_are_refused_not_reused():
     for qi, ki in ((0, 2), (1, 1)):
         rc, exp = s.orc.process_query(s.db_ntt, p.dimensions, q2[qi], keys[ki])
         assert rc == 0 and np.array_equal(got[qi], exp)
-    # the single-query selection protects its set the same way
-    srv.unstage_batch()
+    # the single-query selection is checked the same way
     srv.use_keyset(c)
-    srv.use_keyset(b)                                            # b is current, c is the least recently used
-    d2 = srv.install_keyset(b"client-a-again", keys[0])          # evicts c, never the selected b
+    srv.use_keyset(b)                                            # b selected; c is now the least recently used
+    d2 = srv.install_keyset(b"client-a-again", keys[0])          # evicts c
     assert (d2 & 0xFFF) == (c & 0xFFF)
-    assert np.array_equal(srv.process_query(q2[1]), got[1])
+    assert np.array_equal(srv.process_query(q2[1]), got[1])      # b: still there
+    srv.use_keyset(d2)
+    e2 = srv.install_keyset(b"client-c-again", keys[2])          # evicts b (d2 was used last)
+    assert (e2 & 0xFFF) == (b & 0xFFF)
+    e3 = srv.install_keyset(b"client-b-again", keys[1])          # evicts d2 -- the selected set
+    assert (e3 & 0xFFF) == (d2 & 0xFFF)
+    with pytest.raises(pir_amd.PirGpuError) as e:
+        srv.process_query(q2[1])
+    assert e.value.code == pir_amd.StatusCode.FAILED_PRECONDITION and "stale" in e.value.message
+    srv.use_keyset(0)
     db.close()

@@ -1,5 +1,6 @@
 // link stubs for the device-side entry points wire.cpp references (never called by the validation path)
 #include "../include/pirgpu.h"
+#include "../pir_amd/csrc/wire.h"
 extern "C" {
 int pirgpu_get_params(const pirgpu_ctx*, pirgpu_params*) { return 13; }
 uint64_t pirgpu_reply_ct_count(const pirgpu_ctx*) { return 0; }
@@ -25,6 +26,7 @@ int pirgpu_query_use_keyset(pirgpu_ctx*, uint32_t) { return 13; }
 uint32_t pirgpu_current_keyset(pirgpu_ctx*) { return 0; }
 int pirgpu_batch_set_keysets(pirgpu_ctx*, const uint32_t*, uint32_t) { return 13; }
 int pirgpu_query_stage(pirgpu_ctx*, const uint64_t*, uint32_t) { return 13; }
+int pirgpu_query_stage_async(pirgpu_ctx*, const uint64_t*, uint32_t) { return 13; }
 int pirgpu_query_run(pirgpu_ctx*) { return 13; }
 int pirgpu_query_fetch(pirgpu_ctx*, uint64_t*, uint64_t, uint64_t*) { return 13; }
 uint64_t* pirgpu_host_query_buffer(pirgpu_ctx*, uint32_t) { return nullptr; }

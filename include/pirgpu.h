@@ -155,6 +155,8 @@ int pirgpu_keyset_verify(pirgpu_ctx* ctx, uint32_t slot, const uint8_t* id, size
 int pirgpu_keyset_claim(pirgpu_ctx* ctx, const uint8_t* id, size_t id_len, uint32_t* slot);
 int pirgpu_keyset_release(pirgpu_ctx* ctx, uint32_t slot);
 int pirgpu_keyset_set_key(pirgpu_ctx* ctx, uint32_t slot, uint32_t galois_elt, const uint64_t* key);
+/* n keys of one set in one call (one wait for all uploads instead of one per key). */
+int pirgpu_keyset_set_keys(pirgpu_ctx* ctx, uint32_t slot, uint32_t n, const uint32_t* galois_elts, const uint64_t* const* keys);
 int pirgpu_query_use_keyset(pirgpu_ctx* ctx, uint32_t slot);
 int pirgpu_batch_set_keysets(pirgpu_ctx* ctx, const uint32_t* slots, uint32_t count);
 int pirgpu_keyset_stats(pirgpu_ctx* ctx, uint64_t stats[4]);

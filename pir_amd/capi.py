@@ -93,6 +93,7 @@ SIGNATURES = {
     "pirgpu_keyset_claim": (C.c_int, [C.c_void_p, u8p, C.c_size_t, C.POINTER(C.c_uint32)]),
     "pirgpu_keyset_release": (C.c_int, [C.c_void_p, C.c_uint32]),
     "pirgpu_keyset_set_key": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, u64p]),
+    "pirgpu_keyset_set_keys": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_void_p)]),
     "pirgpu_query_use_keyset": (C.c_int, [C.c_void_p, C.c_uint32]),
     "pirgpu_batch_set_keysets": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]),
     "pirgpu_batch_stage_async": (C.c_int, [C.c_void_p, u64p, C.c_uint32, C.c_uint32]),

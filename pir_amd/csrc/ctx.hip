@@ -1435,7 +1435,7 @@ int pirgpu_db_read_plaintext(pirgpu_ctx* c, uint64_t pt_index, uint64_t* out) {
 // Uploads one Galois key into a key set slot (SEAL's NTT order at the boundary, device order in HBM).  A new client's
 // first request pays for 12 of these (N = 4096): the staging buffer is allocated once per context and the key buffers
 // of emptied sets are recycled, so the steady state of a server whose clients come and go allocates nothing.
-static void upload_key(pirgpu_ctx* c, uint32_t slot, uint32_t g, const uint64_t* key) {
+static void upload_key(pirgpu_ctx* c, uint32_t slot, uint32_t g, const uint64_t* key, bool wait = true) {
   if (slot >= c->keysets.size()) throw Fail{PIRGPU_INVALID_ARGUMENT, "key set slot out of range"};
   if (!key || !(g & 1) || g >= 2 * c->N) throw Fail{PIRGPU_INVALID_ARGUMENT, "invalid Galois element"};
   const size_t words = (size_t)c->k * 2 * (c->k + 1) * c->N;
@@ -1462,7 +1462,8 @@ static void upload_key(pirgpu_ctx* c, uint32_t slot, uint32_t g, const uint64_t*
   HIP_TRY(hipMemcpyAsync(c->d_key_stage, key, words * 8, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(launch_ntt_reorder(c->stream, c->N, c->d_key_stage, dev, (uint64_t)c->k * 2 * (c->k + 1), true,
                              c->mode != kNttInt));
-  HIP_TRY(hipStreamSynchronize(c->stream));   // the lanes / workers that will read the key do not follow this stream
+  // the lanes / workers that will read the key do not follow this stream: the caller (or this call) waits once
+  if (wait) HIP_TRY(hipStreamSynchronize(c->stream));
   ++c->key_uploads;
 }
 
@@ -1620,6 +1621,18 @@ int pirgpu_keyset_release(pirgpu_ctx* c, uint32_t slot) {
 int pirgpu_keyset_set_key(pirgpu_ctx* c, uint32_t slot, uint32_t g, const uint64_t* key) {
   return guarded(c, [&]() -> int {
     upload_key(c, resolve_slot(c, slot), g, key);
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_keyset_set_keys(pirgpu_ctx* c, uint32_t slot, uint32_t n, const uint32_t* galois_elts, const uint64_t* const* keys) {
+  return guarded(c, [&]() -> int {
+    if (n && (!galois_elts || !keys)) return fail(c, PIRGPU_INVALID_ARGUMENT, "null buffer");
+    const uint32_t index = resolve_slot(c, slot);
+    // one wait for the whole set (a new client's 12 keys: 12 stream synchronisations used to be a quarter of its
+    // first request); the staging buffer's reuse from key to key is covered by stream order
+    for (uint32_t i = 0; i < n; ++i) upload_key(c, index, galois_elts[i], keys[i], false);
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return PIRGPU_OK;
   });
 }

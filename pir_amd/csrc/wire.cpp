@@ -477,8 +477,14 @@ void resolve_keys(const Server& sv, Job& job, bool speculative, bool* unverified
                              parsed);
   rc = pirgpu_keyset_claim(sv.ctx, job.pr.galois_keys, job.pr.galois_keys_len, &slot);
   if (rc) throw Err{rc, pirgpu_last_error(sv.ctx)};
-  for (auto& kv : parsed) {
-    rc = pirgpu_keyset_set_key(sv.ctx, slot, (uint32_t)(2 * kv.first + 1), kv.second.data());
+  {
+    std::vector<uint32_t> elts;
+    std::vector<const uint64_t*> ptrs;
+    for (auto& kv : parsed) {
+      elts.push_back((uint32_t)(2 * kv.first + 1));
+      ptrs.push_back(kv.second.data());
+    }
+    rc = pirgpu_keyset_set_keys(sv.ctx, slot, (uint32_t)elts.size(), elts.data(), ptrs.data());   // one wait for the set
     if (rc) {
       const std::string msg = pirgpu_last_error(sv.ctx);
       (void)pirgpu_keyset_release(sv.ctx, slot);

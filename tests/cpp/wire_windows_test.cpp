@@ -260,6 +260,13 @@ int pirgpu_keyset_set_key(pirgpu_ctx* c, uint32_t slot, uint32_t, const uint64_t
   ++c->uploads;
   return 0;
 }
+int pirgpu_keyset_set_keys(pirgpu_ctx* c, uint32_t slot, uint32_t n, const uint32_t* elts, const uint64_t* const* keys) {
+  for (uint32_t i = 0; i < n; ++i) {
+    const int rc = pirgpu_keyset_set_key(c, slot, elts[i], keys[i]);
+    if (rc) return rc;
+  }
+  return 0;
+}
 int pirgpu_keyset_pin(pirgpu_ctx* c, uint32_t slot) {
   std::lock_guard<std::recursive_mutex> lk(c->mu);
   uint32_t i;

@@ -116,3 +116,30 @@ def test_bench_output_stage_does_not_shadow_the_measurement_state():
     emit_line = next(n for n in ast.walk(main) if isinstance(n, ast.FunctionDef) and n.name == "emit_line")
     shadowed = targets(emit_line, skip_nested=False) & targets(main, skip_nested=True)
     assert shadowed <= {"t0", "_"}, shadowed      # t0: a timer both use locally; _: loop dummies -- never read across
+
+
+def test_bench_traffic_staleness_and_timed_blocks(tmp_path, monkeypatch):
+    """roofline.traffic is a RECORDED figure -- bench.py says whether the scan kernel's source is
+    still the one the PMC passes profiled (`traffic_stale`), and a timed block shorter than a second is repeated and the
+    median block reported."""
+    import hashlib
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    traffic, src, stale = bench.recorded_traffic(3, 20, 1, True)
+    newest = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_scan_traffic.json"))[-1]
+    pm = json.load(open(os.path.join(ROOT, "profiles", newest)))
+    assert traffic == pm["configs"]["cfg3"]["traffic_bytes_per_launch"] and newest in src
+    have = hashlib.sha256(open(os.path.join(ROOT, "pir_amd", "csrc", "scan_mfma.hip"), "rb").read()).hexdigest()[:16]
+    assert stale == (pm["scan_source_sha16"] != have)          # committed state: False; a changed kernel: True
+    monkeypatch.setattr(bench, "scan_source_sha16", lambda: "0" * 16)
+    assert bench.recorded_traffic(3, 20, 1, True)[2] is True
+    assert bench.recorded_traffic(3, 19, 1, True) == (None, None, None)        # another shape: nothing recorded
+    # timed blocks: 10 ms steps x 5 = 50 ms per block -> repeated up to 9 times (odd), median reported
+    calls = []
+    t = bench.timed_steps(lambda: (calls.append(1), time.sleep(0.01)), lambda: None, 5, 1, None, False, None, "cpu")
+    assert len(bench.BLOCK_LOG[-1]) == 9 and len(calls) == 1 + 9 * 5
+    assert 0.045 < t < 0.2 and abs(t - sorted(bench.BLOCK_LOG[-1])[4]) < 1e-5
+    # a block of a second or more is not repeated
+    t = bench.timed_steps(lambda: time.sleep(0.26), lambda: None, 4, 0, None, False, None, "cpu")
+    assert len(bench.BLOCK_LOG[-1]) == 1 and t >= 1.0

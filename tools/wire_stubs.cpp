@@ -21,6 +21,7 @@ size_t pirgpu_keyset_blob(pirgpu_ctx*, uint32_t, const uint8_t** b) { if (b) *b 
 int pirgpu_keyset_claim(pirgpu_ctx*, const uint8_t*, size_t, uint32_t*) { return 13; }
 int pirgpu_keyset_release(pirgpu_ctx*, uint32_t) { return 13; }
 int pirgpu_keyset_set_key(pirgpu_ctx*, uint32_t, uint32_t, const uint64_t*) { return 13; }
+int pirgpu_keyset_set_keys(pirgpu_ctx*, uint32_t, uint32_t, const uint32_t*, const uint64_t* const*) { return 13; }
 int pirgpu_keyset_stats(pirgpu_ctx*, uint64_t*) { return 13; }
 int pirgpu_query_use_keyset(pirgpu_ctx*, uint32_t) { return 13; }
 uint32_t pirgpu_current_keyset(pirgpu_ctx*) { return 0; }

@@ -194,6 +194,24 @@ def timed_steps(step, barrier, steps, warmup, dist, use_dist, torch, dev, min_se
     return float(np.median(times))
 
 
+def batch_launch_block(bs, scan_bytes, info, k, N):
+    """roofline.batch_launch: the scan launch as it runs inside the batched step (pirgpu_batch_scan_timings)."""
+    if "error" in bs or not bs.get("launches"):
+        return bs
+    row_tiles = (info["rows"] + 15) // 16
+    sel = scan_bytes // row_tiles                      # packed selectors of a group: the database's bytes of ONE row tile
+    outb = bs["queries"] * info["rows"] * 2 * k * N * 8
+    moved = scan_bytes + sel + outb
+    sec = bs["mean_ms"] * 1e-3
+    return {**bs, "stored_database_bytes": scan_bytes, "packed_selector_bytes": sel, "row_sum_bytes": outb,
+            "achieved_GBps": moved / sec / 1e9, "frac": moved / sec / 1e9 / HBM_PEAK_GBS,
+            "frac_database_bytes_only": scan_bytes / sec / 1e9 / HBM_PEAK_GBS,
+            "note": "HIP events on the lane's stream around the scan launches of 6 more steps after the timed region: "
+                    "`workgroups` persistent workgroups (half the chip) beside the other lane's transform kernels, 8 queries "
+                    "per pass -- bound per CU (loads in flight), not by HBM; mean = as it shares the chip, min = its least "
+                    "disturbed instance"}
+
+
 def scan_source_sha16():
     """What the PMC traffic file is stamped with (tools/pmc_scan_traffic.sh): the scan kernel's source as it was profiled."""
     import hashlib
@@ -470,6 +488,10 @@ def main():
                          "algorithmic_bytes_definition": "packed operand-layout bytes of this GPU's shard = what one "
                                                          "launch must read (DESIGN.md section 5)",
                          "launches_averaged": timings["runs"],
+                         # the launch that serves the headline step: `workgroups` persistent workgroups beside the other
+                         # lane's transform kernels, 8 queries per pass -- bound per CU (loads in flight), not by HBM;
+                         # bytes = the same stored database + the group's packed selectors + its row sums
+                         **({"batch_launch": batch_launch_block(batch_scan, scan_bytes, info, k, N)} if batch_scan else {}),
                          # d = 1: the selection vector (one ciphertext per plaintext = 2x the database in u64) is read
                          # by the same launch; SURVEY 8(d)'s B_q leaves it out, so `frac` is a lower bound there
                          **({"d1_selector_bytes": pp.num_pt * 2 * k * N * 8,
@@ -840,6 +862,18 @@ def main():
         forced_check = bool(np.array_equal(got, srv.fetch_batch()))
         print("forced-dist check: replies through the collective path equal plain replies: %s" % forced_check, file=sys.stderr)
     batch_replies = srv.fetch_batch() if world == 1 and not use_dist else None
+    # the database pass as it runs INSIDE the step just timed (roofline.kernel_ms above is the single-query launch on the
+    # whole chip): HIP events around the batch pipeline's scan launches over a few more steps, outside the timed region
+    batch_scan = None
+    if world == 1 and not use_dist and info["mfma"]:
+        try:
+            srv.set_profiling(True)
+            for _ in range(6):
+                srv.run_batch()
+            batch_scan = srv.batch_scan_timings()
+            srv.set_profiling(False)
+        except Exception as e:     # noqa: BLE001 -- measurement extra only
+            batch_scan = {"error": repr(e)}
     arm_watchdog()
 
     # =========================== replicas (reference point, multi-GPU only) ===========================

@@ -348,6 +348,12 @@ void pirgpu_free(void* p);
 int pirgpu_last_timings(pirgpu_ctx* ctx, float phase_ms[6], uint32_t* runs);
 /* Enable/disable the phase events above (default off: zero overhead). */
 int pirgpu_set_profiling(pirgpu_ctx* ctx, int enabled);
+/* Measurement, batch pipeline: with profiling enabled, the database-pass launches of the batches run since (up to 64)
+ * are bracketed with HIP events on their lane's stream.  Mean / minimum duration of those launches -- the scan as it
+ * actually runs inside the headline step: `workgroups` persistent workgroups (0 = one per CU) beside the other lane's
+ * kernels, `queries` queries per pass -- and their number; waits for the batch and resets the collection. */
+int pirgpu_batch_scan_timings(pirgpu_ctx* ctx, float* mean_ms, float* min_ms, uint32_t* launches, uint32_t* workgroups,
+                              uint32_t* queries);
 /* Bytes a single-query pass over the database reads: the digit-packed operand-layout copy when that pass
  * is the int8-MFMA scan (info[7] of pirgpu_scan_info), else num_pt(shard) * k * N * 8. */
 uint64_t pirgpu_scan_bytes(const pirgpu_ctx* ctx);
@@ -364,7 +370,9 @@ int pirgpu_scan_info(pirgpu_ctx* ctx, uint32_t info[8]);
  * another group) -- DESIGN.md section 6 lists them.  A name that was not set falls back to the environment variable
  * PIRGPU_<NAME> (the A/B scripts under tools/ use that), then to the built-in default; get_option returns -1 for
  * "built-in default".  Options that shape the workspace must be set before the context is first used
- * (FailedPrecondition afterwards).  The arithmetic flavour (PIRGPU_NTT_MODE) is fixed at pirgpu_create. */
+ * (FailedPrecondition afterwards).  The arithmetic flavour (PIRGPU_NTT_MODE) is fixed at pirgpu_create.
+ * Environment variables are honoured only when PIRGPU_ALLOW_ENV=1 is set too (tests, A/B scripts): by default a
+ * context's behaviour depends on its parameters and pirgpu_set_option alone. */
 int pirgpu_set_option(pirgpu_ctx* ctx, const char* name, int64_t value);
 int pirgpu_get_option(pirgpu_ctx* ctx, const char* name, int64_t* value);
 /* Arithmetic flavour of the transform kernels of this context: 0 = 64-bit integer Shoup/Harvey butterflies (any

@@ -150,6 +150,7 @@ SIGNATURES = {
     "pirgpu_get_params": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
     "pirgpu_reply_copy_to_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "pirgpu_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "pirgpu_batch_scan_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "pirgpu_scan_bytes": (C.c_uint64, [C.c_void_p]),
     "pirgpu_scan_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
 }

@@ -241,6 +241,8 @@ struct pirgpu_ctx {
   MfmaGeom mg{};
   uint32_t mfma_nq = kMaxMfmaQueries;       // queries per database pass in batch mode
   bool mfma_single = true;                  // single queries use it too (off for matrices wider than one chunk)
+  bool scan_f64_fold = false;               // the scan folds its digit diagonals in exact fp64 arithmetic (option
+                                            // SCAN_F64_FOLD; every data modulus below 2^50)
   bool split_upper = false;                 // upper level as transform-to-scratch + elementwise MAC (N >= 16384 in the fp64
                                             // flavours, where the fused kernel spills; PIRGPU_SPLIT_UPPER=0/1 overrides)
   uint64_t split_upper_words = (3ull << 30) / 8;  // scratch budget per lane / worker (PIRGPU_SPLIT_UPPER_MB)
@@ -271,6 +273,11 @@ struct pirgpu_ctx {
   hipEvent_t ev_main_join = nullptr;        // pirgpu_join_stream onto a caller's stream: the main stream's position
 
   bool prof = false;
+  // batch pipeline under profiling: HIP events around the scan launches of the groups (the launch that serves the
+  // headline step runs on `scan_wgs_batch` workgroups beside the other lane's kernels -- not the full-chip single-query
+  // launch the roofline block quotes); read out by pirgpu_batch_scan_timings
+  std::vector<hipEvent_t> bscan_ev;   // pairs (start, stop)
+  uint32_t bscan_n = 0, bscan_wgs = 0, bscan_nq = 0;
   static constexpr int kMaxProfRuns = 256;
   std::vector<hipEvent_t> ev;  // kMaxProfRuns x (PH_COUNT + 1), created lazily
   int prof_runs = 0;           // runs recorded since the last read-out
@@ -380,13 +387,13 @@ void build_tables(pirgpu_ctx* c) {
   }
   // NTT arithmetic flavour (ntt_core.h).  PIRGPU_NTT_MODE=0 forces the integer path.
   c->mode = qmax < (1ull << 46) ? kNttF64 : (qmax < (1ull << 49) ? kNttF64Wide : kNttInt);
-  if (const char* v = getenv("PIRGPU_NTT_MODE")) {
+  if (const char* v = pirgpu_env("PIRGPU_NTT_MODE")) {
     int want = atoi(v);
     if (want == kNttInt || (want == kNttF64Wide && c->mode != kNttInt) || want == c->mode) c->mode = want;
   }
   hp.ntt_mode = c->mode;
   hp.f64_lazy_inv = (64 - (uint32_t)__builtin_clzll(qmax)) + c->logN <= 52 ? 1u : 0u;
-  if (const char* v = getenv("PIRGPU_F64_LAZY_INV")) hp.f64_lazy_inv = atoi(v) ? hp.f64_lazy_inv : 0u;
+  if (const char* v = pirgpu_env("PIRGPU_F64_LAZY_INV")) hp.f64_lazy_inv = atoi(v) ? hp.f64_lazy_inv : 0u;
   const uint64_t p = c->prm.special_prime, t = c->prm.plain_modulus;
   hp.p_half = p >> 1;
   hp.p_f = (double)p;
@@ -400,6 +407,11 @@ void build_tables(pirgpu_ctx* c) {
     hp.p_inv_s[j] = hm::shoup(hp.p_inv[j], q);
     hp.p_inv_f[j] = hp.p_inv[j] > q / 2 ? -(double)(q - hp.p_inv[j]) : (double)hp.p_inv[j];
     hp.lift_inc[j] = q - (t % q);
+    uint64_t w = (1ull << 32) % q, acc = w;
+    for (int e = 0; e < 3; ++e) {     // 2^(32 (e + 1)) mod q, centred
+      hp.fold_w[j][e] = acc > q / 2 ? -(double)(q - acc) : (double)acc;
+      acc = hm::mulmod(acc, w, q);
+    }
   }
   // CiphertextReencoder::Encode order (reference ct_reencoder.cpp:49-69)
   const uint32_t b = hm::bits_per_coeff(t);
@@ -435,7 +447,7 @@ int64_t option(const pirgpu_ctx* c, const char* name, int64_t dflt, bool* presen
   auto it = c->opts.find(name);
   if (it != c->opts.end()) return it->second;
   const std::string env = std::string("PIRGPU_") + name;
-  const char* v = getenv(env.c_str());
+  const char* v = pirgpu_env(env.c_str());
   if (v && *v) return strtoll(v, nullptr, 10);
   if (present) *present = false;
   return dflt;
@@ -579,6 +591,11 @@ void ensure_workspace(pirgpu_ctx* c) {
     //   PIRGPU_SCAN_MFMA_SINGLE: a single query on a matrix wider than one column chunk pays the partial-sum
     //   round trip for one query only; there the 64-bit kernels on the u64 copy are faster (cfg 4: 5.6 vs 6.4 ms)
     c->mfma_single = env_u32("PIRGPU_SCAN_MFMA_SINGLE", c->mg.nchunks == 1 ? 1 : 0) != 0;
+    //   PIRGPU_SCAN_F64_FOLD  fp64 fold of the digit diagonals (moduli below 2^50).  Default: on from 6 digits per
+    //   residue (cfg 4: scan 4.53 against 4.76 ms, cfg 5: 8.33 against 8.57, same box); at 5 digits (cfg 3) the
+    //   single-query pass measured 3 % slower with it (0.212 against 0.206 ms) and the batch step 0.5 % faster: off
+    c->scan_f64_fold = env_u32("PIRGPU_SCAN_F64_FOLD", c->mg.L >= 6 ? 1 : 0) != 0;
+    for (uint32_t j = 0; j < k; ++j) c->scan_f64_fold = c->scan_f64_fold && (c->hp.mod[j].q >> 50) == 0;
     // selectors as doubles inside a lane: every query ciphertext must go through ks_last_ntt_kernel (>= 2 items each)
     const uint64_t rem = c->dim_sum % N;
     c->sel_f64 = c->want_sel_f64 && c->mfma_on && c->mode != kNttInt && c->fuse_last_level && c->last_level_ntt &&
@@ -879,7 +896,23 @@ void scan_group_mfma(pirgpu_ctx* c, hipStream_t st, uint8_t*& selp, const MfmaPt
   // the streams' state at enqueue time); a lone group gets the whole chip
   const bool share = share_chip && !profiled && c->scan_wgs_batch;
   const uint32_t wgs = share ? c->scan_wgs_batch : 0;
-  HIP_TRY(launch_scan_mfma(st, c->dp, c->mg, c->d_dbp, packed, out, n, c->scan_rows, kN, words, wgs));
+  constexpr uint32_t kMaxBscan = 64;
+  const bool timed = c->prof && !profiled && c->bscan_n < kMaxBscan;
+  if (timed) {
+    while (c->bscan_ev.size() < 2 * (size_t)(c->bscan_n + 1)) {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreate(&e));
+      c->bscan_ev.push_back(e);
+    }
+    HIP_TRY(hipEventRecord(c->bscan_ev[2 * c->bscan_n], st));
+  }
+  HIP_TRY(launch_scan_mfma(st, c->dp, c->mg, c->d_dbp, packed, out, n, c->scan_rows, kN, words, wgs, c->scan_f64_fold));
+  if (timed) {
+    HIP_TRY(hipEventRecord(c->bscan_ev[2 * c->bscan_n + 1], st));
+    ++c->bscan_n;
+    c->bscan_wgs = wgs;
+    c->bscan_nq = n;
+  }
   if (c->mg.nchunks > 1)
     HIP_TRY(launch_reduce_splits(st, c->dp, part, c->mg.nchunks, words, out_base, n, (uint64_t)c->mg.nchunks * words, words));
 }
@@ -1149,6 +1182,7 @@ void pirgpu_destroy(pirgpu_ctx* c) {
     for (hipEvent_t e : b.st_events) (void)hipEventDestroy(e);
   }
   for (auto& e : c->ev) (void)hipEventDestroy(e);
+  for (auto& e : c->bscan_ev) (void)hipEventDestroy(e);
   for (Worker& w : c->workers) {
     if (w.ev_expanded) (void)hipEventDestroy(w.ev_expanded);
     if (w.ev_scanned) (void)hipEventDestroy(w.ev_scanned);
@@ -1213,7 +1247,7 @@ static const struct { const char* name; bool early; } kOptions[] = {
     {"SCAN_MQ_SINGLE_LIMB", true}, {"SCAN_ROWS", true}, {"SCAN_BLOCK", true}, {"SCAN_NSPLIT", true},
     {"FUSE_LAST", true}, {"FUSE_MAC_COMBINE", true}, {"LAST_NTT", true}, {"SEL_F64", true}, {"TREE40", true},
     {"FUSE_MAC_NODES", true}, {"SPLIT_UPPER", true}, {"SPLIT_UPPER_MB", true}, {"PACK40", true},
-    {"SCAN_MFMA", true}, {"SCAN_MFMA_WIDE", true}, {"SCAN_MFMA_TOP4", true}, {"SCAN_MFMA_NQ", true}, {"SCAN_MFMA_SINGLE", true}, {"LANES", true}, {"HEAD_LEVELS", true}, {"HEAD_MODE", true},
+    {"SCAN_MFMA", true}, {"SCAN_MFMA_WIDE", true}, {"SCAN_MFMA_TOP4", true}, {"SCAN_MFMA_NQ", true}, {"SCAN_MFMA_SINGLE", true}, {"LANES", true}, {"HEAD_LEVELS", true}, {"HEAD_MODE", true}, {"SCAN_F64_FOLD", true},
 };
 
 int pirgpu_set_option(pirgpu_ctx* c, const char* name, int64_t value) {
@@ -2744,6 +2778,7 @@ int pirgpu_set_profiling(pirgpu_ctx* c, int enabled) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->prof = enabled != 0;
     c->prof_runs = 0;
+    c->bscan_n = 0;
     return PIRGPU_OK;
   });
 }
@@ -2777,6 +2812,28 @@ int pirgpu_last_timings(pirgpu_ctx* c, float ms[6], uint32_t* runs) {
       *runs = 0;
     }
     memcpy(ms, c->timings, sizeof(c->timings));
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_batch_scan_timings(pirgpu_ctx* c, float* mean_ms, float* min_ms, uint32_t* launches, uint32_t* workgroups,
+                              uint32_t* queries) {
+  return guarded(c, [&]() -> int {
+    if (!mean_ms || !min_ms || !launches) return fail(c, PIRGPU_INVALID_ARGUMENT, "null buffer");
+    sync_batch_streams(c);
+    double sum = 0, mn = 1e30;
+    for (uint32_t i = 0; i < c->bscan_n; ++i) {
+      float t = 0;
+      HIP_TRY(hipEventElapsedTime(&t, c->bscan_ev[2 * i], c->bscan_ev[2 * i + 1]));
+      sum += t;
+      mn = std::min<double>(mn, t);
+    }
+    *launches = c->bscan_n;
+    *mean_ms = c->bscan_n ? (float)(sum / c->bscan_n) : 0.f;
+    *min_ms = c->bscan_n ? (float)mn : 0.f;
+    if (workgroups) *workgroups = c->bscan_wgs;
+    if (queries) *queries = c->bscan_nq;
+    c->bscan_n = 0;
     return PIRGPU_OK;
   });
 }

@@ -20,6 +20,8 @@ constexpr int kMaxScanQueries = 4;       // queries sharing one database pass in
 #endif
 constexpr int ntt_log_ept(int logN) { return logN >= 14 ? PIRGPU_LOG_EPT14 : 4; }
 
+#include "env_gate.h"
+
 // One RNS modulus with the Barrett ratio floor(2^128 / q) (SEAL Modulus::const_ratio).
 struct ModConst {
   uint64_t q;
@@ -78,6 +80,8 @@ struct DevParams {
   // fp64 flavours: 1 when (bits of the largest modulus) + log2 N <= 52 -- the sums of a whole inverse transform
   // (they at most double per stage) then stay below 2^52 without the per-pass renormalisation
   uint32_t f64_lazy_inv;
+  // MFMA scan, fp64 fold (all data moduli < 2^50): 2^32, 2^64, 2^96 mod q_j as centred doubles
+  double fold_w[kMaxPrimes][3];
 };
 
 }  // namespace pirgpu

@@ -141,8 +141,9 @@ hipError_t launch_db_unpack(hipStream_t st, const DevParams* P, const MfmaGeom& 
 hipError_t launch_sel_pack(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const MfmaPtrs& sv, uint32_t nq,
                            uint8_t* selp, uint32_t cols, uint32_t kN, bool sel_f64 = false);
 // wgs: persistent workgroups of the launch (0 = one per CU; the batch pipeline asks for fewer, see scan_mfma.hip)
+// f64_fold: fold the digit diagonals in exact fp64 arithmetic (every data modulus below 2^50)
 hipError_t launch_scan_mfma(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp,
                             const uint8_t* selp, const MfmaPtrs& out, uint32_t nq, uint32_t rows, uint32_t kN,
-                            uint64_t chunk_stride, uint32_t wgs = 0);
+                            uint64_t chunk_stride, uint32_t wgs = 0, bool f64_fold = false);
 
 }  // namespace pirgpu

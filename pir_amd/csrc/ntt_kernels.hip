@@ -1361,7 +1361,7 @@ static hipError_t op_upper_fused(hipStream_t st, int mode, const DevParams* P, u
 #define PIRGPU_UF_ARGS P, src, svq, part, n_rows, n_dim, n_children_total, sv_first, C, chunk_len, n_chunks, src_qstride, part_qstride
   if (sel_f64 && mode == kNttInt) return hipErrorInvalidValue;
   if constexpr (kUpperLdsTw) {
-    static const bool lds_tw = !(getenv("PIRGPU_UPPER_LDS_TW") && atoi(getenv("PIRGPU_UPPER_LDS_TW")) == 0);
+    static const bool lds_tw = !(pirgpu_env("PIRGPU_UPPER_LDS_TW") && atoi(pirgpu_env("PIRGPU_UPPER_LDS_TW")) == 0);
     if (lds_tw && mode != kNttInt) {
       const size_t lds = kLdsBytes + (size_t)N * 8;
       if (mode == kNttF64 && sel_f64) hipLaunchKernelGGL((upper_fused_kernel<kNttF64, true, true>), grid, dim3(NT), lds, st, PIRGPU_UF_ARGS);

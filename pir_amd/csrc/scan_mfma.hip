@@ -223,7 +223,10 @@ struct ChunkPlan {
 // of the pass) -- and writes to out.p[q] + ch * chunk_stride (partial sums when nchunks > 1).
 // TOP4: the top digit of both operands is stored as nibbles (above): its database tiles stay packed in two registers per
 // lane until their k-step is due; the selectors' are unpacked once per slot block.
-template <int L, int KS, int NW, bool TOP4>
+// F64F: the digit diagonals are folded in exact fp64 arithmetic (all data moduli < 2^50): four diagonals combine exactly
+// in one double (|C| < 2^49.01), chunk c times 2^(32 c) mod q with the 6-operation exact product of arith.h --
+// ~45 full-rate operations per value against ~170 mostly quarter-rate 64-bit integer ones.  Same canonical residues.
+template <int L, int KS, int NW, bool TOP4, bool F64F = false>
 __global__ void __launch_bounds__(NW * 64)
 scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ dbp, const uint8_t* __restrict__ selp,
                  MfmaPtrs out, uint32_t nq, uint32_t rows, uint32_t RT, uint32_t KG, uint32_t kN,
@@ -294,9 +297,12 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
   for (; blk < nblocks; blk += wgs_in_chunk) {
     const uint32_t j0 = blk * NW;
     const uint32_t j = j0 + w;
-    const ModConst m = P->mod[j >> P->logN];
+    const uint32_t mi = j >> P->logN;
+    const ModConst m = P->mod[mi];
     // multiple of q that makes every 40-bit group positive: 2^57 <= bias < 2^58, |group| < 2^56.1
     const uint64_t bias = m.q << (58 - (64 - __builtin_clzll(m.q)));
+    [[maybe_unused]] const F64Mod fm{P->tab[mi].qd, P->tab[mi].qinvd};
+    [[maybe_unused]] const double fw0 = P->fold_w[mi][0], fw1 = P->fold_w[mi][1], fw2 = P->fold_w[mi][2];
     const uint8_t* abase = dbp + (size_t)j * slab + chunk_base;
     const uint32_t nblk = blk + wgs_in_chunk;
     const bool has_next = nblk < nblocks;
@@ -336,16 +342,31 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         uint64_t r = 0;
+        if constexpr (F64F) {
+          // chunks of four diagonals, exact in a double: C_c = ((T[4c+3] 256 + T[4c+2]) 256 + T[4c+1]) 256 + T[4c]
+          constexpr int NC = (NS + 3) / 4;
+          double acc = 0.0;
 #pragma unroll
-        for (int grp = NG - 1; grp >= 0; --grp) {
-          int64_t G = 0;
+          for (int c = NC - 1; c >= 0; --c) {
+            double C = 0.0;
 #pragma unroll
-          for (int s = grp * 5; s < grp * 5 + 5 && s < NS; ++s) G += (int64_t)T[s][i] << (8 * (s - grp * 5));
-          if (grp == NG - 1 && NG > 1) {
-            r = (uint64_t)(G + (int64_t)bias);   // top group: < 2^58, reduced together with the next one (bias = 0 mod q)
-          } else {
-            const u128 v = ((u128)r << 40) + (uint64_t)(G + (int64_t)bias);
-            r = reduce128((uint64_t)v, (uint64_t)(v >> 64), m);
+            for (int s = (4 * c + 3 < NS ? 4 * c + 3 : NS - 1); s >= 4 * c; --s) C = __builtin_fma(C, 256.0, (double)T[s][i]);
+            if (c == 0) acc += f64_norm(C, fm);
+            else acc += f64_mulmod(C, c == 1 ? fw0 : (c == 2 ? fw1 : fw2), fm);
+          }
+          r = f64_to_u64(f64_canon(f64_norm(acc, fm), fm));
+        } else {
+#pragma unroll
+          for (int grp = NG - 1; grp >= 0; --grp) {
+            int64_t G = 0;
+#pragma unroll
+            for (int s = grp * 5; s < grp * 5 + 5 && s < NS; ++s) G += (int64_t)T[s][i] << (8 * (s - grp * 5));
+            if (grp == NG - 1 && NG > 1) {
+              r = (uint64_t)(G + (int64_t)bias);   // top group: < 2^58, reduced together with the next one (bias = 0 mod q)
+            } else {
+              const u128 v = ((u128)r << 40) + (uint64_t)(G + (int64_t)bias);
+              r = reduce128((uint64_t)v, (uint64_t)(v >> 64), m);
+            }
           }
         }
         stage[buf][g * 4 + i][i16][w] = r;
@@ -465,44 +486,51 @@ hipError_t launch_sel_pack(hipStream_t st, const DevParams* P, const MfmaGeom& g
   return hipGetLastError();
 }
 
-template <int L, int KS, int NW, bool TOP4>
-static void launch_scan_mfma_variant(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp,
-                                     const uint8_t* selp, const MfmaPtrs& out, uint32_t nq, uint32_t rows, uint32_t kN,
-                                     uint64_t chunk_stride, uint32_t wgs_req) {
+static uint32_t scan_wgs_all() {
   // persistent workgroups: one per CU and chunk (at most), each walking its share of the kN/8 slot blocks
   static const uint32_t wgs_all = [] {
-    const char* v = getenv("PIRGPU_SCAN_MFMA_WGS");
+    const char* v = pirgpu_env("PIRGPU_SCAN_MFMA_WGS");
     if (v && *v) return (uint32_t)strtoul(v, nullptr, 10);
     hipDeviceProp_t prop;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256u;
     return (uint32_t)prop.multiProcessorCount;
   }();
+  return wgs_all;
+}
+
+template <int L, int KS, int NW, bool TOP4, bool F64F>
+static void launch_scan_mfma_variant(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp,
+                                     const uint8_t* selp, const MfmaPtrs& out, uint32_t nq, uint32_t rows, uint32_t kN,
+                                     uint64_t chunk_stride, uint32_t wgs_req) {
   // wgs_req (batch pipeline): a workgroup takes a CU's whole register file, so a launch on fewer CUs leaves the others
   // to the VALU-bound kernels of the other lane -- the HBM-bound pass and the transforms then really overlap
-  const uint32_t wgs = wgs_req ? std::min(wgs_req, wgs_all) : wgs_all;
+  const uint32_t wgs = wgs_req ? std::min(wgs_req, scan_wgs_all()) : scan_wgs_all();
   // equal shares of the chip for the (equal) column chunks
   ChunkPlan plan{};
   plan.nchunks = gm.nchunks;
   const uint32_t share = std::min<uint32_t>(kN / NW, std::max<uint32_t>(1, wgs / std::min<uint32_t>(gm.nchunks, wgs)));
   for (uint32_t c = 0; c <= gm.nchunks; ++c) plan.first[c] = c * share;   // share >= 1: no chunk without workgroups
-  hipLaunchKernelGGL((scan_mfma_kernel<L, KS, NW, TOP4>), dim3(gm.nchunks * share), dim3(NW * 64), 0, st, P, dbp, selp, out, nq,
+  hipLaunchKernelGGL((scan_mfma_kernel<L, KS, NW, TOP4, F64F>), dim3(gm.nchunks * share), dim3(NW * 64), 0, st, P, dbp, selp, out, nq,
                      rows, gm.RT, gm.KG, kN, chunk_stride, plan, gm.GC);
 }
 
 hipError_t launch_scan_mfma(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp,
                             const uint8_t* selp, const MfmaPtrs& out, uint32_t nq, uint32_t rows, uint32_t kN,
-                            uint64_t chunk_stride, uint32_t wgs) {
+                            uint64_t chunk_stride, uint32_t wgs, bool f64_fold) {
+#define PIRGPU_MFMA_ARGS st, P, gm, dbp, selp, out, nq, rows, kN, chunk_stride, wgs
 #define PIRGPU_MFMA_CASE(L_, KS_, NW_)                                                                    \
   if (gm.L == L_ && gm.KS == KS_ && gm.NW == NW_) {                                                                 \
     if constexpr (L_ <= 6) {                                                                                         \
       if (gm.top4) {                                                                                                 \
-        launch_scan_mfma_variant<L_, KS_, NW_, true>(st, P, gm, dbp, selp, out, nq, rows, kN, chunk_stride, wgs);    \
+        if (f64_fold) launch_scan_mfma_variant<L_, KS_, NW_, true, true>(PIRGPU_MFMA_ARGS);                          \
+        else launch_scan_mfma_variant<L_, KS_, NW_, true, false>(PIRGPU_MFMA_ARGS);                                  \
         return hipGetLastError();                                                                                    \
       }                                                                                                              \
     }                                                                                                                \
     if (gm.top4) return hipErrorInvalidValue;                                                                        \
-    launch_scan_mfma_variant<L_, KS_, NW_, false>(st, P, gm, dbp, selp, out, nq, rows, kN, chunk_stride, wgs);       \
+    if (f64_fold) launch_scan_mfma_variant<L_, KS_, NW_, false, true>(PIRGPU_MFMA_ARGS);                             \
+    else launch_scan_mfma_variant<L_, KS_, NW_, false, false>(PIRGPU_MFMA_ARGS);                                     \
     return hipGetLastError();                                                                                        \
   }
   PIRGPU_MFMA_CASE(5, 1, 8) PIRGPU_MFMA_CASE(5, 2, 8) PIRGPU_MFMA_CASE(5, 3, 8)
@@ -512,6 +540,7 @@ hipError_t launch_scan_mfma(hipStream_t st, const DevParams* P, const MfmaGeom& 
   PIRGPU_MFMA_CASE(6, 3, 4) PIRGPU_MFMA_CASE(6, 4, 4) PIRGPU_MFMA_CASE(6, 5, 4) PIRGPU_MFMA_CASE(6, 6, 4) PIRGPU_MFMA_CASE(6, 7, 4)
   PIRGPU_MFMA_CASE(7, 3, 4) PIRGPU_MFMA_CASE(7, 4, 4) PIRGPU_MFMA_CASE(7, 5, 4) PIRGPU_MFMA_CASE(7, 6, 4)
 #undef PIRGPU_MFMA_CASE
+#undef PIRGPU_MFMA_ARGS
   return hipErrorInvalidValue;
 }
 

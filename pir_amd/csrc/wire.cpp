@@ -11,6 +11,7 @@
 // with SEAL's BlakePRNG + sample_poly_uniform restated in wire_codec.cpp).
 #include "wire.h"
 #include "wire_codec.h"
+#include "env_gate.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -362,7 +363,7 @@ class Pool {
   Pool() {
     const size_t hw = std::thread::hardware_concurrency();
     size_t n = std::max<size_t>(1, std::min<size_t>(16, hw ? hw / 2 : 1));   // never more than half the machine
-    if (const char* v = getenv("PIRGPU_WIRE_THREADS")) n = std::max<size_t>(1, std::min<size_t>(64, (size_t)atoi(v)));
+    if (const char* v = pirgpu_env("PIRGPU_WIRE_THREADS")) n = std::max<size_t>(1, std::min<size_t>(64, (size_t)atoi(v)));
     for (size_t i = 0; i < n; ++i) {
       threads_.emplace_back([this] { run(); });
       threads_.back().detach();
@@ -421,7 +422,7 @@ struct RelinCache {
 };
 
 struct Trace {   // PIRGPU_WIRE_TRACE=1: host-side phase times of a window, to stderr
-  bool on = getenv("PIRGPU_WIRE_TRACE") != nullptr;
+  bool on = pirgpu_env("PIRGPU_WIRE_TRACE") != nullptr;
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   void mark(const char* what, int window = -1) {
     if (!on) return;

@@ -461,6 +461,15 @@ class PIRServer:
         self._check(self.lib.pirgpu_reduce_fixup_device(self.db.handle, C.c_void_p(device_ptr),
                                                         self.db.reply_ct_count()))
 
+    def batch_scan_timings(self) -> Dict[str, float]:
+        """Database-pass launches of the batches run since set_profiling(True): mean / min ms, how many, their shape."""
+        mean, mn = C.c_float(0), C.c_float(0)
+        n, wgs, nq = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        self._check(self.lib.pirgpu_batch_scan_timings(self.db.handle, C.byref(mean), C.byref(mn), C.byref(n), C.byref(wgs),
+                                                       C.byref(nq)))
+        return {"mean_ms": float(mean.value), "min_ms": float(mn.value), "launches": int(n.value),
+                "workgroups": int(wgs.value), "queries": int(nq.value)}
+
     def ntt_mode(self) -> int:
         """0 integer / 1 fp64 / 2 wide fp64 butterflies (pirgpu_ntt_mode)."""
         return int(self.lib.pirgpu_ntt_mode(self.db.handle))

@@ -10,6 +10,10 @@ try:
 except ImportError:
     pass
 
+# the library honours its PIRGPU_* tuning / flavour variables only behind this gate (pir_amd/csrc/env_gate.h); the tests
+# that sweep flavours and geometries through the environment need it open
+os.environ.setdefault("PIRGPU_ALLOW_ENV", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -124,3 +124,23 @@ def test_expansion_fallback_paths(monkeypatch, knob):
     rc, exp8 = s.orc.process_query(s.db_ntt, s.params.dimensions, queries[8], keys)
     assert rc == 0 and np.array_equal(batch[8], exp8)
     db.close()
+
+
+def test_environment_knobs_need_the_gate():
+    """PIRGPU_NTT_MODE (and every other PIRGPU_* knob of the library) is read only when
+    PIRGPU_ALLOW_ENV=1 is set as well -- a server's arithmetic flavour does not depend on stray environment variables."""
+    import os
+    import subprocess
+    import sys
+    code = ("import pir_amd, sys; sys.path.insert(0, 'tests'); "
+            "from pir_amd import parameters as P; "
+            "pp = P.create_pir_parameters(100, 288, 2, P.generate_encryption_params(4096, 24)); "
+            "db = pir_amd.PIRDatabase.Create(pp); srv = pir_amd.PIRServer(db, pp); print('MODE', srv.ntt_mode())")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for gate in ("0", "1"):
+        env = dict(os.environ, PIRGPU_NTT_MODE="0", PIRGPU_ALLOW_ENV=gate)
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[gate] = int(r.stdout.split("MODE")[1].split()[0])
+    assert out == {"0": 1, "1": 0}          # closed: the flavour the moduli call for (fp64); open: the forced integer flavour

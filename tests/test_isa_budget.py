@@ -128,8 +128,10 @@ def scan_isa(tmp_path_factory):
     return out.read_text().split("\n")
 
 
-def _scan_descriptor(isa, L, KS, NW, top4=True):
-    name = "_ZN6pirgpu16scan_mfma_kernelILi%dELi%dELi%dELb%dEEE" % (L, KS, NW, 1 if top4 else 0)
+def _scan_descriptor(isa, L, KS, NW, top4=True, f64_fold=None):
+    # the variant a context runs by default: the fp64 fold of the digit diagonals from 6 digits per residue on
+    f64_fold = (L >= 6) if f64_fold is None else f64_fold
+    name = "_ZN6pirgpu16scan_mfma_kernelILi%dELi%dELi%dELb%dELb%dEEE" % (L, KS, NW, 1 if top4 else 0, 1 if f64_fold else 0)
     i = next(i for i, l in enumerate(isa) if ".amdhsa_kernel " + name in l)
     block = "\n".join(isa[i:i + 40])
     get = lambda key: int(re.search(r"\.amdhsa_%s (\d+)" % key, block).group(1))

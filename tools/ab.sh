@@ -1,4 +1,5 @@
 #!/bin/bash
+export PIRGPU_ALLOW_ENV=1   # the library reads PIRGPU_* knobs only behind this gate (csrc/env_gate.h)
 # usage: tools/ab.sh "ENV_A" "ENV_B" [rounds]   -- interleaved A/B of bench.py on the same box
 A="$1"; B="$2"; R=${3:-3}
 for i in $(seq $R); do

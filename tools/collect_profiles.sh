@@ -1,4 +1,5 @@
 #!/bin/bash
+export PIRGPU_ALLOW_ENV=1   # the library reads PIRGPU_* knobs only behind this gate (csrc/env_gate.h)
 # Collects the round's committed profile artifacts on the GPU box (run through gpurun from the repo root):
 # PMC passes -> VALU roofline (bench.py embeds it), plain + rocprofv3-profiled default bench, cfg 2/4/5 reference runs.
 # Results land in gpurun_out/final/; copy what is to be judged into profiles/.

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PIRGPU_ALLOW_ENV=1   # the library reads PIRGPU_* knobs only behind this gate (csrc/env_gate.h)
 # Fuzz the request parser (wire.cpp + wire_codec.cpp, device-free validation entry) under ASan + UBSan.
 # Host only; run from the repo root:  bash tools/fuzz_wire_asan.sh
 set -e

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PIRGPU_ALLOW_ENV=1   # the library reads PIRGPU_* knobs only behind this gate (csrc/env_gate.h)
 # Per-kernel SQ / TCC counters of the whole query path from rocprofv3 PMC passes (kernel trace only, one
 # counter group per pass; FETCH_SIZE and WRITE_SIZE cannot share a pass).  Run on the GPU box from the repo root:
 #   bash tools/pmc_kernels.sh [tag] [bench args...]  -> gpurun_out/pmc_<tag>_<group>/, gpurun_out/pmc_<tag>.json

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PIRGPU_ALLOW_ENV=1   # the library reads PIRGPU_* knobs only behind this gate (csrc/env_gate.h)
 # HBM traffic of the single-query scan launch from rocprofv3 PMC counters, for BASELINE configs 3, 4 and 5:
 # FETCH_SIZE and WRITE_SIZE in separate passes (they do not fit one pass), kernel trace only.  Run on the GPU box
 # from the repo root:

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PIRGPU_ALLOW_ENV=1   # the library reads PIRGPU_* knobs only behind this gate (csrc/env_gate.h)
 # A/B on one box: top digit of database + selectors as a nibble (default where the moduli allow) vs as a full byte
 cd $GRAFT_REPO_ROOT
 run() { env $1 python3 bench.py --no-cpu-baseline --steps ${3:-60} --latency-runs ${4:-100} $2 2>/dev/null | python3 -c "

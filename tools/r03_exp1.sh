@@ -1,4 +1,5 @@
 #!/bin/bash
+export PIRGPU_ALLOW_ENV=1   # the library reads PIRGPU_* knobs only behind this gate (csrc/env_gate.h)
 # round-3 experiment 1: full GPU suite, then wide (4-wave) vs 8-wave MFMA scan on cfg 3/4/5
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/exp1; rm -rf $O; mkdir -p $O

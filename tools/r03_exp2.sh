@@ -1,4 +1,5 @@
 #!/bin/bash
+export PIRGPU_ALLOW_ENV=1   # the library reads PIRGPU_* knobs only behind this gate (csrc/env_gate.h)
 # round-3 experiment 2: full GPU suite (key sets, wide scan), bench with multi-client extra, cfg 3 wide vs narrow
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/exp2; rm -rf $O; mkdir -p $O

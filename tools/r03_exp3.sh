@@ -1,4 +1,5 @@
 #!/bin/bash
+export PIRGPU_ALLOW_ENV=1   # the library reads PIRGPU_* knobs only behind this gate (csrc/env_gate.h)
 # round-3 experiment 3: GPU suite (pipelined rows step, multi-client), forced single-rank RCCL bench through the pipeline
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/exp3; rm -rf $O; mkdir -p $O

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PIRGPU_ALLOW_ENV=1   # the library reads PIRGPU_* knobs only behind this gate (csrc/env_gate.h)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/exp4; rm -rf $O; mkdir -p $O
 f() { grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl"; }

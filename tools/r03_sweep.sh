@@ -1,4 +1,5 @@
 #!/bin/bash
+export PIRGPU_ALLOW_ENV=1   # the library reads PIRGPU_* knobs only behind this gate (csrc/env_gate.h)
 # quick same-box sweep of the batch pipeline's run-time knobs (cfg 3, 64 queries per step)
 cd $GRAFT_REPO_ROOT
 run() { env $1 python3 bench.py --no-cpu-baseline --steps 60 --latency-runs 5 2>/dev/null | python3 -c "

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PIRGPU_ALLOW_ENV=1   # the library reads PIRGPU_* knobs only behind this gate (csrc/env_gate.h)
 # single-query latency against the upper level's workgroup target (and a few other launch-shape knobs)
 cd $GRAFT_REPO_ROOT
 run() { env $1 python3 bench.py --no-cpu-baseline --steps 10 --latency-runs 300 2>/dev/null | python3 -c "

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PIRGPU_ALLOW_ENV=1   # the library reads PIRGPU_* knobs only behind this gate (csrc/env_gate.h)
 # A/B of the N = 16384 transform organisation on one box: 32 residues per thread in 512-thread workgroups (with / without
 # twiddle prefetch) against 16 residues per thread in 1024-thread workgroups; rebuilds the library for each variant.
 cd $GRAFT_REPO_ROOT

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PIRGPU_ALLOW_ENV=1   # the library reads PIRGPU_* knobs only behind this gate (csrc/env_gate.h)
 # A/B of the head-stream expansion levels (PIRGPU_HEAD_LEVELS) on one box, interleaved
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r4e; mkdir -p $O

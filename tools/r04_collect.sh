@@ -1,4 +1,5 @@
 #!/bin/bash
+export PIRGPU_ALLOW_ENV=1   # the library reads PIRGPU_* knobs only behind this gate (csrc/env_gate.h)
 # round 4 profile collection (one gpurun call): tools/collect_profiles.sh r04 + the PMC traffic passes of the scan kernel,
 # stamped with the commit and the scan source's hash, + the wire-load kernel trace
 cd $GRAFT_REPO_ROOT

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PIRGPU_ALLOW_ENV=1   # the library reads PIRGPU_* knobs only behind this gate (csrc/env_gate.h)
 # round 4, GPU call 1: new tests, default bench (wire legs), lane / worker experiments
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r4a; mkdir -p $O

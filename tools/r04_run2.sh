@@ -1,4 +1,5 @@
 #!/bin/bash
+export PIRGPU_ALLOW_ENV=1   # the library reads PIRGPU_* knobs only behind this gate (csrc/env_gate.h)
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r4b; mkdir -p $O
 timeout 600 python tools/r04_debug_t42.py > $O/debug_t42.log 2>&1

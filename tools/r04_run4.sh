@@ -1,4 +1,5 @@
 #!/bin/bash
+export PIRGPU_ALLOW_ENV=1   # the library reads PIRGPU_* knobs only behind this gate (csrc/env_gate.h)
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r4d; mkdir -p $O
 timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -12 > $O/tests_all.log

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PIRGPU_ALLOW_ENV=1   # the library reads PIRGPU_* knobs only behind this gate (csrc/env_gate.h)
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r4e; mkdir -p $O
 python tools/r04_wire_load.py 2 20 > $O/wire_load.log 2>&1

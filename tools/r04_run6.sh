@@ -1,4 +1,5 @@
 #!/bin/bash
+export PIRGPU_ALLOW_ENV=1   # the library reads PIRGPU_* knobs only behind this gate (csrc/env_gate.h)
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r4f; mkdir -p $O
 for rep in 1 2; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PIRGPU_ALLOW_ENV=1   # the library reads PIRGPU_* knobs only behind this gate (csrc/env_gate.h)
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r4h; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_wire_extras.py tests/test_gpu_multi_client.py tests/test_gpu_client_roundtrip.py tests/test_cpp_facade.py tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -5 > $O/tests.log

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PIRGPU_ALLOW_ENV=1   # the library reads PIRGPU_* knobs only behind this gate (csrc/env_gate.h)
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r4i; mkdir -p $O
 PIRGPU_SCAN_PAIR=1 timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_multi_client.py tests/test_gpu_mfma_scan.py tests/test_gpu_wire_extras.py -m gpu -x -q 2>&1 | tail -8 > $O/tests_pair.log

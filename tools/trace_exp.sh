@@ -1,3 +1,4 @@
+export PIRGPU_ALLOW_ENV=1   # the library reads PIRGPU_* knobs only behind this gate (csrc/env_gate.h)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 T=$1
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/$T -- python3 bench.py --no-cpu-baseline --steps 20 > gpurun_out/$T.json 2>gpurun_out/$T.err

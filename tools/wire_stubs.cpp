@@ -30,6 +30,8 @@ int pirgpu_query_stage(pirgpu_ctx*, const uint64_t*, uint32_t) { return 13; }
 int pirgpu_query_stage_async(pirgpu_ctx*, const uint64_t*, uint32_t) { return 13; }
 int pirgpu_query_run(pirgpu_ctx*) { return 13; }
 int pirgpu_query_fetch(pirgpu_ctx*, uint64_t*, uint64_t, uint64_t*) { return 13; }
+int pirgpu_query_fetch_begin(pirgpu_ctx*, uint64_t*, uint64_t, uint64_t*, uint64_t*) { return 13; }
+int pirgpu_query_fetch_wait(pirgpu_ctx*, int) { return 13; }
 uint64_t* pirgpu_host_query_buffer(pirgpu_ctx*, uint32_t) { return nullptr; }
 uint64_t* pirgpu_host_reply_buffer(pirgpu_ctx*, uint32_t) { return nullptr; }
 int pirgpu_keyset_pin(pirgpu_ctx*, uint32_t) { return 13; }

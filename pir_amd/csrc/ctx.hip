@@ -246,6 +246,10 @@ struct pirgpu_ctx {
   bool split_upper = false;                 // upper level as transform-to-scratch + elementwise MAC (N >= 16384 in the fp64
                                             // flavours, where the fused kernel spills; PIRGPU_SPLIT_UPPER=0/1 overrides)
   uint64_t split_upper_words = (3ull << 30) / 8;  // scratch budget per lane / worker (PIRGPU_SPLIT_UPPER_MB)
+  // rings that fill a CU with ONE workgroup (N >= 16384): the transform kernels of the wide expansion levels and of the
+  // split upper level run several transforms of one source per workgroup, so that stores drain under the next
+  // transform (option LOOP_TRANSFORMS)
+  bool loop_transforms = false;
   uint32_t fuse_mac_nodes = 128;            // ... from this many tree ciphertexts per level on (narrower levels are latency-
                                             // bound: two dependent transform kernels cost more than mac + light combine)
   bool fuse_mac_combine = true;             // levels below the last: combine step in the data residues' MAC + inverse-NTT
@@ -269,6 +273,7 @@ struct pirgpu_ctx {
   hipEvent_t ev_head_tail = nullptr;        // the head stream's position (an upload into a batch set waits for it)
   hipStream_t copy_stream = nullptr;        // device-to-host downloads of finished groups (pirgpu_batch_set_host_replies):
                                             // a lane that downloaded its own replies sat idle for 8 MB of PCIe per group
+  hipEvent_t ev_fetch[2] = {nullptr, nullptr};   // pirgpu_query_fetch_begin: the two halves of the reply's download
   hipEvent_t ev_fork = nullptr;             // pirgpu_fork: the main stream's position
   hipEvent_t ev_main_join = nullptr;        // pirgpu_join_stream onto a caller's stream: the main stream's position
 
@@ -576,6 +581,7 @@ void ensure_workspace(pirgpu_ctx* c) {
     c->head_mode = std::min<uint32_t>(env_u32("PIRGPU_HEAD_MODE", c->head_mode), 2);
     c->split_upper = env_u32("PIRGPU_SPLIT_UPPER", c->logN >= 14 ? 1 : 0) != 0 && c->mode != kNttInt;
     c->split_upper_words = (uint64_t)env_u32("PIRGPU_SPLIT_UPPER_MB", 3072) * (1ull << 20) / 8;
+    c->loop_transforms = env_u32("PIRGPU_LOOP_TRANSFORMS", c->logN >= 14 ? 1 : 0) != 0 && c->mode != kNttInt;
     c->pack40 = env_u32("PIRGPU_PACK40", 1) != 0;
     // 5-byte storage of the key-switch intermediates: the fp64 flavours store x + q (|x| <= q), so q < 2^39
     for (uint32_t j = 0; j <= k; ++j) c->pack40 = c->pack40 && (c->hp.mod[j].q >> 39) == 0;
@@ -773,7 +779,8 @@ uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* 
     const bool last_ntt = fuse_last && j + 1 == logm && c->last_level_ntt;
     const bool c0_in_digit = last_ntt && ks_digit_takes_c0(nodes);
     if (cur40 && c0_in_digit != last_ntt) throw Fail{PIRGPU_INTERNAL, "5-byte tree reached a level that cannot read it"};
-    HIP_TRY(c->ops->ks_digit(st, c->mode, c->dp, k, cur, g, nodes, dig, c->pack40, c0_in_digit ? prod : nullptr, cur40));
+    HIP_TRY(c->ops->ks_digit(st, c->mode, c->dp, k, cur, g, nodes, dig, c->pack40, c0_in_digit ? prod : nullptr, cur40,
+                             c->loop_transforms));
     // (a group of B queries reaches the width at which the fused form pays one level earlier than a single query:
     // measured +0.6 % batched with the threshold at 64 tree ciphertexts, while a single query loses latency below 128)
     const uint32_t fuse_from = B > 1 ? std::max<uint32_t>(c->fuse_mac_nodes / 2, 1) : c->fuse_mac_nodes;
@@ -1001,7 +1008,7 @@ void post_scan_stage(pirgpu_ctx* c, const Stage& sg, Worker* profiled) {
       }
       for (uint32_t b0 = 0; b0 < c->dims[l]; b0 += blk) {
         HIP_TRY(c->ops->upper_ntt(st, c->mode, c->dp, k, c->E, sg.lvl[l + 1], *sg.up_scratch, (uint32_t)rows, c->dims[l],
-                                  (uint32_t)nch, (uint32_t)C, b0, blk, sg.n, c->lvl_cts[l + 1] * ctw));
+                                  (uint32_t)nch, (uint32_t)C, b0, blk, sg.n, c->lvl_cts[l + 1] * ctw, c->loop_transforms));
         HIP_TRY(launch_upper_mac(st, c->dp, *sg.up_scratch, sg.sel, sg.pt_buf, sg.lvl[l], sg.n, (uint32_t)rows, (uint32_t)C,
                                  c->E, k, N, sv_first, b0, blk, c->dims[l], b0 == 0, b0 + blk >= c->dims[l], c->pt_words,
                                  c->lvl_cts[l] * ctw));
@@ -1208,6 +1215,8 @@ void pirgpu_destroy(pirgpu_ctx* c) {
     (void)hipStreamSynchronize(c->copy_stream);
     (void)hipStreamDestroy(c->copy_stream);
   }
+  for (hipEvent_t e : c->ev_fetch)
+    if (e) (void)hipEventDestroy(e);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_main_join) (void)hipEventDestroy(c->ev_main_join);
   for (size_t i = 1; i < c->workers.size(); ++i)
@@ -1247,7 +1256,7 @@ static const struct { const char* name; bool early; } kOptions[] = {
     {"SCAN_MQ_SINGLE_LIMB", true}, {"SCAN_ROWS", true}, {"SCAN_BLOCK", true}, {"SCAN_NSPLIT", true},
     {"FUSE_LAST", true}, {"FUSE_MAC_COMBINE", true}, {"LAST_NTT", true}, {"SEL_F64", true}, {"TREE40", true},
     {"FUSE_MAC_NODES", true}, {"SPLIT_UPPER", true}, {"SPLIT_UPPER_MB", true}, {"PACK40", true},
-    {"SCAN_MFMA", true}, {"SCAN_MFMA_WIDE", true}, {"SCAN_MFMA_TOP4", true}, {"SCAN_MFMA_NQ", true}, {"SCAN_MFMA_SINGLE", true}, {"LANES", true}, {"HEAD_LEVELS", true}, {"HEAD_MODE", true}, {"SCAN_F64_FOLD", true},
+    {"SCAN_MFMA", true}, {"SCAN_MFMA_WIDE", true}, {"SCAN_MFMA_TOP4", true}, {"SCAN_MFMA_NQ", true}, {"SCAN_MFMA_SINGLE", true}, {"LANES", true}, {"HEAD_LEVELS", true}, {"HEAD_MODE", true}, {"SCAN_F64_FOLD", true}, {"LOOP_TRANSFORMS", true},
 };
 
 int pirgpu_set_option(pirgpu_ctx* c, const char* name, int64_t value) {
@@ -1920,6 +1929,37 @@ int pirgpu_query_fetch(pirgpu_ctx* c, uint64_t* reply, uint64_t cap, uint64_t* c
   });
 }
 
+// pirgpu_query_fetch in two halves: both downloads are queued at once, the caller serialises the first half of the
+// reply while the second is still crossing PCIe (a megabyte of memcpy against 20 us of transfer: the tail of a lone
+// request).  fetch_begin returns the number of ciphertexts in the first part; fetch_wait(part) blocks until that part has
+// landed in `reply` (pinned host memory).
+int pirgpu_query_fetch_begin(pirgpu_ctx* c, uint64_t* reply, uint64_t cap, uint64_t* count, uint64_t* first_part) {
+  return guarded(c, [&]() -> int {
+    if (c->workers.empty()) return fail(c, PIRGPU_FAILED_PRECONDITION, "no query has been run");
+    Worker& w = c->workers[0];
+    if (!w.reply_valid) return fail(c, PIRGPU_FAILED_PRECONDITION, "no query has been run");
+    if (!reply || cap < c->reply_cts) return fail(c, PIRGPU_INVALID_ARGUMENT, "reply buffer too small");
+    for (hipEvent_t& e : c->ev_fetch)
+      if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    const uint64_t a = (c->reply_cts + 1) / 2;
+    HIP_TRY(hipMemcpyAsync(reply, w.lvl[0], a * c->ctw * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipEventRecord(c->ev_fetch[0], c->stream));
+    if (c->reply_cts > a)
+      HIP_TRY(hipMemcpyAsync(reply + a * c->ctw, w.lvl[0] + a * c->ctw, (c->reply_cts - a) * c->ctw * 8, hipMemcpyDeviceToHost,
+                             c->stream));
+    HIP_TRY(hipEventRecord(c->ev_fetch[1], c->stream));
+    if (count) *count = c->reply_cts;
+    if (first_part) *first_part = a;
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_query_fetch_wait(pirgpu_ctx* c, int part) {
+  if (!c || part < 0 || part > 1 || !c->ev_fetch[part]) return PIRGPU_INVALID_ARGUMENT;
+  if (hipEventSynchronize(c->ev_fetch[part]) != hipSuccess) return fail(c, PIRGPU_INTERNAL, "waiting for the reply failed");
+  return PIRGPU_OK;
+}
+
 int pirgpu_process_query(pirgpu_ctx* c, const uint64_t* query, uint32_t nq, uint64_t* reply, uint64_t cap,
                          uint64_t* count) {
   int rc = pirgpu_query_stage(c, query, nq);
@@ -2007,7 +2047,7 @@ int pirgpu_substitute_power_x(pirgpu_ctx* c, uint64_t* ct, uint32_t power) {
     key.B = 1;
     HIP_TRY(hipMemcpyAsync(w.res_b, ct, c->ctw * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(launch_tree_convert(c->stream, c->dp, c->mode, w.res_b, w.res_a, c->ctw, true));
-    HIP_TRY(c->ops->ks_digit(c->stream, c->mode, c->dp, c->k, w.res_a, power, 1, w.dig, c->pack40, nullptr, false));
+    HIP_TRY(c->ops->ks_digit(c->stream, c->mode, c->dp, c->k, w.res_a, power, 1, w.dig, c->pack40, nullptr, false, false));
     HIP_TRY(c->ops->ks_mac_intt(c->stream, c->mode, c->dp, c->k, w.dig, key, 1, w.prod, c->pack40, 0, c->k + 1));
     HIP_TRY(launch_ks_combine(c->stream, c->dp, c->mode, c->N, c->k, w.res_a, w.prod, galois_inverse(power, c->N), 1, 0,
                               false, /*hi_limit: unused without the expand step*/ 0, c->pack40, w.res_b));

@@ -44,7 +44,8 @@ struct NttOps {
   // product buffer c0_out (NTT-domain last level), sparing ks_last_ntt its own launch for that (c0_done)
   // tree40: res_in holds the tree in the 5-byte form (wide levels of the fused expansion, ks_mac_combine's tout40)
   hipError_t (*ks_digit)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* res_in,
-                         uint32_t galois_elt, uint32_t nodes, uint64_t* dig, bool pack40, uint64_t* c0_out, bool tree40);
+                         uint32_t galois_elt, uint32_t nodes, uint64_t* dig, bool pack40, uint64_t* c0_out, bool tree40,
+                         bool loop_targets);   // loop_targets (fp64 flavours, wide levels): one workgroup per source, k + 1 transforms each
   // key-level moduli I_base .. I_base + I_count - 1 (all: 0, k + 1; the special prime alone: k, 1)
   hipError_t (*ks_mac_intt)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* dig,
                             const KeyPtrs& key, uint32_t nodes, uint64_t* prod, bool pack40, uint32_t I_base,
@@ -66,7 +67,7 @@ struct NttOps {
   hipError_t (*upper_ntt)(hipStream_t st, int mode, const DevParams* P, uint32_t k, uint32_t enc_count,
                           const uint64_t* src, uint64_t* scratch, uint32_t n_rows, uint32_t n_dim,
                           uint32_t n_children_total, uint32_t C, uint32_t b0, uint32_t blk, uint32_t n_queries,
-                          uint64_t src_qstride);
+                          uint64_t src_qstride, bool loop_source);   // loop_source: one workgroup per (child, source polynomial)
   // data residues of one level below the last: MAC + inverse transform + combine with the special-prime product
   // (already in `prod`) + tree butterfly, tree_in -> tree_out (fp64 flavours); tin40 / tout40: that tree buffer holds
   // 5-byte polynomials (5 N bytes each, offset form) instead of doubles -- tout40 needs shift_pow < N / 16

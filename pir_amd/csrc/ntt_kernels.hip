@@ -310,7 +310,13 @@ tree_c0_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
 // One level of the expansion tree, part 1a: for node n, key-level modulus I and
 // RNS digit J:  dig[n][I][J] = NTT_I(sigma_g(c1)_J mod m_I)  (device NTT order, stored in
 // the flavour's register type).  grid = (nodes, k+1, k).  T40: the tree is in the 5-byte form (tree_load).
-template <int MODE, bool P40, bool T40 = false>
+//
+// LOOPI (fp64 flavours, wide levels): one workgroup per (node, J) source polynomial runs the k+1 transforms itself, one
+// after the other -- grid = nodes * k.  The source is loaded and permuted ONCE, and the store of transform I drains
+// while transform I + 1 computes.  That is the overlap rings with several workgroups per CU get from their neighbours;
+// at N = 16384 one polynomial of doubles fills the LDS, a CU holds ONE workgroup, and without the loop its load,
+// transform and store phases run strictly one after the other (cfg 5).
+template <int MODE, bool P40, bool T40 = false, bool LOOPI = false>
 __global__ void __launch_bounds__(NT)
 ks_digit_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ res_in, uint32_t galois_elt,
                 uint64_t* __restrict__ dig, uint64_t* __restrict__ c0_out, uint32_t digit_blocks) {
@@ -325,6 +331,54 @@ ks_digit_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ re
       tree_c0_ntt_body<MODE, P40, T40>(P, res_in, c0_out, b / k, b % k, tid);
       return;
     }
+  }
+  if constexpr (LOOPI) {
+    static_assert(MODE != kNttInt, "fp64 flavours only");
+    const uint32_t xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
+    const uint32_t J = t % k, node = (t / k) * 8 + xcd;
+    double* sd = reinterpret_cast<double*>(smem_raw);
+    const double qJd = P->tab[J].qd;
+    const uint32_t raw0 = tid * galois_elt, rstep = (uint32_t)NT * galois_elt;
+    double base[EPT];   // sigma_g(c1)_J, canonical in [0, q_J), in the transform's input layout
+    {
+      double c1[EPT];
+      tree_load<T40>(res_in, ((size_t)node * 2 + 1) * k + J, tid, qJd, c1);
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const uint32_t raw = raw0 + (uint32_t)e * rstep;
+        const uint64_t sign = (uint64_t)((raw << (31 - LOGN)) & 0x80000000u) << 32;
+        double v = __longlong_as_double((long long)((uint64_t)__double_as_longlong(c1[e]) ^ sign));
+        v = v < 0.0 ? v + qJd : v;  // -0.0 stays 0
+        sd[lds_idx<R_>(raw & (N - 1))] = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) base[e] = sd[lds_lin_base<NT, R_>(tid) + lds_lin_off<NT, R_>(e)];
+    }
+#pragma clang loop unroll(disable)
+    for (uint32_t I = 0; I <= k; ++I) {
+      const typename A::Mod m = A::mod(P, I);
+      const bool norm_in = MODE == kNttF64Wide && I != J;
+      double x[EPT];
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) x[e] = norm_in ? f64_norm(base[e], m) : base[e];
+      __syncthreads();  // the permutation / the previous transform is done with the LDS words
+      const size_t poly = ((size_t)node * (k + 1) + I) * k + J;
+      // the thread index as the transform sees it is opaque per iteration: otherwise every LDS / twiddle address of
+      // every pass is hoisted out of the loop and stays live across it (the 128-VGPR budget then spills)
+      uint32_t tl = tid;
+      asm volatile("" : "+v"(tl));
+      if constexpr (P40) {
+        ntt_forward<MODE, LOGN, kPF, /*CANON=*/false>(x, smem_raw, P, I, tl);
+        store40f(reinterpret_cast<uint8_t*>(dig) + poly * kPoly40, tl, x, f64_pack_magic(m.q));
+      } else {
+        ntt_forward<MODE, LOGN, kPF>(x, smem_raw, P, I, tl);
+        double* out = reinterpret_cast<double*>(dig) + poly * N;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) out[e * NT + tl] = x[e];
+      }
+    }
+    return;
   }
   uint32_t node = blockIdx.x, I = blockIdx.y, J = blockIdx.z;
   if (gridDim.y == 1) {
@@ -1056,7 +1110,11 @@ upper_fused_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
 // then forms the products with the selectors elementwise.  Costs a round trip of the transformed plaintexts through
 // HBM (bounded by processing the children in blocks) and saves the spills: fp64 flavours only.
 // grid = (queries * n_rows * C * blk, E, k); child ii = b0 + (blockIdx.x % blk) of row r.
-template <int MODE>
+// LOOP: one workgroup per (child, SOURCE polynomial) -- grid.y = 2 k, grid.z = 1 -- loads the source once and runs the
+// transforms of all its Encode chunks under all k target moduli one after the other (3 x 4 = 12 at cfg 5); the store of
+// one drains under the next (see ks_digit_kernel, LOOPI: the overlap a ring with one workgroup per CU does not get
+// from neighbouring workgroups).
+template <int MODE, bool LOOP = false>
 __global__ void __launch_bounds__(NT)
 upper_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ src_all, double* __restrict__ scratch,
                  uint32_t n_rows, uint32_t n_dim, uint32_t n_children_total, uint32_t C, uint32_t b0, uint32_t blk,
@@ -1068,47 +1126,81 @@ upper_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ s
   const uint32_t cc = (blockIdx.x / blk) % C;
   const uint32_t r = (blockIdx.x / (blk * C)) % n_rows;
   const uint32_t qi = blockIdx.x / (blk * C * n_rows);
-  const uint32_t e_idx = blockIdx.y, jt = blockIdx.z;
   const uint32_t ii = b0 + iib;
   const uint32_t child0 = r * n_dim;
   uint32_t nchild = n_children_total > child0 ? n_children_total - child0 : 0;
   if (nchild > n_dim) nchild = n_dim;
-  double* out = scratch + (((((size_t)qi * n_rows + r) * C + cc) * blk + iib) * E + e_idx) * k * N + (size_t)jt * N;
-  typename A::T x[EPT];
+  // chunks [e_lo, e_hi) x target moduli [jt_lo, jt_hi) of this workgroup; every chunk of the range reads the same source
+  uint32_t e_lo = blockIdx.y, e_hi = blockIdx.y + 1, jt_lo = blockIdx.z, jt_hi = blockIdx.z + 1;
+  if constexpr (LOOP) {
+    const uint32_t want_p = blockIdx.y / k, want_j = blockIdx.y % k;
+    e_lo = E, e_hi = 0;
+    for (uint32_t e = 0; e < E; ++e)   // Encode order is (polynomial, residue, chunk): one contiguous range
+      if (P->enc_poly[e] == want_p && P->enc_res[e] == want_j) {
+        e_lo = e < e_lo ? e : e_lo;
+        e_hi = e + 1;
+      }
+    jt_lo = 0, jt_hi = k;
+    if (e_lo >= e_hi) return;
+  }
+  double* out0 = scratch + ((((size_t)qi * n_rows + r) * C + cc) * blk + iib) * E * k * N;   // [chunk][target modulus][N]
   if (ii >= nchild) {  // beyond the database: contributes nothing (uniform per workgroup)
+    for (uint32_t e_idx = e_lo; e_idx < e_hi; ++e_idx)
+      for (uint32_t jt = jt_lo; jt < jt_hi; ++jt) {
+        double* out = out0 + ((size_t)e_idx * k + jt) * N;
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) out[e * NT + tid] = 0.0;
+        for (int e = 0; e < EPT; ++e) out[e * NT + tid] = 0.0;
+      }
     return;
   }
-  const ModConst mc = P->mod[jt];
-  const typename A::Mod m = A::mod(P, jt);
-  const uint32_t sp = P->enc_poly[e_idx], sj = P->enc_res[e_idx], sh = P->enc_shift[e_idx];
+  const uint32_t sp = P->enc_poly[e_lo], sj = P->enc_res[e_lo];
   const uint64_t mask = (1ull << P->enc_bits) - 1;
   const uint64_t thr = P->plain_thr;
-  const uint64_t inc = P->lift_inc[jt] >= mc.q ? P->lift_inc[jt] - mc.q : P->lift_inc[jt];
-  const bool fast_lift = P->enc_bits <= 31 && P->t < mc.q;
   const double td = (double)P->t;
   const uint32_t thr32 = (uint32_t)thr, mask32 = (uint32_t)mask;
   const uint64_t* in = src_all + (size_t)qi * src_qstride + ((((size_t)(child0 + ii) * C + cc) * 2 + sp) * k + sj) * N;
-  if (fast_lift) {
+  uint64_t in_raw[EPT];
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-      const uint32_t v = (uint32_t)(in[e * NT + tid] >> sh) & mask32;
-      const double d = (double)v;
-      x[e] = v >= thr32 ? d - td : d;
-    }
-  } else {
+  for (int e = 0; e < EPT; ++e) in_raw[e] = in[e * NT + tid];
+  bool first = true;
+  // target modulus outside, chunk inside: the chunk extraction then changes every iteration and stays a few
+  // instructions in front of the transform instead of being hoisted into 32 more live registers
+#pragma clang loop unroll(disable)
+  for (uint32_t jt = jt_lo; jt < jt_hi; ++jt) {
+    const ModConst mc = P->mod[jt];
+    const typename A::Mod m = A::mod(P, jt);
+    const uint64_t inc = P->lift_inc[jt] >= mc.q ? P->lift_inc[jt] - mc.q : P->lift_inc[jt];
+    const bool fast_lift = P->enc_bits <= 31 && P->t < mc.q;
+#pragma clang loop unroll(disable)
+    for (uint32_t e_idx = e_lo; e_idx < e_hi; ++e_idx) {
+      const uint32_t sh = P->enc_shift[e_idx];
+      typename A::T x[EPT];
+      if (fast_lift) {
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-      uint64_t v = (in[e * NT + tid] >> sh) & mask;
-      uint64_t rr = reduce64(v, mc);
-      if (v >= thr) rr = add_mod(rr, inc, mc.q);
-      x[e] = A::in(rr, m);
+        for (int e = 0; e < EPT; ++e) {
+          const uint32_t v = (uint32_t)(in_raw[e] >> sh) & mask32;
+          const double d = (double)v;
+          x[e] = v >= thr32 ? d - td : d;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          uint64_t v = (in_raw[e] >> sh) & mask;
+          uint64_t rr = reduce64(v, mc);
+          if (v >= thr) rr = add_mod(rr, inc, mc.q);
+          x[e] = A::in(rr, m);
+        }
+      }
+      if (LOOP && !first) __syncthreads();  // the previous transform may still be reading LDS
+      first = false;
+      uint32_t tl = tid;
+      if constexpr (LOOP) asm volatile("" : "+v"(tl));   // see ks_digit_kernel, LOOPI: no address hoisting across the loop
+      ntt_forward<MODE, LOGN, kPF, /*CANON=*/false>(x, smem_raw, P, jt, tl);
+      double* out = out0 + ((size_t)e_idx * k + jt) * N;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) out[e * NT + tl] = x[e];
     }
   }
-  ntt_forward<MODE, LOGN, kPF, /*CANON=*/false>(x, smem_raw, P, jt, tid);
-#pragma unroll
-  for (int e = 0; e < EPT; ++e) out[e * NT + tid] = x[e];
 }
 
 // ------------------------------------------------------------------ host side
@@ -1153,6 +1245,10 @@ static hipError_t configure_mode() {
     PIRGPU_SET((ks_mac_combine_kernel<MODE, true, true, false>));
     PIRGPU_SET((ks_mac_combine_kernel<MODE, true, true, true>));
     PIRGPU_SET((ks_digit_kernel<MODE, true, true>));
+    PIRGPU_SET((ks_digit_kernel<MODE, false, false, true>));
+    PIRGPU_SET((ks_digit_kernel<MODE, true, false, true>));
+    PIRGPU_SET((ks_digit_kernel<MODE, true, true, true>));
+    PIRGPU_SET((upper_ntt_kernel<MODE, true>));
     PIRGPU_SET((ks_last_level_kernel<MODE, false>));
     PIRGPU_SET((ks_last_level_kernel<MODE, true>));
     PIRGPU_SET((tree_c0_ntt_kernel<MODE, false>));
@@ -1214,10 +1310,29 @@ static hipError_t op_db_encode(hipStream_t st, int mode, const DevParams* P, uin
 // the product buffer c0_out (what tree_c0_ntt_kernel does), as extra workgroups of the same launch
 static hipError_t op_ks_digit(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* res_in,
                               uint32_t galois_elt, uint32_t nodes, uint64_t* dig, bool pack40, uint64_t* c0_out,
-                              bool tree40) {
+                              bool tree40, bool loop_targets) {
   const bool wide = ks_digit_takes_c0(nodes);
   if (c0_out && (!wide || mode == kNttInt)) return hipErrorInvalidValue;
   if (tree40 && (!pack40 || mode == kNttInt)) return hipErrorInvalidValue;
+  if (loop_targets && wide && mode != kNttInt) {
+    // one workgroup per source polynomial, the k + 1 target moduli in a loop (ks_digit_kernel, LOOPI)
+    const uint32_t digit_blocks = nodes * k;
+    const dim3 grid(digit_blocks + (c0_out ? nodes * k : 0));
+#define PIRGPU_KSD_LOOP(M, P40_, T40_)                                                                              \
+  hipLaunchKernelGGL((ks_digit_kernel<M, P40_, T40_, true>), grid, dim3(NT), kLdsBytes, st, P, res_in, galois_elt, dig, \
+                     c0_out, digit_blocks)
+    if (mode == kNttF64) {
+      if (tree40) PIRGPU_KSD_LOOP(kNttF64, true, true);
+      else if (pack40) PIRGPU_KSD_LOOP(kNttF64, true, false);
+      else PIRGPU_KSD_LOOP(kNttF64, false, false);
+    } else {
+      if (tree40) PIRGPU_KSD_LOOP(kNttF64Wide, true, true);
+      else if (pack40) PIRGPU_KSD_LOOP(kNttF64Wide, true, false);
+      else PIRGPU_KSD_LOOP(kNttF64Wide, false, false);
+    }
+#undef PIRGPU_KSD_LOOP
+    return hipGetLastError();
+  }
   const uint32_t digit_blocks = wide ? nodes * (k + 1) * k : 0xffffffffu;
   const dim3 grid = wide ? dim3(digit_blocks + (c0_out ? nodes * k : 0)) : dim3(nodes, k + 1, k);
   if (tree40) {
@@ -1338,9 +1453,21 @@ static hipError_t op_ks_last_ntt(hipStream_t st, int mode, const DevParams* P, u
 static hipError_t op_upper_ntt(hipStream_t st, int mode, const DevParams* P, uint32_t k, uint32_t enc_count,
                                const uint64_t* src, uint64_t* scratch, uint32_t n_rows, uint32_t n_dim,
                                uint32_t n_children_total, uint32_t C, uint32_t b0, uint32_t blk, uint32_t n_queries,
-                               uint64_t src_qstride) {
-  const dim3 grid(n_queries * n_rows * C * blk, enc_count, k);
+                               uint64_t src_qstride, bool loop_source) {
   double* out = reinterpret_cast<double*>(scratch);
+  if (loop_source) {   // one workgroup per (child, source polynomial): all its chunks x target moduli in a loop
+    const dim3 lgrid(n_queries * n_rows * C * blk, 2 * k, 1);
+    if (mode == kNttF64)
+      hipLaunchKernelGGL((upper_ntt_kernel<kNttF64, true>), lgrid, dim3(NT), kLdsBytes, st, P, src, out, n_rows, n_dim,
+                         n_children_total, C, b0, blk, src_qstride);
+    else if (mode == kNttF64Wide)
+      hipLaunchKernelGGL((upper_ntt_kernel<kNttF64Wide, true>), lgrid, dim3(NT), kLdsBytes, st, P, src, out, n_rows, n_dim,
+                         n_children_total, C, b0, blk, src_qstride);
+    else
+      return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
+  const dim3 grid(n_queries * n_rows * C * blk, enc_count, k);
   if (mode == kNttF64)
     hipLaunchKernelGGL(upper_ntt_kernel<kNttF64>, grid, dim3(NT), kLdsBytes, st, P, src, out, n_rows, n_dim,
                        n_children_total, C, b0, blk, src_qstride);

@@ -285,7 +285,10 @@ struct Server {               // what serving needs to know about a context
 // Upper bound of what append_reply adds for a reply of n ciphertexts (tags and varint lengths: < 32 bytes each)
 size_t reply_bytes_bound(const Shape& sh, uint64_t n) { return 32 + n * (32 + saved_ciphertext_size(sh)); }
 
-void append_reply(OutBuf& out, const Shape& sh, const uint64_t* cts_words, uint64_t n, size_t ctw) {
+// `ready(i)` (optional) is called before ciphertext i is copied: the caller can wait there for the part of the download
+// that holds it.
+void append_reply(OutBuf& out, const Shape& sh, const uint64_t* cts_words, uint64_t n, size_t ctw,
+                  const std::function<void(uint64_t)>& ready = nullptr) {
   const size_t ct_size = saved_ciphertext_size(sh);
   std::string per_ct_head;                                    // Ciphertexts.ct = 1: tag + length + the object's prefix
   per_ct_head.push_back((char)((1 << 3) | 2));
@@ -298,6 +301,7 @@ void append_reply(OutBuf& out, const Shape& sh, const uint64_t* cts_words, uint6
   out.reserve(out.n + reply_head.size() + n * per_ct);
   out.append(reply_head.data(), reply_head.size());
   for (uint64_t i = 0; i < n; ++i) {
+    if (ready) ready(i);
     out.append(per_ct_head.data(), per_ct_head.size());
     out.append(cts_words + i * ctw, ctw * 8);
   }
@@ -533,9 +537,17 @@ void run_single(const Server& sv, Job& job, const std::pair<const uint8_t*, size
   (void)pirgpu_query_use_keyset(sv.ctx, callers_slot);
   if (rc) throw Err{rc, msg};
   if (while_running) while_running();
-  rc = pirgpu_query_fetch(sv.ctx, hr, sv.n_reply, &got);
+  // the reply comes back in two halves queued together: the first is serialised while the second crosses PCIe
+  uint64_t first_part = 0;
+  rc = pirgpu_query_fetch_begin(sv.ctx, hr, sv.n_reply, &got, &first_part);
   if (rc) throw Err{rc, pirgpu_last_error(sv.ctx)};
-  append_reply(job.out, sv.sh, hr, got, sv.ctw);
+  int wrc = 0;
+  append_reply(job.out, sv.sh, hr, got, sv.ctw, [&](uint64_t i) {
+    if (i == 0 && !wrc) wrc = pirgpu_query_fetch_wait(sv.ctx, 0);
+    if (i == first_part && !wrc) wrc = pirgpu_query_fetch_wait(sv.ctx, 1);
+  });
+  if (!wrc && first_part >= got) wrc = pirgpu_query_fetch_wait(sv.ctx, 1);
+  if (wrc) throw Err{wrc, pirgpu_last_error(sv.ctx)};
 }
 
 // One WINDOW of requests on its way through the batch pipeline: up to kMaxRequestBatch queries of at most

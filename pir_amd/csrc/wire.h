@@ -37,6 +37,10 @@ void pirgpu_wire_forget(struct pirgpu_ctx* ctx);
 // while it stages + queues a window, installs a client's keys, or serves a lone query; NOT while a queued window runs.
 void pirgpu_request_lock(struct pirgpu_ctx* ctx);
 void pirgpu_request_unlock(struct pirgpu_ctx* ctx);
+// pirgpu_query_fetch in two halves (both downloads queued at once): *first_part ciphertexts land first (fetch_wait(0)),
+// the rest with fetch_wait(1); `reply` is pinned host memory.  Lets the caller serialise one half under the other's transfer.
+int pirgpu_query_fetch_begin(struct pirgpu_ctx* ctx, uint64_t* reply, uint64_t cap_cts, uint64_t* count, uint64_t* first_part);
+int pirgpu_query_fetch_wait(struct pirgpu_ctx* ctx, int part);
 // Queries in flight as last set with pirgpu_set_concurrency (1 by default).
 uint32_t pirgpu_get_concurrency(struct pirgpu_ctx* ctx);
 #ifdef __cplusplus

@@ -93,6 +93,7 @@ struct pirgpu_ctx {
   std::vector<uint64_t> w0_query, w0_reply;
   uint32_t w0_slot = 0;
   bool fail_next_run = false;
+  std::shared_ptr<Event> fetch_ev[2];
   std::atomic<uint32_t> delay_us{150};   // upper bound of the executor's random delay per task
 
   pirgpu_ctx() {
@@ -433,6 +434,37 @@ int pirgpu_query_fetch(pirgpu_ctx* c, uint64_t* reply, uint64_t cap, uint64_t* c
   c->drain();
   mock_reply(c->w0_query.data(), c->keysets[c->w0_slot].sum, reply);
   *count = kReplyCts;
+  return 0;
+}
+// the lone query's reply in two halves: the second half is written LATER (on the executor), so a serialiser that did
+// not wait for it would read stale bytes
+int pirgpu_query_fetch_begin(pirgpu_ctx* c, uint64_t* reply, uint64_t cap, uint64_t* count, uint64_t* first_part) {
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  if (cap < kReplyCts) return fail(c, PIRGPU_INVALID_ARGUMENT, "reply buffer too small");
+  auto full = std::make_shared<std::vector<uint64_t>>(kReplyCts * kCtw);
+  mock_reply(c->w0_query.data(), c->keysets[c->w0_slot].sum, full->data());
+  const uint64_t a = (kReplyCts + 1) / 2;
+  for (int part = 0; part < 2; ++part) {
+    c->fetch_ev[part] = std::make_shared<Event>();
+    auto ev = c->fetch_ev[part];
+    const uint64_t lo = part ? a : 0, hi = part ? kReplyCts : a;
+    memset(reply + lo * kCtw, 0xEE, (hi - lo) * kCtw * 8);
+    c->push([=] {
+      memcpy(reply + lo * kCtw, full->data() + lo * kCtw, (hi - lo) * kCtw * 8);
+      ev->set();
+    });
+  }
+  *count = kReplyCts;
+  *first_part = a;
+  return 0;
+}
+int pirgpu_query_fetch_wait(pirgpu_ctx* c, int part) {
+  std::shared_ptr<Event> ev;
+  {
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    ev = c->fetch_ev[part];
+  }
+  ev->wait();
   return 0;
 }
 }  // extern "C"

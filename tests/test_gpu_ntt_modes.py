@@ -126,6 +126,35 @@ def test_expansion_fallback_paths(monkeypatch, knob):
     db.close()
 
 
+@pytest.mark.parametrize("chain,items,off", [("n4096_36bit", 12000, None), ("n4096_36bit", 12000, "PIRGPU_TREE40"),
+                                             ("n4096_36bit", 12000, "PIRGPU_PACK40"), ("n8192_44bit", 24000, None),
+                                             ("n16384_49bit", 49000, None)])
+def test_looped_transforms_match_the_oracle(monkeypatch, chain, items, off):
+    """LOOP_TRANSFORMS (the N = 16384 default; forced on for the smaller rings here): at the wide expansion levels one
+    workgroup runs the k + 1 digit transforms of a source polynomial, and at the split upper level all chunks x target
+    moduli of a child's source polynomial, instead of one transform per workgroup.  More than 32 leaves and a full group
+    of 8 queries reach the wide levels (>= 256 tree ciphertexts per launch); every storage form of the digits (5-byte
+    tree and digits, 5-byte digits only, doubles) must give the oracle's reply, single and batched."""
+    N, moduli, _ = CHAINS[chain]
+    monkeypatch.setenv("PIRGPU_LOOP_TRANSFORMS", "1")
+    monkeypatch.setenv("PIRGPU_SPLIT_UPPER", "1")
+    if off:
+        monkeypatch.setenv(off, "0")
+    s = PirSetup(items, 288, 2, N=N, plain_bits=24, moduli=moduli)
+    assert sum(s.params.dimensions) > 32, s.params.dimensions
+    db, srv = _server(s)
+    rng = np.random.default_rng(5)
+    keys = {(N >> j) + 1: random_key(s.orc, rng) for j in range(N.bit_length() - 1)}
+    srv.set_galois_keys(keys)
+    queries = random_ct(s.orc, rng, 9)[:, None]
+    batch = srv.process_batch(queries, n_workers=9)          # one full group of 8 + a group of 1
+    for i in (0, 8):
+        rc, exp = s.orc.process_query(s.db_ntt, s.params.dimensions, queries[i], keys)
+        assert rc == 0 and np.array_equal(batch[i], exp), i
+    assert np.array_equal(srv.process_query(queries[3]), batch[3])
+    db.close()
+
+
 def test_environment_knobs_need_the_gate():
     """PIRGPU_NTT_MODE (and every other PIRGPU_* knob of the library) is read only when
     PIRGPU_ALLOW_ENV=1 is set as well -- a server's arithmetic flavour does not depend on stray environment variables."""

@@ -54,7 +54,7 @@ def _descriptor(isa, prefix):
 
 
 P = "_ZN6pirgpu5deg12"
-FOUR_WAVE = ["15ks_digit_kernelILi1ELb1ELb0E", "15ks_digit_kernelILi1ELb1ELb1E", "18ks_mac_intt_kernelILi1ELb1E",
+FOUR_WAVE = ["15ks_digit_kernelILi1ELb1ELb0ELb0E", "15ks_digit_kernelILi1ELb1ELb1ELb0E", "18ks_mac_intt_kernelILi1ELb1E",
              "21ks_mac_combine_kernelILi1ELb1ELb0ELb0E", "21ks_mac_combine_kernelILi1ELb1ELb1ELb1E",
              "18ks_last_ntt_kernelILi1ELb1ELb0E", "18ks_last_ntt_kernelILi1ELb1ELb1E", "16ntt_batch_kernelILi1ELb1E",
              "18tree_c0_ntt_kernelILi1ELb1E"]
@@ -105,13 +105,34 @@ P13 = "_ZN6pirgpu5deg13"
 
 @pytest.mark.parametrize("kernel", ["18ks_mac_intt_kernelILi1ELb0E", "21ks_mac_combine_kernelILi1ELb0ELb0ELb0E",
                                     "18ks_last_ntt_kernelILi1ELb0ELb0E", "18ks_last_ntt_kernelILi1ELb0ELb1E",
-                                    "15ks_digit_kernelILi1ELb0ELb0E"])
+                                    "15ks_digit_kernelILi1ELb0ELb0ELb0E"])
 def test_n8192_transform_kernels(isa13, kernel):
     vgprs, scratch = _descriptor(isa13, P13 + kernel)
     assert scratch == 0 and vgprs <= 128, (kernel, vgprs, scratch)
     if "digit" not in kernel:
         batches = _loop_load_batches(_function(isa13, P13 + kernel))
         assert batches and max(batches) >= 30, (kernel, batches)
+
+
+# N = 16384 (cfg 5: 48/49-bit moduli, wide fp64 flavour): 1024-thread workgroups, ONE per CU, 128 registers per wave
+P14 = "_ZN6pirgpu5deg14"
+
+
+@pytest.fixture(scope="module")
+def isa14(tmp_path_factory):
+    return _compile(tmp_path_factory, 14)
+
+
+@pytest.mark.parametrize("kernel,spill", [("15ks_digit_kernelILi2ELb0ELb0ELb0E", 0), ("16upper_ntt_kernelILi2ELb0E", 0),
+                                          ("18ks_mac_intt_kernelILi2ELb0E", 0), ("21ks_mac_combine_kernelILi2ELb0ELb0ELb0E", 0),
+                                          ("18ks_last_ntt_kernelILi2ELb0ELb0E", 0), ("16ntt_batch_kernelILi2ELb1E", 0),
+                                          # the looped forms (several transforms of one source per workgroup) hold the
+                                          # source across the transform: upper_ntt fits, ks_digit reloads 4 doubles of
+                                          # it per transform from scratch (32 of the 128 KiB it stores)
+                                          ("16upper_ntt_kernelILi2ELb1E", 0), ("15ks_digit_kernelILi2ELb0ELb0ELb1E", 48)])
+def test_n16384_transform_kernels(isa14, kernel, spill):
+    vgprs, scratch = _descriptor(isa14, P14 + kernel)
+    assert vgprs <= 128 and scratch <= spill, (kernel, vgprs, scratch)
 
 
 # ---- the database scan (scan_mfma.hip): register budgets of the two workgroup shapes ---------------------------------

@@ -290,9 +290,30 @@ __device__ __forceinline__ void fwd_stages(typename A::T (&x)[1 << R], const typ
   }
 }
 
+// The LDS exchange between two passes.  The threads that trade residues when a pass leaves window LB for the next
+// window (forward; the inverse runs the same exchanges the other way round) differ only in the bits [next window, LB)
+// of their index: with LB <= 6 they are lanes of ONE 64-wide wavefront, whose LDS instructions execute in order --
+// the exchange then needs no workgroup barrier, only the compiler kept from reordering it.  At N = 16384 that is two
+// of the three exchanges of a transform (windows 10 -> 6 -> 2 -> 0), at N = 4096 one of two (8 -> 4 -> 0): after the
+// first exchange the waves of a workgroup drift apart and overlap each other's LDS, twiddle and butterfly phases --
+// which matters most where a CU holds a single workgroup (N = 16384) and a barrier idles the whole CU.
+#ifndef PIRGPU_WAVE_LOCAL_EXCHANGE
+#define PIRGPU_WAVE_LOCAL_EXCHANGE 1
+#endif
+template <int WINDOW>
+__device__ __forceinline__ void exchange_sync() {
+  if constexpr (PIRGPU_WAVE_LOCAL_EXCHANGE != 0 && WINDOW <= 6) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
+}
+
 // Runs the pass whose twiddles are in Wcur on window LB (relative bits RHI..0), then the rest.
 // PF: load the next pass's twiddles before this pass's butterflies (hides their L2 latency, costs
-// 30-60 registers); without PF they are loaded at the start of their own pass.
+// 30-60 registers); without PF they are loaded between this pass's butterflies and the exchange.
 template <typename A, int LOGN, int LB, int RHI, bool PF, typename TP>
 __device__ __forceinline__ void fwd_chain(typename A::T (&x)[Plan<LOGN>::EPT], typename A::T* s, TP tw,
                                           const typename A::Mod& m, uint32_t tid,
@@ -307,9 +328,11 @@ __device__ __forceinline__ void fwd_chain(typename A::T (&x)[Plan<LOGN>::EPT], t
       __builtin_amdgcn_sched_barrier(0);
     }
     fwd_stages<A, R, RHI, 0>(x, Wcur, m);
-    lds_store_pass<LB, R>(s, x, tid);
-    __syncthreads();
+    // without PF the next pass's twiddles are requested here, once this pass's are dead: their latency hides under
+    // the exchange instead of following it
     if constexpr (!PF) load_twiddles<A, LOGN, NLB, NRHI, 0>(Wnext, tw, tid >> NLB);
+    lds_store_pass<LB, R>(s, x, tid);
+    exchange_sync<LB>();
     lds_load_pass<NLB, R>(s, x, tid);
     fwd_chain<A, LOGN, NLB, NRHI, PF>(x, s, tw, m, tid, Wnext);
   } else {
@@ -392,9 +415,9 @@ __device__ __forceinline__ void inv_chain(typename A::T (&x)[Plan<LOGN>::EPT], t
     inv_stages<A, R, RLO, false>(x, Wcur, ninv, iw1n, m);
 #pragma unroll
     for (int e = 0; e < Plan<LOGN>::EPT; ++e) x[e] = A::pass_norm(x[e], m);
-    lds_store_pass<LB, R>(s, x, tid);
-    __syncthreads();
     if constexpr (!PF) load_twiddles<A, LOGN, NLB, R - 1, NRLO>(Wnext, itw, tid >> NLB);
+    lds_store_pass<LB, R>(s, x, tid);
+    exchange_sync<NLB>();
     lds_load_pass<NLB, R>(s, x, tid);
     inv_chain<A, LOGN, NLB, NRLO, PF>(x, s, itw, ninv, iw1n, m, tid, Wnext);
   } else {

@@ -221,53 +221,73 @@ __global__ void tree_export_kernel(const DevParams* __restrict__ P, const double
 }
 
 // Split upper level, part 2 (see upper_ntt_kernel): products of the transformed plaintexts of one block of children
-// with both selector polynomials, summed over the block.  One thread per (query, row, cc, chunk e, target modulus,
-// slot i); both components share the plaintext load.  Sums are signed representatives kept as doubles in `acc`
-// between blocks; the last block writes canonical residues (u64) where reduce_splits_kernel would have.
-__global__ void upper_mac_kernel(const DevParams* __restrict__ P, const double* __restrict__ scratch, MfmaPtrs svq,
-                                 double* __restrict__ acc_all, uint64_t* __restrict__ out_all, uint32_t n_rows, uint32_t C,
-                                 uint32_t E, uint32_t sv_first, uint32_t b0, uint32_t blk, uint32_t n_dim, int first,
-                                 int last, uint64_t acc_qstride, uint64_t out_qstride) {
+// with both selector polynomials, summed over the block.  One thread per (query, row, cc, GROUP of EG Encode chunks,
+// target modulus, slot i): the two selector words of a child are loaded once and multiplied into the EG chunks'
+// transformed plaintexts (one thread per chunk re-read the selectors E times -- at cfg 5, E = 24, that was 17 x the
+// selectors' bytes from HBM and more than the transformed plaintexts themselves: 7.4 GB per launch against 3.3).
+// Sums are signed representatives kept as doubles in `acc` between blocks; the last block writes canonical residues
+// (u64) where reduce_splits_kernel would have.
+template <int EG>
+__global__ void __launch_bounds__(256)
+upper_mac_kernel(const DevParams* __restrict__ P, const double* __restrict__ scratch, MfmaPtrs svq,
+                 double* __restrict__ acc_all, uint64_t* __restrict__ out_all, uint32_t n_rows, uint32_t C,
+                 uint32_t E, uint32_t sv_first, uint32_t b0, uint32_t blk, uint32_t n_dim, int first,
+                 int last, uint64_t acc_qstride, uint64_t out_qstride) {
   const uint32_t N = P->N, k = P->k;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;   // slot
-  const uint32_t jt = blockIdx.y % k, e_idx = blockIdx.y / k;
+  const uint32_t jt = blockIdx.y % k, e0 = (blockIdx.y / k) * EG;
   const uint32_t cc = blockIdx.z % C, r = (blockIdx.z / C) % n_rows, qi = blockIdx.z / (C * n_rows);
   if (i >= N) return;
   const F64Mod m{P->tab[jt].qd, P->tab[jt].qinvd};
   const uint64_t* sv = reinterpret_cast<const uint64_t*>(svq.p[qi]);
-  const double* x = scratch + ((((size_t)qi * n_rows + r) * C + cc) * blk * E + e_idx) * k * N + (size_t)jt * N + i;
-  const size_t child_stride = (size_t)E * k * N;
-  double a0 = 0.0, a1 = 0.0;
+  const size_t chunk_stride = (size_t)k * N;                    // scratch is [child in block][chunk][target modulus][N]
+  const double* x = scratch + ((((size_t)qi * n_rows + r) * C + cc) * blk * E + e0) * chunk_stride + (size_t)jt * N + i;
+  const size_t child_stride = (size_t)E * chunk_stride;
+  double a0[EG], a1[EG];
+#pragma unroll
+  for (int g = 0; g < EG; ++g) a0[g] = a1[g] = 0.0;
   uint32_t since = 0;
-  for (uint32_t iib = 0; iib < blk; ++iib) {
-    const uint32_t ii = b0 + iib;
-    if (ii >= n_dim) break;
-    const double v = x[(size_t)iib * child_stride];
-    const uint64_t* s0 = sv + (((size_t)(sv_first + ii) * 2 + 0) * k + jt) * N + i;
-    a0 += f64_mulmod(v, f64_from_u64(s0[0]), m);
-    a1 += f64_mulmod(v, f64_from_u64(s0[(size_t)k * N]), m);
+  const uint32_t n_here = b0 < n_dim ? (n_dim - b0 < blk ? n_dim - b0 : blk) : 0;
+  for (uint32_t iib = 0; iib < n_here; ++iib) {
+    const uint64_t* s0 = sv + (((size_t)(sv_first + b0 + iib) * 2 + 0) * k + jt) * N + i;
+    const double w0 = f64_from_u64(s0[0]), w1 = f64_from_u64(s0[(size_t)k * N]);
+    double v[EG];
+#pragma unroll
+    for (int g = 0; g < EG; ++g) v[g] = x[(size_t)iib * child_stride + (size_t)g * chunk_stride];
+#pragma unroll
+    for (int g = 0; g < EG; ++g) {
+      a0[g] += f64_mulmod(v[g], w0, m);
+      a1[g] += f64_mulmod(v[g], w1, m);
+    }
     if (++since == 8) {
       since = 0;
-      a0 = f64_norm(a0, m);
-      a1 = f64_norm(a1, m);
+#pragma unroll
+      for (int g = 0; g < EG; ++g) {
+        a0[g] = f64_norm(a0[g], m);
+        a1[g] = f64_norm(a1[g], m);
+      }
     }
   }
-  const size_t slot = (((size_t)r * C + cc) * E + e_idx);
-  const size_t o0 = ((slot * 2 + 0) * k + jt) * N + i, o1 = ((slot * 2 + 1) * k + jt) * N + i;
   double* acc = acc_all + (size_t)qi * acc_qstride;
-  if (!first) {
-    a0 += acc[o0];
-    a1 += acc[o1];
-  }
-  a0 = f64_norm(a0, m);
-  a1 = f64_norm(a1, m);
-  if (last) {
-    uint64_t* out = out_all + (size_t)qi * out_qstride;
-    out[o0] = f64_to_u64(f64_canon(a0, m));
-    out[o1] = f64_to_u64(f64_canon(a1, m));
-  } else {
-    acc[o0] = a0;
-    acc[o1] = a1;
+  uint64_t* out = out_all + (size_t)qi * out_qstride;
+#pragma unroll
+  for (int g = 0; g < EG; ++g) {
+    const size_t slot = (((size_t)r * C + cc) * E + e0 + g);
+    const size_t o0 = ((slot * 2 + 0) * k + jt) * N + i, o1 = ((slot * 2 + 1) * k + jt) * N + i;
+    double s0 = a0[g], s1 = a1[g];
+    if (!first) {
+      s0 += acc[o0];
+      s1 += acc[o1];
+    }
+    s0 = f64_norm(s0, m);
+    s1 = f64_norm(s1, m);
+    if (last) {
+      out[o0] = f64_to_u64(f64_canon(s0, m));
+      out[o1] = f64_to_u64(f64_canon(s1, m));
+    } else {
+      acc[o0] = s0;
+      acc[o1] = s1;
+    }
   }
 }
 
@@ -873,10 +893,28 @@ hipError_t launch_upper_mac(hipStream_t st, const DevParams* P, const uint64_t* 
                             uint64_t* acc, uint64_t* out, uint32_t n_queries, uint32_t n_rows, uint32_t C,
                             uint32_t enc_count, uint32_t k, uint32_t N, uint32_t sv_first, uint32_t b0, uint32_t blk,
                             uint32_t n_dim, bool first, bool last, uint64_t acc_qstride, uint64_t out_qstride) {
-  const dim3 grid((N + 255) / 256, enc_count * k, n_queries * n_rows * C);
-  hipLaunchKernelGGL(upper_mac_kernel, grid, dim3(256), 0, st, P, reinterpret_cast<const double*>(scratch), svq,
-                     reinterpret_cast<double*>(acc), out, n_rows, C, enc_count, sv_first, b0, blk, n_dim, first ? 1 : 0,
-                     last ? 1 : 0, acc_qstride, out_qstride);
+  // Encode chunks per thread: the largest divisor of E up to 12 (E = 2 * ExpansionRatio: 8 at cfg 3, 24 at cfg 5)
+  uint32_t eg = 1;
+  for (uint32_t c : {12u, 8u, 6u, 4u, 3u, 2u})
+    if (enc_count % c == 0) {
+      eg = c;
+      break;
+    }
+  const dim3 grid((N + 255) / 256, enc_count / eg * k, n_queries * n_rows * C);
+#define PIRGPU_UPPER_MAC(EG_)                                                                                          \
+  hipLaunchKernelGGL(upper_mac_kernel<EG_>, grid, dim3(256), 0, st, P, reinterpret_cast<const double*>(scratch), svq, \
+                     reinterpret_cast<double*>(acc), out, n_rows, C, enc_count, sv_first, b0, blk, n_dim, first ? 1 : 0, \
+                     last ? 1 : 0, acc_qstride, out_qstride)
+  switch (eg) {
+    case 12: PIRGPU_UPPER_MAC(12); break;
+    case 8: PIRGPU_UPPER_MAC(8); break;
+    case 6: PIRGPU_UPPER_MAC(6); break;
+    case 4: PIRGPU_UPPER_MAC(4); break;
+    case 3: PIRGPU_UPPER_MAC(3); break;
+    case 2: PIRGPU_UPPER_MAC(2); break;
+    default: PIRGPU_UPPER_MAC(1); break;
+  }
+#undef PIRGPU_UPPER_MAC
   PIRGPU_LAUNCH_CHECK();
   return hipSuccess;
 }

@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(NT) probe(double* __restrict__ acc, const doub
       for (int e = 0; e < EPT; ++e) {
         const double v = __builtin_trunc(x[e]) * s0[p * N + e * NT + threadIdx.x];
         if (MODE == 0) unsafeAtomicAdd(a0 + p * N + e * NT + threadIdx.x, v);
-        else if (MODE == 1) a0[((size_t)blockIdx.x * rep + r) % 4096 * 2 * N + p * N + e * NT + threadIdx.x] = v;
+        else if (MODE == 1) acc[(((size_t)blockIdx.x * rep + r) % 4096) * 2 * N + p * N + e * NT + threadIdx.x] = v;
         else if (v == 1.2345) a0[0] = v;
       }
   }

@@ -246,10 +246,10 @@ struct pirgpu_ctx {
   bool split_upper = false;                 // upper level as transform-to-scratch + elementwise MAC (N >= 16384 in the fp64
                                             // flavours, where the fused kernel spills; PIRGPU_SPLIT_UPPER=0/1 overrides)
   uint64_t split_upper_words = (3ull << 30) / 8;  // scratch budget per lane / worker (PIRGPU_SPLIT_UPPER_MB)
-  // rings that fill a CU with ONE workgroup (N >= 16384): the transform kernels of the wide expansion levels and of the
-  // split upper level run several transforms of one source per workgroup, so that stores drain under the next
-  // transform (option LOOP_TRANSFORMS)
-  bool loop_transforms = false;
+  // the digit kernel of the wide expansion levels and the transform kernel of the split upper level run all transforms
+  // of one source polynomial in ONE workgroup: one load and one permutation per source, stores drain under the next
+  // transform (option LOOP_TRANSFORMS; fp64 flavours)
+  bool loop_transforms = true;
   uint32_t fuse_mac_nodes = 128;            // ... from this many tree ciphertexts per level on (narrower levels are latency-
                                             // bound: two dependent transform kernels cost more than mac + light combine)
   bool fuse_mac_combine = true;             // levels below the last: combine step in the data residues' MAC + inverse-NTT
@@ -581,7 +581,7 @@ void ensure_workspace(pirgpu_ctx* c) {
     c->head_mode = std::min<uint32_t>(env_u32("PIRGPU_HEAD_MODE", c->head_mode), 2);
     c->split_upper = env_u32("PIRGPU_SPLIT_UPPER", c->logN >= 14 ? 1 : 0) != 0 && c->mode != kNttInt;
     c->split_upper_words = (uint64_t)env_u32("PIRGPU_SPLIT_UPPER_MB", 3072) * (1ull << 20) / 8;
-    c->loop_transforms = env_u32("PIRGPU_LOOP_TRANSFORMS", c->logN >= 14 ? 1 : 0) != 0 && c->mode != kNttInt;
+    c->loop_transforms = env_u32("PIRGPU_LOOP_TRANSFORMS", 1) != 0 && c->mode != kNttInt;
     c->pack40 = env_u32("PIRGPU_PACK40", 1) != 0;
     // 5-byte storage of the key-switch intermediates: the fp64 flavours store x + q (|x| <= q), so q < 2^39
     for (uint32_t j = 0; j <= k; ++j) c->pack40 = c->pack40 && (c->hp.mod[j].q >> 39) == 0;

@@ -932,24 +932,10 @@ void serve(pirgpu_ctx* ctx, Combiner& cb, int first_set, Job* const* jobs, size_
     win[slot] = Window();
     return slot;
   };
-  // A call that would fit ONE window, alone on the context (the other batch set is free right now): two half windows
-  // instead, so that the second is parsed into pinned memory and uploaded under the first's GPU work and the first's
-  // replies come down and are serialised under the second's -- a lone caller's call used to fill and drain the
-  // pipeline by itself (13.7 ms per 64 requests against 12.0 with two callers).  Under load the other set is taken and
-  // nothing changes.
-  size_t window_cap = kMaxRequestBatch;
-  {
-    const char* e = pirgpu_env("PIRGPU_WIRE_SPLIT");
-    const bool split = !e || atoi(e) != 0;
-    if (split && may_overlap && total_queries >= 32 && total_queries <= kMaxRequestBatch) {
-      std::lock_guard<std::mutex> lk(cb.m);
-      const int got = cb.take_set();
-      if (got >= 0) {
-        sets[1] = got;
-        window_cap = ((total_queries + 1) / 2 + 7) / 8 * 8;   // whole groups of 8 queries
-      }
-    }
-  }
+  // (Round 4 tried cutting a lone call that fits one window into two half windows in flight together: no gain for a
+  // lone caller -- windows of 32 run the GPU less efficiently than they overlap -- and 5 % lost with two callers, whose
+  // calls then grab both batch sets from each other.  One window per <= 64 queries it stays.)
+  const size_t window_cap = kMaxRequestBatch;
   size_t ji = 0;        // next request
   uint32_t qi = 0;      // its next query
   while (ji < n) {

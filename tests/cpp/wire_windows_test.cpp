@@ -764,31 +764,6 @@ int main() {
     printf("(f) 8 threads, 12 clients on 4 slots OK (%llu windows, %llu evictions, %llu in flight at most)\n",
            (unsigned long long)ctx.windows.load(), (unsigned long long)ctx.evictions, (unsigned long long)ctx.max_in_flight.load());
   }
-  {  // (h) a lone call that would fit one window is served as two half windows in flight together (whole groups of 8);
-     // a call below 32 queries stays one window; a request of 40 queries is cut 24 + 16
-    pirgpu_ctx ctx;
-    ctx.delay_us = 40000;   // slow enough that the second half is queued while the first runs, under a sanitizer too
-    std::vector<const Client*> cl;
-    std::vector<std::vector<std::vector<uint64_t>>> qs;
-    for (uint32_t i = 0; i < 44; ++i) {
-      cl.push_back(&clients[i % 12]);
-      qs.push_back({make_query(20000 + i)});
-    }
-    many_requests(&ctx, cl, qs);
-    CHECK(ctx.windows == 2 && ctx.max_in_flight == 2);
-    no_pins_left(&ctx);
-    const uint64_t before = ctx.windows;
-    cl.resize(20);
-    qs.resize(20);
-    many_requests(&ctx, cl, qs);
-    CHECK(ctx.windows == before + 1);
-    std::vector<std::vector<uint64_t>> q;
-    for (uint32_t i = 0; i < 40; ++i) q.push_back(make_query(21000 + i));
-    one_request(&ctx, clients[5], q);
-    CHECK(ctx.windows == before + 3);
-    no_pins_left(&ctx);
-    printf("(h) lone call split into two half windows OK\n");
-  }
   {  // (g) capacity 1: one window in flight, one client per window
     pirgpu_ctx ctx;
     ctx.cap = 1;

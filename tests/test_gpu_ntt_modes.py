@@ -126,22 +126,24 @@ def test_expansion_fallback_paths(monkeypatch, knob):
     db.close()
 
 
-@pytest.mark.parametrize("chain,items,off", [("n4096_36bit", 12000, None), ("n4096_36bit", 12000, "PIRGPU_TREE40"),
-                                             ("n4096_36bit", 12000, "PIRGPU_PACK40"), ("n8192_44bit", 24000, None),
-                                             ("n16384_49bit", 49000, None)])
-def test_looped_transforms_match_the_oracle(monkeypatch, chain, items, off):
-    """LOOP_TRANSFORMS (the N = 16384 default; forced on for the smaller rings here): at the wide expansion levels one
-    workgroup runs the k + 1 digit transforms of a source polynomial, and at the split upper level all chunks x target
-    moduli of a child's source polynomial, instead of one transform per workgroup.  More than 32 leaves and a full group
-    of 8 queries reach the wide levels (>= 256 tree ciphertexts per launch); every storage form of the digits (5-byte
-    tree and digits, 5-byte digits only, doubles) must give the oracle's reply, single and batched."""
+@pytest.mark.parametrize("chain,items,off,d", [("n4096_36bit", 45000, None, 2), ("n4096_36bit", 45000, "PIRGPU_TREE40", 2),
+                                               ("n4096_36bit", 45000, "PIRGPU_PACK40", 2), ("n8192_44bit", 95000, None, 2),
+                                               ("n16384_49bit", 49000, None, 2), ("n4096_36bit", 1400, None, 3),
+                                               ("n16384_49bit", 5000, None, 3)])
+def test_looped_transforms_match_the_oracle(monkeypatch, chain, items, off, d):
+    """LOOP_TRANSFORMS (the default of the fp64 flavours): at the wide expansion levels -- from 1024 (tree ciphertext,
+    digit) pairs per launch on -- one workgroup runs the k + 1 digit transforms of a source polynomial, and at the split
+    upper level (the N = 16384 default, forced on for the smaller rings here) all chunks x target moduli of a child's
+    source polynomial, instead of one transform per workgroup.  A full group of 8 queries with more than 64 leaves
+    (32 at k = 4) reaches those levels; every storage form of the digits (5-byte tree and digits, 5-byte digits only,
+    doubles) must give the oracle's reply, single and batched; d = 3 runs two split upper levels."""
     N, moduli, _ = CHAINS[chain]
     monkeypatch.setenv("PIRGPU_LOOP_TRANSFORMS", "1")
     monkeypatch.setenv("PIRGPU_SPLIT_UPPER", "1")
     if off:
         monkeypatch.setenv(off, "0")
-    s = PirSetup(items, 288, 2, N=N, plain_bits=24, moduli=moduli)
-    assert sum(s.params.dimensions) > 32, s.params.dimensions
+    s = PirSetup(items, 288, d, N=N, plain_bits=24, moduli=moduli)
+    assert d == 3 or sum(s.params.dimensions) > (32 if N == 16384 else 64), s.params.dimensions
     db, srv = _server(s)
     rng = np.random.default_rng(5)
     keys = {(N >> j) + 1: random_key(s.orc, rng) for j in range(N.bit_length() - 1)}

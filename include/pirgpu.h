@@ -366,8 +366,9 @@ uint64_t pirgpu_scan_bytes(const pirgpu_ctx* ctx);
 int pirgpu_scan_info(pirgpu_ctx* ctx, uint32_t info[8]);
 /* Options by name (case-insensitive), e.g. "scan_mfma" (0 keeps the 64-bit multiply-accumulate scan for d >= 2),
  * "scan_mfma_wide" (0 / 1 forces the 8-wave / 4-wave scan kernel), "lanes", "upper_blocks", "fuse_last", "last_ntt",
- * "tree40", "sel_f64", "split_upper", "scan_mfma_wgs_batch" (workgroups of a database pass that shares the chip with
- * another group) -- DESIGN.md section 6 lists them.  A name that was not set falls back to the environment variable
+ * "tree40", "sel_f64", "split_upper", "loop_transforms" (0: one transform per workgroup everywhere),
+ * "scan_mfma_wgs_batch" (workgroups of a database pass that shares the chip with another group) -- DESIGN.md section 6
+ * lists them.  A name that was not set falls back to the environment variable
  * PIRGPU_<NAME> (the A/B scripts under tools/ use that), then to the built-in default; get_option returns -1 for
  * "built-in default".  Options that shape the workspace must be set before the context is first used
  * (FailedPrecondition afterwards).  The arithmetic flavour (PIRGPU_NTT_MODE) is fixed at pirgpu_create.

@@ -1,11 +1,11 @@
 // ntt_core.h -- register-resident negacyclic NTT for one workgroup per polynomial.
 //
 // One workgroup of N/EPT threads transforms one polynomial; every thread keeps EPT = 2^R
-// residues in registers and runs up to R butterfly stages per pass: EPT = 16 (R = 4) up to
-// N = 8192 -- a 4096-point transform is 3 register passes with 2 LDS exchanges -- and
-// EPT = 32 (R = 5) at N = 16384 (round 4): 512 threads instead of 1024, so a workgroup's waves
-// get 256 VGPRs each instead of 128 (twiddle prefetch and the fused kernels fit again), and
-// 14 = 5 + 5 + 4 stages are 3 passes with 2 exchanges instead of 4 with 3.  A pass with
+// residues in registers and runs up to R butterfly stages per pass: EPT = 16 (R = 4) for every
+// degree -- a 4096-point transform is 3 register passes with 2 LDS exchanges, a 16384-point
+// one 4 passes with 3 exchanges in a 1024-thread workgroup.  The code is written for any R:
+// EPT = 32 (R = 5) at N = 16384 -- 512 threads whose waves get 256 VGPRs, 14 = 5 + 5 + 4 stages
+// in 3 passes -- was built and measured 7 % slower (device_params.h, ntt_log_ept).  A pass with
 // window LB owns, per thread, the EPT residues
 //     idx = (outer << (LB+R)) | (e << LB) | inner,      tid = (outer << LB) | inner.
 //

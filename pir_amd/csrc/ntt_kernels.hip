@@ -38,11 +38,12 @@ constexpr int LOGN = PIRGPU_LOGN;
 constexpr int NT = Plan<LOGN>::NT;
 constexpr int N = Plan<LOGN>::N;
 constexpr int R_ = Plan<LOGN>::R;        // butterfly stages per register pass
-constexpr int EPT = Plan<LOGN>::EPT;     // residues per thread: 16, or 32 at N = 16384 (512-thread workgroups, 256 VGPRs)
+constexpr int EPT = Plan<LOGN>::EPT;     // residues per thread: 16 (32 at N = 16384 with -DPIRGPU_LOG_EPT14=5, device_params.h)
 constexpr size_t kLdsBytes = (size_t)Plan<LOGN>::LDS_WORDS * 8;
-// twiddle prefetch one pass ahead costs 30 (EPT = 16) / 62 (EPT = 32) VGPRs.  Round 4: N = 16384 runs 32 residues per
-// thread in 512-thread workgroups, whose waves have 256 VGPRs -- the prefetch is on for every degree again (rounds 1-3:
-// 1024-thread workgroups under a 128-VGPR cap, prefetch off, four passes instead of three)
+// twiddle prefetch one pass ahead costs 30 (EPT = 16) / 62 (EPT = 32) VGPRs: on up to N = 8192; the 1024-thread
+// workgroups of N = 16384 have 128 VGPRs per wave and request a pass's twiddles between the previous pass's butterflies
+// and the exchange instead (ntt_core.h).  (The 32-residue organisation of N = 16384 -- 512 threads, 256 VGPRs -- has the
+// room; PIRGPU_PF14 = 0 switches the prefetch off there for the A/B of tools/r04_ab_ept.sh.)
 #ifndef PIRGPU_PF14
 #define PIRGPU_PF14 1
 #endif

@@ -129,6 +129,8 @@ def test_expansion_fallback_paths(monkeypatch, knob):
 @pytest.mark.parametrize("chain,items,off,d", [("n4096_36bit", 45000, None, 2), ("n4096_36bit", 45000, "PIRGPU_TREE40", 2),
                                                ("n4096_36bit", 45000, "PIRGPU_PACK40", 2), ("n8192_44bit", 95000, None, 2),
                                                ("n16384_49bit", 49000, None, 2), ("n4096_36bit", 1400, None, 3),
+                                               ("n4096_36bit", 45000, "PIRGPU_LOOP_TRANSFORMS", 2),   # the one-transform-per-workgroup forms at the same sizes
+                                               ("n16384_49bit", 49000, "PIRGPU_LOOP_TRANSFORMS", 2),
                                                ("n16384_49bit", 5000, None, 3)])
 def test_looped_transforms_match_the_oracle(monkeypatch, chain, items, off, d):
     """LOOP_TRANSFORMS (the default of the fp64 flavours): at the wide expansion levels -- from 1024 (tree ciphertext,

@@ -48,6 +48,20 @@ constexpr size_t kLdsBytes = (size_t)Plan<LOGN>::LDS_WORDS * 8;
 #define PIRGPU_PF14 1
 #endif
 constexpr bool kPF = LOGN < 14 || (EPT == 32 && PIRGPU_PF14 != 0);   // 1024-thread workgroups (EPT = 16 at N = 16384): 128 VGPRs, no room
+// the looped kernels (several transforms of one source per workgroup) hold the source across the transform: with the
+// prefetch they need 138-142 VGPRs at N <= 8192 -- three waves per SIMD instead of four.  Capping them at 128 with the
+// twiddles loaded between the previous pass's butterflies and the exchange instead (-DPIRGPU_PF_LOOP=0) was measured
+// on one box, three alternating runs: cfg 3 5 331 / 5 350 / 5 405 against 5 376 / 5 431 / 5 442 queries/s with the
+// prefetch, cfg 4 445 against 447 -- the prefetch at three waves wins (tools/r04_ab_loopregs.sh).
+#ifndef PIRGPU_PF_LOOP
+#define PIRGPU_PF_LOOP 1
+#endif
+constexpr bool kPFLoop = kPF && (EPT == 32 || PIRGPU_PF_LOOP != 0);
+#if PIRGPU_PF_LOOP
+#define PIRGPU_FOUR_WAVES
+#else
+#define PIRGPU_FOUR_WAVES __attribute__((amdgpu_waves_per_eu(4)))
+#endif
 // upper_fused_kernel with the twiddle table in LDS (exchange buffer + N doubles of LDS per workgroup, ~245 VGPRs).
 // N = 8192 spills there (four passes, more temporaries: 256 VGPRs + 76 bytes of scratch, cfg 4 363 -> 352 queries/s)
 // and N = 16384 runs the split upper level anyway.
@@ -318,7 +332,7 @@ tree_c0_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
 // at N = 16384 one polynomial of doubles fills the LDS, a CU holds ONE workgroup, and without the loop its load,
 // transform and store phases run strictly one after the other (cfg 5).
 template <int MODE, bool P40, bool T40 = false, bool LOOPI = false>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT) PIRGPU_FOUR_WAVES   // 128 VGPRs: four waves per SIMD (the looped form would take 131-138)
 ks_digit_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ res_in, uint32_t galois_elt,
                 uint64_t* __restrict__ dig, uint64_t* __restrict__ c0_out, uint32_t digit_blocks) {
   using A = Arith<MODE>;
@@ -370,10 +384,10 @@ ks_digit_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ re
       uint32_t tl = tid;
       asm volatile("" : "+v"(tl));
       if constexpr (P40) {
-        ntt_forward<MODE, LOGN, kPF, /*CANON=*/false>(x, smem_raw, P, I, tl);
+        ntt_forward<MODE, LOGN, kPFLoop, /*CANON=*/false>(x, smem_raw, P, I, tl);
         store40f(reinterpret_cast<uint8_t*>(dig) + poly * kPoly40, tl, x, f64_pack_magic(m.q));
       } else {
-        ntt_forward<MODE, LOGN, kPF>(x, smem_raw, P, I, tl);
+        ntt_forward<MODE, LOGN, kPFLoop>(x, smem_raw, P, I, tl);
         double* out = reinterpret_cast<double*>(dig) + poly * N;
 #pragma unroll
         for (int e = 0; e < EPT; ++e) out[e * NT + tl] = x[e];
@@ -1116,7 +1130,7 @@ upper_fused_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
 // one drains under the next (see ks_digit_kernel, LOOPI: the overlap a ring with one workgroup per CU does not get
 // from neighbouring workgroups).
 template <int MODE, bool LOOP = false>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT) PIRGPU_FOUR_WAVES
 upper_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ src_all, double* __restrict__ scratch,
                  uint32_t n_rows, uint32_t n_dim, uint32_t n_children_total, uint32_t C, uint32_t b0, uint32_t blk,
                  uint64_t src_qstride) {
@@ -1196,7 +1210,7 @@ upper_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ s
       first = false;
       uint32_t tl = tid;
       if constexpr (LOOP) asm volatile("" : "+v"(tl));   // see ks_digit_kernel, LOOPI: no address hoisting across the loop
-      ntt_forward<MODE, LOGN, kPF, /*CANON=*/false>(x, smem_raw, P, jt, tl);
+      ntt_forward<MODE, LOGN, LOOP ? kPFLoop : kPF, /*CANON=*/false>(x, smem_raw, P, jt, tl);
       double* out = out0 + ((size_t)e_idx * k + jt) * N;
 #pragma unroll
       for (int e = 0; e < EPT; ++e) out[e * NT + tl] = x[e];

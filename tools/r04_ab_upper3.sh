@@ -1,6 +1,8 @@
 #!/bin/bash
 # upper_fused at three waves per SIMD (plain variant, registers capped at 168, 96 workgroups per query) against the
-# shipped LDS-twiddle variant at two waves per SIMD; library rebuilt per variant
+# shipped LDS-twiddle variant at two waves per SIMD; library rebuilt per variant.  The capped build needs one line that
+# is NOT in the tree (the experiment lost): `#ifdef PIRGPU_UPPER_WAVES` ->
+# `__attribute__((amdgpu_waves_per_eu(PIRGPU_UPPER_WAVES)))` on upper_fused_kernel in ntt_kernels.hip.
 export PIRGPU_ALLOW_ENV=1
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r4y; mkdir -p $O

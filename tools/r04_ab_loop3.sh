@@ -1,4 +1,6 @@
 #!/bin/bash
+# three alternating same-box runs: LOOP_TRANSFORMS off / on at cfg 3 and cfg 4; and the split upper level taking its
+# children in NTT form (PIRGPU_UPPER_SRC_NTT -- that option lost and is no longer in the tree)
 export PIRGPU_ALLOW_ENV=1
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r4s; mkdir -p $O

@@ -585,6 +585,41 @@ def main():
                                                                    "(the reference client's default) for the seeded figures"}
             except Exception as e:   # measurement extra only
                 out["wire_process_request_ms"] = {"error": repr(e)}
+            # the reference's OTHER three benchmarks at this size (benchmark.cpp:56-69, 81-95): SetupDb on the device,
+            # ClientCreateRequest / ClientProcessResponse on the host with the product client library
+            try:
+                idx = 123457 % pp.num_items
+                t_req, t_rsp = [], []
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    r1 = cl.CreateRequest([idx])
+                    t_req.append((time.perf_counter() - t0) * 1e3)
+                rsp1 = srv.ProcessRequest(r1)
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    items = cl.ProcessResponse([idx], rsp1)
+                    t_rsp.append((time.perf_counter() - t0) * 1e3)
+                t_db = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    db2 = pir_amd.PIRDatabase.Create(pp, device=local_rank)
+                    db2.populate(raw)
+                    db2.finalize(release_staging=True)
+                    db2.lib.pirgpu_sync(db2.handle)
+                    t_db.append((time.perf_counter() - t0) * 1e3)
+                    db2.close()
+                out["reference_benchmarks_ms"] = {
+                    "SetupDb": round(float(np.median(t_db)), 2),
+                    "ClientCreateRequest": round(float(np.median(t_req)), 3),
+                    "ServerProcessRequest": out["wire_process_request_ms"].get("repeat_seeded_keys_median_of_12"),
+                    "ClientProcessResponse": round(float(np.median(t_rsp)), 3),
+                    "item_recovered": bool(items[0] == raw[idx].tobytes()),
+                    "note": "benchmark.cpp's four cases at THIS configuration (the reference registers them for 2^8..2^16 "
+                            "items, QUERIES_PER_REQUEST = 1): SetupDb = PIRDatabase::Create + populate from host bytes "
+                            "(H2D, encode, NTT, operand layout) on the GPU; the two Client cases run on the host in "
+                            "libpirclient.so (single thread); ServerProcessRequest = the seeded-keys request above"}
+            except Exception as e:   # measurement extra only
+                out["reference_benchmarks_ms"] = {"error": repr(e)}
         if world == 1 and not use_dist and args.config == 3 and not skip_wire:
             # several CLIENTS at once (the reference's keys are per request, server.cpp:46-48): `batch` clients with
             # different Galois keys, one query each, through the same batch pipeline -- every group of 8 holds 8

@@ -250,6 +250,7 @@ struct pirgpu_ctx {
   // of one source polynomial in ONE workgroup: one load and one permutation per source, stores drain under the next
   // transform (option LOOP_TRANSFORMS; fp64 flavours)
   bool loop_transforms = true;
+  uint32_t loop_min_sources = 1024;         // ... from this many (tree ciphertext, digit) sources per launch on (option LOOP_MIN_SOURCES)
   uint32_t fuse_mac_nodes = 128;            // ... from this many tree ciphertexts per level on (narrower levels are latency-
                                             // bound: two dependent transform kernels cost more than mac + light combine)
   bool fuse_mac_combine = true;             // levels below the last: combine step in the data residues' MAC + inverse-NTT
@@ -582,6 +583,7 @@ void ensure_workspace(pirgpu_ctx* c) {
     c->split_upper = env_u32("PIRGPU_SPLIT_UPPER", c->logN >= 14 ? 1 : 0) != 0 && c->mode != kNttInt;
     c->split_upper_words = (uint64_t)env_u32("PIRGPU_SPLIT_UPPER_MB", 3072) * (1ull << 20) / 8;
     c->loop_transforms = env_u32("PIRGPU_LOOP_TRANSFORMS", 1) != 0 && c->mode != kNttInt;
+    c->loop_min_sources = env_u32("PIRGPU_LOOP_MIN_SOURCES", c->loop_min_sources);
     c->pack40 = env_u32("PIRGPU_PACK40", 1) != 0;
     // 5-byte storage of the key-switch intermediates: the fp64 flavours store x + q (|x| <= q), so q < 2^39
     for (uint32_t j = 0; j <= k; ++j) c->pack40 = c->pack40 && (c->hp.mod[j].q >> 39) == 0;
@@ -780,7 +782,7 @@ uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* 
     const bool c0_in_digit = last_ntt && ks_digit_takes_c0(nodes);
     if (cur40 && c0_in_digit != last_ntt) throw Fail{PIRGPU_INTERNAL, "5-byte tree reached a level that cannot read it"};
     HIP_TRY(c->ops->ks_digit(st, c->mode, c->dp, k, cur, g, nodes, dig, c->pack40, c0_in_digit ? prod : nullptr, cur40,
-                             c->loop_transforms));
+                             c->loop_transforms && (uint64_t)nodes * k >= c->loop_min_sources));
     // (a group of B queries reaches the width at which the fused form pays one level earlier than a single query:
     // measured +0.6 % batched with the threshold at 64 tree ciphertexts, while a single query loses latency below 128)
     const uint32_t fuse_from = B > 1 ? std::max<uint32_t>(c->fuse_mac_nodes / 2, 1) : c->fuse_mac_nodes;
@@ -1256,7 +1258,7 @@ static const struct { const char* name; bool early; } kOptions[] = {
     {"SCAN_MQ_SINGLE_LIMB", true}, {"SCAN_ROWS", true}, {"SCAN_BLOCK", true}, {"SCAN_NSPLIT", true},
     {"FUSE_LAST", true}, {"FUSE_MAC_COMBINE", true}, {"LAST_NTT", true}, {"SEL_F64", true}, {"TREE40", true},
     {"FUSE_MAC_NODES", true}, {"SPLIT_UPPER", true}, {"SPLIT_UPPER_MB", true}, {"PACK40", true},
-    {"SCAN_MFMA", true}, {"SCAN_MFMA_WIDE", true}, {"SCAN_MFMA_TOP4", true}, {"SCAN_MFMA_NQ", true}, {"SCAN_MFMA_SINGLE", true}, {"LANES", true}, {"HEAD_LEVELS", true}, {"HEAD_MODE", true}, {"SCAN_F64_FOLD", true}, {"LOOP_TRANSFORMS", true},
+    {"SCAN_MFMA", true}, {"SCAN_MFMA_WIDE", true}, {"SCAN_MFMA_TOP4", true}, {"SCAN_MFMA_NQ", true}, {"SCAN_MFMA_SINGLE", true}, {"LANES", true}, {"HEAD_LEVELS", true}, {"HEAD_MODE", true}, {"SCAN_F64_FOLD", true}, {"LOOP_TRANSFORMS", true}, {"LOOP_MIN_SOURCES", true},
 };
 
 int pirgpu_set_option(pirgpu_ctx* c, const char* name, int64_t value) {

@@ -1329,9 +1329,9 @@ static hipError_t op_ks_digit(hipStream_t st, int mode, const DevParams* P, uint
   const bool wide = ks_digit_takes_c0(nodes);
   if (c0_out && (!wide || mode == kNttInt)) return hipErrorInvalidValue;
   if (tree40 && (!pack40 || mode == kNttInt)) return hipErrorInvalidValue;
-  // ... from 4 workgroups per CU on: below that (a lone query's last levels at k = 2) the k + 1 transforms of a source
-  // in parallel finish sooner than in a row
-  if (loop_targets && wide && mode != kNttInt && nodes * k >= 1024) {
+  // (the caller asks for it from ~4 workgroups per CU on: below that -- a lone query's last levels at k = 2 -- the
+  // k + 1 transforms of a source in parallel finish sooner than in a row; ctx.hip, loop_min_sources)
+  if (loop_targets && wide && mode != kNttInt) {
     // one workgroup per source polynomial, the k + 1 target moduli in a loop (ks_digit_kernel, LOOPI)
     const uint32_t digit_blocks = nodes * k;
     const dim3 grid(digit_blocks + (c0_out ? nodes * k : 0));

@@ -261,13 +261,16 @@ def main():
                          "north-star mode and always the headline `value`; 'queries' = every GPU holds the whole "
                          "database and serves its own share of the batch (replicas, no data-path collective); "
                          "'both' (default) = time rows for `value` and replicas as the named extra `replicas_reference`")
-    ap.add_argument("--exchange", choices=["auto", "packed", "u64", "replicated"],
+    ap.add_argument("--exchange", choices=["auto", "packed", "u64", "replicated", "slots"],
                     default=os.environ.get("PIRGPU_EXCHANGE", "auto"),
                     help="rows mode: what is exchanged per query -- packed = column selectors in the scan's operand "
                          "layout (all-gather) + each rank's own row selectors (all-to-all); u64 = whole NTT-form "
                          "selection vectors (all-gather); replicated = nothing: every rank expands every query itself "
-                         "and only the partial replies are reduced; auto = with several GPUs, replicated and packed are both run for a few "
-                         "steps on this machine's links and the faster one is timed (`exchange_autotune` in the line; "
+                         "and only the partial replies are reduced; slots = the database is sharded by NTT SLOT instead of by "
+                         "row (every rank holds 1/N of the slots of every plaintext): all-to-all of each query's packed "
+                         "column selectors' slot slices, all-to-all of the row sums back to the query's owner, no reduce; "
+                         "auto = with several GPUs, replicated, packed and slots are all run for the full W + K "
+                         "steps on this machine's links and the fastest one is the headline (`exchange_autotune` in the line; "
                          "PIRGPU_EXCHANGE_AUTOTUNE=0: replicated at 2 GPUs -- one xGMI link --, packed beyond); u64 when a "
                          "shard cannot take the packed path (d != 2, no MFMA scan)")
     ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5],
@@ -437,6 +440,12 @@ def main():
             pass
         if world == 1:
             parallelism = "single GPU" + (" (collective code path forced with one rank)" if use_dist else "")
+        elif exchange == "slots":
+            parallelism = ("database slot-sharded over %d GPUs (every rank holds 1/%d of the NTT slots of every plaintext, "
+                           "dyadic base case of database.cpp:185-194); every rank expands %d of the %d queries of a step; "
+                           "all-to-all of the packed column selectors' slot slices, scan of all rows on the rank's slots, "
+                           "all-to-all of the row sums back to the query's owner, upper level there (RCCL; no reduce)"
+                           % (world, world, per_rank, batch))
         else:
             parallelism = ("database row-sharded over %d GPUs; every rank expands %d of the %d queries of a step; "
                            % (world, batch if exchange == "replicated" else per_rank, batch)) + \
@@ -517,6 +526,9 @@ def main():
         out.update(out_extra)
         if forced_check is not None:
             out["forced_dist_replies_equal_plain"] = forced_check
+        if use_dist and exchange == "slots" and slots_details:
+            out["exchange_bytes_received_per_query_per_gpu"] = slots_details["exchange_bytes_received_per_query_per_gpu"]
+            out["slots_step"] = slots_details
         if use_dist and bufs is not None and exchange == "packed":
             out["exchange_bytes_received_per_query_per_gpu"] = bufs.exchange_bytes_per_query(world)
             out["rows_step"] = {"pipelined": pipe is not None,
@@ -858,7 +870,59 @@ def main():
         pipes.clear()
         return el
 
-    if use_dist and autotune:
+    slots_details = None
+    slots_replies = [None]
+
+    def measure_slots():
+        """The slot-sharded step: its own context (this rank's 1 / world of the NTT slots of every plaintext), the
+        synchronous form for serial phase times, the pipelined form for the contract's W + K steps."""
+        nonlocal slots_details
+        cuts = D.slot_cuts(k * N, world)
+        sdb = pir_amd.PIRDatabase.Create(pp, device=local_rank, slots=(cuts[rank], cuts[rank + 1]) if world > 1 else None)
+        try:
+            sdb.populate(raw)
+            sdb.finalize(release_staging=True)
+            ssrv = pir_amd.PIRServer(sdb, pp)
+            ssrv.set_galois_keys(keys)
+            ssrv.set_concurrency(workers)
+            ssrv.stage_batch(queries)
+            sbarrier = barrier_for(ssrv)
+            sb = D.SlotsBuffers(ssrv, batch, rank, world, torch, dev)
+            for _ in range(2):
+                D.run_batch_slots(ssrv, sb, dist, rank, world, comm)
+            acc = None
+            for _ in range(5):
+                ph = D.run_batch_slots(ssrv, sb, dist, rank, world, comm)
+                acc = ph if acc is None else {kk: acc[kk] + v for kk, v in ph.items()}
+            phases = {kk: round(v / 5, 4) for kk, v in acc.items()}
+            per_q = sb.exchange_bytes_per_query(world)
+            del sb
+            spipe = D.SlotsPipeline(ssrv, batch, rank, world, dist, torch, dev)
+            pipes.append(spipe)
+            el = timed_steps(spipe.submit, sbarrier, args.steps, args.warmup, dist, use_dist, torch, dev)
+            pipes.clear()
+            slots_replies[0] = spipe.replies(spipe.step - 1).cpu().numpy().view(np.uint64).copy()
+            slots_details = {"pipelined": True, "phases_ms_serial": phases, "serial_sum_ms": round(sum(phases.values()), 4),
+                             "exchange_bytes_received_per_query_per_gpu": per_q,
+                             "database_bytes_per_gpu": ssrv.scan_bytes(), "slots_per_gpu": cuts[rank + 1] - cuts[rank],
+                             "note": "every rank holds 1/%d of the NTT slots of EVERY plaintext; per step it receives its "
+                                     "slots of every query's packed column selectors, scans all rows, returns the row sums "
+                                     "to the rank that expanded the query; that rank runs the upper level with the row "
+                                     "selectors it kept -- no row-selector exchange, no reduce" % world}
+            return el
+        finally:
+            pipes.clear()
+            sdb.close()
+
+    slots_ok = use_dist and args.dims == 2 and info["mfma"] and info["chunks"] == 1 and (k * N) % (16 * world) == 0
+    if use_dist and args.exchange == "slots":
+        if not slots_ok:
+            raise SystemExit("--exchange slots needs d = 2 and the int8-MFMA scan in one column chunk")
+        exchange = "slots"
+        elapsed = measure_slots()
+        qps = args.steps * batch / elapsed
+        headline_blocks = BLOCK_LOG[-1]
+    elif use_dist and autotune:
         # Which form of the rows step is faster depends on what the links between THESE GPUs sustain (DESIGN.md section
         # 7: replicated expansion costs every rank the whole expansion but moves only replies; the packed exchange
         # partitions the expansion but ships ~14 MB of selectors per query to every rank) -- so it is measured, not
@@ -873,8 +937,8 @@ def main():
         el_p = measure("packed")
         tune = {"ms_per_step": {"replicated": round(el_r / args.steps * 1e3, 4), "packed": round(el_p / args.steps * 1e3, 4)},
                 "steps_each": args.steps,
-                "note": "both forms of the row-sharded step timed over the full W + K steps on this machine's links; "
-                        "the faster one is the headline"}
+                "note": "every form of the sharded step (rows + replicated expansion, rows + packed selector exchange, "
+                        "slots) timed over the full W + K steps on this machine's links; the fastest one is the headline"}
         if el_p < el_r:
             exchange = "packed"
             elapsed, qps = el_p, args.steps * batch / el_p
@@ -883,6 +947,27 @@ def main():
             tune["packed_details"] = {"exchange_bytes_received_per_query_per_gpu": bufs.exchange_bytes_per_query(world),
                                       "phases_ms_serial": serial_phases}
             bufs = pipe = serial_phases = None
+        # third candidate: the database sharded by NTT slot instead of by row
+        if slots_ok and os.environ.get("PIRGPU_AUTOTUNE_SLOTS", "1") != "0":
+            try:
+                el_s = measure_slots()
+                tune["ms_per_step"]["slots"] = round(el_s / args.steps * 1e3, 4)
+                if el_s < elapsed:
+                    if exchange == "packed":
+                        tune["packed_details"] = {"exchange_bytes_received_per_query_per_gpu": bufs.exchange_bytes_per_query(world),
+                                                  "phases_ms_serial": serial_phases}
+                    exchange = "slots"
+                    elapsed, qps = el_s, args.steps * batch / el_s
+                    headline_blocks = BLOCK_LOG[-1]
+                    bufs = pipe = serial_phases = None
+                else:
+                    tune["slots_details"] = slots_details
+            except Exception as e:     # noqa: BLE001 -- a candidate that fails must not cost the measured headline
+                park_if_aborting()
+                import traceback as _tb
+                _tb.print_exc()
+                tune["ms_per_step"]["slots"] = None
+                tune["slots_error"] = repr(e)
         tune["chosen"] = exchange
         out_extra["exchange_autotune"] = tune
     else:
@@ -890,7 +975,8 @@ def main():
         qps = args.steps * batch / elapsed
         headline_blocks = BLOCK_LOG[-1]
     if use_dist and world == 1:   # forced single-rank run: the reduced replies must equal the plain ones
-        got = ((pipe.replies(pipe.step - 1) if pipe is not None else bufs.replies) if exchange == "packed"
+        got = slots_replies[0] if exchange == "slots" else \
+              ((pipe.replies(pipe.step - 1) if pipe is not None else bufs.replies) if exchange == "packed"
                else (rpipe.replies(rpipe.step - 1) if rpipe is not None else redb)).cpu().numpy().view(np.uint64)
         srv.stage_batch(queries)
         srv.run_batch()

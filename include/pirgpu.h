@@ -52,7 +52,7 @@ typedef struct pirgpu_ctx pirgpu_ctx;
 /* What PIRContext + PIRParameters carry (reference context.h:36-84,
  * pir/proto/payload.proto:45-69), flattened. */
 typedef struct pirgpu_params {
-  uint32_t poly_modulus_degree;            /* N, power of two, 1024..32768 */
+  uint32_t poly_modulus_degree;            /* N: 2048, 4096, 8192 or 16384 */
   uint32_t num_data_primes;                /* k: ciphertext level (first_context_data) */
   uint64_t coeff_modulus[PIRGPU_MAX_PRIMES]; /* q_0..q_{k-1} */
   uint64_t special_prime;                  /* key-switching prime p (last of SEAL's coeff_modulus) */
@@ -72,6 +72,12 @@ typedef struct pirgpu_params {
    * e.g. dimensions[0],dimensions[0]; its partial reply is all zero). */
   uint32_t shard_begin;
   uint32_t shard_end;
+  /* Slot sharding for multi-GPU (not in the reference; d = 2): this context holds the NTT slots
+   * [slot_begin, slot_end) -- multiples of 16 out of the ring's k * N, device order -- of EVERY plaintext and serves the
+   * pirgpu_slots_* step only; 0,0 = all slots.  (The base case of PIRDatabase::multiply, reference database.cpp:185-194,
+   * is a dyadic product in NTT form: independent per slot.) */
+  uint32_t slot_begin;
+  uint32_t slot_end;
 } pirgpu_params;
 
 /* PIRContext::Create + PIRDatabase::Create(params) (reference context.cpp:37-50,
@@ -277,6 +283,37 @@ int pirgpu_reduce_fixup_device_async(pirgpu_ctx* ctx, uint64_t* device_ptr, uint
 int pirgpu_pack40_supported(pirgpu_ctx* ctx);
 int pirgpu_pack40_device_async(pirgpu_ctx* ctx, const uint64_t* words_in, uint32_t* packed, uint64_t words, void* stream);
 int pirgpu_unpack40_device_async(pirgpu_ctx* ctx, const uint32_t* packed, uint64_t* words_out, uint64_t words, void* stream);
+
+/* Slot-sharded multi-GPU step (not in the reference; d = 2, int8-MFMA scan).  G ranks hold the
+ * slots [slot_cuts[g], slot_cuts[g+1]) of every plaintext (contexts created with slot_begin / slot_end; a context that
+ * holds all slots serves the step too, as the G = 1 case).  One step of B queries, B / G per rank:
+ *   slots_expand   oblivious expansion + selector NTT (reference server.cpp:105-171, database.cpp:190,222) of the staged
+ *                  queries [first, first + count) in groups of 8; the whole NTT-form selection vectors stay in device_sv
+ *                  (count x dim_sum ciphertexts, the context's own element type -- only slots_finish reads them) and the
+ *                  column selectors are packed into the scan's B-operand layout, cut by destination rank: piece
+ *                  [rank r][group g] of device_packed = the slots of rank r of group g, pirgpu_slots_packed_bytes(ctx,
+ *                  slots of r) bytes each -- the send buffer of an all-to-all whose split sizes are groups x that;
+ *   slots_scan     the base case of PIRDatabase::multiply (database.cpp:185-194,238-247) on this context's slots for
+ *                  n_ranks x per_rank queries in ONE launch: device_packed = the all-to-all's receive buffer,
+ *                  [source rank][group][my slots of that group]; row sums go to device_rowsums as
+ *                  [source rank][query][row][component][my slots] u64 -- the send buffer of the all-to-all back;
+ *   slots_finish   for the `count` queries this rank expanded: device_rowsums = that all-to-all's receive buffer,
+ *                  [rank h][query][row][component][slots of h]; puts the pieces together and runs the rest of
+ *                  PIRDatabase::multiply (inverse NTT, CiphertextReencoder::Encode, upper level, database.cpp:196-254)
+ *                  with the row selectors in device_sv; reply i (reply_ct_count ciphertexts) at device_replies + i.
+ * All three only queue work on the context's lanes.  after / then (hipStream_t of the caller, NULL = none): the lanes a
+ * call uses first wait -- on the device -- for everything queued on `after` so far, and `then` waits for everything the
+ * call queued: the caller's collectives are ordered against the step without a host wait and without a barrier over
+ * all lanes.  Needs pirgpu_set_concurrency(>= 8).  No rank exchanges row selectors and there is no reduce: every reply
+ * is computed whole by the rank that owns its query. */
+uint64_t pirgpu_slots_packed_bytes(pirgpu_ctx* ctx, uint32_t slots);
+int pirgpu_slots_expand_async(pirgpu_ctx* ctx, uint32_t first, uint32_t count, uint8_t* device_packed, uint64_t* device_sv,
+                              const uint32_t* slot_cuts, uint32_t n_ranks, void* after, void* then);
+int pirgpu_slots_scan_async(pirgpu_ctx* ctx, const uint8_t* device_packed, uint32_t n_ranks, uint32_t per_rank,
+                            uint64_t* device_rowsums, void* after, void* then);
+int pirgpu_slots_finish_async(pirgpu_ctx* ctx, const uint64_t* device_rowsums, uint32_t count, const uint64_t* device_sv,
+                              const uint32_t* slot_cuts, uint32_t n_ranks, uint64_t* device_replies, void* after,
+                              void* then);
 
 /* PIRServer::oblivious_expansion (reference server.cpp:105-146): one ciphertext
  * -> num_items ciphertexts, coefficient form. */

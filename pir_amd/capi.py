@@ -32,11 +32,13 @@ class Params(C.Structure):
         ("device", C.c_int32),
         ("shard_begin", C.c_uint32),
         ("shard_end", C.c_uint32),
+        ("slot_begin", C.c_uint32),
+        ("slot_end", C.c_uint32),
     ]
 
 
-def make_params(params, device: int = 0, shard=None) -> Params:
-    """PIRParameters (+ device / first-dimension shard) -> the pirgpu_params struct of include/pirgpu.h."""
+def make_params(params, device: int = 0, shard=None, slots=None) -> Params:
+    """PIRParameters (+ device / first-dimension shard / slot shard) -> the pirgpu_params struct of include/pirgpu.h."""
     enc = params.encryption_parameters
     p = Params()
     p.poly_modulus_degree = enc.poly_modulus_degree
@@ -60,6 +62,8 @@ def make_params(params, device: int = 0, shard=None) -> Params:
         if b == e:                      # empty shard: (0, 0) means "whole database" in the C ABI
             b = e = params.dimensions[0]
         p.shard_begin, p.shard_end = b, e
+    if slots is not None:
+        p.slot_begin, p.slot_end = int(slots[0]), int(slots[1])
     return p
 
 
@@ -85,6 +89,13 @@ SIGNATURES = {
     "pirgpu_batch_expand_packed": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                              C.POINTER(C.c_uint32), C.c_uint32]),
     "pirgpu_batch_run_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "pirgpu_slots_packed_bytes": (C.c_uint64, [C.c_void_p, C.c_uint32]),
+    "pirgpu_slots_expand_async": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                            C.POINTER(C.c_uint32), C.c_uint32, C.c_void_p, C.c_void_p]),
+    "pirgpu_slots_scan_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                          C.c_void_p]),
+    "pirgpu_slots_finish_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32),
+                                            C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pirgpu_set_galois_key": (C.c_int, [C.c_void_p, C.c_uint32, u64p]),
     "pirgpu_clear_galois_keys": (C.c_int, [C.c_void_p]),
     "pirgpu_set_keyset_capacity": (C.c_int, [C.c_void_p, C.c_uint32]),

@@ -187,6 +187,11 @@ struct pirgpu_ctx {
   uint64_t reply_cts = 1;
   uint64_t P = 0;              // num_pt of the whole database
   uint32_t sb = 0, se = 0;     // shard of top-level indices
+  // slot shard (multi-GPU): this context holds the NTT slots [slot0, slot0 + nslots) of EVERY
+  // plaintext (device order) in the scan's operand layout; nslots == k N: the whole ring
+  uint32_t slot0 = 0, nslots = 0;
+  bool slot_sharded = false;
+  hipEvent_t ev_after = nullptr;   // pirgpu_slots_*: the position of the caller's `after` stream
   uint64_t pt_begin = 0, pt_end = 0;  // plaintext range held by this context
   uint32_t bits = 0;           // bits per coefficient for item packing
 
@@ -594,6 +599,9 @@ void ensure_workspace(pirgpu_ctx* c) {
     c->mg = mfma_geometry(c->hp, c->scan_rows, c->scan_cols, wide_given ? (int)(wide != 0) : -1,
                           env_u32("PIRGPU_SCAN_MFMA_TOP4", 1) != 0);
     c->mfma_on = env_u32("PIRGPU_SCAN_MFMA", 1) != 0 && d >= 2 && c->mg.L != 0 && c->scan_rows >= 8 && shard_pts > 0;
+    if (c->slot_sharded && (!c->mfma_on || c->mg.nchunks != 1 || c->nslots % c->mg.NW))
+      throw Fail{PIRGPU_INVALID_ARGUMENT, "a slot shard needs the int8-MFMA scan in one column chunk (d = 2, >= 8 rows, "
+                                          "moduli below 2^55, at most 28 column groups)"};
     c->mfma_nq = std::max<uint32_t>(1, std::min<uint32_t>(env_u32("PIRGPU_SCAN_MFMA_NQ", kMaxMfmaQueries),
                                                           kMaxMfmaQueries));
     //   PIRGPU_SCAN_MFMA_SINGLE: a single query on a matrix wider than one column chunk pays the partial-sum
@@ -873,11 +881,21 @@ const uint64_t* scan_selectors(pirgpu_ctx* c, Worker& w) {
 
 bool mq_usable(pirgpu_ctx* c) { return c->scan_nsplit == 1 && c->scan_rows >= 1 && c->scan_cols >= 1; }
 
+// bytes of the operand-layout copy this context holds (its slots of every plaintext)
+size_t dbp_bytes(const pirgpu_ctx* c) { return (size_t)c->nslots * c->mg.RT * c->mg.KG * c->mg.tile_bytes; }
+
+// A slot shard holds 1 / G of every plaintext: it serves the pirgpu_slots_* step only.
+void refuse_slot_shard(const pirgpu_ctx* c) {
+  if (c->slot_sharded)
+    throw Fail{PIRGPU_FAILED_PRECONDITION, "this context is a slot shard: it serves the pirgpu_slots_* entry points only"};
+}
+
 // Brings the operand-layout copy of the database up to date (after loads); one-time cost per load.
 void ensure_packed(pirgpu_ctx* c) {
   if (!c->mfma_on || c->packed_valid) return;
-  if (!c->d_dbp) c->d_dbp = c->dalloc<uint8_t>(c->mg.db_bytes);
-  HIP_TRY(launch_db_pack(c->stream, c->dp, c->mg, c->d_db, c->d_dbp, c->scan_rows, c->scan_cols, c->k * c->N));
+  if (!c->d_dbp) c->d_dbp = c->dalloc<uint8_t>(dbp_bytes(c));
+  HIP_TRY(launch_db_pack(c->stream, c->dp, c->mg, c->d_db, c->d_dbp, c->scan_rows, c->scan_cols, c->k * c->N, c->slot0,
+                         c->nslots));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->packed_valid = true;
 }
@@ -891,9 +909,10 @@ void scan_group_mfma(pirgpu_ctx* c, hipStream_t st, uint8_t*& selp, const MfmaPt
   const uint32_t kN = c->k * c->N;
   const uint64_t words = (uint64_t)c->scan_rows * c->ctw;
   ensure_packed(c);
-  MfmaPtrs out{};
-  for (uint32_t q = 0; q < n; ++q)
-    out.p[q] = c->mg.nchunks > 1 ? part + (size_t)q * c->mg.nchunks * words : out_base + (size_t)q * words;
+  // query q of the group writes at out + q * qstride: the lane's row sums, or -- matrices wider than one chunk -- its
+  // per-chunk partial sums
+  uint64_t* const out = c->mg.nchunks > 1 ? part : out_base;
+  const uint64_t out_qstride = c->mg.nchunks > 1 ? (uint64_t)c->mg.nchunks * words : words;
   if (!packed) {  // with `packed` the group's digit-packed column selectors already exist (multi-GPU exchange)
     if (!selp) selp = c->dalloc<uint8_t>(c->mg.sel_bytes);
     HIP_TRY(launch_sel_pack(st, c->dp, c->mg, col_sel, n, selp, c->scan_cols, kN, sel_f64));
@@ -915,7 +934,8 @@ void scan_group_mfma(pirgpu_ctx* c, hipStream_t st, uint8_t*& selp, const MfmaPt
     }
     HIP_TRY(hipEventRecord(c->bscan_ev[2 * c->bscan_n], st));
   }
-  HIP_TRY(launch_scan_mfma(st, c->dp, c->mg, c->d_dbp, packed, out, n, c->scan_rows, kN, words, wgs, c->scan_f64_fold));
+  HIP_TRY(launch_scan_mfma(st, c->dp, c->mg, c->d_dbp, packed, out, out_qstride, n, c->scan_rows, kN, words, wgs,
+                           c->scan_f64_fold));
   if (timed) {
     HIP_TRY(hipEventRecord(c->bscan_ev[2 * c->bscan_n + 1], st));
     ++c->bscan_n;
@@ -931,6 +951,7 @@ void scan_group_mfma(pirgpu_ctx* c, hipStream_t st, uint8_t*& selp, const MfmaPt
 void scan_on_device(pirgpu_ctx* c, Worker& w) {
   const uint32_t N = c->N, k = c->k, d = c->d;
   const size_t ctw = c->ctw;
+  refuse_slot_shard(c);
   if (c->n_loaded != c->pt_end - c->pt_begin)
     throw Fail{PIRGPU_FAILED_PRECONDITION, "database not fully loaded"};
   check_transparent(c);
@@ -1133,6 +1154,16 @@ int pirgpu_create(const pirgpu_params* p, pirgpu_ctx** out) {
     c->se = p->shard_end;
     if (c->sb == 0 && c->se == 0) c->se = c->dims[0];
     if (c->sb > c->se || c->se > c->dims[0]) return bail(PIRGPU_INVALID_ARGUMENT, "invalid shard range");
+    {
+      const uint32_t kN = k * N;
+      c->slot0 = p->slot_begin;
+      c->nslots = (p->slot_begin == 0 && p->slot_end == 0) ? kN : p->slot_end - p->slot_begin;
+      if (p->slot_end > kN || (p->slot_end && p->slot_end <= p->slot_begin) || c->slot0 % 16 || c->nslots % 16)
+        return bail(PIRGPU_INVALID_ARGUMENT, "invalid slot range (multiples of 16 inside [0, k N))");
+      c->slot_sharded = c->nslots != kN;
+      if (c->slot_sharded && (c->d != 2 || c->sb != 0 || c->se != c->dims[0]))
+        return bail(PIRGPU_INVALID_ARGUMENT, "a slot shard needs d = 2 and all rows (no row shard)");
+    }
     c->pt_begin = std::min<uint64_t>((uint64_t)c->sb * c->stride[1], c->P);
     c->pt_end = std::min<uint64_t>((uint64_t)c->se * c->stride[1], c->P);
     const uint32_t bdef = hm::bits_per_coeff(p->plain_modulus);
@@ -1220,6 +1251,7 @@ void pirgpu_destroy(pirgpu_ctx* c) {
   for (hipEvent_t e : c->ev_fetch)
     if (e) (void)hipEventDestroy(e);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_after) (void)hipEventDestroy(c->ev_after);
   if (c->ev_main_join) (void)hipEventDestroy(c->ev_main_join);
   for (size_t i = 1; i < c->workers.size(); ++i)
     if (c->workers[i].stream) (void)hipStreamDestroy(c->workers[i].stream);
@@ -1259,6 +1291,7 @@ static const struct { const char* name; bool early; } kOptions[] = {
     {"FUSE_LAST", true}, {"FUSE_MAC_COMBINE", true}, {"LAST_NTT", true}, {"SEL_F64", true}, {"TREE40", true},
     {"FUSE_MAC_NODES", true}, {"SPLIT_UPPER", true}, {"SPLIT_UPPER_MB", true}, {"PACK40", true},
     {"SCAN_MFMA", true}, {"SCAN_MFMA_WIDE", true}, {"SCAN_MFMA_TOP4", true}, {"SCAN_MFMA_NQ", true}, {"SCAN_MFMA_SINGLE", true}, {"LANES", true}, {"HEAD_LEVELS", true}, {"HEAD_MODE", true}, {"SCAN_F64_FOLD", true}, {"LOOP_TRANSFORMS", true}, {"LOOP_MIN_SOURCES", true},
+    {"SLOTS_SCAN_WGS", false},
 };
 
 int pirgpu_set_option(pirgpu_ctx* c, const char* name, int64_t value) {
@@ -1331,7 +1364,7 @@ uint64_t pirgpu_scan_bytes(const pirgpu_ctx* cc) {
     return 0;
   }
   // bytes a single-query pass over the database must read: the operand-layout copy when that pass is the MFMA scan
-  return c->mfma_on && c->mfma_single ? (uint64_t)c->mg.db_bytes : (c->pt_end - c->pt_begin) * c->k * c->N * 8;
+  return c->mfma_on && c->mfma_single ? (uint64_t)dbp_bytes(c) : (c->pt_end - c->pt_begin) * c->k * c->N * 8;
 }
 
 int pirgpu_ntt_mode(const pirgpu_ctx* c) { return c ? c->mode : -1; }
@@ -1459,6 +1492,7 @@ int pirgpu_db_read_plaintext(pirgpu_ctx* c, uint64_t pt_index, uint64_t* out) {
     try {
       const uint64_t* src = c->d_db ? c->d_db + (pt_index - c->pt_begin) * c->k * c->N : nullptr;
       if (!src) {  // staging released: gather the digits of this plaintext from the operand layout
+        refuse_slot_shard(c);   // ... which a slot shard holds only 1 / G of
         const uint64_t local = pt_index - c->pt_begin;
         uint64_t* tmp = stage + (size_t)c->k * c->N;
         HIP_TRY(launch_db_unpack(c->stream, c->dp, c->mg, c->d_dbp, tmp, (uint32_t)(local / c->scan_cols),
@@ -2273,8 +2307,11 @@ static void ensure_head_slot(pirgpu_ctx* c, HeadSlot& hs) {
   }
 }
 
+// sv_dst (optional): the selection vector of query q goes to sv_dst + q * dim_sum ciphertexts (caller-owned memory that
+// outlives the members' buffers: the slot-sharded step keeps its row selectors there for two steps) instead of the
+// members' own buffers.
 static void expand_group_on_lane(pirgpu_ctx* c, BatchLane& ln, Worker* const* members, uint32_t B, uint32_t first,
-                                 bool sel_f64 = false) {
+                                 bool sel_f64 = false, uint64_t* sv_dst = nullptr) {
   const uint32_t N = c->N, k = c->k;
   const uint32_t nq = c->dim_sum / N + 1;
   const size_t ctw = c->ctw, qwords = (size_t)nq * ctw;
@@ -2292,7 +2329,7 @@ static void expand_group_on_lane(pirgpu_ctx* c, BatchLane& ln, Worker* const* me
     MfmaPtrs dst{};
     uint32_t ksets[kMaxMfmaQueries];   // every query of the group is switched with its own client's keys
     for (uint32_t q = 0; q < B; ++q) {
-      dst.p[q] = members[q]->sv_ntt + produced * ctw;
+      dst.p[q] = (sv_dst ? sv_dst + (size_t)q * c->dim_sum * ctw : members[q]->sv_ntt) + produced * ctw;
       ksets[q] = first + q < c->bs().batch_keysets.size() ? c->bs().batch_keysets[first + q] : 0;
     }
     const uint64_t* roots = c->bs().d_bquery + (size_t)first * qwords + (size_t)qc * ctw;
@@ -2455,6 +2492,7 @@ static void batch_run_impl(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv
   batch_run_impl_body(c, count, ext_sv);
 }
 static void batch_run_impl_body(pirgpu_ctx* c, uint32_t count, const uint64_t* ext_sv) {
+  refuse_slot_shard(c);
   c->bs().host_reply_done = false;   // set again by the path that queues per-group downloads (batch_run_mfma)
   const size_t rwords = (size_t)c->reply_cts * c->ctw;
   const size_t svwords = (size_t)c->dim_sum * c->ctw;
@@ -2670,6 +2708,7 @@ int pirgpu_batch_run_packed(pirgpu_ctx* c, const uint8_t* device_packed, uint32_
     ensure_workspace(c);
     if (c->d != 2 || !c->mfma_on)
       return fail(c, PIRGPU_FAILED_PRECONDITION, "packed selector exchange needs d = 2 and the int8-MFMA scan");
+    refuse_slot_shard(c);
     const uint64_t count = (uint64_t)n_ranks * per_rank;
     if (!device_packed || !device_rows || count == 0 || count > 4096) return fail(c, PIRGPU_INVALID_ARGUMENT, "invalid batch");
     if (c->n_loaded != c->pt_end - c->pt_begin) return fail(c, PIRGPU_FAILED_PRECONDITION, "database not fully loaded");
@@ -2689,6 +2728,195 @@ int pirgpu_batch_run_packed(pirgpu_ctx* c, const uint8_t* device_packed, uint32_
     c->in_batch = false;
     c->bs().batch_count = (uint32_t)count;
     c->bs().batch_valid = true;
+    return PIRGPU_OK;
+  });
+}
+
+// ---- slot-sharded multi-GPU step ----
+//
+// The base case of PIRDatabase::multiply (reference database.cpp:185-194) is a dyadic product in NTT form: independent
+// per NTT slot.  G ranks therefore each hold the slots [cut[g], cut[g+1]) of EVERY plaintext (1 / G of the bytes; the
+// operand layout has the slot outermost) and a step of B queries runs as
+//   E  rank g expands its own B / G queries (groups of 8) and packs their column selectors, cut by destination rank;
+//   X1 all-to-all: rank h receives ITS slots of every group's packed column selectors (1 / G of each);
+//   S  rank h scans its slots for all B queries in one launch: full row tiles, row sums [query][row, comp][its slots];
+//   X2 all-to-all: the row sums go back to the rank that expanded the query;
+//   U  that rank puts the slot pieces together and runs inverse NTT + upper level for its own queries on ALL rows with
+//      the row selectors it kept: reply i ends on the rank that owns query i.  No row-selector exchange, no reduce.
+// The three entry points queue E, S and U on the lanes without waiting for the device.  `after` / `then` (hipStream_t
+// of the caller, may be NULL) order them against the caller's collectives: every lane the call uses first waits for what
+// is queued on `after` so far, and `then` waits for what the call queued.
+
+namespace {
+
+void check_cuts(pirgpu_ctx* c, const uint32_t* cuts, uint32_t n_ranks, SliceMap& map) {
+  const uint32_t kN = c->k * c->N;
+  if (!cuts || n_ranks == 0 || n_ranks > (uint32_t)kMaxSlices || cuts[0] != 0 || cuts[n_ranks] != kN)
+    throw Fail{PIRGPU_INVALID_ARGUMENT, "slot cuts must run from 0 to k N over at most 16 ranks"};
+  map = SliceMap{};
+  map.n = n_ranks;
+  for (uint32_t r = 0; r <= n_ranks; ++r) {
+    if (cuts[r] % 16 || (r && cuts[r] < cuts[r - 1])) throw Fail{PIRGPU_INVALID_ARGUMENT, "slot cuts must be non-decreasing multiples of 16"};
+    map.cut[r] = cuts[r];
+  }
+}
+
+void lane_after(pirgpu_ctx* c, hipStream_t lane, void* after) {
+  if (!after) return;
+  if (!c->ev_after) HIP_TRY(hipEventCreateWithFlags(&c->ev_after, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(c->ev_after, (hipStream_t)after));
+  HIP_TRY(hipStreamWaitEvent(lane, c->ev_after, 0));
+}
+
+void lane_then(BatchLane& ln, void* then) {
+  if (!then) return;
+  if (!ln.ev_join) HIP_TRY(hipEventCreateWithFlags(&ln.ev_join, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(ln.ev_join, ln.stream));
+  HIP_TRY(hipStreamWaitEvent((hipStream_t)then, ln.ev_join, 0));
+}
+
+void check_slots_ctx(pirgpu_ctx* c) {
+  ensure_workspace(c);
+  if (c->d != 2 || !c->mfma_on || c->mg.nchunks != 1 || c->sb != 0 || c->se != c->dims[0])
+    throw Fail{PIRGPU_FAILED_PRECONDITION, "the slot-sharded step needs d = 2, all rows and the int8-MFMA scan in one column chunk"};
+}
+
+}  // namespace
+
+uint64_t pirgpu_slots_packed_bytes(pirgpu_ctx* c, uint32_t slots) {
+  uint64_t bytes = 0;
+  (void)guarded(c, [&]() -> int {
+    ensure_workspace(c);
+    if (c->d == 2 && c->mfma_on && c->mg.nchunks == 1) bytes = (uint64_t)slots * c->mg.KG * c->mg.tile_bytes;
+    return PIRGPU_OK;
+  });
+  return bytes;
+}
+
+int pirgpu_slots_expand_async(pirgpu_ctx* c, uint32_t first, uint32_t count, uint8_t* device_packed, uint64_t* device_sv,
+                              const uint32_t* slot_cuts, uint32_t n_ranks, void* after, void* then) {
+  return guarded(c, [&]() -> int {
+    check_slots_ctx(c);
+    SliceMap map;
+    check_cuts(c, slot_cuts, n_ranks, map);
+    if (!c->bs().staged_count || (uint64_t)first + count > c->bs().staged_count)
+      return fail(c, PIRGPU_INVALID_ARGUMENT, "query range outside the staged batch");
+    if (!device_packed || !device_sv || count == 0) return fail(c, PIRGPU_INVALID_ARGUMENT, "null buffer");
+    const uint32_t W = std::max<uint32_t>(1, std::min<uint32_t>(c->n_active, (uint32_t)c->workers.size()));
+    if (W < std::min<uint32_t>(count, kMaxMfmaQueries))
+      return fail(c, PIRGPU_FAILED_PRECONDITION, "groups need min(count, 8) workers (pirgpu_set_concurrency)");
+    ensure_lanes(c, true);
+    c->prof_cur = -1;
+    check_staged_keysets(c);
+    const size_t ctw = c->ctw, svwords = (size_t)c->dim_sum * ctw;
+    const uint32_t kN = c->k * c->N;
+    const uint32_t G = std::min<uint32_t>(kMaxMfmaQueries, W), nl = lanes_in_use(c, G);
+    const uint32_t groups = (count + kMaxMfmaQueries - 1) / kMaxMfmaQueries;
+    const uint64_t slot_bytes = (uint64_t)c->mg.KG * c->mg.tile_bytes;
+    if (after && c->head_stream) lane_after(c, c->head_stream, after);
+    uint32_t g = 0;
+    for (uint32_t j0 = 0; j0 < count; j0 += kMaxMfmaQueries, ++g) {
+      const uint32_t B = std::min<uint32_t>(kMaxMfmaQueries, count - j0);
+      BatchLane& ln = c->lanes[c->groups_run++ % nl];
+      const uint32_t li = (uint32_t)(&ln - c->lanes.data());
+      lane_after(c, ln.stream, after);
+      Worker* members[kMaxMfmaQueries];
+      for (uint32_t q = 0; q < B; ++q) {
+        members[q] = &c->workers[(li * G + q) % W];
+        HIP_TRY(hipStreamWaitEvent(ln.stream, members[q]->ev_done, 0));
+      }
+      uint64_t* sv_dst = device_sv + (size_t)j0 * svwords;
+      expand_group_on_lane(c, ln, members, B, first + j0, c->sel_f64, sv_dst);
+      // the group's column selectors -> B-operand tiles, rank r's slots as piece [r][group g] of the send buffer
+      MfmaPtrs sv{};
+      for (uint32_t q = 0; q < B; ++q) sv.p[q] = sv_dst + (size_t)q * svwords + (size_t)c->sv_off[1] * ctw;
+      for (uint32_t r = 0; r < n_ranks; ++r)
+        map.off[r] = ((uint64_t)groups * map.cut[r] + (uint64_t)g * (map.cut[r + 1] - map.cut[r])) * slot_bytes;
+      HIP_TRY(launch_sel_pack(ln.stream, c->dp, c->mg, sv, B, device_packed, c->scan_cols, kN, c->sel_f64, &map));
+      for (uint32_t q = 0; q < B; ++q) HIP_TRY(hipEventRecord(members[q]->ev_done, ln.stream));
+      lane_then(ln, then);
+    }
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_slots_scan_async(pirgpu_ctx* c, const uint8_t* device_packed, uint32_t n_ranks, uint32_t per_rank,
+                            uint64_t* device_rowsums, void* after, void* then) {
+  return guarded(c, [&]() -> int {
+    check_slots_ctx(c);
+    const uint64_t count = (uint64_t)n_ranks * per_rank;
+    if (!device_packed || !device_rowsums || count == 0 || count > 4096) return fail(c, PIRGPU_INVALID_ARGUMENT, "invalid batch");
+    if (c->n_loaded != c->pt_end - c->pt_begin) return fail(c, PIRGPU_FAILED_PRECONDITION, "database not fully loaded");
+    check_transparent(c);
+    ensure_packed(c);
+    ensure_lanes(c, true);
+    c->prof_cur = -1;
+    const uint32_t W = std::max<uint32_t>(1, std::min<uint32_t>(c->n_active, (uint32_t)c->workers.size()));
+    const uint32_t nl = lanes_in_use(c, std::min<uint32_t>(kMaxMfmaQueries, W));
+    BatchLane& ln = c->lanes[c->groups_run++ % nl];
+    lane_after(c, ln.stream, after);
+    const uint32_t groups = (per_rank + kMaxMfmaQueries - 1) / kMaxMfmaQueries;
+    const uint64_t piece = (uint64_t)c->nslots * c->mg.KG * c->mg.tile_bytes;      // my slots of one packed group
+    const uint64_t qwords = (uint64_t)c->scan_rows * 2 * c->nslots;                // row sums of one query on my slots
+    // workgroups: the pass shares the chip with the other lane's expansion like the single-GPU batch pass (option
+    // SLOTS_SCAN_WGS; 0 = one per CU)
+    const uint32_t wgs = (uint32_t)std::max<int64_t>(0, option(c, "SLOTS_SCAN_WGS", c->scan_wgs_batch));
+    ScanGroups grp{};
+    auto flush = [&]() {
+      if (!grp.n) return;
+      HIP_TRY(launch_scan_mfma_groups(ln.stream, c->dp, c->mg, c->d_dbp, grp, c->scan_rows, 0, wgs, c->scan_f64_fold, c->slot0,
+                                      c->nslots, qwords, c->nslots));
+      grp = ScanGroups{};
+    };
+    for (uint32_t r = 0; r < n_ranks; ++r)
+      for (uint32_t g = 0; g < groups; ++g) {
+        grp.sel[grp.n] = device_packed + ((uint64_t)r * groups + g) * piece;
+        grp.out[grp.n] = device_rowsums + ((uint64_t)r * per_rank + (uint64_t)g * kMaxMfmaQueries) * qwords;
+        grp.nq[grp.n] = (uint8_t)std::min<uint32_t>(kMaxMfmaQueries, per_rank - g * kMaxMfmaQueries);
+        if (++grp.n == (uint32_t)kMaxScanGroups) flush();
+      }
+    flush();
+    lane_then(ln, then);
+    return PIRGPU_OK;
+  });
+}
+
+int pirgpu_slots_finish_async(pirgpu_ctx* c, const uint64_t* device_rowsums, uint32_t count, const uint64_t* device_sv,
+                              const uint32_t* slot_cuts, uint32_t n_ranks, uint64_t* device_replies, void* after,
+                              void* then) {
+  return guarded(c, [&]() -> int {
+    check_slots_ctx(c);
+    SliceMap map;
+    check_cuts(c, slot_cuts, n_ranks, map);
+    if (!device_rowsums || !device_sv || !device_replies || count == 0 || count > 4096)
+      return fail(c, PIRGPU_INVALID_ARGUMENT, "invalid batch");
+    ensure_lanes(c, true);
+    c->prof_cur = -1;
+    const uint32_t W = std::max<uint32_t>(1, std::min<uint32_t>(c->n_active, (uint32_t)c->workers.size()));
+    const uint32_t nl = lanes_in_use(c, std::min<uint32_t>(kMaxMfmaQueries, W));
+    const size_t ctw = c->ctw, svwords = (size_t)c->dim_sum * ctw, rwords = (size_t)c->reply_cts * ctw;
+    const uint32_t kN = c->k * c->N, RC = c->scan_rows * 2;
+    const uint64_t words = (uint64_t)c->scan_rows * ctw;
+    struct Flag {
+      bool& f;
+      explicit Flag(bool& x) : f(x) { f = true; }
+      ~Flag() { f = false; }
+    } flag(c->in_batch);
+    for (uint32_t j0 = 0; j0 < count; j0 += kMaxMfmaQueries) {
+      const uint32_t B = std::min<uint32_t>(kMaxMfmaQueries, count - j0);
+      BatchLane& ln = c->lanes[c->groups_run++ % nl];
+      lane_after(c, ln.stream, after);
+      // rank h's block of the receive buffer holds [count][RC][slots of h]: the group's queries are rows j0 .. j0 + B of it
+      HIP_TRY(launch_slots_assemble(ln.stream, device_rowsums, ln.lvl[c->d - 1], map, RC, kN, B, words, count, j0));
+      uint64_t* lvl_ptrs[PIRGPU_MAX_DIMS];
+      for (uint32_t l = 0; l < c->d; ++l) lvl_ptrs[l] = ln.lvl[l];
+      lvl_ptrs[0] = device_replies + (size_t)j0 * rwords;
+      Stage sg{ln.stream, lvl_ptrs, ln.pt_buf, B, MfmaPtrs{}, false, &ln.up_scratch, &ln.up_scratch_words};
+      for (uint32_t q = 0; q < B; ++q) sg.sel.p[q] = device_sv + (size_t)(j0 + q) * svwords;
+      sg.sel_f64 = c->sel_f64;
+      post_scan_stage(c, sg, nullptr);
+      lane_then(ln, then);
+    }
     return PIRGPU_OK;
   });
 }

@@ -9,12 +9,31 @@ namespace pirgpu {
 
 constexpr int kMaxScanChunks = 16;    // column chunks of one MFMA scan pass (wider matrices use the 64-bit kernels)
 constexpr int kMaxMfmaQueries = 8;   // (query, comp) pairs fill the 16 columns of one MFMA tile
+constexpr int kMaxScanGroups = 16;   // groups of <= 8 queries one scan launch can serve (slot-sharded multi-GPU step)
+constexpr int kMaxSlices = 16;       // slot ranges (= ranks) a packed selector buffer / row-sum exchange can be cut into
 
 constexpr uint32_t kKsWideLevel = 256;   // nodes per launch from which the key-switch kernels use the XCD-aware 1-D grid
 inline bool ks_digit_takes_c0(uint32_t nodes) { return nodes >= kKsWideLevel && nodes % 8 == 0; }
 
 struct MfmaPtrs {                    // one pointer per query of a group (by-value kernel argument)
   const void* p[kMaxMfmaQueries];
+};
+
+// Groups of one scan launch (by-value kernel argument): group g reads its packed selectors at sel[g] and writes query q
+// to out[g] + q * out_qstride.
+struct ScanGroups {
+  uint32_t n;
+  const uint8_t* sel[kMaxScanGroups];
+  uint64_t* out[kMaxScanGroups];
+  uint8_t nq[kMaxScanGroups];
+};
+
+// Slot ranges [cut[r], cut[r+1]) (multiples of 16, cut[0] = 0, cut[n] = k N) and, for sel_pack, the byte offset of each
+// range's piece in the output buffer.
+struct SliceMap {
+  uint32_t n;
+  uint32_t cut[kMaxSlices + 1];
+  uint64_t off[kMaxSlices];
 };
 
 // Galois keys for ONE Galois element of the queries expanded together: tree ciphertext n (= node * B + query) is
@@ -135,16 +154,28 @@ struct MfmaGeom {
 
 // wide_override: -1 = choose by width, 0 / 1 = force the 8-wave / 4-wave kernel
 MfmaGeom mfma_geometry(const DevParams& hp, uint32_t rows, uint32_t cols, int wide_override = -1, bool allow_top4 = true);
+// slot0 / nslots: the slots of the ring the packed copy holds (nslots = 0: all from slot0 on), local index j - slot0
 hipError_t launch_db_pack(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint64_t* db, uint8_t* dbp,
-                          uint32_t rows, uint32_t cols, uint32_t kN);
+                          uint32_t rows, uint32_t cols, uint32_t kN, uint32_t slot0 = 0, uint32_t nslots = 0);
 hipError_t launch_db_unpack(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp, uint64_t* out,
                             uint32_t row, uint32_t col, uint32_t kN);
+// map: the output cut into per-rank pieces by slot ranges (nullptr: one piece)
 hipError_t launch_sel_pack(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const MfmaPtrs& sv, uint32_t nq,
-                           uint8_t* selp, uint32_t cols, uint32_t kN, bool sel_f64 = false);
+                           uint8_t* selp, uint32_t cols, uint32_t kN, bool sel_f64 = false, const SliceMap* map = nullptr);
 // wgs: persistent workgroups of the launch (0 = one per CU; the batch pipeline asks for fewer, see scan_mfma.hip)
 // f64_fold: fold the digit diagonals in exact fp64 arithmetic (every data modulus below 2^50)
+// one group of nq <= 8 queries over the whole ring; query q writes [rows][2][kN] at out + q * out_qstride
 hipError_t launch_scan_mfma(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp,
-                            const uint8_t* selp, const MfmaPtrs& out, uint32_t nq, uint32_t rows, uint32_t kN,
-                            uint64_t chunk_stride, uint32_t wgs = 0, bool f64_fold = false);
+                            const uint8_t* selp, uint64_t* out, uint64_t out_qstride, uint32_t nq, uint32_t rows,
+                            uint32_t kN, uint64_t chunk_stride, uint32_t wgs = 0, bool f64_fold = false);
+// several groups over the slots [slot0, slot0 + nslots) in one launch (dbp / selectors / output indexed by local slot,
+// an output row is out_rstride slots long)
+hipError_t launch_scan_mfma_groups(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp,
+                                   const ScanGroups& grp, uint32_t rows, uint64_t chunk_stride, uint32_t wgs, bool f64_fold,
+                                   uint32_t slot0, uint32_t nslots, uint64_t out_qstride, uint32_t out_rstride);
+// row sums of queries q0 .. q0 + nq - 1 (of the nq_total the receive buffer holds per rank) back from the per-rank slot
+// pieces of the all-to-all receive buffer to [query][row, comp][kN] at dst + (q - q0) * dst_qstride
+hipError_t launch_slots_assemble(hipStream_t st, const uint64_t* src, uint64_t* dst, const SliceMap& map, uint32_t RC,
+                                 uint32_t kN, uint32_t nq, uint64_t dst_qstride, uint32_t nq_total, uint32_t q0);
 
 }  // namespace pirgpu

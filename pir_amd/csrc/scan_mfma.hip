@@ -100,13 +100,14 @@ __device__ __forceinline__ void to_digits(uint64_t x, uint64_t q, int8_t (&d)[L]
   }
 }
 
-// database u64 [rows][cols][kN] (zero-padded rows) -> packed.  block = 16 rows x 16 slots; grid = (kN/16, RT, KG)
+// database u64 [rows][cols][kN] (zero-padded rows) -> packed.  block = 16 rows x 16 slots; grid = (slots/16, RT, KG).
+// slot0: first slot of the packed copy (a slot-sharded context packs only its own slots, local index j - slot0)
 template <int L, bool TOP4>
 __global__ void __launch_bounds__(256)
 db_pack_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ db, uint8_t* __restrict__ dbp,
-               uint32_t rows, uint32_t cols, uint32_t kN, uint32_t RT, uint32_t KG, uint32_t GC) {
+               uint32_t rows, uint32_t cols, uint32_t kN, uint32_t RT, uint32_t KG, uint32_t GC, uint32_t slot0) {
   constexpr uint32_t TB = tile_bytes(L, TOP4);
-  const uint32_t j = blockIdx.x * 16 + (threadIdx.x & 15);
+  const uint32_t j = slot0 + blockIdx.x * 16 + (threadIdx.x & 15);
   const uint32_t r16 = threadIdx.x >> 4;
   const uint32_t rt = blockIdx.y, kg = blockIdx.z;
   const uint32_t r = rt * 16 + r16;
@@ -125,20 +126,23 @@ db_pack_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ db,
 #pragma unroll
   for (int a = 0; a < L; ++a) {
     if (TOP4 && a == L - 1) {
-      *reinterpret_cast<v2i*>(dbp + db_tile_offset(j, rt, kg, a, TB, RT, KG, GC) + r16 * 8) = pack_top4(o[a]);
+      *reinterpret_cast<v2i*>(dbp + db_tile_offset(j - slot0, rt, kg, a, TB, RT, KG, GC) + r16 * 8) = pack_top4(o[a]);
     } else {
       v4i v;
       __builtin_memcpy(&v, o[a], 16);
-      *reinterpret_cast<v4i*>(dbp + db_tile_offset(j, rt, kg, a, TB, RT, KG, GC) + r16 * 16) = v;
+      *reinterpret_cast<v4i*>(dbp + db_tile_offset(j - slot0, rt, kg, a, TB, RT, KG, GC) + r16 * 16) = v;
     }
   }
 }
 
-// selectors (per query u64 [cols][2][kN], NTT form) -> packed.  block = 16 x * 16 slots; grid = (kN/16, KG)
+// selectors (per query u64 [cols][2][kN], NTT form) -> packed.  block = 16 x * 16 slots; grid = (kN/16, KG).
+// map (slot-sharded multi-GPU step): the packed buffer is cut by slot ranges -- slots [cut[r], cut[r+1]) (multiples of
+// 16) start at byte off[r], local slot index inside -- so that every destination rank's slice is one contiguous piece
+// of an all-to-all send buffer; n = 0: one piece, the plain layout.
 template <int L, bool TOP4>
 __global__ void __launch_bounds__(256)
 sel_pack_kernel(const DevParams* __restrict__ P, MfmaPtrs sv, uint32_t nq, uint8_t* __restrict__ selp, uint32_t cols,
-                uint32_t kN, uint32_t KG, int sel_f64) {
+                uint32_t kN, uint32_t KG, int sel_f64, SliceMap map) {
   constexpr uint32_t TB = tile_bytes(L, TOP4);
   const uint32_t j = blockIdx.x * 16 + (threadIdx.x & 15);
   const uint32_t x = threadIdx.x >> 4;
@@ -159,7 +163,15 @@ sel_pack_kernel(const DevParams* __restrict__ P, MfmaPtrs sv, uint32_t nq, uint8
 #pragma unroll
     for (int b = 0; b < L; ++b) o[b][t] = (uint8_t)d[b];
   }
-  uint8_t* blk = selp + ((size_t)j * KG + kg) * TB;
+  uint32_t jl = j;
+  size_t piece = 0;
+  if (map.n) {
+    uint32_t r = 0;
+    while (r + 1 < map.n && j >= map.cut[r + 1]) ++r;
+    jl = j - map.cut[r];
+    piece = map.off[r];
+  }
+  uint8_t* blk = selp + piece + ((size_t)jl * KG + kg) * TB;
 #pragma unroll
   for (int b = 0; b < L; ++b) {
     if (TOP4 && b == L - 1) {
@@ -215,22 +227,30 @@ struct ChunkPlan {
 // registers each -- selectors of up to 3 k-steps; NW = 4 ("wide"): one wave per SIMD with the whole 512-entry register
 // file (VGPRs + AGPRs: MFMA operands may live in either), selectors of up to 7 k-steps = 28 column groups in registers,
 // so the matrices of cfg 4 / 5 (27 / 21 column groups) are scanned in ONE chunk with all but the last k-step full.  A workgroup is persistent: it walks
-// the slot blocks blk = i, i + n_c, ... (i = its index among the n_c workgroups of its chunk) and, while it folds
-// and stores the last row tile of one block, the selector tiles and the first database tiles of its next block are
-// already in flight (one workgroup per CU at this register count, so nothing else would hide that latency).
+// the units u = i, i + n_c, ... (i = its index among the n_c workgroups of its chunk; a unit = one slot block of one
+// group of queries, u = group * nblocks + block) and, while it folds and stores the last row tile of one unit, the
+// selector tiles and the first database tiles of its next unit are already in flight (one workgroup per CU at this
+// register count, so nothing else would hide that latency).
 // Chunk ch covers column groups [ch * GC, (ch + 1) * GC) with GC = ceil(KG / nchunks) <= 4 KS -- equal chunks, so
 // that equal shares of the chip finish together (7 k-steps split 3/3/1 left a third of the CUs idle for two thirds
-// of the pass) -- and writes to out.p[q] + ch * chunk_stride (partial sums when nchunks > 1).
+// of the pass) -- and writes to out + ch * chunk_stride (partial sums when nchunks > 1).
+// Groups (ScanGroups): one launch serves up to kMaxScanGroups groups of <= 8 queries over the SAME database slots --
+// group g reads its packed selectors at sel[g] and writes query q of the group to out[g] + q * out_qstride.  One group
+// is the single-GPU pass; several are the slot-sharded multi-GPU step, where a rank scans its slots for every query of
+// the step in one launch.
+// Slots: the launch covers the slots [slot0, slot0 + nslots) of the ring's k N; database, packed selectors and output
+// are indexed by the LOCAL slot j - slot0 (a slot-sharded context holds only its own slots of every plaintext), a row
+// of the output is out_rstride slots long.  slot0 = 0, nslots = out_rstride = k N: the whole database.
 // TOP4: the top digit of both operands is stored as nibbles (above): its database tiles stay packed in two registers per
-// lane until their k-step is due; the selectors' are unpacked once per slot block.
+// lane until their k-step is due; the selectors' are unpacked once per unit.
 // F64F: the digit diagonals are folded in exact fp64 arithmetic (all data moduli < 2^50): four diagonals combine exactly
 // in one double (|C| < 2^49.01), chunk c times 2^(32 c) mod q with the 6-operation exact product of arith.h --
 // ~45 full-rate operations per value against ~170 mostly quarter-rate 64-bit integer ones.  Same canonical residues.
 template <int L, int KS, int NW, bool TOP4, bool F64F = false>
 __global__ void __launch_bounds__(NW * 64)
-scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ dbp, const uint8_t* __restrict__ selp,
-                 MfmaPtrs out, uint32_t nq, uint32_t rows, uint32_t RT, uint32_t KG, uint32_t kN,
-                 uint64_t chunk_stride, ChunkPlan plan, uint32_t GC) {
+scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ dbp, ScanGroups grp, uint32_t rows,
+                 uint32_t RT, uint32_t KG, uint64_t chunk_stride, ChunkPlan plan, uint32_t GC, uint32_t slot0,
+                 uint32_t nslots, uint64_t out_qstride, uint32_t out_rstride) {
   constexpr uint32_t TB = tile_bytes(L, TOP4);
   constexpr int LF = TOP4 ? L - 1 : L;   // digits stored as full bytes
   constexpr int NS = 2 * L - 1;        // digit diagonals
@@ -241,13 +261,13 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int g = l >> 4, i16 = l & 15;
   constexpr int LOGNW = NW == 8 ? 3 : 2;
-  const uint32_t nblocks = kN >> LOGNW;
+  const uint32_t nblocks = nslots >> LOGNW;
+  const uint32_t nunits = nblocks * grp.n;
   uint32_t ch = 0;
   while (ch + 1 < plan.nchunks && blockIdx.x >= plan.first[ch + 1]) ++ch;
   const uint32_t wg_in_chunk = blockIdx.x - plan.first[ch], wgs_in_chunk = plan.first[ch + 1] - plan.first[ch];
   const uint32_t kg0 = ch * GC;                                   // GC <= 4 KS column groups per chunk
   const uint32_t gc = KG - kg0 < GC ? KG - kg0 : GC;              // column groups of this chunk
-  const uint32_t nx = 2 * nq;
   const size_t slab = (size_t)RT * KG * TB;                       // database bytes of one slot
   const size_t chunk_base = (size_t)RT * kg0 * TB;                // this chunk inside a slot
   const size_t rt_stride = (size_t)gc * TB;
@@ -255,11 +275,14 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
 
   v4i B[KS][L], A[KS][LF];
   v2i A4[KS];                           // TOP4: the top digit's tiles, packed
-  auto load_B = [&](uint32_t j) {
+  // selector tiles of (local) slot jl of group gi
+  auto load_B = [&](uint32_t gi, uint32_t jl) {
+    const uint8_t* selp = grp.sel[gi];
+    const uint32_t nx = 2u * grp.nq[gi];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const uint32_t gl = ks * 4 + g, kg = kg0 + gl;
-      const uint8_t* blk = selp + ((size_t)j * KG + kg) * TB;
+      const uint8_t* blk = selp + ((size_t)jl * KG + kg) * TB;
 #pragma unroll
       for (int b = 0; b < L; ++b) {
         B[ks][b] = v4i{0, 0, 0, 0};   // columns beyond the group's queries stay zero and are neither packed nor read
@@ -278,10 +301,11 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
     if constexpr (TOP4) A4[ks] = load_tile8(blk + (L - 1) * 256 + lane8);
   };
 
-  uint32_t blk = wg_in_chunk;
-  if (blk >= nblocks) return;
-  load_B(blk * NW + w);
+  uint32_t u = wg_in_chunk;
+  if (u >= nunits) return;
   {
+    const uint32_t gi = u / nblocks, blk = u - gi * nblocks;
+    load_B(gi, blk * NW + w);
     const uint8_t* abase = dbp + (size_t)(blk * NW + w) * slab + chunk_base;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -294,18 +318,22 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
   }
 
   uint32_t parity = 0;
-  for (; blk < nblocks; blk += wgs_in_chunk) {
-    const uint32_t j0 = blk * NW;
-    const uint32_t j = j0 + w;
+  for (; u < nunits; u += wgs_in_chunk) {
+    const uint32_t gi = u / nblocks, blk = u - gi * nblocks;
+    const uint32_t j0 = blk * NW;            // local slot of wave 0
+    const uint32_t j = slot0 + j0 + w;       // this wave's slot of the ring
     const uint32_t mi = j >> P->logN;
     const ModConst m = P->mod[mi];
+    const uint32_t nx = 2u * grp.nq[gi];
+    uint64_t* const obase = grp.out[gi] + ch * chunk_stride;
     // multiple of q that makes every 40-bit group positive: 2^57 <= bias < 2^58, |group| < 2^56.1
     const uint64_t bias = m.q << (58 - (64 - __builtin_clzll(m.q)));
     [[maybe_unused]] const F64Mod fm{P->tab[mi].qd, P->tab[mi].qinvd};
     [[maybe_unused]] const double fw0 = P->fold_w[mi][0], fw1 = P->fold_w[mi][1], fw2 = P->fold_w[mi][2];
-    const uint8_t* abase = dbp + (size_t)j * slab + chunk_base;
-    const uint32_t nblk = blk + wgs_in_chunk;
-    const bool has_next = nblk < nblocks;
+    const uint8_t* abase = dbp + (size_t)(j0 + w) * slab + chunk_base;
+    const uint32_t nu = u + wgs_in_chunk;
+    const bool has_next = nu < nunits;
+    const uint32_t ngi = nu / nblocks, nblk = nu - ngi * nblocks;
     const uint8_t* nbase = dbp + (size_t)(nblk * NW + w) * slab + chunk_base;
 
     for (uint32_t rt = 0; rt < RT; ++rt) {
@@ -314,7 +342,7 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
       for (int s = 0; s < NS; ++s) T[s] = v4i{0, 0, 0, 0};
       const bool last = rt + 1 == RT;   // wave-uniform
       // ring of KS k-steps of A tiles: slot ks is refilled right after use with the same step of the next
-      // row tile (or of the next block's first row tile)
+      // row tile (or of the next unit's first row tile)
       const uint8_t* next_tile = last ? nbase : abase + (size_t)(rt + 1) * rt_stride;
       const bool refill = !last || has_next;
 #pragma unroll
@@ -335,7 +363,7 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
         const uint32_t gl = ks * 4 + g;
         if (refill && gl < gc) load_A(ks, next_tile, gl);
       }
-      if (last && has_next) load_B(nblk * NW + w);   // all MFMAs of this block are issued: B is free
+      if (last && has_next) load_B(ngi, nblk * NW + w);   // all MFMAs of this unit are issued: B is free
       // lane (g, i16) holds rows rt*16 + g*4 + i (i < 4) of column x = i16:  value = sum_s T[s] 2^(8 s)
       const int buf = parity;
       parity ^= 1;
@@ -357,11 +385,11 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
           r = f64_to_u64(f64_canon(f64_norm(acc, fm), fm));
         } else {
 #pragma unroll
-          for (int grp = NG - 1; grp >= 0; --grp) {
+          for (int gq = NG - 1; gq >= 0; --gq) {
             int64_t G = 0;
 #pragma unroll
-            for (int s = grp * 5; s < grp * 5 + 5 && s < NS; ++s) G += (int64_t)T[s][i] << (8 * (s - grp * 5));
-            if (grp == NG - 1 && NG > 1) {
+            for (int s = gq * 5; s < gq * 5 + 5 && s < NS; ++s) G += (int64_t)T[s][i] << (8 * (s - gq * 5));
+            if (gq == NG - 1 && NG > 1) {
               r = (uint64_t)(G + (int64_t)bias);   // top group: < 2^58, reduced together with the next one (bias = 0 mod q)
             } else {
               const u128 v = ((u128)r << 40) + (uint64_t)(G + (int64_t)bias);
@@ -382,12 +410,31 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
         if (x < (int)nx && r < rows) {
           typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
           const u64x2 v = {stage[buf][r16][x][part * 2], stage[buf][r16][x][part * 2 + 1]};   // two 8-byte LDS reads
-          uint64_t* dst = (uint64_t*)out.p[x >> 1] + ch * chunk_stride + ((size_t)r * 2 + (x & 1)) * kN + j0 + part * 2;
+          uint64_t* dst = obase + (size_t)(x >> 1) * out_qstride + ((size_t)r * 2 + (x & 1)) * out_rstride + j0 + part * 2;
           *reinterpret_cast<u64x2*>(dst) = v;
         }
       }
     }
   }
+}
+
+// Slot-sharded multi-GPU step: the row sums of a rank's own nq_total queries arrive from every rank h as
+// [query][row, comp][slots of h] (the all-to-all's receive buffer; rank h's block starts at word nq_total * RC * cut[h]);
+// this puts the queries q0 .. q0 + gridDim.z - 1 back into the [query][row, comp][k N] layout the inverse transform
+// reads.  Two words per thread; cuts are multiples of 16.
+__global__ void __launch_bounds__(256)
+slots_assemble_kernel(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, SliceMap map, uint32_t RC, uint32_t kN,
+                      uint64_t dst_qstride, uint32_t nq_total, uint32_t q0) {
+  const uint32_t j = (blockIdx.x * 256 + threadIdx.x) * 2;
+  const uint32_t rc = blockIdx.y, q = blockIdx.z;
+  if (j >= kN) return;
+  uint32_t h = 0;
+  while (h + 1 < map.n && j >= map.cut[h + 1]) ++h;
+  const uint32_t c0 = map.cut[h], width = map.cut[h + 1] - c0;
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  const uint64_t* s = src + (size_t)nq_total * RC * c0 + ((size_t)(q0 + q) * RC + rc) * width + (j - c0);
+  *reinterpret_cast<u64x2*>(dst + (size_t)q * dst_qstride + (size_t)rc * kN + j) =
+      __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(s));
 }
 
 // ------------------------------------------------------------------ host side
@@ -432,20 +479,25 @@ MfmaGeom mfma_geometry(const DevParams& hp, uint32_t rows, uint32_t cols, int wi
 }
 
 hipError_t launch_db_pack(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint64_t* db, uint8_t* dbp,
-                          uint32_t rows, uint32_t cols, uint32_t kN) {
-  const dim3 grid(kN / 16, gm.RT, gm.KG);
+                          uint32_t rows, uint32_t cols, uint32_t kN, uint32_t slot0, uint32_t nslots) {
+  if (nslots == 0) nslots = kN - slot0;
+  if (slot0 % 16 || nslots % 16 || slot0 + nslots > kN) return hipErrorInvalidValue;
+  const dim3 grid(nslots / 16, gm.RT, gm.KG);
+#define PIRGPU_DBPACK(L_, T_) \
+  hipLaunchKernelGGL((db_pack_kernel<L_, T_>), grid, dim3(256), 0, st, P, db, dbp, rows, cols, kN, gm.RT, gm.KG, gm.GC, slot0)
   switch (gm.L) {
     case 5:
-      if (gm.top4) hipLaunchKernelGGL((db_pack_kernel<5, true>), grid, dim3(256), 0, st, P, db, dbp, rows, cols, kN, gm.RT, gm.KG, gm.GC);
-      else hipLaunchKernelGGL((db_pack_kernel<5, false>), grid, dim3(256), 0, st, P, db, dbp, rows, cols, kN, gm.RT, gm.KG, gm.GC);
+      if (gm.top4) PIRGPU_DBPACK(5, true);
+      else PIRGPU_DBPACK(5, false);
       break;
     case 6:
-      if (gm.top4) hipLaunchKernelGGL((db_pack_kernel<6, true>), grid, dim3(256), 0, st, P, db, dbp, rows, cols, kN, gm.RT, gm.KG, gm.GC);
-      else hipLaunchKernelGGL((db_pack_kernel<6, false>), grid, dim3(256), 0, st, P, db, dbp, rows, cols, kN, gm.RT, gm.KG, gm.GC);
+      if (gm.top4) PIRGPU_DBPACK(6, true);
+      else PIRGPU_DBPACK(6, false);
       break;
-    case 7: hipLaunchKernelGGL((db_pack_kernel<7, false>), grid, dim3(256), 0, st, P, db, dbp, rows, cols, kN, gm.RT, gm.KG, gm.GC); break;
+    case 7: PIRGPU_DBPACK(7, false); break;
     default: return hipErrorInvalidValue;
   }
+#undef PIRGPU_DBPACK
   return hipGetLastError();
 }
 
@@ -468,21 +520,40 @@ hipError_t launch_db_unpack(hipStream_t st, const DevParams* P, const MfmaGeom& 
 }
 
 hipError_t launch_sel_pack(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const MfmaPtrs& sv, uint32_t nq,
-                           uint8_t* selp, uint32_t cols, uint32_t kN, bool sel_f64) {
+                           uint8_t* selp, uint32_t cols, uint32_t kN, bool sel_f64, const SliceMap* map) {
   const int f = sel_f64 ? 1 : 0;
   const dim3 grid(kN / 16, gm.KG);
+  SliceMap m{};
+  if (map) {
+    m = *map;
+    if (m.n > (uint32_t)kMaxSlices || m.cut[0] != 0 || m.cut[m.n] != kN) return hipErrorInvalidValue;
+    for (uint32_t r = 0; r <= m.n; ++r)
+      if (m.cut[r] % 16) return hipErrorInvalidValue;
+  }
+#define PIRGPU_SELPACK(L_, T_) \
+  hipLaunchKernelGGL((sel_pack_kernel<L_, T_>), grid, dim3(256), 0, st, P, sv, nq, selp, cols, kN, gm.KG, f, m)
   switch (gm.L) {
     case 5:
-      if (gm.top4) hipLaunchKernelGGL((sel_pack_kernel<5, true>), grid, dim3(256), 0, st, P, sv, nq, selp, cols, kN, gm.KG, f);
-      else hipLaunchKernelGGL((sel_pack_kernel<5, false>), grid, dim3(256), 0, st, P, sv, nq, selp, cols, kN, gm.KG, f);
+      if (gm.top4) PIRGPU_SELPACK(5, true);
+      else PIRGPU_SELPACK(5, false);
       break;
     case 6:
-      if (gm.top4) hipLaunchKernelGGL((sel_pack_kernel<6, true>), grid, dim3(256), 0, st, P, sv, nq, selp, cols, kN, gm.KG, f);
-      else hipLaunchKernelGGL((sel_pack_kernel<6, false>), grid, dim3(256), 0, st, P, sv, nq, selp, cols, kN, gm.KG, f);
+      if (gm.top4) PIRGPU_SELPACK(6, true);
+      else PIRGPU_SELPACK(6, false);
       break;
-    case 7: hipLaunchKernelGGL((sel_pack_kernel<7, false>), grid, dim3(256), 0, st, P, sv, nq, selp, cols, kN, gm.KG, f); break;
+    case 7: PIRGPU_SELPACK(7, false); break;
     default: return hipErrorInvalidValue;
   }
+#undef PIRGPU_SELPACK
+  return hipGetLastError();
+}
+
+hipError_t launch_slots_assemble(hipStream_t st, const uint64_t* src, uint64_t* dst, const SliceMap& map, uint32_t RC,
+                                 uint32_t kN, uint32_t nq, uint64_t dst_qstride, uint32_t nq_total, uint32_t q0) {
+  if (map.n == 0 || map.n > (uint32_t)kMaxSlices || map.cut[0] != 0 || map.cut[map.n] != kN || q0 + nq > nq_total)
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL(slots_assemble_kernel, dim3((kN / 2 + 255) / 256, RC, nq), dim3(256), 0, st, src, dst, map, RC, kN,
+                     dst_qstride, nq_total, q0);
   return hipGetLastError();
 }
 
@@ -501,24 +572,26 @@ static uint32_t scan_wgs_all() {
 
 template <int L, int KS, int NW, bool TOP4, bool F64F>
 static void launch_scan_mfma_variant(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp,
-                                     const uint8_t* selp, const MfmaPtrs& out, uint32_t nq, uint32_t rows, uint32_t kN,
-                                     uint64_t chunk_stride, uint32_t wgs_req) {
+                                     const ScanGroups& grp, uint32_t rows, uint64_t chunk_stride, uint32_t wgs_req,
+                                     uint32_t slot0, uint32_t nslots, uint64_t out_qstride, uint32_t out_rstride) {
   // wgs_req (batch pipeline): a workgroup takes a CU's whole register file, so a launch on fewer CUs leaves the others
   // to the VALU-bound kernels of the other lane -- the HBM-bound pass and the transforms then really overlap
   const uint32_t wgs = wgs_req ? std::min(wgs_req, scan_wgs_all()) : scan_wgs_all();
   // equal shares of the chip for the (equal) column chunks
   ChunkPlan plan{};
   plan.nchunks = gm.nchunks;
-  const uint32_t share = std::min<uint32_t>(kN / NW, std::max<uint32_t>(1, wgs / std::min<uint32_t>(gm.nchunks, wgs)));
+  const uint32_t units = nslots / NW * std::max<uint32_t>(grp.n, 1);
+  const uint32_t share = std::min<uint32_t>(units, std::max<uint32_t>(1, wgs / std::min<uint32_t>(gm.nchunks, wgs)));
   for (uint32_t c = 0; c <= gm.nchunks; ++c) plan.first[c] = c * share;   // share >= 1: no chunk without workgroups
-  hipLaunchKernelGGL((scan_mfma_kernel<L, KS, NW, TOP4, F64F>), dim3(gm.nchunks * share), dim3(NW * 64), 0, st, P, dbp, selp, out, nq,
-                     rows, gm.RT, gm.KG, kN, chunk_stride, plan, gm.GC);
+  hipLaunchKernelGGL((scan_mfma_kernel<L, KS, NW, TOP4, F64F>), dim3(gm.nchunks * share), dim3(NW * 64), 0, st, P, dbp, grp,
+                     rows, gm.RT, gm.KG, chunk_stride, plan, gm.GC, slot0, nslots, out_qstride, out_rstride);
 }
 
-hipError_t launch_scan_mfma(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp,
-                            const uint8_t* selp, const MfmaPtrs& out, uint32_t nq, uint32_t rows, uint32_t kN,
-                            uint64_t chunk_stride, uint32_t wgs, bool f64_fold) {
-#define PIRGPU_MFMA_ARGS st, P, gm, dbp, selp, out, nq, rows, kN, chunk_stride, wgs
+hipError_t launch_scan_mfma_groups(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp,
+                                   const ScanGroups& grp, uint32_t rows, uint64_t chunk_stride, uint32_t wgs, bool f64_fold,
+                                   uint32_t slot0, uint32_t nslots, uint64_t out_qstride, uint32_t out_rstride) {
+  if (grp.n == 0 || grp.n > (uint32_t)kMaxScanGroups || nslots == 0 || nslots % gm.NW) return hipErrorInvalidValue;
+#define PIRGPU_MFMA_ARGS st, P, gm, dbp, grp, rows, chunk_stride, wgs, slot0, nslots, out_qstride, out_rstride
 #define PIRGPU_MFMA_CASE(L_, KS_, NW_)                                                                    \
   if (gm.L == L_ && gm.KS == KS_ && gm.NW == NW_) {                                                                 \
     if constexpr (L_ <= 6) {                                                                                         \
@@ -542,6 +615,18 @@ hipError_t launch_scan_mfma(hipStream_t st, const DevParams* P, const MfmaGeom& 
 #undef PIRGPU_MFMA_CASE
 #undef PIRGPU_MFMA_ARGS
   return hipErrorInvalidValue;
+}
+
+// One group of up to 8 queries over the whole ring (the single-GPU pass): query q writes to out + q * out_qstride.
+hipError_t launch_scan_mfma(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp,
+                            const uint8_t* selp, uint64_t* out, uint64_t out_qstride, uint32_t nq, uint32_t rows,
+                            uint32_t kN, uint64_t chunk_stride, uint32_t wgs, bool f64_fold) {
+  ScanGroups grp{};
+  grp.n = 1;
+  grp.sel[0] = selp;
+  grp.out[0] = out;
+  grp.nq[0] = (uint8_t)nq;
+  return launch_scan_mfma_groups(st, P, gm, dbp, grp, rows, chunk_stride, wgs, f64_fold, 0, kN, out_qstride, kN);
 }
 
 }  // namespace pirgpu

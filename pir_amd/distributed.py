@@ -544,3 +544,272 @@ class RowsReplicatedPipeline:
 
     def replies(self, step: int):
         return self._replies[step & 1]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Slot-sharded step (pirgpu_slots_*): every rank holds 1 / G of the NTT slots of EVERY plaintext.
+# ------------------------------------------------------------------------------------------------------------------
+
+def slot_cuts(k_n: int, world: int, align: int = 16) -> List[int]:
+    """Slot ranges [cuts[r], cuts[r + 1]) of the ring's k * N NTT slots, contiguous, balanced, multiples of `align`
+    (the packing kernels work on blocks of 16 slots)."""
+    if k_n % align:
+        raise ValueError("k * N must be a multiple of %d" % align)
+    blocks = k_n // align
+    return [(blocks * r // world) * align for r in range(world + 1)]
+
+
+class SlotsBuffers:
+    """Device buffers of one slot-sharded step for one (server, batch size, world)."""
+
+    def __init__(self, server, batch: int, rank: int, world: int, torch, device):
+        if batch % world:
+            raise ValueError("batch size must be a multiple of the world size")
+        self.per = batch // world
+        self.groups = (self.per + GROUP - 1) // GROUP
+        k, N = server.k, server.N
+        self.k_n = k * N
+        self.ctw = 2 * k * N
+        self.cuts = slot_cuts(self.k_n, world)
+        self.width = [self.cuts[r + 1] - self.cuts[r] for r in range(world)]
+        self.mine = self.width[rank]
+        n0 = server.params.dimensions[0]
+        self.rc = 2 * n0
+        dim_sum = sum(server.params.dimensions)
+        reply_cts = server.db.reply_ct_count()
+        piece = [server.slots_packed_bytes(w) for w in self.width]      # one group's packed column selectors, rank r's slots
+        if not all(piece):
+            raise ValueError("the slot-sharded step needs d = 2 and the int8-MFMA scan in one column chunk")
+        self.piece = piece
+        self.packed_send = torch.empty((self.groups * sum(piece),), dtype=torch.uint8, device=device)
+        self.packed_recv = torch.empty((world * self.groups * piece[rank],), dtype=torch.uint8, device=device)
+        self.sv = torch.empty((self.per, dim_sum, self.ctw), dtype=torch.int64, device=device)
+        self.rows_send = torch.empty((batch * self.rc * self.mine,), dtype=torch.int64, device=device)
+        self.rows_recv = torch.empty((self.per * self.rc * self.k_n,), dtype=torch.int64, device=device)
+        self.replies = torch.empty((self.per, reply_cts, 2, k, N), dtype=torch.int64, device=device)
+        self.x1_send = [self.groups * p for p in piece]
+        self.x1_recv = [self.groups * piece[rank]] * world
+        self.x2_send = [self.per * self.rc * self.mine] * world
+        self.x2_recv = [self.per * self.rc * w for w in self.width]
+        # row sums may cross the links in 5 bytes per residue (moduli below 2^40); off by default: at 8 GPUs the
+        # exchange is not what bounds the step and the two packing passes cost compute (PIRGPU_SLOTS_PACK40=1)
+        self.rows40 = (os.environ.get("PIRGPU_SLOTS_PACK40", "0") == "1" and hasattr(server, "pack40_supported")
+                       and server.pack40_supported())
+        if self.rows40:
+            self.rows_send40 = torch.empty((self.rows_send.numel() * 5 // 4,), dtype=torch.int32, device=device)
+            self.rows_recv40 = torch.empty((self.rows_recv.numel() * 5 // 4,), dtype=torch.int32, device=device)
+
+    def exchange_bytes_per_query(self, world: int) -> float:
+        """Bytes a rank receives per query of the batch: its slots of every other rank's packed column selectors +
+        the row sums of its own queries from the other ranks' slots."""
+        batch = self.per * world
+        x1 = (world - 1) * self.groups * self.piece[0]
+        x2 = self.per * self.rc * (self.k_n - self.mine) * (5 if self.rows40 else 8)
+        return (x1 + x2) / batch
+
+    def exchange_selectors(self, comm) -> None:
+        comm.all_to_all(self.packed_recv, self.packed_send, self.x1_recv, self.x1_send, units=self.groups)
+
+    def exchange_rowsums(self, comm, server, stream: int = 0) -> None:
+        if self.rows40:
+            server.pack40_async(self.rows_send.data_ptr(), self.rows_send40.data_ptr(), self.rows_send.numel(), stream)
+            comm.all_to_all(self.rows_recv40, self.rows_send40, [v * 5 // 4 for v in self.x2_recv],
+                            [v * 5 // 4 for v in self.x2_send], units=self.per)
+            server.unpack40_async(self.rows_recv40.data_ptr(), self.rows_recv.data_ptr(), self.rows_recv.numel(), stream)
+        else:
+            comm.all_to_all(self.rows_recv, self.rows_send, self.x2_recv, self.x2_send, units=self.per)
+
+
+def slots_exchange_supported(server) -> bool:
+    """True when this server can take part in the slot-sharded step (d = 2, int8-MFMA scan in one column chunk)."""
+    return hasattr(server, "slots_packed_bytes") and server.slots_packed_bytes(16) > 0
+
+
+def run_batch_slots(server, bufs: SlotsBuffers, dist, rank: int, world: int, comm: Optional[Comm] = None,
+                    first: int = 0) -> dict:
+    """One SYNCHRONOUS slot-sharded step over a staged batch on `world` GPUs (d = 2):
+
+      E  every rank expands its own `per` queries (groups of 8), keeps their NTT-form selection vectors and packs their
+         column selectors into the scan's B-operand layout, cut by destination rank;
+      X1 all-to-all: a rank receives ITS slots of every query's packed column selectors (1 / world of each);
+      S  every rank scans its slots of the WHOLE matrix for all queries of the step in one launch;
+      X2 all-to-all: the row sums return to the rank that expanded the query;
+      U  that rank assembles them and runs inverse NTT + upper level for its own queries with the row selectors it kept.
+
+    Rank r ends with the finished replies of the queries it expanded in bufs.replies (reply i answers query i, reference
+    server.cpp:60-63).  No row-selector exchange, no reduce.  Returns the serial phase times."""
+    comm = comm or Comm(dist, world)
+    server.check_ready()
+    import time
+    t = [time.perf_counter()]
+    lo = first + rank * bufs.per
+    server.slots_expand_async(lo, bufs.per, bufs.packed_send.data_ptr(), bufs.sv.data_ptr(), bufs.cuts)
+    server.sync()
+    t.append(time.perf_counter())
+    bufs.exchange_selectors(comm)
+    t.append(time.perf_counter())
+    server.slots_scan_async(bufs.packed_recv.data_ptr(), world, bufs.per, bufs.rows_send.data_ptr())
+    server.sync()
+    t.append(time.perf_counter())
+    bufs.exchange_rowsums(comm, server)
+    server.sync()
+    t.append(time.perf_counter())
+    server.slots_finish_async(bufs.rows_recv.data_ptr(), bufs.per, bufs.sv.data_ptr(), bufs.cuts, bufs.replies.data_ptr())
+    server.sync()
+    t.append(time.perf_counter())
+    return {"expand_ms": (t[1] - t[0]) * 1e3, "exchange_selectors_ms": (t[2] - t[1]) * 1e3, "scan_ms": (t[3] - t[2]) * 1e3,
+            "exchange_rowsums_ms": (t[4] - t[3]) * 1e3, "finish_ms": (t[5] - t[4]) * 1e3}
+
+
+class _SlotStreamsCpu:
+    """No streams on the CPU (oracle-backed server in the gloo tests): everything is synchronous."""
+
+    def comm(self):
+        return _NoStreams._Ctx()
+
+    def gate_after(self, *events):
+        return 0
+
+    def record(self, name, b):
+        pass
+
+    def comm_wait(self, name, b):
+        pass
+
+    def comm_handle(self):
+        return 0
+
+    def fin_handle(self):
+        return 0
+
+    def synchronize(self):
+        pass
+
+
+class _SlotStreamsGpu:
+    """The communication stream, a `fin` stream the finished steps report to, and a gate stream through which a lane is
+    made to wait for exactly the events it needs (pirgpu_slots_*'s `after` takes a stream's current position)."""
+
+    def __init__(self, torch, device, n_sets):
+        self.torch = torch
+        self.side = torch.cuda.Stream(device=device)
+        self.fin = torch.cuda.Stream(device=device)
+        self.gate = torch.cuda.Stream(device=device)
+        self.ev = {name: [torch.cuda.Event() for _ in range(n_sets)] for name in ("x1", "x2", "u")}
+        self.recorded = {name: [False] * n_sets for name in self.ev}
+
+    def comm(self):
+        return self.torch.cuda.stream(self.side)
+
+    def gate_after(self, *events):
+        """Handle of the gate stream after it has been made to wait for the named events (those recorded so far)."""
+        for name, b in events:
+            if self.recorded[name][b]:
+                self.gate.wait_event(self.ev[name][b])
+        return int(self.gate.cuda_stream)
+
+    def record(self, name, b):
+        self.ev[name][b].record(self.fin if name == "u" else self.side)
+        self.recorded[name][b] = True
+
+    def comm_wait(self, name, b):
+        if self.recorded[name][b]:
+            self.side.wait_event(self.ev[name][b])
+
+    def comm_handle(self):
+        return int(self.side.cuda_stream)
+
+    def fin_handle(self):
+        return int(self.fin.cuda_stream)
+
+    def synchronize(self):
+        self.side.synchronize()
+        self.fin.synchronize()
+        self.gate.synchronize()
+
+
+class SlotsPipeline:
+    """The slot-sharded step of run_batch_slots, PIPELINED over consecutive steps and free of host waits.  What submit(s)
+    queues, in this order:
+
+        lane:   S_(s-1)                    E_s                    U_(s-2)
+        comm:            X2_(s-1)                   X1_s
+
+    so both exchanges of a step run under the compute of its neighbours: E (VALU-bound) shares the chip with S
+    (HBM-bound) like the two lanes of the single-GPU pipeline.  Three buffer sets (the selection vectors of step s are
+    read by U_s two submits later).  Every edge is an event: a lane waits for exactly the exchange it consumes
+    (pirgpu_slots_*'s `after`), the communication stream waits for exactly the lane that produced what it sends
+    (`then`); nothing in submit() blocks the host.  The replies of step s are in `replies(s)` after flush() (or once
+    submit(s + 2) has been followed by a synchronise of the `fin` stream) and are overwritten by submit(s + 5).
+
+    submit(first) serves the staged queries [first + rank * per, first + (rank + 1) * per)."""
+
+    SETS = 3
+
+    def __init__(self, server, batch: int, rank: int, world: int, dist, torch, device, comm: Optional[Comm] = None):
+        self.server, self.rank, self.world = server, rank, world
+        self.sets = [SlotsBuffers(server, batch, rank, world, torch, device) for _ in range(self.SETS)]
+        self.per = self.sets[0].per
+        on_gpu = str(device).startswith("cuda")
+        self.comm = comm or Comm(dist, world, host_sync=False)
+        self.comm.host_sync = False
+        self.streams = _SlotStreamsGpu(torch, device, self.SETS) if on_gpu else _SlotStreamsCpu()
+        self.step = 0            # steps submitted (E + X1 queued)
+        self.scanned = 0         # steps whose S + X2 are queued
+        self.finished = 0        # steps whose U is queued
+
+    def _scan(self, s: int) -> None:
+        """S_s + X2_s."""
+        srv, st, bufs = self.server, self.streams, self.sets[s % self.SETS]
+        b = s % self.SETS
+        srv.slots_scan_async(bufs.packed_recv.data_ptr(), self.world, bufs.per, bufs.rows_send.data_ptr(),
+                             after=st.gate_after(("x1", b)), then=st.comm_handle())
+        st.comm_wait("u", b)                   # the finish that last read rows_recv of this set (three steps ago)
+        with st.comm():
+            bufs.exchange_rowsums(self.comm, srv, st.comm_handle())
+            st.record("x2", b)
+
+    def _finish(self, s: int) -> None:
+        """U_s."""
+        srv, st, bufs = self.server, self.streams, self.sets[s % self.SETS]
+        b = s % self.SETS
+        srv.slots_finish_async(bufs.rows_recv.data_ptr(), bufs.per, bufs.sv.data_ptr(), bufs.cuts, bufs.replies.data_ptr(),
+                               after=st.gate_after(("x2", b)), then=st.fin_handle())
+        st.record("u", b)
+
+    def submit(self, first: int = 0) -> None:
+        srv, st = self.server, self.streams
+        srv.check_ready()
+        s = self.step
+        b = s % self.SETS
+        bufs = self.sets[b]
+        while self.scanned < s:
+            self._scan(self.scanned)
+            self.scanned += 1
+        # E_s refills set b: the exchange that read its send buffer and the finish that read its selection vectors
+        # (both three steps ago) are done
+        srv.slots_expand_async(first + self.rank * bufs.per, bufs.per, bufs.packed_send.data_ptr(), bufs.sv.data_ptr(),
+                               bufs.cuts, after=st.gate_after(("x1", b), ("u", b)), then=st.comm_handle())
+        with st.comm():
+            bufs.exchange_selectors(self.comm)
+            st.record("x1", b)
+        while self.finished + 2 <= s:
+            self._finish(self.finished)
+            self.finished += 1
+        self.step += 1
+
+    def flush(self) -> None:
+        """Queues what is still owed for the last two steps and waits for everything."""
+        s = self.step
+        while self.scanned < s:
+            self._scan(self.scanned)
+            self.scanned += 1
+        while self.finished < s:
+            self._finish(self.finished)
+            self.finished += 1
+        self.streams.synchronize()
+        self.server.sync()
+
+    def replies(self, step: int):
+        """The replies tensor of `step` (0-based submit index): [per, reply_cts, 2, k, N] int64."""
+        return self.sets[step % self.SETS].replies

@@ -47,13 +47,16 @@ def _ptr(a: np.ndarray):
 class PIRDatabase:
     """reference database.h:37-133.  Owns the device context and the HBM-resident encoded database."""
 
-    def __init__(self, params: PIRParameters, device: int = 0, shard: Optional[Sequence[int]] = None):
+    def __init__(self, params: PIRParameters, device: int = 0, shard: Optional[Sequence[int]] = None,
+                 slots: Optional[Sequence[int]] = None):
+        """shard: rows [begin, end) of dimension 0 this context holds; slots: NTT slots [begin, end) of every plaintext
+        it holds (multi-GPU partitionings; default: the whole database)."""
         self.params = params
         enc = params.encryption_parameters
         self.N = enc.poly_modulus_degree
         self.k = len(enc.coeff_modulus) - 1
         self.lib = capi.load()
-        p = capi.make_params(params, device=device, shard=shard)
+        p = capi.make_params(params, device=device, shard=shard, slots=slots)
         self._cparams = p
         h = C.c_void_p()
         rc = self.lib.pirgpu_create(C.byref(p), C.byref(h))
@@ -83,9 +86,9 @@ class PIRDatabase:
 
     # -- reference interface ------------------------------------------------------
     @classmethod
-    def Create(cls, params: PIRParameters, rawdb=None, device: int = 0, shard=None) -> "PIRDatabase":
+    def Create(cls, params: PIRParameters, rawdb=None, device: int = 0, shard=None, slots=None) -> "PIRDatabase":
         """database.cpp:40-58: Create(params) / Create(rawdb, params)."""
-        db = cls(params, device=device, shard=shard)
+        db = cls(params, device=device, shard=shard, slots=slots)
         if rawdb is not None:
             db.populate(rawdb)
         return db
@@ -354,6 +357,31 @@ class PIRServer:
         cuts = (C.c_uint32 * len(row_cuts))(*row_cuts)
         self._check(self.lib.pirgpu_batch_expand_packed(self.db.handle, first, count, C.c_void_p(packed_ptr),
                                                         C.c_void_p(rows_ptr), cuts, len(row_cuts) - 1))
+
+    # -- slot-sharded multi-GPU step (pirgpu_slots_*) -------------------------------
+    def slots_packed_bytes(self, slots: int) -> int:
+        """Bytes of `slots` NTT slots of one packed group of column selectors (0: the step does not apply)."""
+        return int(self.lib.pirgpu_slots_packed_bytes(self.db.handle, int(slots)))
+
+    def slots_expand_async(self, first: int, count: int, packed_ptr: int, sv_ptr: int, slot_cuts, after: int = 0,
+                           then: int = 0) -> None:
+        cuts = (C.c_uint32 * len(slot_cuts))(*slot_cuts)
+        self._check(self.lib.pirgpu_slots_expand_async(self.db.handle, first, count, C.c_void_p(packed_ptr),
+                                                       C.c_void_p(sv_ptr), cuts, len(slot_cuts) - 1,
+                                                       C.c_void_p(after or None), C.c_void_p(then or None)))
+
+    def slots_scan_async(self, packed_ptr: int, n_ranks: int, per_rank: int, rowsums_ptr: int, after: int = 0,
+                         then: int = 0) -> None:
+        self._check(self.lib.pirgpu_slots_scan_async(self.db.handle, C.c_void_p(packed_ptr), n_ranks, per_rank,
+                                                     C.c_void_p(rowsums_ptr), C.c_void_p(after or None),
+                                                     C.c_void_p(then or None)))
+
+    def slots_finish_async(self, rowsums_ptr: int, count: int, sv_ptr: int, slot_cuts, replies_ptr: int, after: int = 0,
+                           then: int = 0) -> None:
+        cuts = (C.c_uint32 * len(slot_cuts))(*slot_cuts)
+        self._check(self.lib.pirgpu_slots_finish_async(self.db.handle, C.c_void_p(rowsums_ptr), count, C.c_void_p(sv_ptr),
+                                                       cuts, len(slot_cuts) - 1, C.c_void_p(replies_ptr),
+                                                       C.c_void_p(after or None), C.c_void_p(then or None)))
 
     # -- the same without host synchronisation + device-side ordering (pipelined multi-GPU step) --------
     def stream_handle(self) -> int:

@@ -76,6 +76,8 @@ class OracleShardServer:
         self.shard_db = setup.db_ntt[self.lo * stride:min(self.hi * stride, self.params.num_pt)]
         self.db = _Db(self.orc.reply_ct_count(len(self.dims)))
         self.queries, self.partials = None, None
+        if len(self.dims) == 2:
+            self._slot_setup(rank, world)
 
     # -- staging / expansion -------------------------------------------------------------------------------
     def stage_batch(self, queries):
@@ -198,6 +200,93 @@ class OracleShardServer:
     def reduce_fixup_device_async(self, ptr, n_cts, stream=0):
         self.reduce_fixup_device_n(ptr, n_cts)
 
+    # -- slot-sharded step (pirgpu_slots_*): this stand-in holds the slots [cuts[rank], cuts[rank+1]) of every plaintext ----
+    # its "packed" format is the raw NTT-form column selectors of a group restricted to a slot range:
+    # u64 [GROUP][n1][2][slots]; row sums and selection vectors are in the oracle's own slot order
+    def _slot_setup(self, rank, world):
+        self.rank, self.world = rank, world
+        self.kN = self.k * self.N
+        self.slot_cut = D.slot_cuts(self.kN, world)
+        self.c0, self.c1 = self.slot_cut[rank], self.slot_cut[rank + 1]
+        n0, n1 = self.dims
+        db = np.zeros((n0 * n1, self.kN), dtype=np.uint64)
+        db[: self.params.num_pt] = np.asarray(self.s.db_ntt).reshape(self.params.num_pt, self.kN)
+        self.db_slots = db[:, self.c0:self.c1].reshape(n0, n1, self.c1 - self.c0).copy()   # ONLY this rank's slots
+        self.qvec = np.repeat(np.array(self.orc.moduli[: self.k], dtype=np.uint64), self.N)
+
+    @staticmethod
+    def _mulmod(a, b, q):
+        """a * b mod q elementwise in uint64 arithmetic (operands < q < 2^42)."""
+        assert int(q.max()) < 1 << 42
+        a0, a1 = a & np.uint64((1 << 21) - 1), a >> np.uint64(21)
+        hi = (a1 * b) % q
+        return ((hi << np.uint64(21)) % q + (a0 * b) % q) % q
+
+    def slots_packed_bytes(self, slots):
+        return D.GROUP * self.dims[1] * 2 * slots * 8 if len(self.dims) == 2 else 0
+
+    def _sv_ntt(self, i):
+        sv = self._sv(i)                                     # coefficient form [dim_sum, 2, k, N]
+        return np.stack([self.orc.ct_ntt_fwd(ct) for ct in sv])
+
+    def slots_expand_async(self, first, count, packed_ptr, sv_ptr, cuts, after=0, then=0):
+        n0, n1 = self.dims
+        G = len(cuts) - 1
+        groups = (count + D.GROUP - 1) // D.GROUP
+        sv_out = _view(sv_ptr, count * (n0 + n1) * self.ctw).reshape(count, n0 + n1, self.ctw)
+        total = groups * D.GROUP * n1 * 2 * self.kN
+        packed = _view(packed_ptr, total)
+        off = [groups * D.GROUP * n1 * 2 * cuts[r] for r in range(G)]        # piece [rank r][group g]
+        for i in range(count):
+            sv = self._sv_ntt(first + i).reshape(n0 + n1, 2, self.kN)
+            sv_out[i] = sv.reshape(n0 + n1, self.ctw)
+            g, q = divmod(i, D.GROUP)
+            for r in range(G):
+                w = cuts[r + 1] - cuts[r]
+                piece = packed[off[r] + g * D.GROUP * n1 * 2 * w: off[r] + (g + 1) * D.GROUP * n1 * 2 * w]
+                piece.reshape(D.GROUP, n1, 2, w)[q] = sv[n0:, :, cuts[r]:cuts[r + 1]]
+
+    def slots_scan_async(self, packed_ptr, n_ranks, per_rank, rowsums_ptr, after=0, then=0):
+        n0, n1 = self.dims
+        w = self.c1 - self.c0
+        groups = (per_rank + D.GROUP - 1) // D.GROUP
+        packed = _view(packed_ptr, n_ranks * groups * D.GROUP * n1 * 2 * w).reshape(n_ranks, groups, D.GROUP, n1, 2, w)
+        out = _view(rowsums_ptr, n_ranks * per_rank * n0 * 2 * w).reshape(n_ranks, per_rank, n0, 2, w)
+        qv = self.qvec[self.c0:self.c1]
+        for r in range(n_ranks):
+            for i in range(per_rank):
+                sel = packed[r, i // D.GROUP, i % D.GROUP]             # [n1][2][w]
+                acc = np.zeros((n0, 2, w), dtype=np.uint64)
+                for col in range(n1):
+                    for comp in range(2):
+                        acc[:, comp] = (acc[:, comp] + self._mulmod(self.db_slots[:, col], sel[col, comp][None, :], qv[None, :])) % qv
+                out[r, i] = acc
+
+    def slots_finish_async(self, rowsums_ptr, count, sv_ptr, cuts, replies_ptr, after=0, then=0):
+        """database.cpp:196-254 on assembled row sums, built from the oracle's primitives."""
+        n0, n1 = self.dims
+        G = len(cuts) - 1
+        src = _view(rowsums_ptr, count * n0 * 2 * self.kN)
+        sv_all = _view(sv_ptr, count * (n0 + n1) * self.ctw).reshape(count, n0 + n1, 2, self.k, self.N)
+        E = 2 * self.orc.expansion_ratio()
+        out = _view(replies_ptr, count * E * self.ctw).reshape(count, E, 2, self.k, self.N)
+        rows = np.empty((count, n0, 2, self.kN), dtype=np.uint64)
+        for h in range(G):
+            w = cuts[h + 1] - cuts[h]
+            blk = src[count * n0 * 2 * cuts[h]: count * n0 * 2 * cuts[h + 1]].reshape(count, n0, 2, w)
+            rows[:, :, :, cuts[h]:cuts[h + 1]] = blk
+        qk = np.array(self.orc.moduli[: self.k], dtype=np.uint64)[None, :, None]
+        for i in range(count):
+            result = np.zeros((E, 2, self.k, self.N), dtype=np.uint64)
+            for r in range(n0):
+                ct = self.orc.ct_ntt_inv(rows[i, r].reshape(2, self.k, self.N).copy())
+                pts = self.orc.reencode(ct)                           # [E][N] coefficients below 2^b
+                sel = np.ascontiguousarray(sv_all[i, r])
+                for e in range(E):
+                    temp = self.orc.multiply_plain_ntt(sel, self.orc.plain_lift_ntt(pts[e]))
+                    result[e] = (result[e] + temp) % qk
+            out[i] = np.stack([self.orc.ct_ntt_inv(result[e].copy()) for e in range(E)])
+
     # -- the collective transparent-ciphertext decision (pirgpu_zero_plaintexts / _set_remote_ / _check_ready) ------
     remote_zero = 0
 
@@ -315,6 +404,28 @@ def rows_step_check(rank, world, d, dbsize, elem, batch, zero_pt=None):
             mine_r = rp.replies(t).numpy().view(np.uint64)
             for i in range(lo, hi):
                 ok &= bool(np.array_equal(mine_r[i - lo], full[i]))
+        srv.stage_batch(queries)
+        # the SLOT-sharded step: every rank holds half of the NTT slots of every plaintext, receives its slots of every
+        # query's column selectors, returns row sums to the query's owner, which finishes its own queries -- synchronous,
+        # then pipelined over four steps (three buffer sets)
+        assert D.slots_exchange_supported(srv)
+        sb = D.SlotsBuffers(srv, batch, rank, world, torch, "cpu")
+        D.run_batch_slots(srv, sb, dist, rank, world, comm)
+        mine_s = sb.replies.numpy().view(np.uint64)
+        for i in range(lo, hi):
+            ok &= bool(np.array_equal(mine_s[i - lo], full[i]))
+            ok &= s.client.process_response(p, indexes[i], mine_s[i - lo]) == s.item(indexes[i])
+        srv.stage_batch(q_all + q_all[:batch])
+        sp = D.SlotsPipeline(srv, batch, rank, world, dist, torch, "cpu", comm=D.Comm(dist, world))
+        for t in range(4):
+            sp.submit(first=t * batch)
+        sp.flush()
+        for t in (1, 2, 3):
+            got = sp.replies(t).numpy().view(np.uint64)
+            for i in range(lo, hi):
+                g = (t * batch + i) % len(q_all)
+                want = full[i] if g < batch else s.orc.process_query(s.db_ntt, p.dimensions, q_all[g], s.galois_keys)[1]
+                ok &= bool(np.array_equal(got[i - lo], want))
         srv.stage_batch(queries)
     # the whole-selection-vector exchange (any d): every rank ends with every reply
     sv_all = torch.empty((batch, p.dim_sum, 2, s.orc.k, 4096), dtype=torch.int64)

@@ -138,6 +138,33 @@ def world8_check(rank, world, rows, per, mode):
             mine = hp.replies(t).numpy().view(np.uint64)
             for i in range(glo, ghi):
                 ok &= bool(np.array_equal(mine[i - glo], want(q_all[t * batch + gi * bpg + i])))
+    elif mode == "slots":
+        # slot-sharded step: every rank holds 1 / 8 of the NTT slots of EVERY plaintext (all rows), scans them for all
+        # queries of the step and returns the row sums to the query's owner; two pipelined steps + the synchronous form
+        srv = OracleShardServer(s, rank, world)
+        steps = 2
+        idx_all, q_all = [], []
+        for t in range(steps):
+            a, b = queries_for(t)
+            idx_all += a
+            q_all += b
+        srv.stage_batch(q_all)
+        assert D.slots_exchange_supported(srv)
+        sb = D.SlotsBuffers(srv, batch, rank, world, torch, "cpu")
+        assert sb.per == per and sb.mine == s.orc.k * 4096 // world
+        D.run_batch_slots(srv, sb, dist, rank, world, comm)
+        mine = sb.replies.numpy().view(np.uint64)
+        for i in range(lo, hi):
+            ok &= bool(np.array_equal(mine[i - lo], want(q_all[i])))
+            ok &= s.client.process_response(p, idx_all[i], mine[i - lo]) == s.item(idx_all[i])
+        sp = D.SlotsPipeline(srv, batch, rank, world, dist, torch, "cpu", comm=D.Comm(dist, world))
+        for t in range(steps):
+            sp.submit(first=t * batch)
+        sp.flush()
+        for t in range(steps):
+            got = sp.replies(t).numpy().view(np.uint64)
+            for i in range(lo, hi):
+                ok &= bool(np.array_equal(got[i - lo], want(q_all[t * batch + i])))
     else:
         raise ValueError(mode)
     return bool(ok)
@@ -160,7 +187,9 @@ def _worker(rank, world, port, rows, per, mode, out_q):
     (21, 9, "pipeline"),      # a full group + a partial one per rank, three pipelined steps over both buffer sets
     (21, 2, "replicated"),    # replicated expansion: reduce-scatter only
     (21, 4, "hybrid"),        # 2 replica groups x 4 row shards (6 / 5-row shards inside a group)
-], ids=["packed-21rows-per8", "packed-13rows-per3", "pipeline-21rows-per9", "replicated-21rows-per2", "hybrid-2x4-21rows"])
+    (13, 3, "slots"),         # slot shards: 1 / 8 of the NTT slots of every plaintext per rank, no reduce
+], ids=["packed-21rows-per8", "packed-13rows-per3", "pipeline-21rows-per9", "replicated-21rows-per2", "hybrid-2x4-21rows",
+        "slots-13rows-per3"])
 def test_world_size_eight_over_gloo(rows, per, mode):
     ctx = mp.get_context("spawn")
     out_q = ctx.Queue()

@@ -14,7 +14,7 @@ NTT_LOGNS = [11, 12, 13, 14]
 HEADERS = ["device_params.h", "env_gate.h", "kernels.h", "host_math.h", "wire.h", "wire_codec.h", "arith.h", "ntt_core.h", NTT_SOURCE, os.path.join("..", "..", "include", "pirgpu.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + \
-    os.environ.get("PIRGPU_BUILD_DEFS", "").split()      # A/B builds of compile-time choices (tools/r04_ab_ept.sh)
+    os.environ.get("PIRGPU_BUILD_DEFS", "").split()      # A/B builds of compile-time choices (tools/experiments/r04_ab_ept.sh)
 
 
 def _stale() -> bool:

@@ -1017,7 +1017,10 @@ void post_scan_stage(pirgpu_ctx* c, const Stage& sg, Worker* profiled) {
       // large rings: transform the re-encoded plaintexts of a block of children into scratch, multiply-accumulate
       // them elementwise, next block (upper_ntt_kernel / upper_mac_kernel)
       const uint64_t unit = (uint64_t)sg.n * rows * C * c->E * k * N;   // scratch words per child of the block
-      uint32_t blk = (uint32_t)std::min<uint64_t>(c->dims[l], std::max<uint64_t>(1, c->split_upper_words / unit));
+      // children per output row that exist in this shard: at the top level of a row shard only its own rows (the
+      // selector buffer of the packed multi-GPU exchange holds no more than those -- reading on to dims[l] ran past it)
+      const uint32_t nd = (uint32_t)kids;
+      uint32_t blk = (uint32_t)std::min<uint64_t>(nd, std::max<uint64_t>(1, c->split_upper_words / unit));
       if (*sg.up_scratch_words < unit * blk) {
         HIP_TRY(hipStreamSynchronize(st));
         if (*sg.up_scratch) {
@@ -1029,11 +1032,11 @@ void post_scan_stage(pirgpu_ctx* c, const Stage& sg, Worker* profiled) {
         *sg.up_scratch = c->dalloc<uint64_t>(unit * blk);
         *sg.up_scratch_words = unit * blk;
       }
-      for (uint32_t b0 = 0; b0 < c->dims[l]; b0 += blk) {
+      for (uint32_t b0 = 0; b0 < nd; b0 += blk) {
         HIP_TRY(c->ops->upper_ntt(st, c->mode, c->dp, k, c->E, sg.lvl[l + 1], *sg.up_scratch, (uint32_t)rows, c->dims[l],
                                   (uint32_t)nch, (uint32_t)C, b0, blk, sg.n, c->lvl_cts[l + 1] * ctw, c->loop_transforms));
         HIP_TRY(launch_upper_mac(st, c->dp, *sg.up_scratch, sg.sel, sg.pt_buf, sg.lvl[l], sg.n, (uint32_t)rows, (uint32_t)C,
-                                 c->E, k, N, sv_first, b0, blk, c->dims[l], b0 == 0, b0 + blk >= c->dims[l], c->pt_words,
+                                 c->E, k, N, sv_first, b0, blk, nd, b0 == 0, b0 + blk >= nd, c->pt_words,
                                  c->lvl_cts[l] * ctw));
       }
       if (l == 0 && profiled) record(c, *profiled, PH_FINAL);
@@ -1732,10 +1735,24 @@ int pirgpu_keyset_unpin(pirgpu_ctx* c, uint32_t slot) {
   return PIRGPU_OK;
 }
 
+// The single-query selection as a handle: the generation it was SELECTED with (not the slot's current one -- a selection
+// that went stale must stay stale), 0 for the default set.
 uint32_t pirgpu_current_keyset(pirgpu_ctx* c) {
   if (!c) return 0;
   std::lock_guard<std::recursive_mutex> lock(c->mu);
-  return slot_handle(c, c->cur_keyset);
+  return c->cur_keyset ? (c->cur_keyset_gen << kSlotBits) | (c->cur_keyset & kSlotMask) : 0;
+}
+
+// wire layer: the selection saved and put back exactly as it was (index, generation), valid or not
+void pirgpu_keyset_selection_get(pirgpu_ctx* c, uint32_t sel[2]) {
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  sel[0] = c->cur_keyset;
+  sel[1] = c->cur_keyset_gen;
+}
+void pirgpu_keyset_selection_set(pirgpu_ctx* c, const uint32_t sel[2]) {
+  std::lock_guard<std::recursive_mutex> lock(c->mu);
+  c->cur_keyset = sel[0];
+  c->cur_keyset_gen = sel[1];
 }
 
 int pirgpu_query_use_keyset(pirgpu_ctx* c, uint32_t slot) {

@@ -14,7 +14,7 @@ constexpr int kMaxScanQueries = 4;       // queries sharing one database pass in
 // waves get 256 VGPRs: twiddle prefetch on, three passes instead of four) against 16 (1024-thread workgroups, 128
 // VGPRs) on one box, round 4: 104.4 against 112.7 queries/s at cfg 5, single query 19.1 against 18.1 ms -- with one
 // workgroup per CU either way (a 16384-point polynomial fills the LDS), sixteen waves hide more latency than eight with
-// twice the registers (-DPIRGPU_LOG_EPT14=5 rebuilds the other organisation, tools/r04_ab_ept.sh).
+// twice the registers (-DPIRGPU_LOG_EPT14=5 rebuilds the other organisation, tools/experiments/r04_ab_ept.sh).
 #ifndef PIRGPU_LOG_EPT14
 #define PIRGPU_LOG_EPT14 4
 #endif

@@ -43,7 +43,7 @@ constexpr size_t kLdsBytes = (size_t)Plan<LOGN>::LDS_WORDS * 8;
 // twiddle prefetch one pass ahead costs 30 (EPT = 16) / 62 (EPT = 32) VGPRs: on up to N = 8192; the 1024-thread
 // workgroups of N = 16384 have 128 VGPRs per wave and request a pass's twiddles between the previous pass's butterflies
 // and the exchange instead (ntt_core.h).  (The 32-residue organisation of N = 16384 -- 512 threads, 256 VGPRs -- has the
-// room; PIRGPU_PF14 = 0 switches the prefetch off there for the A/B of tools/r04_ab_ept.sh.)
+// room; PIRGPU_PF14 = 0 switches the prefetch off there for the A/B of tools/experiments/r04_ab_ept.sh.)
 #ifndef PIRGPU_PF14
 #define PIRGPU_PF14 1
 #endif
@@ -52,7 +52,7 @@ constexpr bool kPF = LOGN < 14 || (EPT == 32 && PIRGPU_PF14 != 0);   // 1024-thr
 // prefetch they need 138-142 VGPRs at N <= 8192 -- three waves per SIMD instead of four.  Capping them at 128 with the
 // twiddles loaded between the previous pass's butterflies and the exchange instead (-DPIRGPU_PF_LOOP=0) was measured
 // on one box, three alternating runs: cfg 3 5 331 / 5 350 / 5 405 against 5 376 / 5 431 / 5 442 queries/s with the
-// prefetch, cfg 4 445 against 447 -- the prefetch at three waves wins (tools/r04_ab_loopregs.sh).
+// prefetch, cfg 4 445 against 447 -- the prefetch at three waves wins (tools/experiments/r04_ab_loopregs.sh).
 #ifndef PIRGPU_PF_LOOP
 #define PIRGPU_PF_LOOP 1
 #endif

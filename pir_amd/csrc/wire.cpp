@@ -337,9 +337,13 @@ class Pool {
       std::lock_guard<std::mutex> lk(g.m);
       ++g.pending;
     }
-    {
+    try {
       std::lock_guard<std::mutex> lk(m_);
       q_.push_back(Task{&g, std::move(fn)});
+    } catch (...) {   // the push failed (allocation): nothing was queued, so nothing will ever count this task down
+      std::lock_guard<std::mutex> lk(g.m);
+      --g.pending;
+      throw;
     }
     cv_.notify_one();
   }
@@ -354,9 +358,12 @@ class Pool {
       for (size_t i; (i = next.fetch_add(1)) < n;) fn(i);
     };
     Group g;
+    struct Waiter {   // whatever unwinds past here, the queued helpers are done with `g`, `next` and `fn` first
+      Group& g;
+      ~Waiter() { g.wait(); }
+    } waiter{g};
     for (size_t t = 0; t < helpers; ++t) submit(g, loop);
     loop();
-    g.wait();
   }
 
  private:
@@ -528,15 +535,27 @@ void run_single(const Server& sv, Job& job, const std::pair<const uint8_t*, size
   uint64_t* hr = pirgpu_host_reply_buffer(sv.ctx, 1);
   if (!hq || !hr) throw Err{PIRGPU_INTERNAL, pirgpu_last_error(sv.ctx)};
   const uint32_t nq = load_query_into(sv.sh, qm.first, qm.second, hq, sv.nq_expected);
-  const uint32_t callers_slot = pirgpu_current_keyset(sv.ctx);   // the direct API's selection survives a request
+  // the direct API's selection survives a request exactly as it was -- a selection that had gone stale stays stale
+  // (round-tripping it through a handle would have re-validated it against the slot's next tenant)
+  uint32_t callers_sel[2];
+  pirgpu_keyset_selection_get(sv.ctx, callers_sel);
   int rc = pirgpu_query_use_keyset(sv.ctx, job.slot);
   uint64_t got = 0;
   if (!rc) rc = pirgpu_query_stage_async(sv.ctx, hq, nq);   // pinned staging, untouched until the fetch below returns
   if (!rc) rc = pirgpu_query_run(sv.ctx);      // asynchronous: every kernel of the path is queued
   const std::string msg = rc ? pirgpu_last_error(sv.ctx) : "";
-  (void)pirgpu_query_use_keyset(sv.ctx, callers_slot);
+  pirgpu_keyset_selection_set(sv.ctx, callers_sel);
   if (rc) throw Err{rc, msg};
-  if (while_running) while_running();
+  if (while_running) {
+    try {
+      while_running();
+    } catch (...) {
+      // the kernels are queued and read this request's key set and pinned staging: nobody may unpin / reuse either
+      // before they are done
+      (void)pirgpu_sync(sv.ctx);
+      throw;
+    }
+  }
   // the reply comes back in two halves queued together: the first is serialised while the second crosses PCIe
   uint64_t first_part = 0;
   rc = pirgpu_query_fetch_begin(sv.ctx, hr, sv.n_reply, &got, &first_part);
@@ -752,6 +771,9 @@ void finish_window(const Server& sv, Window& w, Trace& trace) {
     }
   };
   Pool::Group g;
+  // the tasks capture this frame (g, serialise, w): whatever unwinds past here -- a failed submit included -- waits for
+  // the tasks already queued first
+  auto drain = finally([&g] { g.wait(); });
   size_t next_run = 0;
   uint32_t ready = 0;
   int rc = 0;
@@ -791,8 +813,10 @@ struct Combiner {
   std::condition_variable cv;
   std::deque<Job*> pending;
   bool set_busy[2] = {false, false};
+  int sets_allowed = 2;   // 1 while the context has a single key-set slot: two windows could not both pin a client's set
   RelinCache relin;
   int take_set() {   // call with m held; -1: none free
+    if ((int)set_busy[0] + (int)set_busy[1] >= sets_allowed) return -1;
     for (int i = 0; i < 2; ++i)
       if (!set_busy[i]) {
         set_busy[i] = true;
@@ -801,6 +825,15 @@ struct Combiner {
     return -1;
   }
 };
+
+// Windows pin their clients' key sets, half the slots per window; with ONE slot a second leader's window could never claim
+// a set while the first one's is pinned (a legitimate request would fail with "every key set slot is in use"): such a
+// context serves one window at a time.
+int sets_allowed_for(pirgpu_ctx* ctx) {
+  uint64_t stats[4] = {0, 0, 0, 16};
+  (void)pirgpu_keyset_stats(ctx, stats);
+  return stats[3] >= 2 ? 2 : 1;
+}
 
 // Serves `n` requests on batch set `first_set` (which the caller owns) and, when it is free, the other one: windows of
 // at most kMaxRequestBatch queries / half the key-set capacity in clients, two in flight.
@@ -1093,8 +1126,10 @@ int pirgpu_process_request(pirgpu_ctx* ctx, const uint8_t* request, size_t reque
   job.request = request;
   job.request_len = request_len;
   std::shared_ptr<Combiner> cb = combiner_for(ctx);
+  const int allowed = sets_allowed_for(ctx);   // (asks the context: before the combiner's lock is taken)
   {
     std::unique_lock<std::mutex> lk(cb->m);
+    cb->sets_allowed = allowed;
     cb->pending.push_back(&job);
     while (!job.done) {
       // (nothing pending: this thread's request is being served by another leader -- wait for it)
@@ -1136,8 +1171,10 @@ int pirgpu_process_requests(pirgpu_ctx* ctx, uint32_t n, const uint8_t* const* r
   Trace trace;
   std::shared_ptr<Combiner> cb = combiner_for(ctx);
   int set;
+  const int allowed = sets_allowed_for(ctx);
   {
     std::unique_lock<std::mutex> lk(cb->m);
+    cb->sets_allowed = allowed;
     while ((set = cb->take_set()) < 0) cb->cv.wait(lk);
   }
   serve_guarded(ctx, *cb, set, ptrs.data(), n);

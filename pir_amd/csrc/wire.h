@@ -29,8 +29,14 @@ int pirgpu_keyset_unpin(struct pirgpu_ctx* ctx, uint32_t slot);
 // valid while the slot is pinned (no eviction, no reinstall): the wire layer
 // compares it with a request's bytes on worker threads without taking the context's lock.
 size_t pirgpu_keyset_blob(struct pirgpu_ctx* ctx, uint32_t slot, const uint8_t** blob);
-// Slot pirgpu_query_use_keyset last selected (the wire layer restores it after serving a request).
+// Slot pirgpu_query_use_keyset last selected, as a handle carrying the generation it was selected with.
 uint32_t pirgpu_current_keyset(struct pirgpu_ctx* ctx);
+// The same selection as the raw (slot index, generation) pair, saved and put back UNCHECKED: the wire layer serves a lone
+// request with its client's set selected and restores the direct API's selection exactly as it was -- one that had gone
+// stale meanwhile stays stale (its next use fails with FailedPrecondition) instead of being re-validated against the
+// slot's next tenant.
+void pirgpu_keyset_selection_get(struct pirgpu_ctx* ctx, uint32_t sel[2]);
+void pirgpu_keyset_selection_set(struct pirgpu_ctx* ctx, const uint32_t sel[2]);
 // Drops the wire layer's per-context state (called by pirgpu_destroy).
 void pirgpu_wire_forget(struct pirgpu_ctx* ctx);
 // Request-level critical section (recursive with the per-call lock of the ABI entry points): the wire layer holds it

@@ -60,7 +60,7 @@ class Comm:
     memory, so the same glue runs with two processes on one GPU or on CPU."""
 
     # Largest per-peer message handed to one RCCL call.  RCCL 2.26.6 (ROCm 7.0) copies only the first half of an
-    # all_to_all_single message above 1 GiB (tools/r03_a2a_probe.py, MI355X: every size <= 1024 MiB exact, 1100 MiB
+    # all_to_all_single message above 1 GiB (tools/experiments/r03_a2a_probe.py, MI355X: every size <= 1024 MiB exact, 1100 MiB
     # and up wrong from the middle on); larger messages are cut into pieces at sub-block boundaries.  Real 8-GPU
     # steps stay far below (21 MB per peer at cfg 3); a forced single-rank run of the same step does not.
     MAX_MESSAGE_BYTES = 512 << 20

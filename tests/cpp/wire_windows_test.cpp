@@ -294,6 +294,15 @@ int pirgpu_keyset_stats(pirgpu_ctx* c, uint64_t st[4]) {
   return 0;
 }
 uint32_t pirgpu_current_keyset(pirgpu_ctx* c) { return handle_of(c, c->cur); }
+void pirgpu_keyset_selection_get(pirgpu_ctx* c, uint32_t sel[2]) {
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  sel[0] = c->cur;
+  sel[1] = 0;
+}
+void pirgpu_keyset_selection_set(pirgpu_ctx* c, const uint32_t sel[2]) {
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  c->cur = sel[0];
+}
 int pirgpu_query_use_keyset(pirgpu_ctx* c, uint32_t slot) {
   std::lock_guard<std::recursive_mutex> lk(c->mu);
   uint32_t i;
@@ -415,6 +424,10 @@ int pirgpu_batch_next_host_replies(pirgpu_ctx* c, uint32_t* ready) {
   return 0;
 }
 int pirgpu_batch_fetch(pirgpu_ctx* c, uint64_t*, uint64_t, uint64_t*) { return fail(c, PIRGPU_INTERNAL, "mock: fetch not expected"); }
+int pirgpu_sync(pirgpu_ctx* c) {
+  c->drain();
+  return 0;
+}
 
 int pirgpu_query_stage(pirgpu_ctx* c, const uint64_t* q, uint32_t nq) {
   std::lock_guard<std::recursive_mutex> lk(c->mu);
@@ -768,6 +781,20 @@ int main() {
     pirgpu_ctx ctx;
     ctx.cap = 1;
     many_requests(&ctx, {&clients[0], &clients[1], &clients[0]}, {{make_query(1), make_query(2)}, {make_query(3), make_query(4)}, {make_query(5), make_query(6)}});
+    CHECK(ctx.max_in_flight == 1);
+    no_pins_left(&ctx);
+    // ... also with several CALLING threads, each with its own client (two queries per request: the batch path, whose
+    // windows pin their client's set): with one slot only one leader may have a window open -- a second one's claim would
+    // find the only slot pinned and fail a legitimate request with FailedPrecondition
+    std::vector<std::thread> th;
+    for (int t = 0; t < 4; ++t)
+      th.emplace_back([&, t] {
+        for (int it = 0; it < 10; ++it) {
+          if (t & 1) many_requests(&ctx, {&clients[t]}, {{make_query(100 * t + it), make_query(7 * it + t)}});
+          else one_request(&ctx, clients[t], {make_query(100 * t + it), make_query(7 * it + t)});
+        }
+      });
+    for (auto& x : th) x.join();
     CHECK(ctx.max_in_flight == 1);
     no_pins_left(&ctx);
     printf("(g) capacity 1 OK\n");

@@ -291,7 +291,9 @@ def test_bench_eight_ranks_sharing_one_gpu():
     assert j["config"]["queries_per_step"] == 64 and j["config"]["queries_per_step_per_gpu"] == 8
     assert j["value"] > 0 and j["scaling"] == "strong"
     tune = j["exchange_autotune"]
-    assert set(tune["ms_per_step"]) == {"replicated", "packed"} and tune["chosen"] == j["config"]["exchange"]
+    # all three forms of the sharded step ran: rows + replicated expansion, rows + packed exchange, slot shards
+    assert set(tune["ms_per_step"]) == {"replicated", "packed", "slots"} and tune["chosen"] == j["config"]["exchange"]
+    assert all(v and v > 0 for v in tune["ms_per_step"].values()), tune
     assert j["replicas_reference"]["value"] > 0
     assert j["hybrid_rows_reference"]["value"] > 0 and j["hybrid_rows_reference"]["row_shards_per_group"] == 4
     assert "extras_aborted" not in j

@@ -3,8 +3,8 @@ export PIRGPU_ALLOW_ENV=1   # the library reads PIRGPU_* knobs only behind this 
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/exp4; rm -rf $O; mkdir -p $O
 f() { grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl"; }
-echo "== rccl check full size (chunked all_to_all)"; python3 tools/r03_rccl_check.py 20 64 release 2> $O/c1.err | f
-echo "== rccl check, every collective forced piecewise (1 MB)"; PIRGPU_MAX_COLLECTIVE_MB=1 python3 tools/r03_rccl_check.py 16 24 release 2> $O/c2.err | f
+echo "== rccl check full size (chunked all_to_all)"; python3 tools/experiments/r03_rccl_check.py 20 64 release 2> $O/c1.err | f
+echo "== rccl check, every collective forced piecewise (1 MB)"; PIRGPU_MAX_COLLECTIVE_MB=1 python3 tools/experiments/r03_rccl_check.py 16 24 release 2> $O/c2.err | f
 timeout 1800 python -m pytest tests -m gpu -q -x > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
 tail -4 $O/pytest.log
 sum() { python3 -c "

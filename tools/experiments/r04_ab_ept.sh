@@ -4,7 +4,9 @@ export PIRGPU_ALLOW_ENV=1   # the library reads PIRGPU_* knobs only behind this 
 # twiddle prefetch) against 16 residues per thread in 1024-thread workgroups; rebuilds the library for each variant.
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r4c; mkdir -p $O
-for v in "ept32_pf1:" "ept16:-DPIRGPU_LOG_EPT14=4" "ept32_pf0:-DPIRGPU_PF14=0" ; do
+# (the shipped default is 16 residues per thread, PIRGPU_LOG_EPT14 = 4 in device_params.h: the two 32-residue arms have to
+# ask for theirs, and at 16 residues per thread the prefetch switch has no effect)
+for v in "ept32_pf1:-DPIRGPU_LOG_EPT14=5" "ept16:" "ept32_pf0:-DPIRGPU_LOG_EPT14=5 -DPIRGPU_PF14=0" ; do
   tag=${v%%:*}; defs=${v#*:}
   PIRGPU_BUILD_DEFS="$defs" python -c "from pir_amd import build; build.build(force=True)" > $O/build_$tag.log 2>&1
   for rep in 1 2; do

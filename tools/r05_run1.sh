@@ -7,7 +7,7 @@ timeout 900 python -m pytest tests/test_gpu_slots.py -x -q > gpurun_out/r05_t_sl
 echo "slots rc=$?" > gpurun_out/r05_run1_rc.txt
 timeout 900 python -m pytest tests/test_gpu_mfma_scan.py tests/test_gpu_parity.py tests/test_gpu_distributed.py -x -q > gpurun_out/r05_t_scan.log 2>&1
 echo "scan rc=$?" >> gpurun_out/r05_run1_rc.txt
-timeout 600 python tools/r03_rank_budget.py --slots 3 1,2,4,8 > gpurun_out/r05_budget_slots_cfg3.log 2>&1
+timeout 600 python tools/rank_budget.py --slots 3 1,2,4,8 > gpurun_out/r05_budget_slots_cfg3.log 2>&1
 echo "budget rc=$?" >> gpurun_out/r05_run1_rc.txt
 timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/r05_bench0.json 2> gpurun_out/r05_bench0.err
 echo "bench rc=$?" >> gpurun_out/r05_run1_rc.txt

@@ -47,7 +47,10 @@ def slots_budget():
         db.populate(raw); db.finalize(release_staging=True)
         srv = pir_amd.PIRServer(db, pp); srv.set_galois_keys(keys); srv.set_concurrency(16)
         srv.stage_batch(queries)
-        bufs = [D.SlotsBuffers(srv, batch, 0, G, torch, "cuda:0") for _ in range(3)]
+        # three buffer sets as in SlotsPipeline (one where three would not fit next to the lanes: cfg 5 at G = 2)
+        n_sets = 3 if args.config != 5 or G >= 4 else 1
+        bufs = [D.SlotsBuffers(srv, batch, 0, G, torch, "cuda:0") for _ in range(n_sets)]
+        bufs = (bufs * 3)[:3]
         per = bufs[0].per
         def E(b=bufs[0]):
             srv.slots_expand_async(0, per, b.packed_send.data_ptr(), b.sv.data_ptr(), b.cuts)

@@ -25,10 +25,13 @@ int pirgpu_keyset_set_keys(pirgpu_ctx*, uint32_t, uint32_t, const uint32_t*, con
 int pirgpu_keyset_stats(pirgpu_ctx*, uint64_t*) { return 13; }
 int pirgpu_query_use_keyset(pirgpu_ctx*, uint32_t) { return 13; }
 uint32_t pirgpu_current_keyset(pirgpu_ctx*) { return 0; }
+void pirgpu_keyset_selection_get(pirgpu_ctx*, uint32_t sel[2]) { sel[0] = sel[1] = 0; }
+void pirgpu_keyset_selection_set(pirgpu_ctx*, const uint32_t*) {}
 int pirgpu_batch_set_keysets(pirgpu_ctx*, const uint32_t*, uint32_t) { return 13; }
 int pirgpu_query_stage(pirgpu_ctx*, const uint64_t*, uint32_t) { return 13; }
 int pirgpu_query_stage_async(pirgpu_ctx*, const uint64_t*, uint32_t) { return 13; }
 int pirgpu_query_run(pirgpu_ctx*) { return 13; }
+int pirgpu_sync(pirgpu_ctx*) { return 13; }
 int pirgpu_query_fetch(pirgpu_ctx*, uint64_t*, uint64_t, uint64_t*) { return 13; }
 int pirgpu_query_fetch_begin(pirgpu_ctx*, uint64_t*, uint64_t, uint64_t*, uint64_t*) { return 13; }
 int pirgpu_query_fetch_wait(pirgpu_ctx*, int) { return 13; }

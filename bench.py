@@ -163,6 +163,30 @@ def cpu_baseline_reference_case(pp, raw, keys, query_ct):
     return float(np.median(times)), reply
 
 
+def c_abi_request_timer(srv, request: bytes):
+    """pirgpu_process_request timed AT THE C ABI: serialized pir.Request bytes in, malloc'd serialized pir.Response out,
+    released with pirgpu_free -- what benchmark.cpp:71-79 times around PIRServer::ProcessRequest.  (The Python mirror
+    PIRServer.ProcessRequest additionally copies the megabyte of response into a bytes object: the binding's cost.)
+    Returns a function that serves the request once and returns (milliseconds, response length)."""
+    import ctypes as C
+    lib, handle = srv.lib, srv.db.handle
+    buf = np.frombuffer(request, dtype=np.uint8)
+    ptr = buf.ctypes.data_as(C.POINTER(C.c_uint8))
+    n = len(request)
+
+    def once():
+        resp, rlen = C.c_void_p(), C.c_size_t(0)
+        t0 = time.perf_counter()
+        rc = lib.pirgpu_process_request(handle, ptr, n, C.byref(resp), C.byref(rlen))
+        dt = (time.perf_counter() - t0) * 1e3
+        if rc:
+            raise RuntimeError("pirgpu_process_request failed: %d %s" % (rc, lib.pirgpu_last_error(handle).decode()))
+        lib.pirgpu_free(resp)
+        return dt, int(rlen.value)
+    once.keepalive = buf
+    return once
+
+
 def reference_sweep(pir_amd, device=0, log_sizes=(8, 10, 12, 14, 16), reps=12, with_cpu=True):
     """The reference's own benchmark at the reference's own sizes (benchmark.cpp:17-23, 56-107): 2^8 .. 2^16 items of
     288 bytes, d = 2, N = 4096, 24-bit t, ONE query per request.  Per size the four registered cases -- SetupDb,
@@ -196,10 +220,12 @@ def reference_sweep(pir_amd, device=0, log_sizes=(8, 10, 12, 14, 16), reps=12, w
             req = cl.CreateRequest([idx])
             t_req.append((time.perf_counter() - t0) * 1e3)
         t_srv = []
-        for _ in range(reps + 1):
-            t0 = time.perf_counter()
-            resp = srv.ProcessRequest(req)
-            t_srv.append((time.perf_counter() - t0) * 1e3)
+        t0 = time.perf_counter()
+        resp = srv.ProcessRequest(req)                    # the client's FIRST request (keys parsed, re-sampled, uploaded)
+        t_srv.append((time.perf_counter() - t0) * 1e3)
+        once = c_abi_request_timer(srv, req)
+        for _ in range(reps):
+            t_srv.append(once()[0])
         t_rsp = []
         for _ in range(5):
             t0 = time.perf_counter()
@@ -247,10 +273,10 @@ def reference_sweep(pir_amd, device=0, log_sizes=(8, 10, 12, 14, 16), reps=12, w
         rows.append(row)
     return {"rows": rows,
             "note": "benchmark.cpp's four cases at the sizes the reference registers them for (2^8 .. 2^16 items, 288 B, "
-                    "d = 2, N = 4096, 24-bit t, QUERIES_PER_REQUEST = 1). ServerProcessRequest is timed at the C ABI's "
-                    "Python mirror around serialized pir.Request -> pir.Response bytes (seed-compressed keys, parsing, "
-                    "PCIe both ways, serialisation inside); the CPU figure is the oracle's processQuery on residues "
-                    "(no parsing), one core."}
+                    "d = 2, N = 4096, 24-bit t, QUERIES_PER_REQUEST = 1). ServerProcessRequest is timed at the C ABI "
+                    "(pirgpu_process_request: serialized pir.Request -> malloc'd serialized pir.Response; seed-compressed "
+                    "keys, parsing, key compare, PCIe both ways, serialisation inside; the first request through the "
+                    "Python mirror); the CPU figure is the oracle's processQuery on residues (no parsing), one core."}
 
 
 def build_workload(args, pir_amd):
@@ -675,6 +701,8 @@ def main():
                     t0 = time.perf_counter()
                     resp = srv.ProcessRequest(req)
                     wt.append((time.perf_counter() - t0) * 1e3)
+                once = c_abi_request_timer(srv, req)      # the same request timed at the C ABI itself
+                wc = [once()[0] for _ in range(25)]
                 # the same ciphertext through the residue-level entry point with the same client's keys
                 slot = srv.install_keyset(b"bench-wire-client-0-residues", cl.galois_keys())
                 srv.use_keyset(slot)
@@ -707,6 +735,8 @@ def main():
                                                   "new_client_first_request_on_warm_context": round(float(np.median(new_exp)), 3),
                                                   "new_client_seeded_keys_ms": round(float(np.median(new_seed)), 3),
                                                   "repeat": round(float(np.median(wt[1:])), 3),
+                                                  "repeat_at_c_abi": round(float(np.median(wc[1:])), 3),
+                                                  "repeat_at_c_abi_min": round(float(np.min(wc[1:])), 3),
                                                   "repeat_client_keys_cached_median_of_24": round(float(np.median(wt[1:])), 3),
                                                   "repeat_min": round(float(np.min(wt[1:])), 3),
                                                   "repeat_seeded_keys_median_of_12": round(float(np.median(ws[1:])), 3),
@@ -714,6 +744,9 @@ def main():
                                                   "response_bytes": len(resp),
                                                   "response_equals_residue_path": same,
                                                   "seeded_response_equals_expanded_response": same_s,
+                                                  "timing": "`repeat*` through the Python mirror PIRServer.ProcessRequest (adds one "
+                                                            "copy of the response into a bytes object); `repeat_at_c_abi*` "
+                                                            "around pirgpu_process_request + pirgpu_free alone",
                                                   "requests_from": "pir_amd.PIRClient (product client library): expanded "
                                                                    "key objects for the first block, seed-compressed ones "
                                                                    "(the reference client's default) for the seeded figures"}
@@ -856,6 +889,35 @@ def main():
                 for _ in range(w_steps):
                     ok = one_call(st0)[0] and ok
                 dt1 = time.perf_counter() - t0
+                # ONE calling thread with two calls in flight (pirgpu_process_requests_begin / _end): call i + 1 is handed
+                # over before call i is waited for, so its parsing / staging / queueing run under call i's tail
+                def begin(state):
+                    resp, rlen, status = state
+                    call = C.c_void_p()
+                    rc = lib.pirgpu_process_requests_begin(handle, n_w, ptrs, lens, resp, rlen, status, C.byref(call))
+                    if rc:
+                        raise RuntimeError("pirgpu_process_requests_begin: %d" % rc)
+                    return call
+
+                def end(call, state):
+                    resp, rlen, status = state
+                    lib.pirgpu_process_requests_end(call)
+                    good = all(status[i] == 0 for i in range(n_w))
+                    for i in range(n_w):
+                        if status[i] == 0:
+                            lib.pirgpu_free(resp[i])
+                    return good
+
+                sts = [call_state(), call_state()]
+                ok2 = end(begin(sts[0]), sts[0])
+                t0 = time.perf_counter()
+                pending = begin(sts[0])
+                for i in range(1, w_steps):
+                    nxt = begin(sts[i & 1])
+                    ok2 = end(pending, sts[(i - 1) & 1]) and ok2
+                    pending = nxt
+                ok2 = end(pending, sts[(w_steps - 1) & 1]) and ok2
+                dt2 = time.perf_counter() - t0
                 # sustained load: `callers` threads (ctypes releases the interpreter lock for the duration of a call)
                 oks = [True] * callers
                 gate = threading.Barrier(callers + 1)
@@ -885,6 +947,11 @@ def main():
                                                 "ms_per_call": dtn / w_steps * 1e3,
                                                 "single_caller": {"value": w_steps * n_w / dt1, "unit": "queries/s",
                                                                   "ms_per_call": dt1 / w_steps * 1e3},
+                                                "single_caller_two_calls_in_flight": {
+                                                    "value": w_steps * n_w / dt2, "unit": "queries/s",
+                                                    "ms_per_call": dt2 / w_steps * 1e3, "all_ok": ok2,
+                                                    "note": "one calling thread, pirgpu_process_requests_begin(i + 1) before "
+                                                            "pirgpu_process_requests_end(i)"},
                                                 "all_ok": ok, "repeatable": same, "request_bytes_each": len(reqs[0]),
                                                 "keys": "seed-compressed (product client default)",
                                                 "keysets": srv.keyset_stats(),
@@ -893,7 +960,9 @@ def main():
                                                         "lookup + byte compare, PCIe both ways and response "
                                                         "serialisation inside the timed region, timed at the C ABI; value = "
                                                         "%d calling threads in a loop (sustained load, two request windows "
-                                                        "in flight), single_caller = one thread, call after call" % (n_w, callers)}
+                                                        "in flight), single_caller = one thread, call after call (every call "
+                                                        "fills and drains the pipeline alone), single_caller_two_calls_in_flight "
+                                                        "= one thread using the begin / end form" % (n_w, callers)}
             except Exception as e:   # measurement extra only
                 out["wire_multi_client_qps"] = {"error": repr(e)}
         if world == 1 and not use_dist and not args.no_cpu_baseline:

@@ -368,8 +368,18 @@ int pirgpu_process_request(pirgpu_ctx* ctx, const uint8_t* request, size_t reque
  * layer uses (pinned, one pair per batch set). */
 int pirgpu_process_requests(pirgpu_ctx* ctx, uint32_t n, const uint8_t* const* requests, const size_t* request_lens,
                             uint8_t** responses, size_t* response_lens, int* status);
-/* Message of request i of the calling thread's last pirgpu_process_requests call ("" if it succeeded). */
+/* Message of request i of the calling thread's last pirgpu_process_requests / _end call ("" if it succeeded). */
 const char* pirgpu_request_error(uint32_t i);
+/* The same call in two halves, for ONE calling thread that wants two calls in flight (the reference's harness calls
+ * ProcessRequest synchronously, benchmark.cpp:71-79; a server loop need not): begin hands the call to a serving thread of
+ * the library and returns at once, end waits for it and returns what pirgpu_process_requests would have.  Every array
+ * passed to begin (requests, lengths, responses, status) must stay alive and untouched until end returns; responses and
+ * status are valid after end.  begin(i + 1) before end(i) lets call i + 1's parsing, staging and queueing run under
+ * call i's tail -- what two calling threads get (two request windows in flight), without the caller owning a second
+ * thread.  Every begin must be matched by exactly one end. */
+int pirgpu_process_requests_begin(pirgpu_ctx* ctx, uint32_t n, const uint8_t* const* requests, const size_t* request_lens,
+                                  uint8_t** responses, size_t* response_lens, int* status, void** call);
+int pirgpu_process_requests_end(void* call);
 uint64_t* pirgpu_host_query_buffer(pirgpu_ctx* ctx, uint32_t queries);
 uint64_t* pirgpu_host_reply_buffer(pirgpu_ctx* ctx, uint32_t queries);
 /* Releases a response buffer.  The library keeps up to 256 MB of released buffers for later responses (a fresh megabyte

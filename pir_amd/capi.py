@@ -114,6 +114,10 @@ SIGNATURES = {
     "pirgpu_process_requests": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "pirgpu_request_error": (C.c_char_p, [C.c_uint32]),
+    "pirgpu_process_requests_begin": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                                C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int),
+                                                C.POINTER(C.c_void_p)]),
+    "pirgpu_process_requests_end": (C.c_int, [C.c_void_p]),
     "pirgpu_host_query_buffer": (C.c_void_p, [C.c_void_p, C.c_uint32]),
     "pirgpu_host_reply_buffer": (C.c_void_p, [C.c_void_p, C.c_uint32]),
     "pirgpu_process_query": (C.c_int, [C.c_void_p, u64p, C.c_uint32, u64p, C.c_uint64, u64p]),

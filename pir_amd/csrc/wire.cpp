@@ -1199,4 +1199,44 @@ const char* pirgpu_request_error(uint32_t i) {
   return i < t_request_errors.size() ? t_request_errors[i].c_str() : "";
 }
 
+// pirgpu_process_requests in two halves, so that ONE calling thread can have two calls in flight: begin() hands the call
+// to a serving thread of the library and returns; end() waits for it.  The second call's parsing, staging and queueing
+// then run under the first one's tail (its last groups on the GPU, their download and serialisation) exactly as they do
+// for two calling threads -- a synchronous caller fills and drains the two-lane pipeline alone with every call.
+struct PendingCall {
+  std::thread th;
+  int rc = PIRGPU_INTERNAL;
+  std::vector<std::string> errors;
+};
+
+int pirgpu_process_requests_begin(pirgpu_ctx* ctx, uint32_t n, const uint8_t* const* requests, const size_t* request_lens,
+                                  uint8_t** responses, size_t* response_lens, int* status, void** call) {
+  if (!call) return PIRGPU_INVALID_ARGUMENT;
+  *call = nullptr;
+  if (!ctx || (n && (!requests || !request_lens || !responses || !response_lens || !status))) return PIRGPU_INVALID_ARGUMENT;
+  PendingCall* pc = nullptr;
+  try {
+    pc = new PendingCall();
+    pc->th = std::thread([=] {
+      pc->rc = pirgpu_process_requests(ctx, n, requests, request_lens, responses, response_lens, status);
+      pc->errors = t_request_errors;     // (this serving thread's: handed to the thread that calls end())
+    });
+  } catch (...) {
+    delete pc;
+    return PIRGPU_INTERNAL;
+  }
+  *call = pc;
+  return PIRGPU_OK;
+}
+
+int pirgpu_process_requests_end(void* call) {
+  PendingCall* pc = static_cast<PendingCall*>(call);
+  if (!pc) return PIRGPU_INVALID_ARGUMENT;
+  if (pc->th.joinable()) pc->th.join();
+  const int rc = pc->rc;
+  t_request_errors = std::move(pc->errors);   // pirgpu_request_error(i) on the calling thread answers for this call
+  delete pc;
+  return rc;
+}
+
 }  // extern "C"

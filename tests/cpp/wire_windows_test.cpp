@@ -631,6 +631,48 @@ void many_requests(pirgpu_ctx* ctx, const std::vector<const Client*>& cl, const 
   }
 }
 
+// One call of pirgpu_process_requests in two halves (pirgpu_process_requests_begin / _end): everything the call touches
+// lives here until end() has returned.
+struct AsyncCall {
+  std::vector<const Client*> cl;
+  std::vector<std::vector<std::vector<uint64_t>>> qs;
+  std::vector<std::string> reqs;
+  std::vector<const uint8_t*> ptrs;
+  std::vector<size_t> lens, rlens;
+  std::vector<uint8_t*> resps;
+  std::vector<int> status;
+  void* call = nullptr;
+  void prepare() {
+    const uint32_t n = (uint32_t)cl.size();
+    reqs.resize(n);
+    ptrs.resize(n);
+    lens.resize(n);
+    rlens.assign(n, 0);
+    resps.assign(n, nullptr);
+    status.assign(n, -1);
+    for (uint32_t i = 0; i < n; ++i) {
+      reqs[i] = make_request(*cl[i], qs[i]);
+      ptrs[i] = (const uint8_t*)reqs[i].data();
+      lens[i] = reqs[i].size();
+    }
+  }
+  void begin(pirgpu_ctx* ctx) {
+    const uint32_t n = (uint32_t)cl.size();
+    CHECK(pirgpu_process_requests_begin(ctx, n, ptrs.data(), lens.data(), resps.data(), rlens.data(), status.data(), &call) == 0);
+    CHECK(call != nullptr);
+  }
+  void end(int want_rc = 0) {
+    CHECK(pirgpu_process_requests_end(call) == want_rc);
+    call = nullptr;
+    for (size_t i = 0; i < cl.size(); ++i) {
+      if (status[i]) fprintf(stderr, "async request %zu: status %d (%s)\n", i, status[i], pirgpu_request_error((uint32_t)i));
+      CHECK(status[i] == 0);
+      check_response(*cl[i], qs[i], resps[i], rlens[i]);
+      pirgpu_free(resps[i]);
+    }
+  }
+};
+
 void no_pins_left(pirgpu_ctx* ctx) {
   for (auto& ks : ctx->keysets) CHECK(ks.pins == 0);
   CHECK(ctx->in_flight == 0);
@@ -798,6 +840,32 @@ int main() {
     CHECK(ctx.max_in_flight == 1);
     no_pins_left(&ctx);
     printf("(g) capacity 1 OK\n");
+  }
+  {  // (h) ONE calling thread, two calls in flight (begin / begin / end / begin / end ...): the second call's window is
+     // parsed, staged and queued while the first one's is still on the "GPU"
+    pirgpu_ctx ctx;
+    ctx.delay_us = 6000;
+    const int n_calls = 6;
+    std::vector<AsyncCall> calls(n_calls);
+    for (int c = 0; c < n_calls; ++c)
+      for (uint32_t i = 0; i < 10; ++i) {
+        calls[c].cl.push_back(&clients[(c * 5 + i) % clients.size()]);
+        calls[c].qs.push_back({make_query(70000 + 100 * c + i)});
+        if (i % 4 == 0) calls[c].qs.back().push_back(make_query(80000 + 100 * c + i));
+      }
+    for (auto& c : calls) c.prepare();     // (building the requests is slow under the sanitizers: not between the calls)
+    calls[0].begin(&ctx);
+    for (int c = 1; c < n_calls; ++c) {
+      calls[c].begin(&ctx);
+      calls[c - 1].end();
+    }
+    calls[n_calls - 1].end();
+    CHECK(ctx.max_in_flight == 2);
+    no_pins_left(&ctx);
+    CHECK(pirgpu_process_requests_end(nullptr) == PIRGPU_INVALID_ARGUMENT);
+    void* none = (void*)1;
+    CHECK(pirgpu_process_requests_begin(&ctx, 1, nullptr, nullptr, nullptr, nullptr, nullptr, &none) == PIRGPU_INVALID_ARGUMENT && none == nullptr);
+    printf("(h) one caller, two calls in flight OK (%llu windows)\n", (unsigned long long)ctx.windows.load());
   }
   printf("wire_windows_test OK\n");
   return 0;

@@ -26,3 +26,16 @@ def random_key(orc, rng):
     for i in range(orc.k + 1):
         key[:, :, i, :] = rng.integers(0, orc.moduli[i], size=(orc.k, 2, orc.N), dtype=np.uint64)
     return key
+
+
+def all_to_all_in_process(recvs, sends, recv_splits, send_splits):
+    """What torch.distributed.all_to_all_single does, between in-process 'ranks' (1-D tensors, element splits)."""
+    G = len(sends)
+    for dst in range(G):
+        ro = 0
+        for src in range(G):
+            so = sum(send_splits[src][:dst])
+            n = send_splits[src][dst]
+            assert n == recv_splits[dst][src]
+            recvs[dst][ro:ro + n].copy_(sends[src][so:so + n])
+            ro += n

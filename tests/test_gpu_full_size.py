@@ -124,6 +124,52 @@ def _large_d2(N, moduli, n_items, item_bytes, dims, digits, seed):
     assert np.array_equal(batch[1], srv.process_query(queries[1]))
     db.close()
 
+    # (4) SLOT shards (the multi-GPU step of DESIGN.md section 7.1) at the real size: two contexts, each holding half of
+    # the NTT slots of every plaintext, created one after the other (together they would not fit next to their lanes at
+    # cfg 5).  Expansion and finish do not depend on which slots a context holds, so context 0 expands both "ranks'"
+    # queries and context 1 finishes both; each scans ITS slots for both queries with the 4-wave scan kernel of these
+    # rings; the all-to-alls are tensor copies.  Replies must equal the plain pipeline's, bit for bit.
+    import torch
+    from pir_amd import distributed as D
+    from gpu_helpers import all_to_all_in_process
+    G = 2
+    cuts = D.slot_cuts(orc.k * N, G)
+    bufs = None
+    for g in range(G):
+        dbg = pir_amd.PIRDatabase.Create(pp, raw, slots=(cuts[g], cuts[g + 1]))
+        dbg.finalize(release_staging=True)
+        sg = pir_amd.PIRServer(dbg, pp)
+        sg.set_galois_keys(keys)
+        sg.set_concurrency(8)
+        if g == 0:
+            assert D.slots_exchange_supported(sg) and sg.scan_bytes() * G == info_bytes_whole(sg, dims, orc.k * N)
+            bufs = [D.SlotsBuffers(sg, G, r, G, torch, "cuda:0") for r in range(G)]
+            sg.stage_batch(queries)
+            for r in range(G):           # rank r expands query r
+                sg.slots_expand_async(r, 1, bufs[r].packed_send.data_ptr(), bufs[r].sv.data_ptr(), cuts)
+            sg.sync()
+            all_to_all_in_process([b.packed_recv for b in bufs], [b.packed_send for b in bufs], [b.x1_recv for b in bufs],
+                                  [b.x1_send for b in bufs])
+        sg.slots_scan_async(bufs[g].packed_recv.data_ptr(), G, 1, bufs[g].rows_send.data_ptr())
+        sg.sync()
+        if g == G - 1:
+            all_to_all_in_process([b.rows_recv for b in bufs], [b.rows_send for b in bufs], [b.x2_recv for b in bufs],
+                                  [b.x2_send for b in bufs])
+            for r in range(G):
+                sg.slots_finish_async(bufs[r].rows_recv.data_ptr(), 1, bufs[r].sv.data_ptr(), cuts, bufs[r].replies.data_ptr())
+            sg.sync()
+        dbg.close()
+    for r in range(G):
+        assert np.array_equal(bufs[r].replies.cpu().numpy().view(np.uint64)[0], batch[r]), r
+
+
+def info_bytes_whole(srv, dims, kN):
+    """Bytes of the whole database in the scan's operand layout, from the geometry a context reports."""
+    i = srv.scan_info()
+    per_residue = i["digits"] - (0.5 if i["top_digit_nibble"] else 0.0)
+    tiles = ((dims[0] + 15) // 16) * ((dims[1] + 15) // 16)
+    return int(kN * tiles * 256 * per_residue)
+
 
 def test_cfg4_full_size():
     m = oracle.BFV_DEFAULT[8192]

@@ -35,17 +35,7 @@ def _rank_server(pir_amd, pp, s, slots):
     return srv
 
 
-def _all_to_all(recvs, sends, recv_splits, send_splits):
-    """What torch.distributed.all_to_all_single does, between in-process 'ranks' (1-D tensors, element splits)."""
-    G = len(sends)
-    for dst in range(G):
-        ro = 0
-        for src in range(G):
-            so = sum(send_splits[src][:dst])
-            n = send_splits[src][dst]
-            assert n == recv_splits[dst][src]
-            recvs[dst][ro:ro + n].copy_(sends[src][so:so + n])
-            ro += n
+from gpu_helpers import all_to_all_in_process as _all_to_all   # noqa: E402
 
 
 @pytest.mark.parametrize("G,items,per", [(2, 3000, 4), (8, 3000, 1), (4, 12000, 9), (8, 40000, 2), (3, 3000, 3)])

@@ -122,6 +122,8 @@ struct Stage {
   uint64_t** up_scratch = nullptr;   // owner's scratch for the split upper level, grown on demand
   size_t* up_scratch_words = nullptr;
   bool sel_f64 = false;   // the selectors are exact doubles (a lane's own expansion, pirgpu_ctx::sel_f64)
+  bool rows_inverted = false;   // the row sums in lvl[d - 1] are in coefficient form already (slot-sharded step: the
+                                // inverse transform gathered them out of the exchange buffer)
 };
 
 // One client's Galois keys on the device.  The reference deserialises the keys of every request into a local
@@ -989,7 +991,8 @@ void post_scan_stage(pirgpu_ctx* c, const Stage& sg, Worker* profiled) {
     return;
   }
   if (profiled) record(c, *profiled, PH_UPPER);  // end of scan phase
-  HIP_TRY(c->ops->ntt_batch(st, c->mode, c->dp, sg.lvl[d - 1], (uint64_t)sg.n * c->scan_rows * 2 * k, k, 0, true));
+  if (!sg.rows_inverted)
+    HIP_TRY(c->ops->ntt_batch(st, c->mode, c->dp, sg.lvl[d - 1], (uint64_t)sg.n * c->scan_rows * 2 * k, k, 0, true));
   // upper levels: fused re-encode + lift + NTT + multiply-accumulate over chunks of children,
   // then one kernel folds the chunk sums and applies the inverse NTT
   uint64_t C = 1;  // ciphertexts per child
@@ -1294,7 +1297,7 @@ static const struct { const char* name; bool early; } kOptions[] = {
     {"FUSE_LAST", true}, {"FUSE_MAC_COMBINE", true}, {"LAST_NTT", true}, {"SEL_F64", true}, {"TREE40", true},
     {"FUSE_MAC_NODES", true}, {"SPLIT_UPPER", true}, {"SPLIT_UPPER_MB", true}, {"PACK40", true},
     {"SCAN_MFMA", true}, {"SCAN_MFMA_WIDE", true}, {"SCAN_MFMA_TOP4", true}, {"SCAN_MFMA_NQ", true}, {"SCAN_MFMA_SINGLE", true}, {"LANES", true}, {"HEAD_LEVELS", true}, {"HEAD_MODE", true}, {"SCAN_F64_FOLD", true}, {"LOOP_TRANSFORMS", true}, {"LOOP_MIN_SOURCES", true},
-    {"SLOTS_SCAN_WGS", false},
+    {"SLOTS_SCAN_WGS", false}, {"SLOTS_GATHER_NTT", false},
 };
 
 int pirgpu_set_option(pirgpu_ctx* c, const char* name, int64_t value) {
@@ -2923,14 +2926,21 @@ int pirgpu_slots_finish_async(pirgpu_ctx* c, const uint64_t* device_rowsums, uin
       const uint32_t B = std::min<uint32_t>(kMaxMfmaQueries, count - j0);
       BatchLane& ln = c->lanes[c->groups_run++ % nl];
       lane_after(c, ln.stream, after);
-      // rank h's block of the receive buffer holds [count][RC][slots of h]: the group's queries are rows j0 .. j0 + B of it
-      HIP_TRY(launch_slots_assemble(ln.stream, device_rowsums, ln.lvl[c->d - 1], map, RC, kN, B, words, count, j0));
+      // rank h's block of the receive buffer holds [count][RC][slots of h]: the group's queries are rows j0 .. j0 + B of
+      // it; the inverse transform of the row sums (database.cpp:250-254) gathers them from there (option
+      // SLOTS_GATHER_NTT = 0: a separate assembly pass, then the plain in-place transform)
+      const bool gather = option(c, "SLOTS_GATHER_NTT", 1) != 0;
+      if (gather)
+        HIP_TRY(c->ops->ntt_inv_gather(ln.stream, c->mode, c->dp, c->k, device_rowsums, ln.lvl[c->d - 1], map, RC, B, count, j0));
+      else
+        HIP_TRY(launch_slots_assemble(ln.stream, device_rowsums, ln.lvl[c->d - 1], map, RC, kN, B, words, count, j0));
       uint64_t* lvl_ptrs[PIRGPU_MAX_DIMS];
       for (uint32_t l = 0; l < c->d; ++l) lvl_ptrs[l] = ln.lvl[l];
       lvl_ptrs[0] = device_replies + (size_t)j0 * rwords;
       Stage sg{ln.stream, lvl_ptrs, ln.pt_buf, B, MfmaPtrs{}, false, &ln.up_scratch, &ln.up_scratch_words};
       for (uint32_t q = 0; q < B; ++q) sg.sel.p[q] = device_sv + (size_t)(j0 + q) * svwords;
       sg.sel_f64 = c->sel_f64;
+      sg.rows_inverted = gather;
       post_scan_stage(c, sg, nullptr);
       lane_then(ln, then);
     }

@@ -100,6 +100,12 @@ struct NttOps {
                             const uint64_t* dig, const KeyPtrs& key, uint64_t* prod, const uint64_t* xpow,
                             uint32_t galois_elt, uint32_t galois_inv, uint32_t shift_pow, uint32_t n_items, uint32_t B,
                             const MfmaPtrs& dst, uint32_t nodes, bool pack40, bool out_f64, bool c0_done);
+  // slot-sharded step: inverse NTT of the row sums of queries q0 .. q0 + nq - 1, gathered from the per-rank slot pieces
+  // of the all-to-all receive buffer (nq_total queries per piece, RC = 2 rows polynomials per modulus and query) into
+  // dst[(q - q0)][row, comp][k][N] -- launch_slots_assemble + ntt_batch(inverse) in one pass
+  hipError_t (*ntt_inv_gather)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* src,
+                               uint64_t* dst, const SliceMap& map, uint32_t RC, uint32_t nq, uint32_t nq_total,
+                               uint32_t q0);
 };
 
 const NttOps* ntt_ops_for(uint32_t N);  // nullptr for unsupported degrees

@@ -189,6 +189,36 @@ ntt_batch_kernel(const DevParams* __restrict__ P, uint64_t* __restrict__ data, u
   for (int e = 0; e < EPT; ++e) poly[e * NT + tid] = A::out(x[e], m);
 }
 
+// Slot-sharded multi-GPU step (pirgpu_slots_finish): inverse NTT of the row sums of a rank's own queries, GATHERED out of
+// the all-to-all's receive buffer -- rank h's block holds [query][row, comp][slots of h] (block h starts at word
+// nq_total * RC * cut[h]), a polynomial's N slots lie in up to n of those blocks -- straight into the
+// [query][row, comp][k][N] layout of the lane buffer: what transform_from_ntt_inplace (database.cpp:250-254) does on the
+// row sums, without a separate assembly pass.  grid = nq * RC * k; the slots of one thread increase with e, so the piece
+// index only ever moves forward.
+template <int MODE>
+__global__ void __launch_bounds__(NT)
+ntt_inv_gather_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ src, uint64_t* __restrict__ dst,
+                      SliceMap map, uint32_t RC, uint32_t nq_total, uint32_t q0) {
+  using A = Arith<MODE>;
+  const uint32_t tid = threadIdx.x, k = P->k;
+  const int mi = blockIdx.x % k;
+  const uint32_t rc = (blockIdx.x / k) % RC, q = blockIdx.x / (k * RC);
+  const typename A::Mod m = A::mod(P, mi);
+  typename A::T x[EPT];
+  uint32_t h = 0;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const uint32_t j = (uint32_t)mi * N + e * NT + tid;      // slot of the ring's k N
+    while (h + 1 < map.n && j >= map.cut[h + 1]) ++h;
+    const uint32_t c0 = map.cut[h], width = map.cut[h + 1] - c0;
+    x[e] = A::in(src[(size_t)nq_total * RC * c0 + ((size_t)(q0 + q) * RC + rc) * width + (j - c0)], m);
+  }
+  ntt_inverse<MODE, LOGN, kPF>(x, smem_raw, P, mi, tid);
+  uint64_t* poly = dst + (size_t)blockIdx.x * N;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) poly[e * NT + tid] = A::out(x[e], m);
+}
+
 // Out-of-place forward NTT of ciphertexts: src[ct][2][k][N] (coefficient form)
 // -> dst[ct][2][k][N] (device NTT order); selection vector -> NTT form.  SRC_TREE: the source is the
 // expansion tree (element type A::T: doubles holding signed representatives in the fp64 flavours).
@@ -1235,6 +1265,7 @@ static hipError_t configure_mode() {
   if ((e = hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e
   PIRGPU_SET((ntt_batch_kernel<MODE, false>));
   PIRGPU_SET((ntt_batch_kernel<MODE, true>));
+  PIRGPU_SET(ntt_inv_gather_kernel<MODE>);
   PIRGPU_SET((ct_ntt_fwd_oop_kernel<MODE, false>));
   PIRGPU_SET((ct_ntt_fwd_oop_kernel<MODE, true>));
   PIRGPU_SET(ct_ntt_fwd_split_kernel<MODE>);
@@ -1292,6 +1323,16 @@ static hipError_t op_ntt_batch(hipStream_t st, int mode, const DevParams* P, uin
     PIRGPU_BY_MODE(mode, hipLaunchKernelGGL((ntt_batch_kernel<MODE, false>), dim3((uint32_t)n_polys), dim3(NT),
                                             kLdsBytes, st, P, data, mod_period, mod_base));
   }
+  return hipGetLastError();
+}
+
+static hipError_t op_ntt_inv_gather(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* src,
+                                    uint64_t* dst, const SliceMap& map, uint32_t RC, uint32_t nq, uint32_t nq_total,
+                                    uint32_t q0) {
+  if (map.n == 0 || map.n > (uint32_t)kMaxSlices || map.cut[0] != 0 || map.cut[map.n] != k * (uint32_t)N || q0 + nq > nq_total)
+    return hipErrorInvalidValue;
+  PIRGPU_BY_MODE(mode, hipLaunchKernelGGL(ntt_inv_gather_kernel<MODE>, dim3(nq * RC * k), dim3(NT), kLdsBytes, st, P, src, dst,
+                                          map, RC, nq_total, q0));
   return hipGetLastError();
 }
 
@@ -1532,7 +1573,7 @@ const NttOps* PIRGPU_OPS_NAME() {
   using namespace PIRGPU_DEG_NS;
   static const NttOps ops = {op_configure, op_ntt_batch,   op_ct_ntt_fwd_oop, op_ct_ntt_fwd_split, op_db_encode,
                              op_ks_digit,  op_ks_mac_intt, op_upper_fused,     op_ks_last_level,
-                             op_upper_ntt, op_ks_mac_combine, op_ks_last_ntt};
+                             op_upper_ntt, op_ks_mac_combine, op_ks_last_ntt, op_ntt_inv_gather};
   return &ops;
 }
 

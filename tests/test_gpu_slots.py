@@ -55,6 +55,8 @@ def test_slot_shards_on_one_gpu_reproduce_the_oracle(G, items, per):
     bufs = [D.SlotsBuffers(srvs[g], batch, g, G, torch, "cuda:0") for g in range(G)]
     for rep in range(2):                        # twice: buffers, lanes and workers are reused
         for g in range(G):
+            # second round: the row sums put together by a separate assembly pass instead of inside the inverse transform
+            srvs[g].db.set_option("slots_gather_ntt", 1 - rep)
             srvs[g].stage_batch(queries)
             srvs[g].slots_expand_async(g * per, per, bufs[g].packed_send.data_ptr(), bufs[g].sv.data_ptr(), cuts)
             srvs[g].sync()

@@ -4,7 +4,9 @@ repeat counts; every batch reply must equal the single-query reply of the same q
 configuration is checked against the CPU oracle.  Round 3: every configuration also serves a random number of
 CLIENTS with different Galois keys -- every query of a batch is assigned a random client's resident key set, so the
 groups of 8 mix clients (sometimes with fewer slots than clients: evictions) -- and replies are checked against the
-oracle run with that client's keys.  Run on the GPU box:  python tools/soak.py [seconds]"""
+oracle run with that client's keys.  Round 5: half of the d = 2 configurations also run the SLOT-sharded multi-GPU step
+(1 - 8 slot-shard contexts on the one GPU, all-to-alls as tensor copies) on the same queries and key sets; its replies must
+equal the plain pipeline's.  Run on the GPU box:  python tools/soak.py [seconds]"""
 import os
 import sys
 import time
@@ -26,7 +28,7 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", "1")))
     t_end = time.time() + budget
-    n_cfg = n_batches = n_queries = 0
+    n_cfg = n_batches = n_queries = n_slots_steps = n_slots_queries = 0
     while time.time() < t_end:
         d = int(rng.choice([1, 2, 2, 2, 3]))
         if d == 1:
@@ -80,10 +82,55 @@ def main():
             srv.use_keyset(0)
             n_batches += 1
             n_queries += count
+            # round 5: the SLOT-sharded step on the same queries -- a random number of slot-shard contexts (each holding
+            # 1 / G of the NTT slots of every plaintext), a random number of queries per "rank", mixed clients inside the
+            # groups; the all-to-alls are tensor copies; every reply must equal the plain batch pipeline's
+            if info["mfma"] and info["chunks"] == 1 and d == 2 and rng.integers(0, 2):
+                from pir_amd import distributed as D
+                from gpu_helpers import all_to_all_in_process
+                G = int(rng.choice([1, 2, 3, 4, 8]))
+                per = count // G
+                if per >= 1:
+                    kN = s.orc.k * 4096
+                    cuts = D.slot_cuts(kN, G)
+                    ranks = []
+                    for g in range(G):
+                        dbg = pir_amd.PIRDatabase.Create(pp, s.raw, slots=(cuts[g], cuts[g + 1]) if G > 1 else None)
+                        if rng.integers(0, 2):
+                            dbg.finalize(release_staging=True)
+                        sg = pir_amd.PIRServer(dbg, pp)
+                        sg.set_galois_keys(s.galois_keys)
+                        sg.set_concurrency(int(rng.choice([8, 9, 16])))
+                        mine = who[g * per:(g + 1) * per]
+                        sl = {w: sg.install_keyset(b"soak-client-%d" % w, ckeys[w]) for w in sorted(set(mine))}
+                        sg.stage_batch(queries[:G * per])
+                        sg.set_batch_keysets([sl[w] if g * per <= i < (g + 1) * per else 0 for i, w in enumerate(who[:G * per])])
+                        ranks.append((dbg, sg, D.SlotsBuffers(sg, G * per, g, G, torch, "cuda:0")))
+                    for g, (dbg, sg, b) in enumerate(ranks):
+                        sg.slots_expand_async(g * per, per, b.packed_send.data_ptr(), b.sv.data_ptr(), cuts)
+                        sg.sync()
+                    bufs = [r[2] for r in ranks]
+                    all_to_all_in_process([b.packed_recv for b in bufs], [b.packed_send for b in bufs],
+                                          [b.x1_recv for b in bufs], [b.x1_send for b in bufs])
+                    for dbg, sg, b in ranks:
+                        sg.slots_scan_async(b.packed_recv.data_ptr(), G, per, b.rows_send.data_ptr())
+                        sg.sync()
+                    all_to_all_in_process([b.rows_recv for b in bufs], [b.rows_send for b in bufs],
+                                          [b.x2_recv for b in bufs], [b.x2_send for b in bufs])
+                    for g, (dbg, sg, b) in enumerate(ranks):
+                        sg.slots_finish_async(b.rows_recv.data_ptr(), per, b.sv.data_ptr(), cuts, b.replies.data_ptr())
+                        sg.sync()
+                        mine_r = b.replies.cpu().numpy().view(np.uint64)
+                        for i in range(per):
+                            assert np.array_equal(mine_r[i], got[g * per + i]), ("slots != plain", dims, G, per, g, i, who)
+                        dbg.close()
+                    n_slots_steps += 1
+                    n_slots_queries += G * per
         db.close()
         print("cfg %d dims=%s mfma=%s ok (%d batches, %d queries so far)" % (n_cfg, dims, info["mfma"], n_batches, n_queries),
               flush=True)
-    print("soak OK: %d configurations, %d batches, %d queries" % (n_cfg, n_batches, n_queries))
+    print("soak OK: %d configurations, %d batches, %d queries; %d slot-sharded steps, %d queries"
+          % (n_cfg, n_batches, n_queries, n_slots_steps, n_slots_queries))
 
 
 if __name__ == "__main__":

@@ -1297,7 +1297,7 @@ static const struct { const char* name; bool early; } kOptions[] = {
     {"FUSE_LAST", true}, {"FUSE_MAC_COMBINE", true}, {"LAST_NTT", true}, {"SEL_F64", true}, {"TREE40", true},
     {"FUSE_MAC_NODES", true}, {"SPLIT_UPPER", true}, {"SPLIT_UPPER_MB", true}, {"PACK40", true},
     {"SCAN_MFMA", true}, {"SCAN_MFMA_WIDE", true}, {"SCAN_MFMA_TOP4", true}, {"SCAN_MFMA_NQ", true}, {"SCAN_MFMA_SINGLE", true}, {"LANES", true}, {"HEAD_LEVELS", true}, {"HEAD_MODE", true}, {"SCAN_F64_FOLD", true}, {"LOOP_TRANSFORMS", true}, {"LOOP_MIN_SOURCES", true},
-    {"SLOTS_SCAN_WGS", false}, {"SLOTS_GATHER_NTT", false},
+    {"SLOTS_SCAN_WGS", false}, {"SLOTS_GATHER_NTT", false}, {"SLOTS_SCAN_BLK_MAJOR", false},
 };
 
 int pirgpu_set_option(pirgpu_ctx* c, const char* name, int64_t value) {
@@ -2885,7 +2885,7 @@ int pirgpu_slots_scan_async(pirgpu_ctx* c, const uint8_t* device_packed, uint32_
     auto flush = [&]() {
       if (!grp.n) return;
       HIP_TRY(launch_scan_mfma_groups(ln.stream, c->dp, c->mg, c->d_dbp, grp, c->scan_rows, 0, wgs, c->scan_f64_fold, c->slot0,
-                                      c->nslots, qwords, c->nslots));
+                                      c->nslots, qwords, c->nslots, option(c, "SLOTS_SCAN_BLK_MAJOR", 0) != 0));
       grp = ScanGroups{};
     };
     for (uint32_t r = 0; r < n_ranks; ++r)
@@ -2929,7 +2929,9 @@ int pirgpu_slots_finish_async(pirgpu_ctx* c, const uint64_t* device_rowsums, uin
       // rank h's block of the receive buffer holds [count][RC][slots of h]: the group's queries are rows j0 .. j0 + B of
       // it; the inverse transform of the row sums (database.cpp:250-254) gathers them from there (option
       // SLOTS_GATHER_NTT = 0: a separate assembly pass, then the plain in-place transform)
-      const bool gather = option(c, "SLOTS_GATHER_NTT", 1) != 0;
+      bool gather = option(c, "SLOTS_GATHER_NTT", 1) != 0;
+      const uint32_t nt = c->N >> ntt_log_ept((int)c->logN);    // threads of a transform workgroup
+      for (uint32_t r = 0; r <= n_ranks; ++r) gather = gather && map.cut[r] % nt == 0;
       if (gather)
         HIP_TRY(c->ops->ntt_inv_gather(ln.stream, c->mode, c->dp, c->k, device_rowsums, ln.lvl[c->d - 1], map, RC, B, count, j0));
       else

@@ -178,7 +178,8 @@ hipError_t launch_scan_mfma(hipStream_t st, const DevParams* P, const MfmaGeom& 
 // an output row is out_rstride slots long)
 hipError_t launch_scan_mfma_groups(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp,
                                    const ScanGroups& grp, uint32_t rows, uint64_t chunk_stride, uint32_t wgs, bool f64_fold,
-                                   uint32_t slot0, uint32_t nslots, uint64_t out_qstride, uint32_t out_rstride);
+                                   uint32_t slot0, uint32_t nslots, uint64_t out_qstride, uint32_t out_rstride,
+                                   bool blk_major = false);   // blk_major: units ordered (slot block, group) instead of (group, slot block)
 // row sums of queries q0 .. q0 + nq - 1 (of the nq_total the receive buffer holds per rank) back from the per-rank slot
 // pieces of the all-to-all receive buffer to [query][row, comp][kN] at dst + (q - q0) * dst_qstride
 hipError_t launch_slots_assemble(hipStream_t st, const uint64_t* src, uint64_t* dst, const SliceMap& map, uint32_t RC,

@@ -193,8 +193,10 @@ ntt_batch_kernel(const DevParams* __restrict__ P, uint64_t* __restrict__ data, u
 // the all-to-all's receive buffer -- rank h's block holds [query][row, comp][slots of h] (block h starts at word
 // nq_total * RC * cut[h]), a polynomial's N slots lie in up to n of those blocks -- straight into the
 // [query][row, comp][k][N] layout of the lane buffer: what transform_from_ntt_inplace (database.cpp:250-254) does on the
-// row sums, without a separate assembly pass.  grid = nq * RC * k; the slots of one thread increase with e, so the piece
-// index only ever moves forward.
+// row sums, without a separate assembly pass.  grid = nq * RC * k.  The cuts are multiples of the workgroup size (the host
+// checks; otherwise it keeps the separate pass), so the NT consecutive slots a workgroup loads for one e lie in ONE
+// piece: the piece lookup is scalar (a per-lane index into the by-value map made the compiler spill it to scratch and
+// cost more than the pass it replaced).
 template <int MODE>
 __global__ void __launch_bounds__(NT)
 ntt_inv_gather_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ src, uint64_t* __restrict__ dst,
@@ -204,14 +206,16 @@ ntt_inv_gather_kernel(const DevParams* __restrict__ P, const uint64_t* __restric
   const int mi = blockIdx.x % k;
   const uint32_t rc = (blockIdx.x / k) % RC, q = blockIdx.x / (k * RC);
   const typename A::Mod m = A::mod(P, mi);
+  const size_t row = (size_t)(q0 + q) * RC + rc, per_slot = (size_t)nq_total * RC;
   typename A::T x[EPT];
   uint32_t h = 0;
 #pragma unroll
   for (int e = 0; e < EPT; ++e) {
-    const uint32_t j = (uint32_t)mi * N + e * NT + tid;      // slot of the ring's k N
-    while (h + 1 < map.n && j >= map.cut[h + 1]) ++h;
+    const uint32_t jb = (uint32_t)mi * N + e * NT;           // first slot of this load, workgroup-uniform
+    while (h + 1 < map.n && jb >= map.cut[h + 1]) ++h;
     const uint32_t c0 = map.cut[h], width = map.cut[h + 1] - c0;
-    x[e] = A::in(src[(size_t)nq_total * RC * c0 + ((size_t)(q0 + q) * RC + rc) * width + (j - c0)], m);
+    const uint64_t* piece = src + per_slot * c0 + row * width + (jb - c0);
+    x[e] = A::in(piece[tid], m);
   }
   ntt_inverse<MODE, LOGN, kPF>(x, smem_raw, P, mi, tid);
   uint64_t* poly = dst + (size_t)blockIdx.x * N;
@@ -1331,6 +1335,8 @@ static hipError_t op_ntt_inv_gather(hipStream_t st, int mode, const DevParams* P
                                     uint32_t q0) {
   if (map.n == 0 || map.n > (uint32_t)kMaxSlices || map.cut[0] != 0 || map.cut[map.n] != k * (uint32_t)N || q0 + nq > nq_total)
     return hipErrorInvalidValue;
+  for (uint32_t r = 0; r <= map.n; ++r)
+    if (map.cut[r] % NT) return hipErrorInvalidValue;   // the caller falls back to launch_slots_assemble + ntt_batch
   PIRGPU_BY_MODE(mode, hipLaunchKernelGGL(ntt_inv_gather_kernel<MODE>, dim3(nq * RC * k), dim3(NT), kLdsBytes, st, P, src, dst,
                                           map, RC, nq_total, q0));
   return hipGetLastError();

@@ -250,7 +250,7 @@ template <int L, int KS, int NW, bool TOP4, bool F64F = false>
 __global__ void __launch_bounds__(NW * 64)
 scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ dbp, ScanGroups grp, uint32_t rows,
                  uint32_t RT, uint32_t KG, uint64_t chunk_stride, ChunkPlan plan, uint32_t GC, uint32_t slot0,
-                 uint32_t nslots, uint64_t out_qstride, uint32_t out_rstride) {
+                 uint32_t nslots, uint64_t out_qstride, uint32_t out_rstride, uint32_t blk_major) {
   constexpr uint32_t TB = tile_bytes(L, TOP4);
   constexpr int LF = TOP4 ? L - 1 : L;   // digits stored as full bytes
   constexpr int NS = 2 * L - 1;        // digit diagonals
@@ -301,10 +301,17 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
     if constexpr (TOP4) A4[ks] = load_tile8(blk + (L - 1) * 256 + lane8);
   };
 
+  // unit -> (group, slot block): group-major (u = group * nblocks + block: the launch sweeps the slots once per group) or
+  // block-major (u = block * groups + group: the workgroups running side by side read the SAME database tiles for
+  // different groups, so all but the first reader of a tile can be served by the memory-side cache)
+  // (plain scalar arithmetic at each use: a helper taking references made the compiler keep the pair in scratch)
+#define PIRGPU_UNIT_OF(uu, gi_, blk_)                                  \
+  const uint32_t gi_ = blk_major ? (uu) % grp.n : (uu) / nblocks;      \
+  const uint32_t blk_ = blk_major ? (uu) / grp.n : (uu) - gi_ * nblocks;
   uint32_t u = wg_in_chunk;
   if (u >= nunits) return;
   {
-    const uint32_t gi = u / nblocks, blk = u - gi * nblocks;
+    PIRGPU_UNIT_OF(u, gi, blk)
     load_B(gi, blk * NW + w);
     const uint8_t* abase = dbp + (size_t)(blk * NW + w) * slab + chunk_base;
 #pragma unroll
@@ -319,7 +326,7 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
 
   uint32_t parity = 0;
   for (; u < nunits; u += wgs_in_chunk) {
-    const uint32_t gi = u / nblocks, blk = u - gi * nblocks;
+    PIRGPU_UNIT_OF(u, gi, blk)
     const uint32_t j0 = blk * NW;            // local slot of wave 0
     const uint32_t j = slot0 + j0 + w;       // this wave's slot of the ring
     const uint32_t mi = j >> P->logN;
@@ -333,7 +340,7 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
     const uint8_t* abase = dbp + (size_t)(j0 + w) * slab + chunk_base;
     const uint32_t nu = u + wgs_in_chunk;
     const bool has_next = nu < nunits;
-    const uint32_t ngi = nu / nblocks, nblk = nu - ngi * nblocks;
+    PIRGPU_UNIT_OF(nu, ngi, nblk)
     const uint8_t* nbase = dbp + (size_t)(nblk * NW + w) * slab + chunk_base;
 
     for (uint32_t rt = 0; rt < RT; ++rt) {
@@ -417,6 +424,8 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
     }
   }
 }
+
+#undef PIRGPU_UNIT_OF
 
 // Slot-sharded multi-GPU step: the row sums of a rank's own nq_total queries arrive from every rank h as
 // [query][row, comp][slots of h] (the all-to-all's receive buffer; rank h's block starts at word nq_total * RC * cut[h]);
@@ -573,7 +582,8 @@ static uint32_t scan_wgs_all() {
 template <int L, int KS, int NW, bool TOP4, bool F64F>
 static void launch_scan_mfma_variant(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp,
                                      const ScanGroups& grp, uint32_t rows, uint64_t chunk_stride, uint32_t wgs_req,
-                                     uint32_t slot0, uint32_t nslots, uint64_t out_qstride, uint32_t out_rstride) {
+                                     uint32_t slot0, uint32_t nslots, uint64_t out_qstride, uint32_t out_rstride,
+                                     bool blk_major) {
   // wgs_req (batch pipeline): a workgroup takes a CU's whole register file, so a launch on fewer CUs leaves the others
   // to the VALU-bound kernels of the other lane -- the HBM-bound pass and the transforms then really overlap
   const uint32_t wgs = wgs_req ? std::min(wgs_req, scan_wgs_all()) : scan_wgs_all();
@@ -584,14 +594,15 @@ static void launch_scan_mfma_variant(hipStream_t st, const DevParams* P, const M
   const uint32_t share = std::min<uint32_t>(units, std::max<uint32_t>(1, wgs / std::min<uint32_t>(gm.nchunks, wgs)));
   for (uint32_t c = 0; c <= gm.nchunks; ++c) plan.first[c] = c * share;   // share >= 1: no chunk without workgroups
   hipLaunchKernelGGL((scan_mfma_kernel<L, KS, NW, TOP4, F64F>), dim3(gm.nchunks * share), dim3(NW * 64), 0, st, P, dbp, grp,
-                     rows, gm.RT, gm.KG, chunk_stride, plan, gm.GC, slot0, nslots, out_qstride, out_rstride);
+                     rows, gm.RT, gm.KG, chunk_stride, plan, gm.GC, slot0, nslots, out_qstride, out_rstride,
+                     blk_major ? 1u : 0u);
 }
 
 hipError_t launch_scan_mfma_groups(hipStream_t st, const DevParams* P, const MfmaGeom& gm, const uint8_t* dbp,
                                    const ScanGroups& grp, uint32_t rows, uint64_t chunk_stride, uint32_t wgs, bool f64_fold,
-                                   uint32_t slot0, uint32_t nslots, uint64_t out_qstride, uint32_t out_rstride) {
+                                   uint32_t slot0, uint32_t nslots, uint64_t out_qstride, uint32_t out_rstride, bool blk_major) {
   if (grp.n == 0 || grp.n > (uint32_t)kMaxScanGroups || nslots == 0 || nslots % gm.NW) return hipErrorInvalidValue;
-#define PIRGPU_MFMA_ARGS st, P, gm, dbp, grp, rows, chunk_stride, wgs, slot0, nslots, out_qstride, out_rstride
+#define PIRGPU_MFMA_ARGS st, P, gm, dbp, grp, rows, chunk_stride, wgs, slot0, nslots, out_qstride, out_rstride, blk_major
 #define PIRGPU_MFMA_CASE(L_, KS_, NW_)                                                                    \
   if (gm.L == L_ && gm.KS == KS_ && gm.NW == NW_) {                                                                 \
     if constexpr (L_ <= 6) {                                                                                         \
@@ -626,7 +637,7 @@ hipError_t launch_scan_mfma(hipStream_t st, const DevParams* P, const MfmaGeom& 
   grp.sel[0] = selp;
   grp.out[0] = out;
   grp.nq[0] = (uint8_t)nq;
-  return launch_scan_mfma_groups(st, P, gm, dbp, grp, rows, chunk_stride, wgs, f64_fold, 0, kN, out_qstride, kN);
+  return launch_scan_mfma_groups(st, P, gm, dbp, grp, rows, chunk_stride, wgs, f64_fold, 0, kN, out_qstride, kN, false);
 }
 
 }  // namespace pirgpu

@@ -57,6 +57,7 @@ def test_slot_shards_on_one_gpu_reproduce_the_oracle(G, items, per):
         for g in range(G):
             # second round: the row sums put together by a separate assembly pass instead of inside the inverse transform
             srvs[g].db.set_option("slots_gather_ntt", 1 - rep)
+            srvs[g].db.set_option("slots_scan_blk_major", rep)      # ... and the scan's units in (slot block, group) order
             srvs[g].stage_batch(queries)
             srvs[g].slots_expand_async(g * per, per, bufs[g].packed_send.data_ptr(), bufs[g].sv.data_ptr(), cuts)
             srvs[g].sync()

@@ -74,6 +74,19 @@ def slots_budget():
         for wgs in (0, 64, 192):
             db.set_option("slots_scan_wgs", wgs)
             res["queued_together_scan_wgs_%d_ms" % wgs] = timed(pipelined, srv, nn, warm=3)
+        db.set_option("slots_scan_wgs", 128)
+        # the scan's units ordered (slot block, group): neighbouring workgroups read the same database tiles
+        db.set_option("slots_scan_blk_major", 1)
+        res["S_blk_major_ms"] = timed(S, srv, nn)
+        res["queued_together_blk_major_ms"] = timed(pipelined, srv, nn, warm=3)
+        db.set_option("slots_scan_wgs", 0)
+        res["S_blk_major_all_cus_ms"] = timed(S, srv, nn)
+        db.set_option("slots_scan_blk_major", 0)
+        res["S_all_cus_ms"] = timed(S, srv, nn)
+        db.set_option("slots_scan_wgs", 128)
+        db.set_option("slots_gather_ntt", 0)
+        res["U_separate_assembly_ms"] = timed(U, srv, nn)
+        db.set_option("slots_gather_ntt", 1)
         res["recv_MB_per_step"] = bufs[0].exchange_bytes_per_query(G) * batch / 1e6
         res["recv_selectors_MB"] = (G - 1) * bufs[0].groups * bufs[0].piece[0] / 1e6
         res["recv_rowsums_MB_u64"] = per * bufs[0].rc * (kN - bufs[0].mine) * 8 / 1e6

@@ -18,6 +18,9 @@ cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/${R}_kernel_stats.csv
 python3 tools/trace_summary.py $(find $O/prof -name "*kernel_trace.csv" | head -1) 1000 > $O/${R}_trace_summary.txt
 rm -rf $O/prof
 for c in 2 4 5; do python3 bench.py --config $c --batch 16 --steps 10 --no-cpu-baseline > $O/${R}_bench_cfg${c}_reference.json 2> $O/cfg$c.err; done
+timeout 600 python tools/rank_budget.py --slots 3 1,2,4,8 > $O/budget_slots_cfg3.log 2>&1 && cp gpurun_out/rank_budget_slots_cfg3.json profiles/${R}_rank_budget_slots_cfg3.json
+timeout 900 python tools/rank_budget.py --slots 4 2,4,8 > $O/budget_slots_cfg4.log 2>&1 && cp gpurun_out/rank_budget_slots_cfg4.json profiles/${R}_rank_budget_slots_cfg4.json
+timeout 900 python tools/rank_budget.py --slots 5 4,8 > $O/budget_slots_cfg5.log 2>&1 && cp gpurun_out/rank_budget_slots_cfg5.json profiles/${R}_rank_budget_slots_cfg5.json
 timeout 1500 python -m pytest tests -m gpu -q > $O/gpu_suite.log 2>&1
 echo "suite rc=$?" > $O/rc.txt
 tail -3 $O/gpu_suite.log

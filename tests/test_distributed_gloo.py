@@ -415,6 +415,14 @@ def rows_step_check(rank, world, d, dbsize, elem, batch, zero_pt=None):
         for i in range(lo, hi):
             ok &= bool(np.array_equal(mine_s[i - lo], full[i]))
             ok &= s.client.process_response(p, indexes[i], mine_s[i - lo]) == s.item(indexes[i])
+        os.environ["PIRGPU_SLOTS_PACK40"] = "1"                # ... and with the row sums crossing in 5 bytes per residue
+        try:
+            sb40 = D.SlotsBuffers(srv, batch, rank, world, torch, "cpu")
+        finally:
+            del os.environ["PIRGPU_SLOTS_PACK40"]
+        ok &= sb40.rows40 and not sb.rows40 and sb40.exchange_bytes_per_query(world) < sb.exchange_bytes_per_query(world)
+        D.run_batch_slots(srv, sb40, dist, rank, world, comm)
+        ok &= bool(np.array_equal(sb40.replies.numpy(), sb.replies.numpy()))
         srv.stage_batch(q_all + q_all[:batch])
         sp = D.SlotsPipeline(srv, batch, rank, world, dist, torch, "cpu", comm=D.Comm(dist, world))
         for t in range(4):

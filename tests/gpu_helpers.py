@@ -39,3 +39,8 @@ def all_to_all_in_process(recvs, sends, recv_splits, send_splits):
             assert n == recv_splits[dst][src]
             recvs[dst][ro:ro + n].copy_(sends[src][so:so + n])
             ro += n
+    # the copies run on torch's current stream, the library's kernels on its own non-blocking streams: nothing orders the
+    # two but the host (a product caller uses Comm, which waits, or the entry points' after / then streams)
+    if recvs and recvs[0].is_cuda:
+        import torch
+        torch.cuda.synchronize()

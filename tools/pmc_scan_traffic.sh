@@ -7,6 +7,9 @@ export PIRGPU_ALLOW_ENV=1   # the library reads PIRGPU_* knobs only behind this 
 # gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half the bytes of a 16 B/lane coalesced
 # streaming read -> x2; WRITE_SIZE as reported.
 export TMPDIR=/tmp
+# only the workload's own launches: the wire legs and the reference sweep of the default line run the same kernel on other
+# (tiny) databases -- their full-grid launches with the smallest write volume would be mistaken for the single-query pass
+export PIRGPU_BENCH_SKIP_WIRE=1 PIRGPU_BENCH_SKIP_SWEEP=1
 OUT=${1:-gpurun_out/pmc_scan_traffic.json}
 COMMIT=${2:-unknown}
 shift; shift

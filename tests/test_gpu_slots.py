@@ -38,10 +38,11 @@ def _rank_server(pir_amd, pp, s, slots):
 from gpu_helpers import all_to_all_in_process as _all_to_all   # noqa: E402
 
 
-@pytest.mark.parametrize("G,items,per", [(2, 3000, 4), (8, 3000, 1), (4, 12000, 9), (8, 40000, 2), (3, 3000, 3)])
+@pytest.mark.parametrize("G,items,per", [(2, 3000, 4), (8, 3000, 1), (4, 12000, 9), (8, 40000, 2), (3, 3000, 3), (8, 3000, 17)])
 def test_slot_shards_on_one_gpu_reproduce_the_oracle(G, items, per):
-    """G slot-shard contexts, `per` queries each (9: a full and a partial group per rank; G = 3: uneven slot cuts);
-    12000 / 40000 items: 18 x 18 and 32 x 32 matrices (two row tiles, ragged; two column groups)."""
+    """G slot-shard contexts, `per` queries each (9: a full and a partial group per rank; G = 3: uneven slot cuts; 17 on
+    8 ranks: 24 groups per scan = two launches of at most 16); 12000 / 40000 items: 18 x 18 and 32 x 32 matrices (two row
+    tiles, ragged; two column groups)."""
     from pir_amd import distributed as D
     s, pp, pir_amd = _setup(items)
     p = s.params
@@ -75,6 +76,8 @@ def test_slot_shards_on_one_gpu_reproduce_the_oracle(G, items, per):
         for g in range(G):
             mine = bufs[g].replies.cpu().numpy().view(np.uint64)
             for i in range(per):
+                if per > 9 and (g * per + i) % 7 and rep:        # the big batch: every query once, a sample twice
+                    continue
                 rc, want = s.orc.process_query(s.db_ntt, p.dimensions, queries[g * per + i], s.galois_keys)
                 assert rc == 0
                 assert np.array_equal(mine[i], want), (rep, g, i)

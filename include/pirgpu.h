@@ -376,7 +376,7 @@ const char* pirgpu_request_error(uint32_t i);
  * passed to begin (requests, lengths, responses, status) must stay alive and untouched until end returns; responses and
  * status are valid after end.  begin(i + 1) before end(i) lets call i + 1's parsing, staging and queueing run under
  * call i's tail -- what two calling threads get (two request windows in flight), without the caller owning a second
- * thread.  Every begin must be matched by exactly one end. */
+ * thread.  Every begin must be matched by exactly one end, and the context must outlive every call still pending. */
 int pirgpu_process_requests_begin(pirgpu_ctx* ctx, uint32_t n, const uint8_t* const* requests, const size_t* request_lens,
                                   uint8_t** responses, size_t* response_lens, int* status, void** call);
 int pirgpu_process_requests_end(void* call);

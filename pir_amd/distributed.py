@@ -581,6 +581,7 @@ class SlotsBuffers:
         if not all(piece):
             raise ValueError("the slot-sharded step needs d = 2 and the int8-MFMA scan in one column chunk")
         self.piece = piece
+        self.piece_mine = piece[rank]
         self.packed_send = torch.empty((self.groups * sum(piece),), dtype=torch.uint8, device=device)
         self.packed_recv = torch.empty((world * self.groups * piece[rank],), dtype=torch.uint8, device=device)
         self.sv = torch.empty((self.per, dim_sum, self.ctw), dtype=torch.int64, device=device)
@@ -603,7 +604,7 @@ class SlotsBuffers:
         """Bytes a rank receives per query of the batch: its slots of every other rank's packed column selectors +
         the row sums of its own queries from the other ranks' slots."""
         batch = self.per * world
-        x1 = (world - 1) * self.groups * self.piece[0]
+        x1 = (world - 1) * self.groups * self.piece_mine
         x2 = self.per * self.rc * (self.k_n - self.mine) * (5 if self.rows40 else 8)
         return (x1 + x2) / batch
 

@@ -71,6 +71,17 @@ def slots_budget():
             s_ = step[0]; step[0] += 1
             S(bufs[(s_ + 2) % 3]); E(bufs[s_ % 3]); U(bufs[(s_ + 1) % 3])
         res["S_E_U_queued_together_ms"] = timed(pipelined, srv, nn, warm=3)
+        # other orders of the three calls of a step (the lanes are handed out round robin, call by call): U first puts
+        # [U, S] on one lane and E on the other -- the expansion's narrow, latency-bound first levels then run beside the
+        # VALU-bound upper level, its wide levels beside the HBM-bound scan
+        def order(seq):
+            def f():
+                s_ = step[0]; step[0] += 1
+                for ch in seq:
+                    {"S": S, "E": E, "U": U}[ch](bufs[(s_ + "ESU".index(ch) * 2) % 3])
+            return f
+        for seq in ("UES", "USE", "EUS", "ESU", "SUE"):
+            res["queued_together_order_%s_ms" % seq] = timed(order(seq), srv, nn, warm=3)
         for wgs in (0, 64, 192):
             db.set_option("slots_scan_wgs", wgs)
             res["queued_together_scan_wgs_%d_ms" % wgs] = timed(pipelined, srv, nn, warm=3)

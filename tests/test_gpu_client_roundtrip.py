@@ -55,3 +55,38 @@ def test_two_clients_share_one_server():
     for client, idx in [(a, [3]), (b, [1999]), (a, [77, 78]), (b, [0])]:
         assert client.ProcessResponse(idx, server.ProcessRequest(client.CreateRequest(idx))) == \
             [raw[i].tobytes() for i in idx]
+
+
+@pytest.mark.parametrize("log_items", [8, 10, 12, 14, 16])
+def test_reference_benchmark_sizes_recover_the_item_and_match_the_oracle(log_items):
+    """The reference's own benchmark cases (benchmark.cpp:17-23, 102-104: 2^8 .. 2^16 items of 288 bytes, d = 2, N = 4096,
+    24-bit t, one query per request): the product client's request through the wire-level server, the item back -- the
+    parameters leave a positive noise budget at every one of these sizes -- and the reply equal to the oracle's, bit for
+    bit, on the same query ciphertext and keys."""
+    import oracle
+    from gpu_helpers import to_product_params
+    n = 1 << log_items
+    enc = P.generate_encryption_params(4096, 24)
+    pp = P.create_pir_parameters(n, 288, 2, enc)
+    raw = generate_test_db(n, 288, seed=100 + log_items)
+    db = pir_amd.PIRDatabase.Create(pp, raw)
+    server = pir_amd.PIRServer.Create(db, pp)
+    client = pir_amd.PIRClient.Create(pp, seed=b"reference-sizes-%d" % log_items)
+    idx = (n * 5) // 7
+    response = server.ProcessRequest(client.CreateRequest([idx]))
+    assert client.ProcessResponse([idx], response) == [raw[idx].tobytes()]
+    # the oracle on THIS client's keys and one of its query ciphertexts
+    op = oracle.create_pir_parameters(n, 288, 2, N=4096, plain_bits=24)
+    assert list(op.dimensions) == list(pp.dimensions) and to_product_params(op).num_pt == pp.num_pt
+    orc = oracle.Oracle.from_params(op)
+    rc, db_ntt = orc.db_encode(raw.tobytes(), n, 288, op.items_per_plaintext, op.eff_bits_per_coeff, op.num_pt)
+    assert rc == 0
+    q = client.create_query_for(idx)
+    keys = client.galois_keys()
+    rc, want = orc.process_query(db_ntt, op.dimensions, q, keys)
+    assert rc == 0
+    server.set_galois_keys(keys)
+    got = server.process_query(q)
+    assert np.array_equal(got, want)
+    assert client.noise_budget(got[0]) > 0
+    db.close()

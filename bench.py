@@ -17,8 +17,14 @@ Workload = BASELINE.json configs[2]: N=4096, 2 RNS primes, DB = 2^20 x 288 B, d=
 reference's own benchmark parameters, benchmark.cpp:17-23).
 
 Multi-GPU (launched by torch.distributed.run, one rank per GPU).  The headline `value` is ALWAYS the
-north-star mode: the database row-sharded across the GPUs ("scaling": "strong" -- the same 64 queries per
-step whatever the GPU count):
+north-star mode: the database SHARDED across the GPUs ("scaling": "strong" -- the same 64 queries per
+step whatever the GPU count) -- by row (`rows`) or by NTT slot (`slots`); every form is timed over the full W + K steps
+and the fastest is the headline (`exchange_autotune`, `config.exchange`):
+  slots    every rank holds 1/G of the NTT slots of EVERY plaintext (the base case of PIRDatabase::multiply is a dyadic
+           product, independent per slot), expands batch/G of the step's queries, and the step is two all-to-alls: the
+           packed column selectors' slot slices out (a rank receives 1/G of each query's), the row sums back to the
+           rank that expanded the query, which runs the upper level itself -- no row-selector exchange, no reduce
+           (DESIGN.md section 7.1);
   rows     every rank holds 1/G of the rows, expands batch/G of the step's queries (the expansion does not
            shard by rows, so it is partitioned by query), packs their column selectors into the scan's
            operand layout and lays their row selectors out by owner; one RCCL all-gather (packed column

@@ -412,7 +412,7 @@ uint64_t pirgpu_scan_bytes(const pirgpu_ctx* ctx);
  * digit of database and selectors is stored as a nibble (L - 1/2 bytes per residue instead of L). */
 int pirgpu_scan_info(pirgpu_ctx* ctx, uint32_t info[8]);
 /* Options by name (case-insensitive), e.g. "scan_mfma" (0 keeps the 64-bit multiply-accumulate scan for d >= 2),
- * "scan_mfma_wide" (0 / 1 forces the 8-wave / 4-wave scan kernel), "lanes", "upper_blocks", "fuse_last", "last_ntt",
+ * "scan_mfma_wide" (0 / 1 forces the 8-wave / 4-wave scan kernel), "upper_blocks", "fuse_last", "last_ntt",
  * "tree40", "sel_f64", "split_upper", "loop_transforms" (0: one transform per workgroup everywhere),
  * "scan_mfma_wgs_batch" (workgroups of a database pass that shares the chip with another group) -- DESIGN.md section 6
  * lists them.  A name that was not set falls back to the environment variable

@@ -4,6 +4,20 @@
 // (server.cpp:173-195) and PIRDatabase (database.cpp) on one MI355X: the encoded
 // database, the Galois keys and every intermediate live in HBM; the host only
 // sequences kernel launches on the context's stream.
+//
+// Map of this file (search for "[n]"):
+//   [1]  state: Worker (one query in flight), BatchLane (a group of 8), KeySet, BatchSet, pirgpu_ctx
+//   [2]  helpers: errors, NTT / Encode tables, options, workspace geometry
+//   [3]  oblivious expansion: expand_core (levels: ks_digit -> ks_mac_intt -> ks_mac_combine / ks_combine; last level
+//        in the NTT domain), expand_query_to_sv
+//   [4]  multiply: scan_group_mfma / scan_on_device, post_scan_stage (inverse NTT, upper levels, fold)
+//   [5]  C ABI: create / destroy, options, database loading (db_encode, db_pack), finalize
+//   [6]  C ABI: Galois keys, per-client key sets (handles with generations, pins, LRU)
+//   [7]  C ABI: single query, join / fork, test hooks
+//   [8]  batch pipeline: staging, lanes, expand_group_on_lane, batch_run_mfma (groups of 8 on two lanes)
+//   [9]  multi-GPU entry points: u64 exchange, packed row shards, slot shards (pirgpu_slots_*), fix-up, pack40
+//   [10] measurement
+// The kernels are in kernels.hip, scan_mfma.hip, ntt_kernels.hip (+ ntt_core.h, arith.h); the wire level in wire.cpp.
 #include <hip/hip_runtime.h>
 #include <ctype.h>
 #include <stdint.h>
@@ -53,6 +67,9 @@ enum Phase { PH_EXPAND = 0, PH_SVNTT, PH_SCAN, PH_UPPER, PH_FINAL, PH_COUNT };
 
 }  // namespace
 
+// ======================================================================================================================
+// [1] STATE: workers, lanes, key sets, batch sets, the context
+// ======================================================================================================================
 // Per-query working set: one HIP stream plus every intermediate of one query in flight.
 // A context owns one worker by default; pirgpu_set_concurrency adds more so that several
 // queries overlap on the GPU (the latency-bound expansion of one hides under the
@@ -257,7 +274,7 @@ struct pirgpu_ctx {
   // of one source polynomial in ONE workgroup: one load and one permutation per source, stores drain under the next
   // transform (option LOOP_TRANSFORMS; fp64 flavours)
   bool loop_transforms = true;
-  uint32_t loop_min_sources = 1024;         // ... from this many (tree ciphertext, digit) sources per launch on (option LOOP_MIN_SOURCES)
+  uint32_t loop_min_sources = 1024;         // ... from this many (tree ciphertext, digit) sources per launch on
   uint32_t fuse_mac_nodes = 128;            // ... from this many tree ciphertexts per level on (narrower levels are latency-
                                             // bound: two dependent transform kernels cost more than mac + light combine)
   bool fuse_mac_combine = true;             // levels below the last: combine step in the data residues' MAC + inverse-NTT
@@ -321,6 +338,9 @@ BatchSet& pirgpu_ctx::bs() { return sets[t_batch_set]; }
 
 namespace {
 
+// ======================================================================================================================
+// [2] HELPERS: errors, tables (twiddles, Encode order), options, workspace geometry (ensure_workspace)
+// ======================================================================================================================
 int fail(pirgpu_ctx* c, int code, const std::string& msg) {
   if (c) {
     std::lock_guard<std::recursive_mutex> lock(c->mu);
@@ -556,15 +576,15 @@ void ensure_workspace(pirgpu_ctx* c) {
     c->scan_limb = true;
     for (uint32_t j = 0; j < k; ++j) c->scan_limb = c->scan_limb && (c->hp.mod[j].q >> 50) == 0;
     if (!env_u32("PIRGPU_SCAN_LIMB", 1)) c->scan_limb = false;
-    //   PIRGPU_SCAN_NQ     queries sharing one database pass in batch mode (1, 2, 4)
-    //   PIRGPU_SCAN_MQ_ROWS rows per wave of the multi-query kernel (1, 2, 4)
+    //   (settled in rounds 1 - 2, constants since round 5: 4 queries share one pass of the 64-bit kernels in batch mode,
+    //   one row per wave then; a single query takes four rows per wave with limb accumulators off -- HISTORY section 9)
     //   PIRGPU_SCAN_MQ_SINGLE=0 routes single queries through scan_kernel instead of the LDS-shared
-    //                      scan_mq_kernel (PIRGPU_SCAN_MQ_SINGLE_ROWS = 2 or 4 rows per wave)
-    c->mq_nq = env_u32("PIRGPU_SCAN_NQ", 4);
-    c->mq_rows = env_u32("PIRGPU_SCAN_MQ_ROWS", c->mq_nq == 4 ? 1 : 2);
+    //                      scan_mq_kernel
+    c->mq_nq = 4;
+    c->mq_rows = 1;
     c->mq_single = env_u32("PIRGPU_SCAN_MQ_SINGLE", 1) != 0;
-    c->mq_single_rows = env_u32("PIRGPU_SCAN_MQ_SINGLE_ROWS", 4) == 2 ? 2 : 4;
-    c->mq_single_limb = env_u32("PIRGPU_SCAN_MQ_SINGLE_LIMB", 0) != 0;
+    c->mq_single_rows = 4;
+    c->mq_single_limb = false;
     c->scan_rpt = env_u32("PIRGPU_SCAN_ROWS", 4);
     c->scan_block = env_u32("PIRGPU_SCAN_BLOCK", 256);
     const uint32_t xblocks = (k * N / 2 + c->scan_block - 1) / c->scan_block;
@@ -583,14 +603,14 @@ void ensure_workspace(pirgpu_ctx* c) {
     c->last_level_ntt = env_u32("PIRGPU_LAST_NTT", 1) != 0;
     c->want_sel_f64 = env_u32("PIRGPU_SEL_F64", 1) != 0;
     c->tree40 = env_u32("PIRGPU_TREE40", 1) != 0;
-    c->fuse_mac_nodes = env_u32("PIRGPU_FUSE_MAC_NODES", 128);
+    c->fuse_mac_nodes = 128;       // swept in round 2 (HISTORY section 4): a constant since round 5
     //   PIRGPU_HEAD_LEVELS  expansion levels of a batch group that run ahead on the head stream (0: none)
     c->head_levels = std::min<uint32_t>(env_u32("PIRGPU_HEAD_LEVELS", c->head_levels), 8);
     c->head_mode = std::min<uint32_t>(env_u32("PIRGPU_HEAD_MODE", c->head_mode), 2);
     c->split_upper = env_u32("PIRGPU_SPLIT_UPPER", c->logN >= 14 ? 1 : 0) != 0 && c->mode != kNttInt;
     c->split_upper_words = (uint64_t)env_u32("PIRGPU_SPLIT_UPPER_MB", 3072) * (1ull << 20) / 8;
     c->loop_transforms = env_u32("PIRGPU_LOOP_TRANSFORMS", 1) != 0 && c->mode != kNttInt;
-    c->loop_min_sources = env_u32("PIRGPU_LOOP_MIN_SOURCES", c->loop_min_sources);
+    // (loop_min_sources: swept 512 - 4096 in round 4, 1 024 stays: a constant since round 5)
     c->pack40 = env_u32("PIRGPU_PACK40", 1) != 0;
     // 5-byte storage of the key-switch intermediates: the fp64 flavours store x + q (|x| <= q), so q < 2^39
     for (uint32_t j = 0; j <= k; ++j) c->pack40 = c->pack40 && (c->hp.mod[j].q >> 39) == 0;
@@ -655,6 +675,9 @@ void alloc_worker(pirgpu_ctx* c, Worker& w) {
   HIP_TRY(hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming));
 }
 
+// ======================================================================================================================
+// [3] OBLIVIOUS EXPANSION (server.cpp:105-171): keys per query, expand_core, expand_query_to_sv
+// ======================================================================================================================
 uint32_t galois_inverse(uint32_t g, uint32_t N) {
   // (Z/2N)^* has exponent dividing N, so g^-1 = g^(N-1) mod 2N
   uint64_t mod = 2ull * N, r = 1, b = g % mod;
@@ -873,6 +896,9 @@ void expand_query_to_sv(pirgpu_ctx* c, Worker& w, const uint64_t* d_query, uint3
   }
 }
 
+// ======================================================================================================================
+// [4] MULTIPLY (database.cpp:170-258): the scan (scan_group_mfma / scan_on_device) and everything after it (post_scan_stage)
+// ======================================================================================================================
 // PIRDatabase::multiply on the device (reference database.cpp:170-258), with the
 // selection vector already in NTT form in sv_ntt.  Leaves the reply in lvl[0].
 // selectors of the scanned (last) dimension for this worker's query
@@ -1104,6 +1130,9 @@ void run_staged(pirgpu_ctx* c, Worker& w, bool profile) {
 
 extern "C" {
 
+// ======================================================================================================================
+// [5] C ABI: create / destroy, options, database loading
+// ======================================================================================================================
 const char* pirgpu_create_error(void) { return g_create_error.c_str(); }
 
 int pirgpu_create(const pirgpu_params* p, pirgpu_ctx** out) {
@@ -1292,11 +1321,11 @@ int pirgpu_set_transparent_policy(pirgpu_ctx* c, int allow) {
 // and must be set before the context is first used.
 static const struct { const char* name; bool early; } kOptions[] = {
     {"UPPER_BLOCKS", true}, {"UPPER_BLOCKS_BATCH", true}, {"SCAN_MFMA_WGS_BATCH", false}, {"SCAN_LIMB", true},
-    {"SCAN_NQ", true}, {"SCAN_MQ_ROWS", true}, {"SCAN_MQ_SINGLE", true}, {"SCAN_MQ_SINGLE_ROWS", true},
-    {"SCAN_MQ_SINGLE_LIMB", true}, {"SCAN_ROWS", true}, {"SCAN_BLOCK", true}, {"SCAN_NSPLIT", true},
+    {"SCAN_MQ_SINGLE", true}, {"SCAN_ROWS", true}, {"SCAN_BLOCK", true}, {"SCAN_NSPLIT", true},
     {"FUSE_LAST", true}, {"FUSE_MAC_COMBINE", true}, {"LAST_NTT", true}, {"SEL_F64", true}, {"TREE40", true},
-    {"FUSE_MAC_NODES", true}, {"SPLIT_UPPER", true}, {"SPLIT_UPPER_MB", true}, {"PACK40", true},
-    {"SCAN_MFMA", true}, {"SCAN_MFMA_WIDE", true}, {"SCAN_MFMA_TOP4", true}, {"SCAN_MFMA_NQ", true}, {"SCAN_MFMA_SINGLE", true}, {"LANES", true}, {"HEAD_LEVELS", true}, {"HEAD_MODE", true}, {"SCAN_F64_FOLD", true}, {"LOOP_TRANSFORMS", true}, {"LOOP_MIN_SOURCES", true},
+    {"SPLIT_UPPER", true}, {"SPLIT_UPPER_MB", true}, {"PACK40", true},
+    {"SCAN_MFMA", true}, {"SCAN_MFMA_WIDE", true}, {"SCAN_MFMA_TOP4", true}, {"SCAN_MFMA_NQ", true}, {"SCAN_MFMA_SINGLE", true},
+    {"HEAD_LEVELS", true}, {"HEAD_MODE", true}, {"SCAN_F64_FOLD", true}, {"LOOP_TRANSFORMS", true},
     {"SLOTS_SCAN_WGS", false}, {"SLOTS_GATHER_NTT", false}, {"SLOTS_SCAN_BLK_MAJOR", false},
 };
 
@@ -1517,6 +1546,9 @@ int pirgpu_db_read_plaintext(pirgpu_ctx* c, uint64_t pt_index, uint64_t* out) {
   });
 }
 
+// ======================================================================================================================
+// [6] C ABI: Galois keys and per-client key sets
+// ======================================================================================================================
 // Uploads one Galois key into a key set slot (SEAL's NTT order at the boundary, device order in HBM).  A new client's
 // first request pays for 12 of these (N = 4096): the staging buffer is allocated once per context and the key buffers
 // of emptied sets are recycled, so the steady state of a server whose clients come and go allocates nothing.
@@ -1838,6 +1870,9 @@ uint64_t* pirgpu_host_reply_buffer(pirgpu_ctx* c, uint32_t count) {
   return out;
 }
 
+// ======================================================================================================================
+// [7] C ABI: single query (stage / run / fetch), stream ordering hooks (join / fork), test hooks (expand, substitute, multiply)
+// ======================================================================================================================
 static int query_stage_impl(pirgpu_ctx* c, const uint64_t* query, uint32_t nq, bool wait) {
   return guarded(c, [&]() -> int {
     ensure_workspace(c);
@@ -2156,6 +2191,9 @@ int pirgpu_multiply(pirgpu_ctx* c, const uint64_t* sv, uint64_t sv_count, uint64
   });
 }
 
+// ======================================================================================================================
+// [8] BATCH PIPELINE (server.cpp:60-63): staging, lanes, grouped expansion, batch_run_mfma
+// ======================================================================================================================
 // ---- batch mode: `count` independent queries, spread round-robin over the workers ----
 
 int pirgpu_set_concurrency(pirgpu_ctx* c, uint32_t n_workers) {
@@ -2281,8 +2319,9 @@ static void ensure_batch_capacity(pirgpu_ctx* c, uint32_t count) {
 static void ensure_lanes(pirgpu_ctx* c, bool with_expansion_buffers) {
   const uint32_t N = c->N, k = c->k;
   if (c->lanes.empty()) {
-    uint32_t n_lanes = 2;   // PIRGPU_LANES: groups in flight (each lane = one stream + one set of group buffers)
-    n_lanes = (uint32_t)std::min<int64_t>(4, std::max<int64_t>(1, option(c, "LANES", n_lanes)));
+    // groups in flight (each lane = one stream + one set of group buffers): two -- one, three and four lanes were measured
+    // in rounds 2 and 4 (3 857 / 4 114 / 4 090 against 4 165; 5 304 against 5 427 queries/s), a constant since round 5
+    const uint32_t n_lanes = 2;
     c->lanes.resize(n_lanes);
     for (BatchLane& ln : c->lanes) {
       HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
@@ -2603,6 +2642,9 @@ int pirgpu_batch_run(pirgpu_ctx* c) {
   });
 }
 
+// ======================================================================================================================
+// [9] MULTI-GPU entry points: u64 selector exchange, packed row-shard exchange, slot shards, reply copies, fix-up, pack40
+// ======================================================================================================================
 // ---- query-parallel expansion for multi-GPU ----
 
 int pirgpu_batch_expand(pirgpu_ctx* c, uint32_t first, uint32_t count, uint64_t* device_dst) {
@@ -3074,6 +3116,9 @@ int pirgpu_unpack40_device_async(pirgpu_ctx* c, const uint32_t* packed, uint64_t
   });
 }
 
+// ======================================================================================================================
+// [10] MEASUREMENT: phase timings, batch scan timings
+// ======================================================================================================================
 int pirgpu_set_profiling(pirgpu_ctx* c, int enabled) {
   return guarded(c, [&]() -> int {
     HIP_TRY(hipStreamSynchronize(c->stream));

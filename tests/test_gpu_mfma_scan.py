@@ -159,7 +159,10 @@ def test_options_by_name_replace_the_environment():
     db = pir_amd.PIRDatabase.Create(pp)
     assert db.get_option("scan_mfma") == -1                    # built-in default
     db.set_option("scan_mfma", 0)
-    db.set_option("Lanes", 1)                                  # case-insensitive
+    db.set_option("Head_Levels", 3)                            # case-insensitive
+    with pytest.raises(pir_amd.PirGpuError) as e:              # settled sweeps are constants now (round 5), not options
+        db.set_option("lanes", 1)
+    assert e.value.code == pir_amd.StatusCode.INVALID_ARGUMENT
     assert db.get_option("SCAN_MFMA") == 0
     db.populate(s.raw)
     srv = pir_amd.PIRServer(db, pp)

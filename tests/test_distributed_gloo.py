@@ -39,6 +39,47 @@ def test_shard_range_partitions_rows():
         D.check_sum_fits((1 << 61) - 1, 9)
 
 
+def test_slot_cuts_partition_the_ring():
+    """Slot shards: contiguous, balanced to within one block of 16 slots, multiples of 16, covering [0, k N)."""
+    for k_n in (2 * 2048, 2 * 4096, 3 * 8192, 4 * 16384, 4 * 8192):
+        for world in (1, 2, 3, 4, 5, 8, 16):
+            cuts = D.slot_cuts(k_n, world)
+            assert len(cuts) == world + 1 and cuts[0] == 0 and cuts[-1] == k_n
+            sizes = [b - a for a, b in zip(cuts[:-1], cuts[1:])]
+            assert all(c % 16 == 0 for c in cuts) and min(sizes) > 0 and max(sizes) - min(sizes) <= 16
+    with pytest.raises(ValueError):
+        D.slot_cuts(8200, 2)
+
+
+def test_slots_buffers_split_sizes_add_up():
+    """The four split lists of the two all-to-alls cover their buffers exactly, for even and uneven cuts and partial
+    groups (sizes only: a stand-in server that answers the geometry questions)."""
+    class _Srv:
+        k, N = 2, 4096
+
+        class params:
+            dimensions = [18, 21]
+
+        class db:
+            @staticmethod
+            def reply_ct_count():
+                return 8
+
+        @staticmethod
+        def slots_packed_bytes(slots):
+            return slots * 2 * 1152          # KG = 2 column groups, 1152 bytes per tile set
+
+    for world, batch in ((1, 3), (2, 18), (3, 9), (8, 72), (8, 8)):
+        for rank in range(world):
+            b = D.SlotsBuffers(_Srv, batch, rank, world, torch, "cpu")
+            assert sum(b.x1_send) == b.packed_send.numel() and sum(b.x1_recv) == b.packed_recv.numel()
+            assert sum(b.x2_send) == b.rows_send.numel() and sum(b.x2_recv) == b.rows_recv.numel()
+            assert b.groups == (b.per + D.GROUP - 1) // D.GROUP and b.per * world == batch
+            assert b.x1_recv == [b.groups * b.piece[rank]] * world and b.x2_send == [b.per * b.rc * b.mine] * world
+            if world > 1:
+                assert 0 < b.exchange_bytes_per_query(world) < 2 * 8192 * (18 + 21) * 8
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

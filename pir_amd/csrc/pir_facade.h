@@ -229,6 +229,59 @@ class PIRServer {
     return out;
   }
 
+  // ProcessRequests in two halves (pirgpu_process_requests_begin / _end): ONE calling thread keeps two calls in flight --
+  // Begin(next) before End(previous) -- so the next call's parsing / staging / queueing run under the previous call's
+  // tail.  The request strings must stay alive and untouched until End; every Begin is matched by exactly one End.
+  class PendingRequests {
+   public:
+    PendingRequests() = default;
+    PendingRequests(PendingRequests&&) = default;
+    PendingRequests& operator=(PendingRequests&&) = default;
+    bool valid() const { return call_ != nullptr; }
+
+   private:
+    friend class PIRServer;
+    void* call_ = nullptr;
+    std::vector<const uint8_t*> ptrs_;
+    std::vector<size_t> lens_, rlens_;
+    std::vector<uint8_t*> resps_;
+    std::vector<int> status_;
+  };
+  StatusOr<std::unique_ptr<PendingRequests>> ProcessRequestsBegin(const std::vector<std::string>& requests) const {
+    auto p = std::unique_ptr<PendingRequests>(new PendingRequests());   // heap: the arrays' addresses are handed to the library
+    const uint32_t n = static_cast<uint32_t>(requests.size());
+    p->ptrs_.resize(n);
+    p->lens_.resize(n);
+    p->rlens_.assign(n, 0);
+    p->resps_.assign(n, nullptr);
+    p->status_.assign(n, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+      p->ptrs_[i] = reinterpret_cast<const uint8_t*>(requests[i].data());
+      p->lens_[i] = requests[i].size();
+    }
+    const int rc = pirgpu_process_requests_begin(db_->handle(), n, p->ptrs_.data(), p->lens_.data(), p->resps_.data(),
+                                                 p->rlens_.data(), p->status_.data(), &p->call_);
+    if (rc) return Status(static_cast<StatusCode>(rc), "pirgpu_process_requests_begin failed");
+    return p;
+  }
+  std::vector<StatusOr<std::string>> ProcessRequestsEnd(std::unique_ptr<PendingRequests> p) const {
+    std::vector<StatusOr<std::string>> out;
+    if (!p || !p->call_) return out;
+    pirgpu_process_requests_end(p->call_);
+    p->call_ = nullptr;
+    const uint32_t n = static_cast<uint32_t>(p->status_.size());
+    out.reserve(n);
+    for (uint32_t i = 0; i < n; ++i) {
+      if (p->status_[i]) {
+        out.emplace_back(Status(static_cast<StatusCode>(p->status_[i]), pirgpu_request_error(i)));
+      } else {
+        out.emplace_back(std::string(reinterpret_cast<const char*>(p->resps_[i]), p->rlens_[i]));
+        pirgpu_free(p->resps_[i]);
+      }
+    }
+    return out;
+  }
+
   // what SEALDeserialize<GaloisKeys> yields (server.cpp:46-48)
   Status SetGaloisKeys(const GaloisKeys& keys) const {
     const size_t k = params_->coeff_modulus.size() - 1;

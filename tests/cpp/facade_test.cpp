@@ -79,6 +79,23 @@ int main(int argc, char** argv) {
   }
   std::ofstream(argv[4], std::ios::binary) << *response;
 
+  // the same request through ProcessRequests and through its two-halves form (one caller, two calls in flight):
+  // identical bytes back, a malformed request fails alone
+  {
+    const std::vector<std::string> reqs = {slurp(argv[3]), std::string("\x12\x03zzz", 5), slurp(argv[3])};
+    auto together = (*server)->ProcessRequests(reqs);
+    EXPECT(together.size() == 3 && together[0].ok() && !together[1].ok() && together[2].ok());
+    EXPECT(*together[0] == *response && *together[2] == *response);
+    auto a = (*server)->ProcessRequestsBegin(reqs);
+    auto b = (*server)->ProcessRequestsBegin(reqs);      // second call handed over before the first is waited for
+    EXPECT(a.ok() && b.ok() && (*a)->valid() && (*b)->valid());
+    auto ra = (*server)->ProcessRequestsEnd(std::move(*a));
+    auto rb = (*server)->ProcessRequestsEnd(std::move(*b));
+    EXPECT(ra.size() == 3 && rb.size() == 3);
+    EXPECT(ra[0].ok() && *ra[0] == *response && !ra[1].ok() && ra[1].status().code() == pir::StatusCode::kInvalidArgument);
+    EXPECT(rb[2].ok() && *rb[2] == *response);
+  }
+
   // selection vector of the wrong size -> InvalidArgument (database.cpp:297-300)
   std::vector<pir::Ciphertext> sv(params->DimensionsSum() + 1, pir::Ciphertext((*db)->CtWords(), 0));
   auto mul = (*db)->multiply(sv);

@@ -1145,7 +1145,10 @@ def main():
             pipes.clear()
             sdb.close()
 
-    slots_ok = use_dist and args.dims == 2 and info["mfma"] and info["chunks"] == 1 and (k * N) % (16 * world) == 0
+    # (decided from the whole matrix, not from this rank's row shard: a slot shard holds ALL rows; a configuration the
+    # step cannot take -- matrices wider than one column chunk, moduli of 55 bits and more -- fails in measure_slots,
+    # which the autotune reports as an error of that candidate)
+    slots_ok = use_dist and args.dims == 2 and pp.dimensions[0] >= 8 and (k * N) % (16 * world) == 0
     if use_dist and args.exchange == "slots":
         if not slots_ok:
             raise SystemExit("--exchange slots needs d = 2 and the int8-MFMA scan in one column chunk")

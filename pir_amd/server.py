@@ -294,6 +294,33 @@ class PIRServer:
         self.request_errors = [self.lib.pirgpu_request_error(i).decode() for i in range(n)]   # "" where it succeeded
         return out
 
+    def ProcessRequestsBegin(self, requests: Sequence[bytes]):
+        """ProcessRequests in two halves (pirgpu_process_requests_begin / _end): hands the call to a serving thread of
+        the library and returns a token for ProcessRequestsEnd.  One calling thread keeps two calls in flight by calling
+        Begin for the next batch of requests before End for the previous one."""
+        n = len(requests)
+        bufs = [np.frombuffer(r, dtype=np.uint8) for r in requests]
+        tok = {"n": n, "bufs": bufs, "requests": list(requests),
+               "ptrs": (C.c_void_p * n)(*[b.ctypes.data for b in bufs]),
+               "lens": (C.c_size_t * n)(*[len(r) for r in requests]),
+               "resp": (C.c_void_p * n)(), "rlen": (C.c_size_t * n)(), "status": (C.c_int * n)(), "call": C.c_void_p()}
+        self._check(self.lib.pirgpu_process_requests_begin(self.db.handle, n, tok["ptrs"], tok["lens"], tok["resp"],
+                                                           tok["rlen"], tok["status"], C.byref(tok["call"])))
+        return tok
+
+    def ProcessRequestsEnd(self, tok):
+        """Waits for the call and returns [(status, response bytes or None)] like ProcessRequests."""
+        self.lib.pirgpu_process_requests_end(tok["call"])
+        out = []
+        for i in range(tok["n"]):
+            if tok["status"][i] == 0:
+                out.append((0, C.string_at(tok["resp"][i], tok["rlen"][i])))
+                self.lib.pirgpu_free(tok["resp"][i])
+            else:
+                out.append((int(tok["status"][i]), None))
+        self.request_errors = [self.lib.pirgpu_request_error(i).decode() for i in range(tok["n"])]
+        return out
+
     # -- device-resident split (bench / pipelining) -----------------------------------
     def stage_query(self, query) -> None:
         q = self._cts(query, 4, "query")

@@ -103,6 +103,14 @@ def test_process_requests_equals_one_by_one():
     assert mixed[0] == together[0] and mixed[2] == together[2]
     assert mixed[1][0] == pir_amd.StatusCode.INVALID_ARGUMENT and mixed[1][1] is None
     assert server.request_errors[0] == "" and server.request_errors[2] == "" and server.request_errors[1] != ""
+    # the two-halves form: ONE calling thread, two calls in flight (the second handed over before the first is waited
+    # for); the same bytes come back, the malformed request still fails alone
+    t1 = server.ProcessRequestsBegin(requests)
+    t2 = server.ProcessRequestsBegin([requests[0], bad, requests[2]])
+    assert server.ProcessRequestsEnd(t1) == together
+    got2 = server.ProcessRequestsEnd(t2)
+    assert got2[0] == together[0] and got2[2] == together[2] and got2[1] == (pir_amd.StatusCode.INVALID_ARGUMENT, None)
+    assert server.request_errors[1] != "" and server.request_errors[0] == ""
 
 
 def test_alternating_clients_never_reupload_and_threads_are_combined():

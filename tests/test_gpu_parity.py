@@ -522,3 +522,48 @@ def test_full_size_benchmark_workload():
     for j, qj in enumerate(orc.moduli[: orc.k]):
         acc[:, :, j, :] %= np.uint64(qj)
     assert np.array_equal(acc, replies[1])
+    # (4) SLOT shards at the headline shape: eight contexts, each holding 1 / 8 of the NTT slots of
+    # every plaintext -- what the 8 ranks of `bench.py --gpus 8` hold --, sixteen queries (two per "rank"), the two
+    # all-to-alls as tensor copies; the replies of the four queries above must be the same bits (one of them was checked
+    # against the oracle's full pass), the rest must equal the plain pipeline's
+    import torch
+    from pir_amd import distributed as D
+    from gpu_helpers import all_to_all_in_process
+    G, per = 8, 2
+    more = np.stack([client.create_query_for(params, (65537 * i + 11) % n_items) for i in range(G * per - len(indexes))])
+    q16 = np.concatenate([queries, more])
+    db = pir_amd.PIRDatabase.Create(pp, raw)
+    srv = pir_amd.PIRServer.Create(db, pp)
+    srv.set_galois_keys(keys)
+    plain16 = srv.process_batch(q16, n_workers=16)
+    assert np.array_equal(plain16[:4], replies)
+    db.close()
+    cuts = D.slot_cuts(orc.k * N, G)
+    ranks = []
+    for g in range(G):
+        dbg = pir_amd.PIRDatabase.Create(pp, raw, slots=(cuts[g], cuts[g + 1]))
+        dbg.finalize(release_staging=True)
+        sg = pir_amd.PIRServer(dbg, pp)
+        sg.set_galois_keys(keys)
+        sg.set_concurrency(16)
+        sg.stage_batch(q16)
+        assert sg.scan_bytes() * G == 1141899264            # 1 / 8 of the packed database each
+        ranks.append((dbg, sg, D.SlotsBuffers(sg, G * per, g, G, torch, "cuda:0")))
+    bufs = [r[2] for r in ranks]
+    for g, (_, sg, b) in enumerate(ranks):
+        sg.slots_expand_async(g * per, per, b.packed_send.data_ptr(), b.sv.data_ptr(), cuts)
+        sg.sync()
+    all_to_all_in_process([b.packed_recv for b in bufs], [b.packed_send for b in bufs], [b.x1_recv for b in bufs],
+                          [b.x1_send for b in bufs])
+    for _, sg, b in ranks:
+        sg.slots_scan_async(b.packed_recv.data_ptr(), G, per, b.rows_send.data_ptr())
+        sg.sync()
+    all_to_all_in_process([b.rows_recv for b in bufs], [b.rows_send for b in bufs], [b.x2_recv for b in bufs],
+                          [b.x2_send for b in bufs])
+    for g, (dbg, sg, b) in enumerate(ranks):
+        sg.slots_finish_async(b.rows_recv.data_ptr(), per, b.sv.data_ptr(), cuts, b.replies.data_ptr())
+        sg.sync()
+        got = b.replies.cpu().numpy().view(np.uint64)
+        for i in range(per):
+            assert np.array_equal(got[i], plain16[g * per + i]), (g, i)
+        dbg.close()

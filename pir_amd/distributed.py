@@ -1,6 +1,11 @@
-"""Multi-GPU glue (one process per GPU, torch.distributed over RCCL): row sharding of the database, the
-exchange of what every shard needs from a query, and the sum of the per-shard partial replies.  Not in the
-reference (single-threaded, single-process); see DESIGN.md section 7.
+"""Multi-GPU glue (one process per GPU, torch.distributed over RCCL).  Two ways of sharding the database, see DESIGN.md
+section 7 (neither is in the reference, which is single-threaded and single-process):
+
+  * SLOT shards (run_batch_slots, SlotsPipeline): every rank holds 1 / G of the NTT slots of every plaintext; per step an
+    all-to-all hands it its slots of every query's packed column selectors, it scans all rows for all queries, a second
+    all-to-all returns the row sums to the rank that expanded the query, which finishes its own queries -- no reduce;
+  * ROW shards (run_batch_rows_packed, RowsPipeline, RowsReplicatedPipeline, run_batch_query_parallel): every rank holds
+    1 / G of the rows; the exchange of what every shard needs from a query, and the sum of the per-shard partial replies.
 
 The server object is duck-typed (pir_amd.PIRServer; the CPU tests drive the same code with an oracle-backed
 stand-in), the collectives go through `Comm`, which runs them on the tensors' own device (RCCL) or -- for the

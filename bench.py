@@ -364,6 +364,43 @@ def scan_source_sha16():
         return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
+KERNEL_SOURCES = ("ntt_kernels.hip", "ntt_core.h", "kernels.hip", "arith.h")     # tools/valu_roofline.py stamps these
+
+
+def kernel_sources_sha16():
+    """What the VALU table is stamped with (tools/valu_roofline.py): the transform kernels' sources as they were profiled."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "pir_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def recorded_compute():
+    """roofline_compute: the VALU-issue table of the transform kernels as RECORDED by the newest committed PMC passes
+    (tools/pmc_kernels.sh + tools/valu_roofline.py).  `stale`: False when the kernels' sources are the ones that were
+    profiled, True when they have changed since -- the table is then WITHHELD (only the stamp and the file name are
+    reported: per-kernel numbers of other kernels are not evidence) --, None when the file carries no stamp."""
+    import glob
+    try:
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", VALU_GLOB)))[-1]
+        table = json.load(open(path))
+    except Exception:
+        return None
+    stamp = table.get("kernel_sources_sha16")
+    if not stamp:
+        return {**table, "stale": None, "file": os.path.basename(path),
+                "stale_note": "no kernel_sources_sha16 stamp in this file: whether the kernels have changed since cannot be told"}
+    have = kernel_sources_sha16()
+    if stamp != have:
+        return {"stale": True, "file": os.path.basename(path), "kernel_sources_sha16_profiled": stamp,
+                "kernel_sources_sha16_running": have, "commit_profiled": table.get("commit"),
+                "note": "the transform kernels' sources (%s) have changed since these PMC passes: table withheld; re-run "
+                        "tools/pmc_kernels.sh + tools/valu_roofline.py at this commit" % ", ".join(KERNEL_SOURCES)}
+    return {**table, "stale": False, "file": os.path.basename(path)}
+
+
 def recorded_traffic(config, log_items, world, single_query_mfma):
     """roofline.traffic: HBM bytes per single-query scan launch as RECORDED by the newest committed PMC passes of this
     workload (rocprofv3 --pmc cannot run inside the bench); `stale` says whether the scan kernel's source has changed
@@ -587,11 +624,7 @@ def main():
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         import glob
         traffic, traffic_src, traffic_stale = recorded_traffic(args.config, args.log_items, world, info["single_query_mfma"])
-        compute = None
-        try:   # VALU-issue roofline of the transform kernels (recorded: tools/valu_roofline.py over PMC passes)
-            compute = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", VALU_GLOB)))[-1]))
-        except Exception:
-            pass
+        compute = recorded_compute()   # VALU-issue roofline of the transform kernels (recorded; withheld when stale)
         if world == 1:
             parallelism = "single GPU" + (" (collective code path forced with one rank)" if use_dist else "")
         elif exchange == "slots":
@@ -1004,15 +1037,24 @@ def main():
             emit(cut_off_note)
             os._exit(STALLED_EXIT)
 
-    def arm_watchdog():
-        if not (use_dist and world > 1) or watchdog:
+    stages_after_headline = [1]     # how many stages share PIRGPU_EXTRAS_TIMEOUT_S (set once the candidates are known)
+
+    def arm_watchdog(stage="extras"):
+        """(Re-)arms the watchdog for the next stage after a complete headline measurement: every later candidate form
+        and the reference legs get their OWN slice of PIRGPU_EXTRAS_TIMEOUT_S (the budget divided by the number of such
+        stages), counted from the moment the stage starts -- a form that stalls is cut off at the end of its slice, it
+        cannot eat the time of the stages before it, and the line then names the stage that stalled."""
+        if not (use_dist and world > 1):
             return
-        budget = float(os.environ.get("PIRGPU_EXTRAS_TIMEOUT_S", "300"))
+        for w_ in watchdog:
+            w_.cancel()
+        del watchdog[:]
+        budget = float(os.environ.get("PIRGPU_EXTRAS_TIMEOUT_S", "300")) / max(1, stages_after_headline[0])
 
         def _abort():
             aborting.set()
             if rank == 0:
-                emit(cut_off_note)
+                emit(cut_off_note + " [stage cut off: %s, after %.0f s]" % (stage, budget))
                 time.sleep(6.0)   # the other ranks leave on their own timers (5 s later) while this one still answers
             os._exit(STALLED_EXIT)
 
@@ -1020,6 +1062,15 @@ def main():
         watchdog.append(threading.Timer(budget + (0.0 if rank == 0 else 5.0), _abort))   # rank 0 prints first
         watchdog[0].daemon = True
         watchdog[0].start()
+
+    # tests only: PIRGPU_TEST_STALL=<form> puts a long sleep into every measured step of that candidate form -- what a
+    # collective that never completes on some fabric looks like to the job (tests/test_gpu_distributed.py)
+    stall_form = os.environ.get("PIRGPU_TEST_STALL", "")
+    stall_s = float(os.environ.get("PIRGPU_TEST_STALL_S", "3600"))
+
+    def maybe_stall(form):
+        if stall_form and stall_form == form:
+            time.sleep(stall_s)
 
 
     # ---- (2) throughput: `batch` queries per step (the whole job's), `workers` in flight per GPU
@@ -1035,6 +1086,7 @@ def main():
         D.sync_zero_plaintexts(srv, dist, world, comm, torch, dev)   # the transparent-ciphertext decision is collective
 
     def step_rows():
+        maybe_stall(active[0])
         if not use_dist:
             srv.run_batch()
         elif pipe is not None:
@@ -1082,6 +1134,7 @@ def main():
 
     slots_details = None
     slots_replies = [None]
+    slots_blocks = [None]
 
     def measure_slots():
         """The slot-sharded step: its own context (this rank's 1 / world of the NTT slots of every plaintext), the
@@ -1107,31 +1160,51 @@ def main():
             phases = {kk: round(v / 5, 4) for kk, v in acc.items()}
             per_q = sb.exchange_bytes_per_query(world)
             del sb
-            spipe = D.SlotsPipeline(ssrv, batch, rank, world, dist, torch, dev)
-            pipes.append(spipe)
-            el = timed_steps(spipe.submit, sbarrier, args.steps, args.warmup, dist, use_dist, torch, dev)
-            pipes.clear()
-            slots_replies[0] = spipe.replies(spipe.step - 1).cpu().numpy().view(np.uint64).copy()
-            rowsums = {"u64_ms_per_step": round(el / args.steps * 1e3, 4), "form": "u64"}
-            # the same step with the row sums crossing the links in 5 bytes per residue (-37 % of the second all-to-all
-            # for two packing passes): pays where the links bind (few GPUs = few links); measured, not assumed
-            if world > 1 and ssrv.pack40_supported() and os.environ.get("PIRGPU_SLOTS_PACK40") is None \
-                    and not past_deadline():
-                del spipe
-                os.environ["PIRGPU_SLOTS_PACK40"] = "1"
+            # The timed steps: the pipelined form, with the row sums crossing the links as u64 or in 5 bytes per residue
+            # (-37 % of the second all-to-all for two packing passes).  Which pays depends on the links: at 2 / 4 GPUs
+            # (one / three xGMI links per GPU) the per-link arithmetic of DESIGN.md section 7.1 says the links bind, so
+            # the 5-byte form is measured FIRST there and u64 is the second pass; at 8 GPUs the other way round.  The
+            # second pass only runs inside the watchdog's slice; PIRGPU_SLOTS_PACK40 set: only that form.
+            can40 = world > 1 and ssrv.pack40_supported()
+            forced40 = os.environ.get("PIRGPU_SLOTS_PACK40")
+            if forced40 is not None:
+                forms = ["5 bytes per residue" if (forced40 == "1" and can40) else "u64"]
+            elif can40:
+                forms = ["5 bytes per residue", "u64"] if world <= 4 else ["u64", "5 bytes per residue"]
+            else:
+                forms = ["u64"]
+            rowsums = {"order": forms}
+            el = None
+
+            def stalled_submit(sp):
+                def f():
+                    maybe_stall("slots")
+                    sp.submit()
+                return f
+
+            for fi, form in enumerate(forms):
+                if fi > 0 and past_deadline():
+                    break
+                saved = os.environ.get("PIRGPU_SLOTS_PACK40")
+                os.environ["PIRGPU_SLOTS_PACK40"] = "1" if form != "u64" else "0"
                 try:
                     spipe = D.SlotsPipeline(ssrv, batch, rank, world, dist, torch, dev)
                 finally:
-                    del os.environ["PIRGPU_SLOTS_PACK40"]
+                    if saved is None:
+                        del os.environ["PIRGPU_SLOTS_PACK40"]
+                    else:
+                        os.environ["PIRGPU_SLOTS_PACK40"] = saved
                 pipes.append(spipe)
-                el40 = timed_steps(spipe.submit, sbarrier, args.steps, args.warmup, dist, use_dist, torch, dev)
+                el_f = timed_steps(stalled_submit(spipe), sbarrier, args.steps, args.warmup, dist, use_dist, torch, dev)
                 pipes.clear()
-                rowsums["packed_5_byte_ms_per_step"] = round(el40 / args.steps * 1e3, 4)
-                if el40 < el:
-                    el = el40
-                    rowsums["form"] = "5 bytes per residue"
+                rowsums["u64_ms_per_step" if form == "u64" else "packed_5_byte_ms_per_step"] = round(el_f / args.steps * 1e3, 4)
+                if el is None or el_f < el:
+                    el = el_f
+                    rowsums["form"] = form
                     per_q = spipe.sets[0].exchange_bytes_per_query(world)
                     slots_replies[0] = spipe.replies(spipe.step - 1).cpu().numpy().view(np.uint64).copy()
+                    slots_blocks[0] = BLOCK_LOG[-1]
+                del spipe
             slots_details = {"pipelined": True, "phases_ms_serial": phases, "serial_sum_ms": round(sum(phases.values()), 4),
                              "row_sums_on_the_links": rowsums,
                              "exchange_bytes_received_per_query_per_gpu": per_q,
@@ -1155,55 +1228,62 @@ def main():
         exchange = "slots"
         elapsed = measure_slots()
         qps = args.steps * batch / elapsed
-        headline_blocks = BLOCK_LOG[-1]
+        headline_blocks = slots_blocks[0]
     elif use_dist and autotune:
-        # Which form of the rows step is faster depends on what the links between THESE GPUs sustain (DESIGN.md section
-        # 7: replicated expansion costs every rank the whole expansion but moves only replies; the packed exchange
-        # partitions the expansion but ships ~14 MB of selectors per query to every rank) -- so it is measured, not
-        # assumed: BOTH forms run the contract's W + K steps (same barrier + max-over-ranks timing, every rank sees the
-        # same two numbers) and the faster one is the headline.  Replicated goes first (its only collective is a
-        # reduce-scatter); once it is in hand the watchdog guarantees a line even if the second form stalls.
-        exchange = "replicated"
-        el_r = measure("replicated")
-        elapsed, qps = el_r, args.steps * batch / el_r
-        headline_blocks = BLOCK_LOG[-1]
-        arm_watchdog()
-        el_p = measure("packed")
-        tune = {"ms_per_step": {"replicated": round(el_r / args.steps * 1e3, 4), "packed": round(el_p / args.steps * 1e3, 4)},
-                "steps_each": args.steps,
-                "note": "every form of the sharded step (rows + replicated expansion, rows + packed selector exchange, "
-                        "slots) timed over the full W + K steps on this machine's links; the fastest one is the headline"}
-        if el_p < el_r:
-            exchange = "packed"
-            elapsed, qps = el_p, args.steps * batch / el_p
-            headline_blocks = BLOCK_LOG[-1]
-        else:
-            tune["packed_details"] = {"exchange_bytes_received_per_query_per_gpu": bufs.exchange_bytes_per_query(world),
-                                      "phases_ms_serial": serial_phases}
-            bufs = pipe = serial_phases = None
-        # third candidate: the database sharded by NTT slot instead of by row
-        if slots_ok and os.environ.get("PIRGPU_AUTOTUNE_SLOTS", "1") != "0":
+        # Which form of the sharded step is fastest depends on what the links between THESE GPUs sustain (DESIGN.md
+        # section 7), so it is measured, not assumed: every candidate runs the contract's W + K steps (same barrier +
+        # max-over-ranks timing, every rank sees the same numbers) and the fastest one is the headline.  ORDER: the
+        # slot-sharded step FIRST -- it is the candidate whose per-rank budget meets north_star (1.49 ms per rank-step
+        # at 8 GPUs against 7.92 for replicated) --, then `replicated` (its only collective is a reduce-scatter), then
+        # `packed` (all-gather + all-to-all + reduce-scatter: the form with the most to go wrong on a fabric never seen
+        # before).  As soon as ONE candidate is in hand the watchdog is armed, re-armed per later candidate with that
+        # candidate's own slice of the budget: a form that hangs or crawls costs itself, never the headline.
+        import traceback as _tb
+        order = (["slots"] if slots_ok and os.environ.get("PIRGPU_AUTOTUNE_SLOTS", "1") != "0" else []) + ["replicated", "packed"]
+        stages_after_headline[0] = len(order)      # the later candidates + the reference legs
+        tune = {"ms_per_step": {}, "order": order, "wall_s": {}, "steps_each": args.steps,
+                "watchdog_slice_s": round(float(os.environ.get("PIRGPU_EXTRAS_TIMEOUT_S", "300")) / len(order), 1),
+                "note": "every form of the sharded step (slot shards; rows + replicated expansion; rows + packed selector "
+                        "exchange) timed over the full W + K steps on this machine's links, in `order`; the fastest one "
+                        "is the headline; wall_s = seconds each candidate took including its set-up"}
+        out_extra["exchange_autotune"] = tune     # in the line from now on, whatever happens to a later candidate
+        elapsed = None
+        packed_details = None
+        for cand_i, form in enumerate(order):
+            t_c = time.monotonic()
+            if elapsed is not None:
+                arm_watchdog("candidate " + form)
             try:
-                el_s = measure_slots()
-                tune["ms_per_step"]["slots"] = round(el_s / args.steps * 1e3, 4)
-                if el_s < elapsed:
-                    if exchange == "packed":
-                        tune["packed_details"] = {"exchange_bytes_received_per_query_per_gpu": bufs.exchange_bytes_per_query(world),
-                                                  "phases_ms_serial": serial_phases}
-                    exchange = "slots"
-                    elapsed, qps = el_s, args.steps * batch / el_s
-                    headline_blocks = BLOCK_LOG[-1]
-                    bufs = pipe = serial_phases = None
-                else:
-                    tune["slots_details"] = slots_details
-            except Exception as e:     # noqa: BLE001 -- a candidate that fails must not cost the measured headline
+                el_c = measure_slots() if form == "slots" else measure(form)
+                blocks_c = slots_blocks[0] if form == "slots" else BLOCK_LOG[-1]
+            except Exception as e:     # noqa: BLE001 -- a candidate that fails must not cost the others
                 park_if_aborting()
-                import traceback as _tb
                 _tb.print_exc()
-                tune["ms_per_step"]["slots"] = None
-                tune["slots_error"] = repr(e)
+                tune["ms_per_step"][form] = None
+                tune[form + "_error"] = repr(e)
+                tune["wall_s"][form] = round(time.monotonic() - t_c, 3)
+                if form == "packed":
+                    bufs = pipe = serial_phases = None
+                if elapsed is None and cand_i + 1 == len(order):
+                    raise
+                continue
+            tune["wall_s"][form] = round(time.monotonic() - t_c, 3)
+            tune["ms_per_step"][form] = round(el_c / args.steps * 1e3, 4)
+            if form == "packed":
+                packed_details = {"exchange_bytes_received_per_query_per_gpu": bufs.exchange_bytes_per_query(world),
+                                  "phases_ms_serial": serial_phases}
+            if elapsed is None or el_c < elapsed:
+                exchange = form
+                elapsed, qps = el_c, args.steps * batch / el_c
+                headline_blocks = blocks_c
+            tune["chosen"] = exchange
+        if exchange != "packed":
+            if packed_details:
+                tune["packed_details"] = packed_details
+            bufs = pipe = serial_phases = None
+        if exchange != "slots" and slots_details:
+            tune["slots_details"] = slots_details
         tune["chosen"] = exchange
-        out_extra["exchange_autotune"] = tune
     else:
         elapsed = measure(exchange)
         qps = args.steps * batch / elapsed
@@ -1229,7 +1309,7 @@ def main():
             srv.set_profiling(False)
         except Exception as e:     # noqa: BLE001 -- measurement extra only
             batch_scan = {"error": repr(e)}
-    arm_watchdog()
+    arm_watchdog("reference legs")
 
     # =========================== replicas (reference point, multi-GPU only) ===========================
     # the two reference legs below must never cost the headline: a failure (the same on every rank: they run the same

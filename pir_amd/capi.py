@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpirgpu.so")
+LIB_PATH = os.environ.get("PIRGPU_LIB", os.path.join(HERE, "libpirgpu.so"))   # override: A/B builds (tools/build_variant.py)
 
 MAX_PRIMES, MAX_DIMS = 8, 8
 OK, INVALID_ARGUMENT, FAILED_PRECONDITION, UNIMPLEMENTED, INTERNAL = 0, 3, 9, 12, 13

@@ -232,14 +232,41 @@ class PIRServer {
   // ProcessRequests in two halves (pirgpu_process_requests_begin / _end): ONE calling thread keeps two calls in flight --
   // Begin(next) before End(previous) -- so the next call's parsing / staging / queueing run under the previous call's
   // tail.  The request strings must stay alive and untouched until End; every Begin is matched by exactly one End.
+  // Dropping a PendingRequests without ProcessRequestsEnd (an early return or an exception in the caller) ends the call
+  // in the destructor: the library's serving thread writes into the arrays below until then.
   class PendingRequests {
    public:
     PendingRequests() = default;
-    PendingRequests(PendingRequests&&) = default;
-    PendingRequests& operator=(PendingRequests&&) = default;
+    PendingRequests(const PendingRequests&) = delete;
+    PendingRequests& operator=(const PendingRequests&) = delete;
+    PendingRequests(PendingRequests&& o) noexcept { take(o); }
+    PendingRequests& operator=(PendingRequests&& o) noexcept {
+      if (this != &o) {
+        finish();
+        take(o);
+      }
+      return *this;
+    }
+    ~PendingRequests() { finish(); }
     bool valid() const { return call_ != nullptr; }
 
    private:
+    void take(PendingRequests& o) {   // the vectors' heap blocks (whose addresses the library holds) move with them
+      call_ = o.call_;
+      o.call_ = nullptr;
+      ptrs_ = std::move(o.ptrs_);
+      lens_ = std::move(o.lens_);
+      rlens_ = std::move(o.rlens_);
+      resps_ = std::move(o.resps_);
+      status_ = std::move(o.status_);
+    }
+    void finish() {                   // an unclaimed call: wait for it and free what it produced
+      if (!call_) return;
+      pirgpu_process_requests_end(call_);
+      call_ = nullptr;
+      for (size_t i = 0; i < resps_.size(); ++i)
+        if (!status_[i] && resps_[i]) pirgpu_free(resps_[i]);
+    }
     friend class PIRServer;
     void* call_ = nullptr;
     std::vector<const uint8_t*> ptrs_;

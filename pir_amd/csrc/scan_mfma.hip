@@ -39,6 +39,10 @@ namespace pirgpu {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef unsigned __int128 u128;
 
+#ifndef PIRGPU_SCAN_DIRECT
+#define PIRGPU_SCAN_DIRECT 0
+#endif
+
 // Byte offset of tile (slot j, row tile rt, column group kg, digit a) in the packed database.  Column chunks are
 // the outer dimension inside a slot, so the part of a slot's slab one workgroup row streams is contiguous
 // (a matrix wider than one chunk used to be read as 14-18 KB pieces with gaps: 3.8-4.2 TB/s instead of ~5.8).
@@ -257,7 +261,10 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
   constexpr int NG = (NS + 4) / 5;     // groups of five diagonals (40 bits)
   // results of one row tile, [row][x][slot]: a (row, x) run is padded to 9 words so that the 16 lanes of a row (x = 0..15,
   // 72 bytes apart) hit 16 different 8-byte bank pairs when a wave stores its slot (64 bytes apart they hit two)
-  __shared__ uint64_t stage[2][16][16][NW + 1];
+  // kDirect (-DPIRGPU_SCAN_DIRECT=1): no staging and no workgroup barrier -- every lane stores its four values itself
+  // (8 bytes each; the eight waves' stores to a (row, x) run of eight slots merge in L2) and the waves run decoupled.
+  constexpr bool kDirect = PIRGPU_SCAN_DIRECT != 0;
+  __shared__ uint64_t stage[kDirect ? 1 : 2][kDirect ? 1 : 16][kDirect ? 1 : 16][NW + 1];
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int g = l >> 4, i16 = l & 15;
   constexpr int LOGNW = NW == 8 ? 3 : 2;
@@ -404,8 +411,15 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
             }
           }
         }
-        stage[buf][g * 4 + i][i16][w] = r;
+        if constexpr (kDirect) {
+          const uint32_t row = rt * 16 + g * 4 + i;
+          if ((uint32_t)i16 < nx && row < rows)
+            obase[(size_t)(i16 >> 1) * out_qstride + ((size_t)row * 2 + (i16 & 1)) * out_rstride + j0 + w] = r;
+        } else {
+          stage[buf][g * 4 + i][i16][w] = r;
+        }
       }
+      if constexpr (kDirect) continue;
       __syncthreads();
       // 256 (row, x) runs of NW slots = 8 NW bytes each; 64 NW threads x 16 B, two rounds
 #pragma unroll

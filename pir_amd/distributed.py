@@ -87,6 +87,12 @@ class Comm:
             import torch
             torch.cuda.current_stream(t.device).synchronize()
 
+    def wait(self, t):
+        """Host wait for the collectives queued so far on torch's current stream of t's device (whatever host_sync)."""
+        if t.is_cuda:
+            import torch
+            torch.cuda.current_stream(t.device).synchronize()
+
     def all_gather_inplace(self, full, rank: int):
         """full: [world, ...]; every rank has filled full[rank]."""
         if self.world == 1 and not self.device_native:
@@ -578,8 +584,11 @@ class SlotsBuffers:
         self.cuts = slot_cuts(self.k_n, world)
         self.width = [self.cuts[r + 1] - self.cuts[r] for r in range(world)]
         self.mine = self.width[rank]
-        n0 = server.params.dimensions[0]
-        self.rc = 2 * n0
+        # row sums per query and slot: the C side (pirgpu_slots_scan_async / _finish_async) strides them by 2 * scan_rows,
+        # scan_rows = ceil(num_pt / dimensions[1]) -- equal to dimensions[0] for the reference's CalculateDimensions, smaller
+        # when user-supplied dimensions leave the last rows empty; the exchange must be sized from the same number
+        rows = server.scan_info()["rows"] if hasattr(server, "scan_info") else server.params.dimensions[0]
+        self.rc = 2 * int(rows)
         dim_sum = sum(server.params.dimensions)
         reply_cts = server.db.reply_ct_count()
         piece = [server.slots_packed_bytes(w) for w in self.width]      # one group's packed column selectors, rank r's slots
@@ -617,10 +626,19 @@ class SlotsBuffers:
         comm.all_to_all(self.packed_recv, self.packed_send, self.x1_recv, self.x1_send, units=self.groups)
 
     def exchange_rowsums(self, comm, server, stream: int = 0) -> None:
+        """X2.  stream = 0 is the SYNCHRONOUS form (run_batch_slots): the packing kernels run on the library's own stream,
+        the collective on torch's current one, so the host orders them -- a wait after the pack (the collective must not
+        read rows_send40 before it is written) and after the collective (the unpack must not read rows_recv40 before it
+        has arrived).  With a stream handle (SlotsPipeline: the communication stream, which is also torch's current
+        stream there) pack, collective and unpack are ordered by that stream."""
         if self.rows40:
             server.pack40_async(self.rows_send.data_ptr(), self.rows_send40.data_ptr(), self.rows_send.numel(), stream)
+            if not stream:
+                server.sync()
             comm.all_to_all(self.rows_recv40, self.rows_send40, [v * 5 // 4 for v in self.x2_recv],
                             [v * 5 // 4 for v in self.x2_send], units=self.per)
+            if not stream:
+                comm.wait(self.rows_recv40)
             server.unpack40_async(self.rows_recv40.data_ptr(), self.rows_recv.data_ptr(), self.rows_recv.numel(), stream)
         else:
             comm.all_to_all(self.rows_recv, self.rows_send, self.x2_recv, self.x2_send, units=self.per)

@@ -294,31 +294,66 @@ class PIRServer:
         self.request_errors = [self.lib.pirgpu_request_error(i).decode() for i in range(n)]   # "" where it succeeded
         return out
 
+    class PendingRequests:
+        """A call handed to the library by ProcessRequestsBegin.  The ctypes arrays below are written by the library's
+        serving thread until the call has been ended; a token that is dropped without ProcessRequestsEnd ends it
+        itself (close / __del__), and a second End on the same token is refused."""
+
+        def __init__(self, lib, requests):
+            n = len(requests)
+            self.lib, self.n = lib, n
+            self.requests = list(requests)
+            self.bufs = [np.frombuffer(r, dtype=np.uint8) for r in self.requests]
+            self.ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in self.bufs])
+            self.lens = (C.c_size_t * n)(*[len(r) for r in self.requests])
+            self.resp = (C.c_void_p * n)()
+            self.rlen = (C.c_size_t * n)()
+            self.status = (C.c_int * n)()
+            self.call = C.c_void_p()
+
+        def pending(self) -> bool:
+            return bool(self.call)
+
+        def end(self) -> int:
+            """Waits for the call; returns the library's status code.  The token is spent afterwards."""
+            call, self.call = self.call, C.c_void_p()
+            return int(self.lib.pirgpu_process_requests_end(call))
+
+        def close(self) -> None:
+            if self.pending():
+                self.end()
+                for i in range(self.n):
+                    if self.status[i] == 0 and self.resp[i]:
+                        self.lib.pirgpu_free(self.resp[i])
+
+        def __del__(self):
+            try:
+                self.close()
+            except Exception:       # interpreter shutdown
+                pass
+
     def ProcessRequestsBegin(self, requests: Sequence[bytes]):
         """ProcessRequests in two halves (pirgpu_process_requests_begin / _end): hands the call to a serving thread of
         the library and returns a token for ProcessRequestsEnd.  One calling thread keeps two calls in flight by calling
         Begin for the next batch of requests before End for the previous one."""
-        n = len(requests)
-        bufs = [np.frombuffer(r, dtype=np.uint8) for r in requests]
-        tok = {"n": n, "bufs": bufs, "requests": list(requests),
-               "ptrs": (C.c_void_p * n)(*[b.ctypes.data for b in bufs]),
-               "lens": (C.c_size_t * n)(*[len(r) for r in requests]),
-               "resp": (C.c_void_p * n)(), "rlen": (C.c_size_t * n)(), "status": (C.c_int * n)(), "call": C.c_void_p()}
-        self._check(self.lib.pirgpu_process_requests_begin(self.db.handle, n, tok["ptrs"], tok["lens"], tok["resp"],
-                                                           tok["rlen"], tok["status"], C.byref(tok["call"])))
+        tok = PIRServer.PendingRequests(self.lib, requests)
+        self._check(self.lib.pirgpu_process_requests_begin(self.db.handle, tok.n, tok.ptrs, tok.lens, tok.resp, tok.rlen,
+                                                           tok.status, C.byref(tok.call)))
         return tok
 
     def ProcessRequestsEnd(self, tok):
         """Waits for the call and returns [(status, response bytes or None)] like ProcessRequests."""
-        self.lib.pirgpu_process_requests_end(tok["call"])
+        if not tok.pending():
+            raise PirGpuError(9, "ProcessRequestsEnd: this call has already been ended")   # FailedPrecondition
+        self._check(tok.end())
         out = []
-        for i in range(tok["n"]):
-            if tok["status"][i] == 0:
-                out.append((0, C.string_at(tok["resp"][i], tok["rlen"][i])))
-                self.lib.pirgpu_free(tok["resp"][i])
+        for i in range(tok.n):
+            if tok.status[i] == 0:
+                out.append((0, C.string_at(tok.resp[i], tok.rlen[i])))
+                self.lib.pirgpu_free(tok.resp[i])
             else:
-                out.append((int(tok["status"][i]), None))
-        self.request_errors = [self.lib.pirgpu_request_error(i).decode() for i in range(tok["n"])]
+                out.append((int(tok.status[i]), None))
+        self.request_errors = [self.lib.pirgpu_request_error(i).decode() for i in range(tok.n)]
         return out
 
     # -- device-resident split (bench / pipelining) -----------------------------------

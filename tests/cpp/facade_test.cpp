@@ -94,6 +94,16 @@ int main(int argc, char** argv) {
     EXPECT(ra.size() == 3 && rb.size() == 3);
     EXPECT(ra[0].ok() && *ra[0] == *response && !ra[1].ok() && ra[1].status().code() == pir::StatusCode::kInvalidArgument);
     EXPECT(rb[2].ok() && *rb[2] == *response);
+    // a pending call that is dropped without End (early return in the caller) is ended by the destructor, and a
+    // moved-from handle no longer owns it
+    {
+      auto c = (*server)->ProcessRequestsBegin(reqs);
+      EXPECT(c.ok() && (*c)->valid());
+      pir::PIRServer::PendingRequests moved(std::move(**c));
+      EXPECT(moved.valid() && !(*c)->valid());
+    }
+    auto again = (*server)->ProcessRequests(reqs);
+    EXPECT(again.size() == 3 && again[0].ok() && *again[0] == *response);
   }
 
   // selection vector of the wrong size -> InvalidArgument (database.cpp:297-300)

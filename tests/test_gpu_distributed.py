@@ -291,9 +291,42 @@ def test_bench_eight_ranks_sharing_one_gpu():
     assert j["config"]["queries_per_step"] == 64 and j["config"]["queries_per_step_per_gpu"] == 8
     assert j["value"] > 0 and j["scaling"] == "strong"
     tune = j["exchange_autotune"]
-    # all three forms of the sharded step ran: rows + replicated expansion, rows + packed exchange, slot shards
+    # all three forms of the sharded step ran: slot shards FIRST (the candidate whose budget meets north_star), then rows +
+    # replicated expansion, then rows + packed exchange -- each with its wall seconds in the line
+    assert tune["order"] == ["slots", "replicated", "packed"] and list(tune["ms_per_step"]) == tune["order"]
+    assert set(tune["wall_s"]) == set(tune["order"]) and all(v > 0 for v in tune["wall_s"].values())
     assert set(tune["ms_per_step"]) == {"replicated", "packed", "slots"} and tune["chosen"] == j["config"]["exchange"]
     assert all(v and v > 0 for v in tune["ms_per_step"].values()), tune
     assert j["replicas_reference"]["value"] > 0
     assert j["hybrid_rows_reference"]["value"] > 0 and j["hybrid_rows_reference"]["row_shards_per_group"] == 4
     assert "extras_aborted" not in j
+
+
+def test_bench_a_stalled_candidate_leaves_the_slots_headline():
+    """`bench.py --gpus 2` with the LAST candidate form made to stall (PIRGPU_TEST_STALL=packed: an hour of sleep in every
+    measured step -- what a collective that never completes looks like to the job): the slot-sharded step was measured
+    first and stays the headline, `replicated` ran inside its own slice of PIRGPU_EXTRAS_TIMEOUT_S, the stalled form is cut
+    off at the end of ITS slice, rank 0 prints the line (naming the stage) and every rank exits with the watchdog's code 3.
+    Fresh child processes only (pir_amd/launcher.py): nothing re-executes a process that has touched the GPU."""
+    import json
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(PIRGPU_BENCH_SHARE_GPU="1", PIRGPU_TEST_STALL="packed", PIRGPU_EXTRAS_TIMEOUT_S="120")
+    t0 = time.monotonic()
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--log-items", "16", "--steps", "2",
+                        "--warmup", "1", "--latency-runs", "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    wall = time.monotonic() - t0
+    assert p.returncode == 3, (p.returncode, p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    tune = j["exchange_autotune"]
+    assert tune["order"] == ["slots", "replicated", "packed"] and tune["watchdog_slice_s"] == 40.0
+    assert tune["ms_per_step"]["slots"] > 0 and tune["ms_per_step"]["replicated"] > 0 and "packed" not in tune["ms_per_step"]
+    assert j["config"]["exchange"] == tune["chosen"] and tune["chosen"] in ("slots", "replicated")
+    assert j["value"] > 0 and "candidate packed" in j["extras_aborted"]
+    assert wall < 600          # the stalled form cost its own slice (40 s), not an hour

@@ -111,6 +111,19 @@ def test_process_requests_equals_one_by_one():
     got2 = server.ProcessRequestsEnd(t2)
     assert got2[0] == together[0] and got2[2] == together[2] and got2[1] == (pir_amd.StatusCode.INVALID_ARGUMENT, None)
     assert server.request_errors[1] != "" and server.request_errors[0] == ""
+    # a token is spent by End (a second End used to delete the library's call object twice) ...
+    from pir_amd.server import PirGpuError
+    with pytest.raises(PirGpuError) as e:
+        server.ProcessRequestsEnd(t1)
+    assert e.value.code == 9 and not t1.pending()
+    # ... and a token that is dropped without End ends its call itself: the serving thread writes into the token's
+    # arrays until then
+    t3 = server.ProcessRequestsBegin(requests[:2])
+    assert t3.pending()
+    del t3
+    import gc
+    gc.collect()
+    assert server.ProcessRequests(requests[:2]) == together[:2]
 
 
 def test_alternating_clients_never_reupload_and_threads_are_combined():

@@ -128,6 +128,35 @@ def test_whole_context_serves_the_slots_step_alone_and_pipelined():
     srv.db.close()
 
 
+def test_synchronous_slots_step_with_five_byte_row_sums(monkeypatch):
+    """run_batch_slots with PIRGPU_SLOTS_PACK40=1: the pack kernel runs on the library's stream, the exchange on torch's
+    current one -- the step orders them with host waits (an unordered pack -> all-to-all edge gave the
+    collective a send buffer that had not been written yet).  Several repetitions over different queries with the send
+    buffer poisoned in between, so that a collective that ran ahead of the pack could not pass."""
+    from pir_amd import distributed as D
+    monkeypatch.setenv("PIRGPU_SLOTS_PACK40", "1")
+    items, batch, steps = 3000, 8, 4
+    s, pp, pir_amd = _setup(items)
+    p = s.params
+    srv = _rank_server(pir_amd, pp, s, None)
+    assert srv.pack40_supported()
+    idx = [(items - 5 - 89 * i) % items for i in range(batch * steps)]
+    q_all = np.stack([s.client.create_query_for(p, i) for i in idx])
+    srv.stage_batch(q_all)
+    bufs = D.SlotsBuffers(srv, batch, 0, 1, torch, "cuda:0")
+    assert bufs.rows40 and bufs.rc == 2 * srv.scan_info()["rows"]
+    for t in range(steps):
+        bufs.rows_send40.fill_(-1)
+        bufs.rows_recv40.fill_(-1)
+        bufs.rows_recv.fill_(-1)
+        D.run_batch_slots(srv, bufs, None, 0, 1, D.Comm(None, 1, host_sync=(t % 2 == 0)), first=t * batch)
+        got = bufs.replies.cpu().numpy().view(np.uint64)
+        for i in range(0, batch, 3):
+            rc, want = s.orc.process_query(s.db_ntt, p.dimensions, q_all[t * batch + i], s.galois_keys)
+            assert rc == 0 and np.array_equal(got[i], want), (t, i)
+    srv.db.close()
+
+
 def test_slot_range_errors():
     from pir_amd.server import PirGpuError
     s, pp, pir_amd = _setup(3000)

@@ -143,3 +143,38 @@ def test_bench_traffic_staleness_and_timed_blocks(tmp_path, monkeypatch):
     # a block of a second or more is not repeated
     t = bench.timed_steps(lambda: time.sleep(0.26), lambda: None, 4, 0, None, False, None, "cpu")
     assert len(bench.BLOCK_LOG[-1]) == 1 and t >= 1.0
+
+
+def test_bench_withholds_a_stale_valu_table(tmp_path, monkeypatch):
+    """`roofline_compute` is a RECORDED table (PMC passes cannot run inside the bench).  The file is
+    stamped with the sha256 of the transform kernels' sources (tools/valu_roofline.py); bench.py reports the table only
+    while the sources it runs are the ones that were profiled -- with a doctored hash the field says `stale: true` and the
+    per-kernel numbers are withheld; tools/check_pmc_fresh.py refuses the same file."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench
+    import check_pmc_fresh
+    import valu_roofline
+    assert bench.kernel_sources_sha16() == valu_roofline.kernel_sources_sha16() == check_pmc_fresh.sha16(check_pmc_fresh.KERNEL_SOURCES)
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    table = {"peak": {}, "kernels": {"deg12::ks_digit_kernel<1, true, true, true> grid=2097152": {"valu_issue_frac": 0.68}},
+             "kernel_sources_sha16": bench.kernel_sources_sha16(), "commit": "unknown"}
+    f = prof / "r99_valu_roofline.json"
+    f.write_text(json.dumps(table))
+    real = bench.kernel_sources_sha16()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_sources_sha16", lambda: real)          # (ROOT moved: keep hashing the real sources)
+    fresh = bench.recorded_compute()
+    assert fresh["stale"] is False and fresh["kernels"] == table["kernels"] and fresh["file"] == "r99_valu_roofline.json"
+    assert check_pmc_fresh.check(str(f)) in (0, 1)        # (1 only if the sources have uncommitted edits right now)
+    # a kernel change after the passes = another hash: table withheld
+    table["kernel_sources_sha16"] = "0" * 16
+    f.write_text(json.dumps(table))
+    stale = bench.recorded_compute()
+    assert stale["stale"] is True and "kernels" not in stale and stale["kernel_sources_sha16_profiled"] == "0" * 16
+    assert check_pmc_fresh.check(str(f)) == 1
+    # an older file without a stamp: reported, flagged as untellable
+    del table["kernel_sources_sha16"]
+    f.write_text(json.dumps(table))
+    assert bench.recorded_compute()["stale"] is None

@@ -17,10 +17,30 @@ usage: python tools/valu_roofline.py <tag> [out.json]     (reads gpurun_out/pmc_
 import collections
 import csv
 import glob
+import hashlib
 import json
+import os
+import subprocess
 import sys
 
 SIMDS, CLK = 1024, 2.4e9
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the sources every transform kernel of the table is built from, in this order (bench.py: kernel_sources_sha16)
+KERNEL_SOURCES = ("ntt_kernels.hip", "ntt_core.h", "kernels.hip", "arith.h")
+
+
+def kernel_sources_sha16():
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "pir_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def head_commit():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=9", "HEAD"], capture_output=True, text=True).stdout.strip() or "unknown"
+    except Exception:
+        return "unknown"
 
 
 def short(name):
@@ -61,6 +81,10 @@ def main():
     out = {"peak": {"bound": "valu issue", "wave64_fp64_instruction_cycles_per_simd": 4, "simds": SIMDS, "clock_hz": CLK,
                     "unit": "fraction of VALU issue cycles at the nominal clock"},
            "source": "rocprofv3 --pmc passes (tools/pmc_kernels.sh %s); stand-alone durations from the same passes" % tag,
+           # the transform kernels' sources as profiled (the snapshot on the GPU box): bench.py withholds the table when the
+           # sources it runs differ, tools/check_pmc_fresh.py refuses a file whose stamp is not the committed sources
+           "kernel_sources_sha16": kernel_sources_sha16(), "kernel_sources": list(KERNEL_SOURCES),
+           "commit": os.environ.get("PIRGPU_PROFILED_COMMIT") or head_commit(),
            "kernels": dict(sorted(keep.items(), key=lambda kv: -kv[1]["duration_us"] * kv[1]["dispatches"]))}
     json.dump(out, open(out_path, "w"), indent=1)
     for k, v in out["kernels"].items():

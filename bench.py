@@ -1080,6 +1080,7 @@ def main():
     serial_phases = None
     forced_check = None
     batch_replies = None
+    batch_scan = None        # (read by the line's assembly: must exist before the watchdog can print a line)
     scan_bytes = srv.scan_bytes()
     info = srv.scan_info()
     if use_dist:

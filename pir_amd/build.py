@@ -11,10 +11,15 @@ LIB = os.path.join(HERE, "libpirgpu.so")
 SOURCES = ["kernels.hip", "scan_mfma.hip", "ctx.hip", "wire.cpp", "wire_codec.cpp"]
 NTT_SOURCE = "ntt_kernels.hip"      # compiled once per ring degree (-DPIRGPU_LOGN)
 NTT_LOGNS = [11, 12, 13, 14]
+NTT_PACK_BYTES = [5, 6, 7]          # ... and once per width of the packed key-switch intermediates (-DPIRGPU_PACK_BYTES)
 HEADERS = ["device_params.h", "env_gate.h", "kernels.h", "host_math.h", "wire.h", "wire_codec.h", "arith.h", "ntt_core.h", NTT_SOURCE, os.path.join("..", "..", "include", "pirgpu.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + \
     os.environ.get("PIRGPU_BUILD_DEFS", "").split()      # A/B builds of compile-time choices (tools/experiments/r04_ab_ept.sh)
+
+
+def ntt_object(logn: int, pb: int) -> str:
+    return "ntt_kernels_%d.o" % logn if pb == 5 else "ntt_kernels_%d_p%d.o" % (logn, pb)
 
 
 def _stale() -> bool:
@@ -37,9 +42,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
         jobs.append(([HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) +
                      ["-c", os.path.join(CSRC, src), "-o", obj], obj))
     for logn in NTT_LOGNS:
-        obj = os.path.join(CSRC, "ntt_kernels_%d.o" % logn)
-        jobs.append(([HIPCC] + FLAGS + ["-x", "hip", "-DPIRGPU_LOGN=%d" % logn, "-c", os.path.join(CSRC, NTT_SOURCE),
-                      "-o", obj], obj))
+        for pb in NTT_PACK_BYTES:
+            obj = os.path.join(CSRC, ntt_object(logn, pb))
+            jobs.append(([HIPCC] + FLAGS + ["-x", "hip", "-DPIRGPU_LOGN=%d" % logn, "-DPIRGPU_PACK_BYTES=%d" % pb, "-c",
+                          os.path.join(CSRC, NTT_SOURCE), "-o", obj], obj))
 
     def run(job):
         if verbose:
@@ -47,6 +53,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         subprocess.run(job[0], check=True)
         return job[1]
 
+    jobs.sort(key=lambda j: 0 if "ntt_kernels" in j[1] else 1)      # the long compilations first
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(run, jobs))

@@ -233,6 +233,7 @@ struct pirgpu_ctx {
   std::vector<uint64_t*> key_pool;          // device key buffers of emptied sets, reused by the next upload (no hipMalloc)
   uint64_t* d_key_stage = nullptr;          // one key in SEAL order on its way to device order (allocated once)
   std::map<uint32_t, uint64_t*> xpow;       // shift -> NTT_j(x^(-shift)), [k][N] doubles (NTT-domain last expansion level)
+  std::map<uint32_t, uint16_t*> gperm;      // Galois element g -> [2][N] u16: sigma_g / sigma_(g^-1) on NTT positions (galois_perm_table)
 
   // workspace geometry (computed on first use) and the workers holding the buffers
   bool ws_ready = false;
@@ -267,6 +268,7 @@ struct pirgpu_ctx {
   bool mfma_single = true;                  // single queries use it too (off for matrices wider than one chunk)
   bool scan_f64_fold = false;               // the scan folds its digit diagonals in exact fp64 arithmetic (option
                                             // SCAN_F64_FOLD; every data modulus below 2^50)
+  bool scan_f64_fold_batch = false;         // ... in the launches that serve a group of queries (option SCAN_F64_FOLD_BATCH)
   bool split_upper = false;                 // upper level as transform-to-scratch + elementwise MAC (N >= 16384 in the fp64
                                             // flavours, where the fused kernel spills; PIRGPU_SPLIT_UPPER=0/1 overrides)
   uint64_t split_upper_words = (3ull << 30) / 8;  // scratch budget per lane / worker (PIRGPU_SPLIT_UPPER_MB)
@@ -282,11 +284,14 @@ struct pirgpu_ctx {
   bool fuse_last_level = true;              // last expansion level fused with the selector NTT (PIRGPU_FUSE_LAST=0: off)
   bool last_level_ntt = true;               // ... and carried out in the NTT domain (PIRGPU_LAST_NTT=0: coefficient form)
   bool tree40 = true;                       // expansion tree between fused wide levels as 5-byte polynomials (PIRGPU_TREE40=0: doubles)
+  bool c0_ntt = false;                      // the fused levels keep the tree's c0 polynomials in NTT form (option C0_NTT = 1 / 2; measured slower)
+  bool c0_ntt_split = false;                // ... with component 0 of a level as a launch of its own (C0_NTT = 2)
   bool want_sel_f64 = true;
   bool sel_f64 = false;                     // batch lanes keep their selectors as exact doubles between the last expansion
                                             // level and their two consumers (sel_pack, upper level): no u64 round trip
                                             // (fp64 flavours, MFMA scan, NTT-domain last level; PIRGPU_SEL_F64=0: off)
-  bool pack40 = false;                      // key-switch digits stored in 5 bytes (all moduli < 2^40; PIRGPU_PACK40)
+  bool pack40 = false;                      // key-switch digits stored packed (PIRGPU_PACK40) ...
+  int pack_bytes = 5;                       // ... in 5 (all moduli < 2^39), 6 (< 2^47) or 7 (< 2^55) bytes per residue (PIRGPU_PACK_BYTES)
   uint8_t* d_dbp = nullptr;
   bool packed_valid = false;
   bool staging_released = false;            // pirgpu_db_finalize(release): only the operand-layout copy is left
@@ -601,6 +606,15 @@ void ensure_workspace(pirgpu_ctx* c) {
     c->fuse_last_level = env_u32("PIRGPU_FUSE_LAST", 1) != 0;
     c->fuse_mac_combine = env_u32("PIRGPU_FUSE_MAC_COMBINE", 1) != 0;
     c->last_level_ntt = env_u32("PIRGPU_LAST_NTT", 1) != 0;
+    //   PIRGPU_C0_NTT      c0 of the expansion tree in NTT form from the first fused level on (needs the fused levels and
+    //                      the NTT-domain last level; fp64 flavours)
+    {
+      // 0: off (the default: measured -4 % as two launches, -7.6 % as one kernel, profiles/r06_ab_c0_ntt_*.txt), 1: both
+      // components of a level in one kernel, 2: component 0 as a launch of its own
+      const uint32_t v = env_u32("PIRGPU_C0_NTT", 0);
+      c->c0_ntt = v != 0;
+      c->c0_ntt_split = v >= 2;
+    }
     c->want_sel_f64 = env_u32("PIRGPU_SEL_F64", 1) != 0;
     c->tree40 = env_u32("PIRGPU_TREE40", 1) != 0;
     c->fuse_mac_nodes = 128;       // swept in round 2 (HISTORY section 4): a constant since round 5
@@ -612,8 +626,28 @@ void ensure_workspace(pirgpu_ctx* c) {
     c->loop_transforms = env_u32("PIRGPU_LOOP_TRANSFORMS", 1) != 0 && c->mode != kNttInt;
     // (loop_min_sources: swept 512 - 4096 in round 4, 1 024 stays: a constant since round 5)
     c->pack40 = env_u32("PIRGPU_PACK40", 1) != 0;
-    // 5-byte storage of the key-switch intermediates: the fp64 flavours store x + q (|x| <= q), so q < 2^39
-    for (uint32_t j = 0; j <= k; ++j) c->pack40 = c->pack40 && (c->hp.mod[j].q >> 39) == 0;
+    // packed storage of the key-switch intermediates: the fp64 flavours store x + q (|x| <= q) in the fewest whole bytes
+    // -- 5 for q < 2^39, 6 for q < 2^47 (cfg 4: 43 / 44 bits), 7 for q < 2^55 (cfg 5: 48 / 49 bits) -- instead of doubles;
+    // the integer flavour knows the 5-byte form only.  PIRGPU_PACK_BYTES=<5|6|7> forces a (sufficient) width, 8 = doubles.
+    {
+      uint32_t bits = 0;
+      for (uint32_t j = 0; j <= k; ++j) bits = std::max<uint32_t>(bits, 64 - (uint32_t)__builtin_clzll(c->hp.mod[j].q));
+      const int need = bits <= 39 ? 5 : (bits <= 47 ? 6 : (bits <= 55 ? 7 : 8));
+      int want = (int)env_u32("PIRGPU_PACK_BYTES", (uint32_t)need);
+      if (want < need) want = need;
+      if (c->mode == kNttInt && want != 5) want = 8;
+      if (want > 7) c->pack40 = false;
+      c->pack_bytes = c->pack40 ? want : 5;
+      // (N = 16384 with 7-byte residues: the combine kernel that also reads and writes the TREE packed needs 68 bytes of
+      // scratch under the 128-register cap of a 1024-thread workgroup -- the tree stays in doubles there, digits and
+      // products are packed)
+      if (c->pack40 && c->pack_bytes == 7 && c->logN >= 14 && !env_u32("PIRGPU_TREE40_WIDE", 0)) c->tree40 = false;
+      const NttOps* ops = ntt_ops_for(N, c->pack_bytes);
+      if (ops != c->ops) {
+        c->ops = ops;
+        HIP_TRY(c->ops->configure(c->mode));
+      }
+    }
     //   PIRGPU_SCAN_MFMA_WIDE  0 / 1 forces the 8-wave / 4-wave (one wave per SIMD, up to 7 k-steps) scan kernel
     bool wide_given = false;
     const int64_t wide = option(c, "SCAN_MFMA_WIDE", 0, &wide_given);
@@ -633,7 +667,15 @@ void ensure_workspace(pirgpu_ctx* c) {
     //   residue (cfg 4: scan 4.53 against 4.76 ms, cfg 5: 8.33 against 8.57, same box); at 5 digits (cfg 3) the
     //   single-query pass measured 3 % slower with it (0.212 against 0.206 ms) and the batch step 0.5 % faster: off
     c->scan_f64_fold = env_u32("PIRGPU_SCAN_F64_FOLD", c->mg.L >= 6 ? 1 : 0) != 0;
-    for (uint32_t j = 0; j < k; ++j) c->scan_f64_fold = c->scan_f64_fold && (c->hp.mod[j].q >> 50) == 0;
+    //   PIRGPU_SCAN_F64_FOLD_BATCH  the same choice for the launches that serve a GROUP of queries (batch pipeline on part
+    //   of the chip, slot-sharded step): on whenever the moduli allow -- with 16 result columns per tile instead of 2 the
+    //   fold is 8 x the work per database byte, and there the cheaper fold pays at 5 digits too (round 6, same box, three
+    //   alternating runs: 5 362 / 5 426 / 5 363 against 5 322 / 5 331 / 5 319 queries/s; profiles/r06_ab_scan_store_fold.txt)
+    c->scan_f64_fold_batch = env_u32("PIRGPU_SCAN_F64_FOLD_BATCH", 1) != 0;
+    for (uint32_t j = 0; j < k; ++j) {
+      c->scan_f64_fold = c->scan_f64_fold && (c->hp.mod[j].q >> 50) == 0;
+      c->scan_f64_fold_batch = c->scan_f64_fold_batch && (c->hp.mod[j].q >> 50) == 0;
+    }
     // selectors as doubles inside a lane: every query ciphertext must go through ks_last_ntt_kernel (>= 2 items each)
     const uint64_t rem = c->dim_sum % N;
     c->sel_f64 = c->want_sel_f64 && c->mfma_on && c->mode != kNttInt && c->fuse_last_level && c->last_level_ntt &&
@@ -761,6 +803,35 @@ const uint64_t* xpow_table(pirgpu_ctx* c, hipStream_t st, uint32_t shift) {
   return buf;
 }
 
+// sigma_g acting on NTT-form data (ks_last_ntt_kernel, ks_combine_c0_ntt): SEAL position P holds the evaluation at
+// psi^(2 br(P) + 1), so NTT(sigma_g(a)) = NTT(a) o pi_g with pi_g(P) = br(((2 br(P) + 1) g mod 2N - 1) / 2).  The table
+// holds, for the thread that owns positions EPT t .. EPT t + EPT - 1, the PADDED LDS word index of pi_g(P)'s device slot
+// (ntt_core.h lds_idx), first for g, then for g^-1; built once per Galois element.
+const uint16_t* galois_perm_table(pirgpu_ctx* c, hipStream_t st, uint32_t g) {
+  auto it = c->gperm.find(g);
+  if (it != c->gperm.end()) return it->second;
+  const uint32_t N = c->N, logN = c->logN, R = (uint32_t)ntt_log_ept((int)logN), EPT = 1u << R, NT = N >> R;
+  auto brev = [&](uint32_t v) {
+    uint32_t r = 0;
+    for (uint32_t b = 0; b < logN; ++b) r |= ((v >> b) & 1u) << (logN - 1 - b);
+    return r;
+  };
+  std::vector<uint16_t> h((size_t)2 * N);
+  const uint32_t gs[2] = {g, galois_inverse(g, N)};
+  for (int w = 0; w < 2; ++w)
+    for (uint32_t P = 0; P < N; ++P) {
+      const uint32_t ex = (uint32_t)(((uint64_t)(2 * brev(P) + 1) * gs[w]) & (2 * N - 1));
+      const uint32_t Pin = brev(ex >> 1);
+      const uint32_t slot = (Pin & (EPT - 1)) * NT + (Pin >> R);
+      h[(size_t)w * N + P] = (uint16_t)(slot + (slot >> R));
+    }
+  uint16_t* buf = c->dalloc<uint16_t>((size_t)2 * N);
+  HIP_TRY(hipMemcpy(buf, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  HIP_TRY(hipStreamSynchronize(st));   // (hipMemcpy of pageable memory is synchronous; other streams use the table without an event)
+  c->gperm[g] = buf;
+  return buf;
+}
+
 // oblivious_expansion(ct, n) on the device (reference server.cpp:105-146).
 // Input ciphertext must already be in res_a[0]; returns the buffer holding the
 // next_power_two(n) results.
@@ -776,6 +847,7 @@ const uint64_t* xpow_table(pirgpu_ctx* c, hipStream_t st, uint32_t shift) {
 struct TreeState {
   uint64_t* cur = nullptr;   // buffer holding the current level's ciphertexts
   bool cur40 = false;        // ... as 5-byte polynomials (between fused levels) instead of doubles
+  bool c0ntt = false;        // ... with their c0 polynomials in NTT form (fused levels, ks_combine_c0_ntt)
 };
 
 // Levels [j_begin, j_end) of the tree (j_end clamped to the tree's depth).  `from` (j_begin > 0): where the earlier levels
@@ -794,12 +866,22 @@ uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* 
   if (sel_f64 && !(fuse_last && c->last_level_ntt && n >= 2)) throw Fail{PIRGPU_INTERNAL, "double-form selectors need the NTT-domain last level"};
   uint64_t *cur = res_a, *nxt = res_b;
   bool cur40 = false;   // `cur` holds 5-byte polynomials (between fused levels) instead of doubles
+  bool c0ntt = false;   // `cur` holds its c0 polynomials in NTT form
   if (from) {
     cur = from->cur;
     cur40 = from->cur40;
+    c0ntt = from->c0ntt;
     nxt = res_a;
   }
   const uint32_t j_stop = std::min(j_end, logm);
+  // c0 in NTT form through the fused levels (ks_combine_c0_ntt): only for a tree whose leaves are consumed in NTT form by
+  // ks_last_ntt_kernel -- pirgpu_expand's coefficient-form results keep the coefficient-form tree
+  const bool c0_path = c->c0_ntt && fuse_last && c->last_level_ntt && c->mode != kNttInt && c->fuse_mac_combine;
+  const uint32_t fuse_from = B > 1 ? std::max<uint32_t>(c->fuse_mac_nodes / 2, 1) : c->fuse_mac_nodes;
+  // level j runs the fused form (special-prime product, then data products + combine in one kernel)
+  auto level_fused = [&](uint32_t j) {
+    return c->mode != kNttInt && c->fuse_mac_combine && ((1u << j) * B) >= fuse_from && !(fuse_last && j + 1 == logm);
+  };
   for (uint32_t j = j_begin; j < j_stop; ++j) {
     // (picking a tree up from another buffer: after its first level here the ping-pong is res_a <-> res_b)
     auto level_done = [&]() {
@@ -812,37 +894,45 @@ uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* 
     const KeyPtrs key = keys_for(c, g, ksets, B);   // per query of the group: its own client's key
     const uint32_t nodes = (1u << j) * B;
     const bool last_ntt = fuse_last && j + 1 == logm && c->last_level_ntt;
-    const bool c0_in_digit = last_ntt && ks_digit_takes_c0(nodes);
-    if (cur40 && c0_in_digit != last_ntt) throw Fail{PIRGPU_INTERNAL, "5-byte tree reached a level that cannot read it"};
+    const bool c0_in_digit = last_ntt && !c0ntt && ks_digit_takes_c0(nodes);
+    if (cur40 && !(last_ntt ? (c0ntt || c0_in_digit) : true)) throw Fail{PIRGPU_INTERNAL, "5-byte tree reached a level that cannot read it"};
+    // the root enters a fused level directly (a group wide enough at level 0): its c0 goes to NTT form in place --
+    // never in a buffer handed over by another stream (`from` is read-only; its owner converted it after ITS last level)
+    if (c0_path && !c0ntt && level_fused(j) && !cur40 && !(from && j == j_begin)) {
+      HIP_TRY(c->ops->tree_c0_fwd(st, c->mode, c->dp, k, cur, nodes));
+      c0ntt = true;
+    }
     HIP_TRY(c->ops->ks_digit(st, c->mode, c->dp, k, cur, g, nodes, dig, c->pack40, c0_in_digit ? prod : nullptr, cur40,
                              c->loop_transforms && (uint64_t)nodes * k >= c->loop_min_sources));
     // (a group of B queries reaches the width at which the fused form pays one level earlier than a single query:
     // measured +0.6 % batched with the threshold at 64 tree ciphertexts, while a single query loses latency below 128)
-    const uint32_t fuse_from = B > 1 ? std::max<uint32_t>(c->fuse_mac_nodes / 2, 1) : c->fuse_mac_nodes;
-    if (c->mode != kNttInt && c->fuse_mac_combine && nodes >= fuse_from && !(fuse_last && j + 1 == logm)) {
+    if (level_fused(j)) {
       // special-prime product first (the only one that goes through HBM), then the data residues with the combine
       // step in their epilogue: no data products in HBM, no separate combine pass.  Between two fused levels (and into
       // the NTT-domain last level) the tree is written as 5-byte polynomials: these launches are HBM-bound
       const uint32_t next_nodes = nodes * 2;
       const bool next_last = j + 2 == logm;
-      const bool next_reads40 = next_last ? (fuse_last && c->last_level_ntt && ks_digit_takes_c0(next_nodes))
+      const bool next_reads40 = next_last ? (fuse_last && c->last_level_ntt && (c0ntt || ks_digit_takes_c0(next_nodes)))
                                           : (next_nodes >= fuse_from);
       const bool out40 = c->tree40 && c->pack40 && j + 1 < logm && next_reads40 && (1u << j) < (N >> ntt_log_ept((int)c->logN));
       HIP_TRY(c->ops->ks_mac_intt(st, c->mode, c->dp, k, dig, key, nodes, prod, c->pack40, k, 1));
       HIP_TRY(c->ops->ks_mac_combine(st, c->mode, c->dp, k, dig, key, prod, cur, g, nodes, 1u << j, nxt, c->pack40, cur40,
-                                     out40));
+                                     out40, c0ntt ? xpow_table(c, st, 1u << j) : nullptr,
+                                     c0ntt ? galois_perm_table(c, st, g) : nullptr, c->c0_ntt_split));
       cur40 = out40;
       std::swap(cur, nxt);
       level_done();
       continue;
     }
     if (cur40 && !last_ntt) throw Fail{PIRGPU_INTERNAL, "5-byte tree reached an unfused level"};
+    if (c0ntt && !last_ntt) throw Fail{PIRGPU_INTERNAL, "NTT-form c0 reached an unfused level"};
     if (fuse_last && j + 1 == logm && c->last_level_ntt) {
       // last level in the NTT domain: only the special-prime product is inverse-transformed
       const uint64_t* X = xpow_table(c, st, 1u << j);
       HIP_TRY(c->ops->ks_mac_intt(st, c->mode, c->dp, k, dig, key, nodes, prod, c->pack40, k, 1));
       HIP_TRY(c->ops->ks_last_ntt(st, c->mode, c->dp, k, cur, dig, key, prod, X, g, galois_inverse(g, N), 1u << j, n, B,
-                                  *sel_dst, nodes, c->pack40, sel_f64, c0_in_digit));
+                                  *sel_dst, nodes, c->pack40, sel_f64, c0_in_digit, c0ntt ? (cur40 ? 2 : 1) : 0,
+                                  galois_perm_table(c, st, g)));
       return nullptr;
     }
     HIP_TRY(c->ops->ks_mac_intt(st, c->mode, c->dp, k, dig, key, nodes, prod, c->pack40, 0, k + 1));
@@ -853,13 +943,19 @@ uint64_t* expand_core(pirgpu_ctx* c, hipStream_t st, uint64_t* res_a, uint64_t* 
     // outputs n*B.. of the last level are never read (only the first n results per query are used)
     const uint32_t hi_limit = j + 1 == logm ? n * B : UINT32_MAX;
     HIP_TRY(launch_ks_combine(st, c->dp, c->mode, N, k, cur, prod, galois_inverse(g, N), nodes, 1u << j, true, hi_limit,
-                              c->pack40, nxt));
+                              c->pack40, nxt, c->pack_bytes));
     std::swap(cur, nxt);
+    // the next level is a fused one: this (narrow) level's outputs, in this stream's own buffer, get their c0 transformed
+    if (c0_path && j + 1 < logm && level_fused(j + 1)) {
+      HIP_TRY(c->ops->tree_c0_fwd(st, c->mode, c->dp, k, cur, nodes * 2));
+      c0ntt = true;
+    }
     level_done();
   }
   if (to) {
     to->cur = cur;
     to->cur40 = cur40;
+    to->c0ntt = c0ntt;
   }
   return cur;
 }
@@ -963,7 +1059,7 @@ void scan_group_mfma(pirgpu_ctx* c, hipStream_t st, uint8_t*& selp, const MfmaPt
     HIP_TRY(hipEventRecord(c->bscan_ev[2 * c->bscan_n], st));
   }
   HIP_TRY(launch_scan_mfma(st, c->dp, c->mg, c->d_dbp, packed, out, out_qstride, n, c->scan_rows, kN, words, wgs,
-                           c->scan_f64_fold));
+                           n > 1 ? (c->scan_f64_fold || c->scan_f64_fold_batch) : c->scan_f64_fold));
   if (timed) {
     HIP_TRY(hipEventRecord(c->bscan_ev[2 * c->bscan_n + 1], st));
     ++c->bscan_n;
@@ -1322,10 +1418,10 @@ int pirgpu_set_transparent_policy(pirgpu_ctx* c, int allow) {
 static const struct { const char* name; bool early; } kOptions[] = {
     {"UPPER_BLOCKS", true}, {"UPPER_BLOCKS_BATCH", true}, {"SCAN_MFMA_WGS_BATCH", false}, {"SCAN_LIMB", true},
     {"SCAN_MQ_SINGLE", true}, {"SCAN_ROWS", true}, {"SCAN_BLOCK", true}, {"SCAN_NSPLIT", true},
-    {"FUSE_LAST", true}, {"FUSE_MAC_COMBINE", true}, {"LAST_NTT", true}, {"SEL_F64", true}, {"TREE40", true},
-    {"SPLIT_UPPER", true}, {"SPLIT_UPPER_MB", true}, {"PACK40", true},
+    {"FUSE_LAST", true}, {"FUSE_MAC_COMBINE", true}, {"LAST_NTT", true}, {"C0_NTT", true}, {"SEL_F64", true}, {"TREE40", true},
+    {"SPLIT_UPPER", true}, {"SPLIT_UPPER_MB", true}, {"PACK40", true}, {"PACK_BYTES", true}, {"TREE40_WIDE", true},
     {"SCAN_MFMA", true}, {"SCAN_MFMA_WIDE", true}, {"SCAN_MFMA_TOP4", true}, {"SCAN_MFMA_NQ", true}, {"SCAN_MFMA_SINGLE", true},
-    {"HEAD_LEVELS", true}, {"HEAD_MODE", true}, {"SCAN_F64_FOLD", true}, {"LOOP_TRANSFORMS", true},
+    {"HEAD_LEVELS", true}, {"HEAD_MODE", true}, {"SCAN_F64_FOLD", true}, {"SCAN_F64_FOLD_BATCH", true}, {"LOOP_TRANSFORMS", true},
     {"SLOTS_SCAN_WGS", false}, {"SLOTS_GATHER_NTT", false}, {"SLOTS_SCAN_BLK_MAJOR", false},
 };
 
@@ -2141,7 +2237,7 @@ int pirgpu_substitute_power_x(pirgpu_ctx* c, uint64_t* ct, uint32_t power) {
     HIP_TRY(c->ops->ks_digit(c->stream, c->mode, c->dp, c->k, w.res_a, power, 1, w.dig, c->pack40, nullptr, false, false));
     HIP_TRY(c->ops->ks_mac_intt(c->stream, c->mode, c->dp, c->k, w.dig, key, 1, w.prod, c->pack40, 0, c->k + 1));
     HIP_TRY(launch_ks_combine(c->stream, c->dp, c->mode, c->N, c->k, w.res_a, w.prod, galois_inverse(power, c->N), 1, 0,
-                              false, /*hi_limit: unused without the expand step*/ 0, c->pack40, w.res_b));
+                              false, /*hi_limit: unused without the expand step*/ 0, c->pack40, w.res_b, c->pack_bytes));
     HIP_TRY(launch_tree_convert(c->stream, c->dp, c->mode, w.res_b, w.res_b, c->ctw, false));
     HIP_TRY(hipMemcpyAsync(ct, w.res_b, c->ctw * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -2928,7 +3024,8 @@ int pirgpu_slots_scan_async(pirgpu_ctx* c, const uint8_t* device_packed, uint32_
     ScanGroups grp{};
     auto flush = [&]() {
       if (!grp.n) return;
-      HIP_TRY(launch_scan_mfma_groups(ln.stream, c->dp, c->mg, c->d_dbp, grp, c->scan_rows, 0, wgs, c->scan_f64_fold, c->slot0,
+      HIP_TRY(launch_scan_mfma_groups(ln.stream, c->dp, c->mg, c->d_dbp, grp, c->scan_rows, 0, wgs,
+                                      c->scan_f64_fold || c->scan_f64_fold_batch, c->slot0,
                                       c->nslots, qwords, c->nslots, option(c, "SLOTS_SCAN_BLK_MAJOR", 1) != 0));
       grp = ScanGroups{};
     };

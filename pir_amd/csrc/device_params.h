@@ -18,7 +18,11 @@ constexpr int kMaxScanQueries = 4;       // queries sharing one database pass in
 #ifndef PIRGPU_LOG_EPT14
 #define PIRGPU_LOG_EPT14 4
 #endif
+#ifdef PIRGPU_LOG_EPT_ALL   // prototypes only (tools/ntt_short_proto.hip): every degree with 2^PIRGPU_LOG_EPT_ALL residues per thread
+constexpr int ntt_log_ept(int) { return PIRGPU_LOG_EPT_ALL; }
+#else
 constexpr int ntt_log_ept(int logN) { return logN >= 14 ? PIRGPU_LOG_EPT14 : 4; }
+#endif
 
 #include "env_gate.h"
 

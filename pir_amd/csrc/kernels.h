@@ -93,22 +93,29 @@ struct NttOps {
   hipError_t (*ks_mac_combine)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* dig,
                                const KeyPtrs& key, const uint64_t* prod, const uint64_t* tree_in, uint32_t galois_elt,
                                uint32_t nodes, uint32_t shift_pow, uint64_t* tree_out, bool pack40, bool tin40,
-                               bool tout40);
+                               bool tout40, const uint64_t* xpow_c0ntt,    // xpow_c0ntt != null: the tree's c0 is in NTT form
+                               const uint16_t* perm,    // ... and sigma_g's table for it (ctx.hip galois_perm_table)
+                               bool c0_split);          // ... with component 0 as a launch of its own
   // last expansion level in the NTT domain (fp64 flavours): `prod` holds the special-prime products (ks_mac_intt with
   // I_base = k) and receives NTT(a_0); xpow = NTT_j(x^(-shift_pow)), [k][N] doubles; galois_inv = galois_elt^-1 mod 2N
   hipError_t (*ks_last_ntt)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* tree,
                             const uint64_t* dig, const KeyPtrs& key, uint64_t* prod, const uint64_t* xpow,
                             uint32_t galois_elt, uint32_t galois_inv, uint32_t shift_pow, uint32_t n_items, uint32_t B,
-                            const MfmaPtrs& dst, uint32_t nodes, bool pack40, bool out_f64, bool c0_done);
+                            const MfmaPtrs& dst, uint32_t nodes, bool pack40, bool out_f64, bool c0_done, int c0_tree,
+                            const uint16_t* perm);   // [2][N]: sigma_g, sigma_(g^-1) on NTT positions as padded LDS indices
   // slot-sharded step: inverse NTT of the row sums of queries q0 .. q0 + nq - 1, gathered from the per-rank slot pieces
   // of the all-to-all receive buffer (nq_total queries per piece, RC = 2 rows polynomials per modulus and query) into
   // dst[(q - q0)][row, comp][k][N] -- launch_slots_assemble + ntt_batch(inverse) in one pass
   hipError_t (*ntt_inv_gather)(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* src,
                                uint64_t* dst, const SliceMap& map, uint32_t RC, uint32_t nq, uint32_t nq_total,
                                uint32_t q0);
+  // c0 of `cts` tree ciphertexts (doubles) into NTT form, in place: the tree keeps c0 in NTT form from the first fused
+  // level on (ks_combine_c0_ntt)
+  hipError_t (*tree_c0_fwd)(hipStream_t st, int mode, const DevParams* P, uint32_t k, uint64_t* tree, uint32_t cts);
 };
 
-const NttOps* ntt_ops_for(uint32_t N);  // nullptr for unsupported degrees
+// pack_bytes: width of the packed key-switch intermediates the kernels are built for (5, 6 or 7; ntt_kernels.hip)
+const NttOps* ntt_ops_for(uint32_t N, int pack_bytes = 5);  // nullptr for unsupported degrees
 
 hipError_t launch_ntt_reorder(hipStream_t st, uint32_t N, const uint64_t* in, uint64_t* out, uint64_t n_polys,
                               bool to_device, bool as_f64);
@@ -117,7 +124,8 @@ hipError_t launch_pack40x4(hipStream_t st, const uint64_t* in, uint32_t* out, ui
 hipError_t launch_unpack40x4(hipStream_t st, const uint32_t* in, uint64_t* out, uint64_t words);
 hipError_t launch_ks_combine(hipStream_t st, const DevParams* P, int mode, uint32_t N, uint32_t k,
                              const uint64_t* res_in, const uint64_t* prod, uint32_t galois_inv, uint32_t nodes,
-                             uint32_t shift_pow, bool expand_step, uint32_t hi_limit, bool pack40, uint64_t* res_out);
+                             uint32_t shift_pow, bool expand_step, uint32_t hi_limit, bool pack40, uint64_t* res_out,
+                             int pack_bytes = 5);
 // to_tree with chunk_words != 0: the input consists of chunks of chunk_words words that lie in_stride words apart
 hipError_t launch_tree_convert(hipStream_t st, const DevParams* P, int mode, const uint64_t* in, uint64_t* out,
                                uint64_t words, bool to_tree, uint64_t chunk_words = 0, uint64_t in_stride = 0);

@@ -133,7 +133,8 @@ __global__ void ks_combine_kernel(const DevParams* __restrict__ P, const uint64_
 // (SURVEY App. A.4): with r = (s + floor(p/2)) mod p, r - floor(p/2) is the CENTRED representative c of the
 // special-prime residue s, so delta_j = c mod q_j; c must be exactly centred (a signed representative may be
 // off-centre by eps p, which would change delta by p mod q_j), the data residue may be any representative.
-template <bool P40>
+// PB: bytes per residue of the packed products (0: plain doubles; 5 / 6 / 7: ntt_kernels.hip store40f at that width)
+template <int PB>
 __global__ void ks_combine_f64_kernel(const DevParams* __restrict__ P, const double* __restrict__ res_in,
                                       const uint64_t* __restrict__ prod, uint32_t galois_inv, uint32_t nodes,
                                       uint32_t shift_pow, int expand_step, uint32_t hi_limit,
@@ -154,15 +155,22 @@ __global__ void ks_combine_f64_kernel(const DevParams* __restrict__ P, const dou
 #pragma unroll
   for (int comp = 0; comp < 2; ++comp) {
     double sp, dj;  // special-prime and data-prime residues of the key-switch product (signed representatives)
-    if constexpr (P40) {
-      const uint8_t* pr = reinterpret_cast<const uint8_t*>(prod) + ((size_t)node * 2 + comp) * km * 5 * N;
-      const uint8_t* ps = pr + (size_t)k * 5 * N;
-      const uint8_t* pj = pr + (size_t)j * 5 * N;
-      // high bytes thread-major (ntt_kernels.hip store40f): element e * (N/EPT) + t at 4 N + EPT t + e
+    if constexpr (PB != 0) {
+      const uint8_t* pr = reinterpret_cast<const uint8_t*>(prod) + ((size_t)node * 2 + comp) * km * PB * N;
+      const uint8_t* ps = pr + (size_t)k * PB * N;
+      const uint8_t* pj = pr + (size_t)j * PB * N;
+      // high bytes thread-major (ntt_kernels.hip store40f): the PB - 4 bytes of element e * (N/EPT) + t at 4 N + (PB - 4) (EPT t + e)
       const uint32_t le = (uint32_t)ntt_log_ept((int)P->logN);
-      const size_t hi_at = 4 * (size_t)N + ((size_t)(i & ((N >> le) - 1)) << le) + (i >> (P->logN - le));
-      sp = f64_unpack40(reinterpret_cast<const uint32_t*>(ps)[i], ps[hi_at], f64_pack_magic(pf));
-      dj = f64_unpack40(reinterpret_cast<const uint32_t*>(pj)[i], pj[hi_at], f64_pack_magic(mj.q));
+      const size_t hi_at = 4 * (size_t)N + (PB - 4) * ((((size_t)(i & ((N >> le) - 1))) << le) + (i >> (P->logN - le)));
+      uint32_t hs = 0, hj = 0;
+#pragma unroll
+      for (int b = PB - 5; b >= 0; --b) {
+        hs = (hs << 8) | ps[hi_at + b];
+        hj = (hj << 8) | pj[hi_at + b];
+      }
+      // (the 7-byte form's third byte already carries the 0x30 of the double's exponent: the OR inside f64_unpack40 is idempotent)
+      sp = f64_unpack40(reinterpret_cast<const uint32_t*>(ps)[i], hs, f64_pack_magic(pf));
+      dj = f64_unpack40(reinterpret_cast<const uint32_t*>(pj)[i], hj, f64_pack_magic(mj.q));
     } else {
       const double* pr = reinterpret_cast<const double*>(prod) + ((size_t)node * 2 + comp) * km * N;
       sp = pr[(size_t)k * N + i];
@@ -777,20 +785,19 @@ static inline uint32_t log2u(uint32_t N) {
   return l;
 }
 
-// kernels with an NTT inside are compiled per ring degree (ntt_kernels.hip)
-const NttOps* ntt_ops_11();
-const NttOps* ntt_ops_12();
-const NttOps* ntt_ops_13();
-const NttOps* ntt_ops_14();
+// kernels with an NTT inside are compiled per ring degree and per width of the packed intermediates (ntt_kernels.hip:
+// -DPIRGPU_LOGN, -DPIRGPU_PACK_BYTES; pir_amd/build.py)
+#define PIRGPU_DECL_OPS(L) const NttOps* ntt_ops_##L(); const NttOps* ntt_ops_##L##_p6(); const NttOps* ntt_ops_##L##_p7();
+PIRGPU_DECL_OPS(11) PIRGPU_DECL_OPS(12) PIRGPU_DECL_OPS(13) PIRGPU_DECL_OPS(14)
+#undef PIRGPU_DECL_OPS
 
-const NttOps* ntt_ops_for(uint32_t N) {
+const NttOps* ntt_ops_for(uint32_t N, int pack_bytes) {
+#define PIRGPU_PICK(L) case L: return pack_bytes == 6 ? ntt_ops_##L##_p6() : (pack_bytes == 7 ? ntt_ops_##L##_p7() : ntt_ops_##L());
   switch (log2u(N)) {
-    case 11: return ntt_ops_11();
-    case 12: return ntt_ops_12();
-    case 13: return ntt_ops_13();
-    case 14: return ntt_ops_14();
+    PIRGPU_PICK(11) PIRGPU_PICK(12) PIRGPU_PICK(13) PIRGPU_PICK(14)
     default: return nullptr;
   }
+#undef PIRGPU_PICK
 }
 
 hipError_t launch_ntt_reorder(hipStream_t st, uint32_t N, const uint64_t* in, uint64_t* out, uint64_t n_polys,
@@ -845,18 +852,22 @@ hipError_t launch_unpack40x4(hipStream_t st, const uint32_t* in, uint64_t* out, 
 
 hipError_t launch_ks_combine(hipStream_t st, const DevParams* P, int mode, uint32_t N, uint32_t k,
                              const uint64_t* res_in, const uint64_t* prod, uint32_t galois_inv, uint32_t nodes,
-                             uint32_t shift_pow, bool expand_step, uint32_t hi_limit, bool pack40, uint64_t* res_out) {
+                             uint32_t shift_pow, bool expand_step, uint32_t hi_limit, bool pack40, uint64_t* res_out,
+                             int pack_bytes) {
   const uint64_t total = (uint64_t)nodes * k * N;
   const dim3 grid((uint32_t)((total + 255) / 256)), block(256);
   if (mode != kNttInt) {  // fp64 flavours: tree and products are doubles / offset-packed signed representatives
     const double* in = reinterpret_cast<const double*>(res_in);
     double* out = reinterpret_cast<double*>(res_out);
-    if (pack40)
-      hipLaunchKernelGGL(ks_combine_f64_kernel<true>, grid, block, 0, st, P, in, prod, galois_inv, nodes, shift_pow,
-                         expand_step ? 1 : 0, hi_limit, out);
-    else
-      hipLaunchKernelGGL(ks_combine_f64_kernel<false>, grid, block, 0, st, P, in, prod, galois_inv, nodes, shift_pow,
-                         expand_step ? 1 : 0, hi_limit, out);
+#define PIRGPU_KSC(PB_)                                                                                           \
+  hipLaunchKernelGGL(ks_combine_f64_kernel<PB_>, grid, block, 0, st, P, in, prod, galois_inv, nodes, shift_pow,   \
+                     expand_step ? 1 : 0, hi_limit, out)
+    if (!pack40) PIRGPU_KSC(0);
+    else if (pack_bytes == 5) PIRGPU_KSC(5);
+    else if (pack_bytes == 6) PIRGPU_KSC(6);
+    else if (pack_bytes == 7) PIRGPU_KSC(7);
+    else return hipErrorInvalidValue;
+#undef PIRGPU_KSC
   } else if (pack40) {
     hipLaunchKernelGGL(ks_combine_kernel<true>, grid, block, 0, st, P, res_in, prod, galois_inv, nodes, shift_pow,
                        expand_step ? 1 : 0, hi_limit, res_out);

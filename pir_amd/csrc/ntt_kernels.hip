@@ -24,10 +24,23 @@
 #error "compile with -DPIRGPU_LOGN=<11..14>"
 #endif
 
+// -DPIRGPU_PACK_BYTES=<5|6|7> (default 5): bytes per residue of the PACKED form of the key-switch intermediates and of the
+// tree between fused levels (the "40" in the names below is the 5-byte case).  The fp64 flavours store the unsigned
+// integer x + q of a signed representative |x| <= q: 5 bytes for moduli below 2^39 (cfg 2 / 3), 6 below 2^47 (cfg 4:
+// 43 / 44 bits), 7 below 2^55 (cfg 5: 48 / 49 bits) -- the wide levels are bound by these bytes.  One translation unit
+// per (degree, width): the width is a constant of the whole file, not a template parameter of every kernel.
+#ifndef PIRGPU_PACK_BYTES
+#define PIRGPU_PACK_BYTES 5
+#endif
 #define PIRGPU_CAT2(a, b) a##b
 #define PIRGPU_CAT(a, b) PIRGPU_CAT2(a, b)
+#if PIRGPU_PACK_BYTES == 5
 #define PIRGPU_OPS_NAME PIRGPU_CAT(ntt_ops_, PIRGPU_LOGN)
 #define PIRGPU_DEG_NS PIRGPU_CAT(deg, PIRGPU_LOGN)
+#else
+#define PIRGPU_OPS_NAME PIRGPU_CAT(PIRGPU_CAT(ntt_ops_, PIRGPU_LOGN), PIRGPU_CAT(_p, PIRGPU_PACK_BYTES))
+#define PIRGPU_DEG_NS PIRGPU_CAT(PIRGPU_CAT(deg, PIRGPU_LOGN), PIRGPU_CAT(p, PIRGPU_PACK_BYTES))
+#endif
 
 namespace pirgpu {
 // every degree gets its own namespace: the kernels of the four translation units must
@@ -57,6 +70,27 @@ constexpr bool kPF = LOGN < 14 || (EPT == 32 && PIRGPU_PF14 != 0);   // 1024-thr
 #define PIRGPU_PF_LOOP 1
 #endif
 constexpr bool kPFLoop = kPF && (EPT == 32 || PIRGPU_PF_LOOP != 0);
+// ks_mac_combine_kernel with both of its paths (component 0 in the NTT domain, component 1 through the inverse transform)
+// sits at 126 - 142 registers depending on the compiler's mood; its workgroups wait for loads (k digits + k key
+// polynomials per transform), where the fourth wave per SIMD is worth more than a freer schedule (HISTORY section 9)
+#ifndef PIRGPU_MC_FOUR_WAVES
+#define PIRGPU_MC_FOUR_WAVES 1
+#endif
+#if PIRGPU_MC_FOUR_WAVES && PIRGPU_LOGN <= 12
+#define PIRGPU_MC_WAVES __attribute__((amdgpu_waves_per_eu(4)))
+#else
+#define PIRGPU_MC_WAVES
+#endif
+// The product kernels at N = 8192 with 6-byte digits come out at 132 registers: with 512-thread workgroups that is ONE
+// workgroup per CU instead of two.  Held at 128 there (-DPIRGPU_PK_FOUR_WAVES=0: the compiler's choice).
+#ifndef PIRGPU_PK_FOUR_WAVES
+#define PIRGPU_PK_FOUR_WAVES 1
+#endif
+#if PIRGPU_PK_FOUR_WAVES && PIRGPU_LOGN == 13 && PIRGPU_PACK_BYTES != 5
+#define PIRGPU_PK_WAVES __attribute__((amdgpu_waves_per_eu(4)))
+#else
+#define PIRGPU_PK_WAVES
+#endif
 #if PIRGPU_PF_LOOP
 #define PIRGPU_FOUR_WAVES
 #else
@@ -70,10 +104,14 @@ constexpr uint32_t kWideLevel = kKsWideLevel;  // nodes per launch from which th
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
-// 40-bit polynomial storage for the key-switch intermediates (all moduli < 2^40): N low words (u32)
-// followed by N high bytes = 5 N bytes per polynomial instead of 8 N.  The wide expansion levels are
-// bound by the traffic of these intermediates, not by the transforms.
-constexpr size_t kPoly40 = (size_t)5 * N;
+// Packed polynomial storage for the key-switch intermediates: N low words (u32) followed by N * kHB high bytes = kPB N
+// bytes per polynomial instead of 8 N (kPB = 5: all moduli < 2^39).  The wide expansion levels are bound by the traffic
+// of these intermediates, not by the transforms.
+constexpr int kPB = PIRGPU_PACK_BYTES;         // bytes per residue
+constexpr int kHB = kPB - 4;                   // high bytes per residue: 1, 2, 3
+static_assert(kPB >= 5 && kPB <= 7, "packed residues are 5, 6 or 7 bytes");
+constexpr size_t kPoly40 = (size_t)kPB * N;
+// integer flavour (5-byte form only, element-major: the host never asks the integer flavour for another width)
 __device__ __forceinline__ uint64_t load40(const uint8_t* poly, uint32_t i) {
   return (uint64_t)reinterpret_cast<const uint32_t*>(poly)[i] | ((uint64_t)poly[4 * N + i] << 32);
 }
@@ -82,44 +120,77 @@ __device__ __forceinline__ void store40(uint8_t* poly, uint32_t i, uint64_t v) {
   poly[4 * N + i] = (uint8_t)(v >> 32);
 }
 
-// fp64 flavours: signed representative <-> offset 40-bit storage (arith.h f64_pack40).  The kernels below all hold
-// element e * NT + tid in register e of thread tid, so the high bytes are stored THREAD-MAJOR: byte e of thread tid
-// at 4 N + EPT tid + e.  A thread then moves its EPT high bytes with one 16-byte access (a wave: 1 KiB contiguous)
-// (two at EPT = 32) instead of EPT single-byte ones -- 17 memory instructions per polynomial instead of 32, and no partial-line
-// byte stores.  (The integer flavour keeps the element-major load40/store40 layout above; buffers are never shared
-// between flavours.)
-struct Hi16 {               // the EPT high bytes of a thread (EPT / 4 words)
-  uint32_t w[EPT / 4];
+// fp64 flavours: signed representative <-> offset storage (arith.h f64_pack40: the double 2^52 + x + q carries the integer
+// in its low mantissa bits, so packing is one v_add_f64 and a store of the low kPB bytes).  The kernels below all hold
+// element e * NT + tid in register e of thread tid, so the high bytes are stored THREAD-MAJOR: the kHB bytes of element e
+// of thread tid at 4 N + kHB (EPT tid + e).  A thread then moves its kHB EPT high bytes with kHB 16-byte accesses (a wave:
+// kHB KiB contiguous) instead of EPT narrow ones, and there are no partial-line byte stores.  (The integer flavour keeps
+// the element-major load40 / store40 layout above; buffers are never shared between flavours.)
+constexpr int kHW = kHB * EPT / 4;             // high words per thread
+struct Hi16 {                                  // the high bytes of a thread's EPT residues
+  uint32_t w[kHW];
 };
 __device__ __forceinline__ Hi16 load40f_hi(const uint8_t* poly, uint32_t tid) {
   Hi16 h;
 #pragma unroll
-  for (int g = 0; g < EPT / 16; ++g) {
-    const uint4 v = *reinterpret_cast<const uint4*>(poly + 4 * N + EPT * tid + 16 * g);
+  for (int g = 0; g < kHW / 4; ++g) {
+    const uint4 v = *reinterpret_cast<const uint4*>(poly + 4 * N + (size_t)kHB * EPT * tid + 16 * g);
     h.w[4 * g] = v.x, h.w[4 * g + 1] = v.y, h.w[4 * g + 2] = v.z, h.w[4 * g + 3] = v.w;
   }
   return h;
 }
+// high word of the double 2^52 + u for element e: 0x43300000 | (u >> 32).  5 bytes: one v_perm_b32 (selector bytes: e & 3 of
+// the word, 0, 0x30, 0x43); 6 bytes: one v_perm_b32 (two bytes of the word, 0x30, 0x43); 7 bytes: the three stored bytes
+// (they may straddle two words; the third carries the 0x30 with bits 48.. of u) and an OR with 0x43000000.
+__device__ __forceinline__ uint32_t hi_word(const Hi16& h, int e) {
+  if constexpr (kHB == 1) {
+    return __builtin_amdgcn_perm(0x43300000u, h.w[e >> 2], 0x07060c00u | (uint32_t)(e & 3));
+  } else if constexpr (kHB == 2) {
+    const uint32_t o = 2u * (uint32_t)(e & 1);
+    return __builtin_amdgcn_perm(0x43300000u, h.w[e >> 1], 0x07060000u | ((o + 1u) << 8) | o);
+  } else {
+    const int b = 3 * e, wl = b >> 2;
+    const uint32_t o = (uint32_t)(b & 3);
+    const uint32_t nxt = h.w[wl + 1 < kHW ? wl + 1 : wl];
+    return __builtin_amdgcn_perm(nxt, h.w[wl], 0x0c000000u | ((o + 2u) << 16) | ((o + 1u) << 8) | o) | 0x43000000u;
+  }
+}
 // element e * NT + tid
 __device__ __forceinline__ double load40f(const uint8_t* poly, const Hi16& h, int e, uint32_t tid, double magic) {
   const uint32_t lo = reinterpret_cast<const uint32_t*>(poly)[e * NT + tid];
-  // high word of the double 2^52 + u: 0x43300000 | byte e -- one v_perm_b32 (selector bytes: e & 3 of the word, 0, 0x30, 0x43)
-  const uint32_t hi = __builtin_amdgcn_perm(0x43300000u, h.w[e >> 2], 0x07060c00u | (uint32_t)(e & 3));
-  return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo)) - magic;
+  return __longlong_as_double((long long)(((uint64_t)hi_word(h, e) << 32) | lo)) - magic;
 }
-// four high words' low bytes -> one word, for the EPT / 4 words of a thread
-__device__ __forceinline__ void pack_hi_bytes(const uint32_t (&hb)[EPT], uint32_t (&w)[EPT / 4]) {
+// the EPT high words' low kHB bytes -> the kHW words of a thread
+__device__ __forceinline__ void pack_hi_bytes(const uint32_t (&hb)[EPT], uint32_t (&w)[kHW]) {
+  if constexpr (kHB == 1) {
 #pragma unroll
-  for (int g = 0; g < EPT / 4; ++g) {
-    const uint32_t ab = __builtin_amdgcn_perm(hb[4 * g + 1], hb[4 * g], 0x0c0c0400u);
-    const uint32_t cd = __builtin_amdgcn_perm(hb[4 * g + 3], hb[4 * g + 2], 0x0c0c0400u);
-    w[g] = __builtin_amdgcn_perm(cd, ab, 0x05040100u);
+    for (int g = 0; g < EPT / 4; ++g) {
+      const uint32_t ab = __builtin_amdgcn_perm(hb[4 * g + 1], hb[4 * g], 0x0c0c0400u);
+      const uint32_t cd = __builtin_amdgcn_perm(hb[4 * g + 3], hb[4 * g + 2], 0x0c0c0400u);
+      w[g] = __builtin_amdgcn_perm(cd, ab, 0x05040100u);
+    }
+  } else if constexpr (kHB == 2) {
+#pragma unroll
+    for (int g = 0; g < EPT / 2; ++g) w[g] = __builtin_amdgcn_perm(hb[2 * g + 1], hb[2 * g], 0x05040100u);
+  } else {
+    // byte B of the thread's 3 EPT bytes belongs to element B / 3, byte B % 3: every word draws from two neighbouring elements
+#pragma unroll
+    for (int mw = 0; mw < kHW; ++mw) {
+      const int ea = (4 * mw) / 3;
+      uint32_t sel = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int B = 4 * mw + i, el = B / 3, bi = B % 3;
+        sel |= (uint32_t)(el == ea ? bi : 4 + bi) << (8 * i);
+      }
+      w[mw] = __builtin_amdgcn_perm(hb[ea + 1 < EPT ? ea + 1 : ea], hb[ea], sel);
+    }
   }
 }
-__device__ __forceinline__ void store_hi_words(uint8_t* poly, uint32_t tid, const uint32_t (&w)[EPT / 4]) {
+__device__ __forceinline__ void store_hi_words(uint8_t* poly, uint32_t tid, const uint32_t (&w)[kHW]) {
 #pragma unroll
-  for (int g = 0; g < EPT / 16; ++g)
-    *reinterpret_cast<uint4*>(poly + 4 * N + EPT * tid + 16 * g) = uint4{w[4 * g], w[4 * g + 1], w[4 * g + 2], w[4 * g + 3]};
+  for (int g = 0; g < kHW / 4; ++g)
+    *reinterpret_cast<uint4*>(poly + 4 * N + (size_t)kHB * EPT * tid + 16 * g) = uint4{w[4 * g], w[4 * g + 1], w[4 * g + 2], w[4 * g + 3]};
 }
 __device__ __forceinline__ void store40f(uint8_t* poly, uint32_t tid, const double (&x)[EPT], double magic) {
   uint32_t hb[EPT];
@@ -129,26 +200,9 @@ __device__ __forceinline__ void store40f(uint8_t* poly, uint32_t tid, const doub
     f64_pack40(x[e], magic, lo, hb[e]);
     reinterpret_cast<uint32_t*>(poly)[e * NT + tid] = lo;
   }
-  uint32_t w[EPT / 4];
+  uint32_t w[kHW];
   pack_hi_bytes(hb, w);
   store_hi_words(poly, tid, w);
-}
-
-// Polynomial `poly` (index in units of polynomials) of an expansion-tree buffer, this thread's 16 elements: doubles, or
-// (T40, wide levels of the fused expansion, every modulus < 2^39) the 5-byte offset form with modulus q.
-template <bool T40>
-__device__ __forceinline__ void tree_load(const uint64_t* tree_raw, size_t poly, uint32_t tid, double q, double (&out)[EPT]) {
-  if constexpr (T40) {
-    const uint8_t* pp = reinterpret_cast<const uint8_t*>(tree_raw) + poly * kPoly40;
-    const Hi16 h = load40f_hi(pp, tid);
-    const double magic = f64_pack_magic(q);
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) out[e] = load40f(pp, h, e, tid, magic);
-  } else {
-    const double* pp = reinterpret_cast<const double*>(tree_raw) + poly * N;
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) out[e] = pp[e * NT + tid];
-  }
 }
 
 // Buffer-resource access to one polynomial of u64 words: element e * NT + tid is the thread's byte offset 8 tid (one
@@ -166,6 +220,89 @@ __device__ __forceinline__ uint64_t poly_load_u64(__amdgpu_buffer_rsrc_t r, uint
   const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, tid * 8u, (uint32_t)e * (uint32_t)NT * 8u, 0);
   return ((uint64_t)v.y << 32) | v.x;
 }
+
+// The same loads through a buffer resource (one VGPR of offset per polynomial, scalar element offsets): a product loop
+// built on flat loads needs an address pair per load, and with ~40 registers less the compiler keeps a digit's 33 loads in
+// flight together instead of waiting for each one (ks_combine_c0_ntt; tests/test_isa_budget.py).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bytes_rsrc(const void* base, uint32_t bytes) {
+  const uint64_t b = (uint64_t)base;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, bytes, 0x00020000);
+}
+// 5-byte polynomial at `poly40` (kPoly40 bytes): this thread's EPT elements as signed representatives
+__device__ __forceinline__ void load40f_rsrc(const uint8_t* poly40, uint32_t tid, double magic, double (&out)[EPT]) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t r = bytes_rsrc(poly40, (uint32_t)kPoly40);
+  Hi16 h;
+#pragma unroll
+  for (int g = 0; g < kHW / 4; ++g) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (uint32_t)kHB * EPT * tid + 16u * g, 4u * N, 0);
+    h.w[4 * g] = v.x, h.w[4 * g + 1] = v.y, h.w[4 * g + 2] = v.z, h.w[4 * g + 3] = v.w;
+  }
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const uint32_t lo = __builtin_amdgcn_raw_buffer_load_b32(r, tid * 4u, (uint32_t)e * (uint32_t)NT * 4u, 0);
+    out[e] = __longlong_as_double((long long)(((uint64_t)hi_word(h, e) << 32) | lo)) - magic;
+  }
+}
+__device__ __forceinline__ void loadf64_rsrc(const double* poly, uint32_t tid, double (&out)[EPT]) {
+  const __amdgpu_buffer_rsrc_t r = poly_rsrc(reinterpret_cast<const uint64_t*>(poly));
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) out[e] = __longlong_as_double((long long)poly_load_u64(r, tid, e));
+}
+
+// Polynomial `poly` (index in units of polynomials) of an expansion-tree buffer, this thread's 16 elements: doubles, or
+// (T40, wide levels of the fused expansion, every modulus < 2^39) the 5-byte offset form with modulus q.
+template <bool T40>
+__device__ __forceinline__ void tree_load(const uint64_t* tree_raw, size_t poly, uint32_t tid, double q, double (&out)[EPT]) {
+  if constexpr (T40) {
+    const uint8_t* pp = reinterpret_cast<const uint8_t*>(tree_raw) + poly * kPoly40;
+    const Hi16 h = load40f_hi(pp, tid);
+    const double magic = f64_pack_magic(q);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) out[e] = load40f(pp, h, e, tid, magic);
+  } else {
+    // buffer-resource loads: one VGPR of offset for all EPT elements (flat addressing spends an address pair per one or
+    // two elements -- enough, in the digit kernels, to cross the 128-register line)
+    const __amdgpu_buffer_rsrc_t r = poly_rsrc(tree_raw + poly * N);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) out[e] = __longlong_as_double((long long)poly_load_u64(r, tid, e));
+  }
+}
+
+// SEAL position P -> pi_g(P) -> device slot
+__device__ __forceinline__ uint32_t galois_ntt_slot(uint32_t P, uint32_t g) {
+  const uint32_t r = __brev(P) >> (32 - LOGN);
+  const uint32_t ex = ((2 * r + 1) * g) & (2 * N - 1);
+  const uint32_t Pin = __brev(ex >> 1) >> (32 - LOGN);
+  return (Pin & (uint32_t)(EPT - 1)) * NT + (Pin >> R_);
+}
+
+// sigma_g on NTT-form data as a TABLE (ctx.hip galois_perm_table): entry EPT * tid + e = padded LDS word index
+// lds_idx(galois_ntt_slot(EPT * tid + e, g)), u16 -- a thread's EPT entries are 2 EPT contiguous bytes.  Computing the index
+// costs two bit reversals, a quarter-rate 32-bit multiply and ~10 more integer operations per element (about a third
+// of a transform's issue time per permuted polynomial); the table costs EPT / 8 16-byte loads and one extraction each.
+#ifndef PIRGPU_PERM_TABLE
+#define PIRGPU_PERM_TABLE 1
+#endif
+struct PermIdx {
+  uint32_t w[EPT / 2];   // two u16 indices per word
+};
+__device__ __forceinline__ PermIdx load_perm(const uint16_t* __restrict__ perm, uint32_t tid) {
+  PermIdx r;
+#pragma unroll
+  for (int g = 0; g < EPT / 8; ++g) {
+    const uint4 v = *reinterpret_cast<const uint4*>(perm + (size_t)EPT * tid + 8 * g);
+    r.w[4 * g] = v.x, r.w[4 * g + 1] = v.y, r.w[4 * g + 2] = v.z, r.w[4 * g + 3] = v.w;
+  }
+  return r;
+}
+// padded LDS word index of pi_g(EPT * tid + e)
+__device__ __forceinline__ uint32_t perm_at(const PermIdx& pi, int e, uint32_t tid, uint32_t g) {
+  if constexpr (PIRGPU_PERM_TABLE != 0) return (e & 1) ? pi.w[e >> 1] >> 16 : pi.w[e >> 1] & 0xffffu;
+  else return lds_idx<R_>(galois_ntt_slot(EPT * tid + e, g));
+}
+
 
 // One workgroup per polynomial; modulus index = mod_base + (poly % mod_period).
 // Forward: natural coefficients -> device NTT order; inverse: the reverse.  In place.
@@ -354,6 +491,24 @@ template <int MODE, bool P40>
 __global__ void __launch_bounds__(NT)
 tree_c0_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ tree_raw, uint64_t* __restrict__ prod) {
   tree_c0_ntt_body<MODE, P40, false>(P, tree_raw, prod, blockIdx.x / P->k, blockIdx.x % P->k, threadIdx.x);
+}
+
+// c0 of every tree ciphertext into NTT form, in place (doubles): the transition from the narrow levels (both
+// polynomials in coefficient form, ks_combine_f64_kernel) to the fused levels, which keep c0 in NTT form for the rest of
+// the tree (ks_combine_c0_ntt below).  grid = tree ciphertexts * k.
+template <int MODE>
+__global__ void __launch_bounds__(NT)
+tree_c0_fwd_kernel(const DevParams* __restrict__ P, uint64_t* __restrict__ tree_raw) {
+  static_assert(MODE != kNttInt, "fp64 flavours only");
+  const uint32_t tid = threadIdx.x, k = P->k;
+  const uint32_t node = blockIdx.x / k, j = blockIdx.x % k;
+  double* pp = reinterpret_cast<double*>(tree_raw) + ((size_t)node * 2 * k + j) * N;
+  double x[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) x[e] = pp[e * NT + tid];
+  ntt_forward<MODE, LOGN, kPF, /*CANON=*/false>(x, smem_raw, P, j, tid);
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) pp[e * NT + tid] = x[e];
 }
 
 // One level of the expansion tree, part 1a: for node n, key-level modulus I and
@@ -563,7 +718,7 @@ __device__ __forceinline__ void ks_mac_core(const DevParams* __restrict__ P, con
 // runs it for the special prime alone (I_base = k, I_count = 1) below the last level, where the data residues go
 // through ks_mac_combine_kernel instead.
 template <int MODE, bool P40>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT) PIRGPU_PK_WAVES
 ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ dig_raw, KeyPtrs keys,
                    uint64_t* __restrict__ prod, uint32_t I_base, uint32_t I_count) {
   using A = Arith<MODE>;
@@ -603,6 +758,131 @@ ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
   }
 }
 
+// c0 of one expansion level with the tree's c0 polynomials kept in NTT form (fp64 flavours, fused levels).  c0 is never
+// digit-decomposed: on its way to the leaves it is only permuted (sigma_g), added to and multiplied by monomials -- all
+// of which commute with the transform -- and the leaves are consumed in NTT form (database.cpp:190,222).  So, with
+// C0 = NTT_j(c0) and pi_g the permutation sigma_g induces on NTT positions (ks_last_ntt_kernel below),
+//   G0  = (S_0j - NTT_j(lift(s_0))) p^-1         S_0j the dyadic key-switch product mod q_j (never inverse-transformed),
+//                                                 s_0 the centred special-prime residue (coefficient form, ks_mac_intt)
+//   sub = C0 o pi_g + G0                          NTT_j of apply_galois(ct)'s first polynomial (server.cpp:71)
+//   lo  = C0 + sub,   hi = X (.) (C0 - sub)       X = NTT_j(x^(-2^level)) (server.cpp:97,137-141)
+// One forward transform per (tree ciphertext, data modulus) instead of one inverse one: the same count as before, but
+// the last level finds NTT(a_0) in the tree and tree_c0_ntt_kernel's k transforms per leaf pair disappear; lo / hi are
+// plain contiguous stores (no index rotation for the monomial).  All arithmetic exact mod q_j: same canonical selectors.
+template <int MODE, bool P40, bool TIN40, bool TOUT40>
+__device__ __forceinline__ void ks_combine_c0_ntt(const DevParams* __restrict__ P, const uint64_t* __restrict__ dig_raw,
+                                                  const uint64_t* __restrict__ key_raw, const uint64_t* __restrict__ prod,
+                                                  const uint64_t* __restrict__ tree_in_raw, const double* __restrict__ xpow,
+                                                  const uint16_t* __restrict__ perm, uint32_t galois_elt, uint32_t nodes,
+                                                  uint32_t node, uint32_t j, uint32_t tid, uint64_t* __restrict__ tree_out_raw) {
+  using A = Arith<MODE>;
+  double* sd = reinterpret_cast<double*>(smem_raw);
+  const uint32_t k = P->k, km = k + 1;
+  const typename A::Mod m = A::mod(P, j);
+  const double magic = f64_pack_magic(m.q);
+  double x[EPT];
+  {
+    const double pf = P->p_f, half = P->p_half_f;
+    const size_t spoly = ((size_t)node * 2 + 0) * km + k;
+    [[maybe_unused]] Hi16 hs{};
+    if constexpr (P40) hs = load40f_hi(reinterpret_cast<const uint8_t*>(prod) + spoly * kPoly40, tid);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      double sp;
+      if constexpr (P40)
+        sp = load40f(reinterpret_cast<const uint8_t*>(prod) + spoly * kPoly40, hs, e, tid, f64_pack_magic(pf));
+      else
+        sp = reinterpret_cast<const double*>(prod)[spoly * N + e * NT + tid];
+      sp = sp > half ? sp - pf : sp;   // exact centring (ks_combine_f64_kernel)
+      sp = sp < -half ? sp + pf : sp;
+      x[e] = f64_norm(sp, m);
+    }
+  }
+  ntt_forward<MODE, LOGN, kPF, /*CANON=*/false>(x, smem_raw, P, j, tid);
+  {
+    const size_t dpoly0 = ((size_t)node * km + j) * k;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) x[e] = -x[e];
+    const double* key = reinterpret_cast<const double*>(key_raw);
+    for (uint32_t J = 0; J < k; ++J) {
+      // digit AND key words into arrays first: with the key word loaded inside the product expression the scheduler falls back
+      // to one load + its unpacking + `s_waitcnt vmcnt(0)` at a time (33 dependent round trips per digit; the kernel then
+      // took 102 us at 2 048 workgroups against 50 for its component-1 twin) -- 150 registers, three waves per SIMD
+      double d[EPT], kv[EPT];
+      if constexpr (P40) load40f_rsrc(reinterpret_cast<const uint8_t*>(dig_raw) + (dpoly0 + J) * kPoly40, tid, magic, d);
+      else loadf64_rsrc(reinterpret_cast<const double*>(dig_raw) + (dpoly0 + J) * N, tid, d);
+      loadf64_rsrc(key + (((size_t)J * 2 + 0) * km + j) * N, tid, kv);
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) x[e] += f64_mulmod(d[e], kv[e], m);
+    }
+    const double pinv = P->p_inv_f[j];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) x[e] = f64_mulmod(f64_norm(x[e], m), pinv, m);
+  }
+  // (an opaque copy of the thread index for everything below: see ks_last_ntt_kernel)
+  uint32_t tid_e = tid;
+  asm volatile("" : "+v"(tid_e));
+  double v[EPT];
+  tree_load<TIN40>(tree_in_raw, (size_t)node * 2 * k + j, tid_e, m.q, v);
+  __syncthreads();  // the transform's last exchange is done with the LDS words
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) sd[lds_lin_base<NT, R_>(tid_e) + lds_lin_off<NT, R_>(e)] = v[e];
+  __syncthreads();
+  {
+    [[maybe_unused]] PermIdx pi{};
+    if constexpr (PIRGPU_PERM_TABLE != 0) pi = load_perm(perm, tid_e);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) x[e] += sd[perm_at(pi, e, tid_e, galois_elt)];
+  }
+  const double* X = xpow + (size_t)j * N;
+  const size_t plo = (size_t)node * 2 * k + j, phi = ((size_t)node + nodes) * 2 * k + j;
+  // lo first, then hi, through ONE temporary array: both outputs live together cost a fourth wave per SIMD
+  double t[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) t[e] = f64_norm(v[e] + x[e], m);
+  if constexpr (TOUT40) {
+    store40f(reinterpret_cast<uint8_t*>(tree_out_raw) + plo * kPoly40, tid_e, t, magic);
+  } else {
+    double* tlo = reinterpret_cast<double*>(tree_out_raw) + plo * N;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) tlo[e * NT + tid_e] = t[e];
+  }
+  // (X's 16 loads hoisted above the lo stores cost 146 - 153 registers, three waves per SIMD: their address is opaque until
+  // the lo stores are out)
+  uint32_t tid_x = tid_e;   // (tid_e dies here)
+  asm volatile("" : "+v"(tid_x) : : "memory");
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) t[e] = f64_mulmod(f64_norm(v[e] - x[e], m), X[e * NT + tid_x], m);
+  if constexpr (TOUT40) {
+    store40f(reinterpret_cast<uint8_t*>(tree_out_raw) + phi * kPoly40, tid_x, t, magic);
+  } else {
+    double* thi = reinterpret_cast<double*>(tree_out_raw) + phi * N;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) thi[e * NT + tid_x] = t[e];
+  }
+}
+
+// ks_combine_c0_ntt as a launch of its own (grid = nodes * k, XCD-aware for wide levels): the form in which the two
+// components of a level do not share a kernel -- each keeps its own registers and its own 20 KB of code (the combined
+// kernel is 39 KB of instructions next to the other lane's kernel in a 64 KB instruction cache shared by two CUs).
+template <int MODE, bool P40, bool TIN40, bool TOUT40>
+__global__ void __launch_bounds__(NT)
+ks_c0_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ dig_raw, KeyPtrs keys,
+                 const uint64_t* __restrict__ prod, const uint64_t* __restrict__ tree_in_raw, uint32_t galois_elt,
+                 uint32_t nodes, uint64_t* __restrict__ tree_out_raw, const double* __restrict__ xpow,
+                 const uint16_t* __restrict__ perm) {
+  static_assert(MODE != kNttInt, "fp64 flavours only");
+  const uint32_t k = P->k;
+  uint32_t node = blockIdx.x, j = blockIdx.y;
+  if (gridDim.y == 1) {
+    const uint32_t xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
+    j = t % k;
+    node = (t / k) * 8 + xcd;
+  }
+  ks_combine_c0_ntt<MODE, P40, TIN40, TOUT40>(P, dig_raw, keys.p[node % keys.B], prod, tree_in_raw, xpow, perm, galois_elt, nodes,
+                                              node, j, threadIdx.x, tree_out_raw);
+}
+
 // Parts 1b + 2 for the DATA residues of one expansion level below the last (fp64 flavours): the workgroup of
 // (tree ciphertext, data modulus j, component) forms S[c][j], runs its inverse transform and -- instead of storing
 // the product -- applies ks_combine_f64_kernel's arithmetic while the polynomial is in registers: divide-and-round
@@ -611,12 +891,15 @@ ks_mac_intt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
 // One transform per workgroup and nothing live across it (the fused variants with several transforms per workgroup
 // lost to their register pressure); saves the data products' round trip and the separate
 // HBM-bound combine pass.  grid = (nodes, k, 2) or the XCD-aware 1-D equivalent.
-template <int MODE, bool P40, bool TIN40 = false, bool TOUT40 = false>
-__global__ void __launch_bounds__(NT)
+// C0NTT: the tree's c0 polynomials are in NTT form -- the workgroups of component 0 run ks_combine_c0_ntt instead
+// (xpow = NTT_j(x^(-shift_pow)), [k][N] doubles in device order).
+template <int MODE, bool P40, bool TIN40 = false, bool TOUT40 = false, bool C0NTT = false>
+__global__ void __launch_bounds__(NT) PIRGPU_MC_WAVES PIRGPU_PK_WAVES
 ks_mac_combine_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ dig_raw,
                       KeyPtrs keys, const uint64_t* __restrict__ prod,
                       const uint64_t* __restrict__ tree_in_raw, uint32_t galois_elt, uint32_t nodes, uint32_t shift_pow,
-                      uint64_t* __restrict__ tree_out_raw) {
+                      uint64_t* __restrict__ tree_out_raw, const double* __restrict__ xpow,
+                      const uint16_t* __restrict__ perm, uint32_t comp1_only) {   // comp1_only: the grid covers component 1 alone
   using A = Arith<MODE>;
   static_assert(MODE != kNttInt, "fp64 flavours only");
   double* sd = reinterpret_cast<double*>(smem_raw);
@@ -624,10 +907,19 @@ ks_mac_combine_kernel(const DevParams* __restrict__ P, const uint64_t* __restric
   uint32_t node = blockIdx.x, j = blockIdx.y, comp = blockIdx.z;
   if (gridDim.y == 1 && gridDim.z == 1) {
     const uint32_t xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
-    comp = t & 1;
-    const uint32_t u = t >> 1;
+    comp = comp1_only ? 1 : t & 1;
+    const uint32_t u = comp1_only ? t : t >> 1;
     j = u % k;
     node = (u / k) * 8 + xcd;
+  } else if (comp1_only) {
+    comp = 1;
+  }
+  if constexpr (C0NTT) {
+    if (comp == 0) {   // uniform per workgroup
+      ks_combine_c0_ntt<MODE, P40, TIN40, TOUT40>(P, dig_raw, keys.p[node % keys.B], prod, tree_in_raw, xpow, perm, galois_elt,
+                                                  nodes, node, j, tid, tree_out_raw);
+      return;
+    }
   }
   const typename A::Mod m = A::mod(P, j);
   double g[EPT];
@@ -650,7 +942,7 @@ ks_mac_combine_kernel(const DevParams* __restrict__ P, const uint64_t* __restric
       g[e] = f64_mulmod(g[e] - f64_norm(sp, m), pinv, m);
     }
   }
-  if (comp == 0) {  // + sigma_g(c0)
+  if (!C0NTT && comp == 0) {  // + sigma_g(c0)
     const uint32_t raw0 = tid * galois_elt, rstep = (uint32_t)NT * galois_elt;
     double c0[EPT];
     tree_load<TIN40>(tree_in_raw, (size_t)node * 2 * k + j, tid, m.q, c0);
@@ -691,12 +983,12 @@ ks_mac_combine_kernel(const DevParams* __restrict__ P, const uint64_t* __restric
       f64_pack40(d, magic, l32, hb[e]);
       reinterpret_cast<uint32_t*>(phi)[(e * NT + tid - shift_pow) & (N - 1)] = l32;
     }
-    uint32_t w[EPT / 4];
+    uint32_t w[kHW];
     pack_hi_bytes(hb, w);
-    uint32_t o[EPT / 4];
+    uint32_t o[kHW];
 #pragma unroll
-    for (int q4 = 0; q4 < EPT / 4; ++q4)   // borrowing threads: destination byte e' holds source byte e' + 1 (mod EPT)
-      o[q4] = borrow ? __builtin_amdgcn_alignbyte(w[(q4 + 1) % (EPT / 4)], w[q4], 1) : w[q4];
+    for (int q4 = 0; q4 < kHW; ++q4)   // borrowing threads: destination element e' holds source element e' + 1 (mod EPT): kHB bytes on
+      o[q4] = borrow ? __builtin_amdgcn_alignbyte(w[(q4 + 1) % kHW], w[q4], kHB) : w[q4];
     store_hi_words(phi, tid_d, o);
   } else {
     const size_t off = opoly * N;
@@ -819,24 +1111,19 @@ ks_last_level_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict
 // All arithmetic is exact mod q_j, so the selectors are the same canonical residues (reference server.cpp:137-141
 // followed by database.cpp:190,222).
 
-// SEAL position P -> pi_g(P) -> device slot
-__device__ __forceinline__ uint32_t galois_ntt_slot(uint32_t P, uint32_t g) {
-  const uint32_t r = __brev(P) >> (32 - LOGN);
-  const uint32_t ex = ((2 * r + 1) * g) & (2 * N - 1);
-  const uint32_t Pin = __brev(ex >> 1) >> (32 - LOGN);
-  return (Pin & (uint32_t)(EPT - 1)) * NT + (Pin >> R_);
-}
-
 // One workgroup per (tree ciphertext, data modulus j, component): one forward transform (of the lifted special
 // residue), then the dyadic products and the epilogue above; writes selector `slot` and -- if < n_items --
 // selector `slot + shift_pow` of query q (tree ciphertext index = slot * B + query).  xpow = X for the k data
 // moduli, [k][N] doubles in device order.  grid = (nodes, k, 2) or the XCD-aware 1-D equivalent.
-template <int MODE, bool P40, bool OUTF64 = false>
+// C0T: where NTT(a_0) comes from -- 0: the product buffer's spare slot (tree_c0_ntt_kernel / the digit launch's extra
+// workgroups), 1 / 2: the tree itself, whose c0 polynomials are in NTT form (doubles / 5-byte form; ks_combine_c0_ntt).
+template <int MODE, bool P40, bool OUTF64 = false, int C0T = 0>
 __global__ void __launch_bounds__(NT)
 ks_last_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__ dig_raw,
                    KeyPtrs keys, const uint64_t* __restrict__ prod,
                    const double* __restrict__ xpow, uint32_t galois_elt, uint32_t galois_inv, uint32_t shift_pow,
-                   uint32_t n_items, uint32_t B, MfmaPtrs dst) {
+                   uint32_t n_items, uint32_t B, MfmaPtrs dst, const uint64_t* __restrict__ tree_raw,
+                   const uint16_t* __restrict__ perm) {   // perm: [2][N], sigma_g then sigma_(g^-1) (galois_perm_table)
   using A = Arith<MODE>;
   static_assert(MODE != kNttInt, "fp64 flavours only");
   double* sd = reinterpret_cast<double*>(smem_raw);
@@ -913,16 +1200,22 @@ ks_last_ntt_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
   double a[EPT];
   {
     double v[EPT];
-    if (comp == 0) load_poly(prod, (size_t)node * 2 * km + j, v, tid_e);
-    else load_poly(dig_raw, dpoly0 + j, v, tid_e);
+    if (comp == 0) {
+      if constexpr (C0T == 0) load_poly(prod, (size_t)node * 2 * km + j, v, tid_e);
+      else tree_load<C0T == 2>(tree_raw, (size_t)node * 2 * k + j, tid_e, m.q, v);
+    } else {
+      load_poly(dig_raw, dpoly0 + j, v, tid_e);
+    }
     __syncthreads();  // the transform's last exchange is done with the LDS words
 #pragma unroll
     for (int e = 0; e < EPT; ++e) sd[lds_lin_base<NT, R_>(tid_e) + lds_lin_off<NT, R_>(e)] = v[e];
     __syncthreads();
     const uint32_t gel = comp == 0 ? galois_elt : galois_inv;
+    [[maybe_unused]] PermIdx pi{};
+    if constexpr (PIRGPU_PERM_TABLE != 0) pi = load_perm(perm + (comp == 0 ? 0 : N), tid_e);
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
-      const double w = sd[lds_idx<R_>(galois_ntt_slot(EPT * tid_e + e, gel))];
+      const double w = sd[perm_at(pi, e, tid_e, gel)];
       if (comp == 0) {
         a[e] = v[e];
         x[e] += w;
@@ -1294,6 +1587,17 @@ static hipError_t configure_mode() {
     PIRGPU_SET((ks_mac_combine_kernel<MODE, true, false, true>));
     PIRGPU_SET((ks_mac_combine_kernel<MODE, true, true, false>));
     PIRGPU_SET((ks_mac_combine_kernel<MODE, true, true, true>));
+    PIRGPU_SET((ks_mac_combine_kernel<MODE, false, false, false, true>));
+    PIRGPU_SET((ks_mac_combine_kernel<MODE, true, false, false, true>));
+    PIRGPU_SET((ks_mac_combine_kernel<MODE, true, false, true, true>));
+    PIRGPU_SET((ks_mac_combine_kernel<MODE, true, true, false, true>));
+    PIRGPU_SET((ks_mac_combine_kernel<MODE, true, true, true, true>));
+    PIRGPU_SET(tree_c0_fwd_kernel<MODE>);
+    PIRGPU_SET((ks_c0_ntt_kernel<MODE, false, false, false>));
+    PIRGPU_SET((ks_c0_ntt_kernel<MODE, true, false, false>));
+    PIRGPU_SET((ks_c0_ntt_kernel<MODE, true, false, true>));
+    PIRGPU_SET((ks_c0_ntt_kernel<MODE, true, true, false>));
+    PIRGPU_SET((ks_c0_ntt_kernel<MODE, true, true, true>));
     PIRGPU_SET((ks_digit_kernel<MODE, true, true>));
     PIRGPU_SET((ks_digit_kernel<MODE, false, false, true>));
     PIRGPU_SET((ks_digit_kernel<MODE, true, false, true>));
@@ -1307,6 +1611,12 @@ static hipError_t configure_mode() {
     PIRGPU_SET((ks_last_ntt_kernel<MODE, true>));
     PIRGPU_SET((ks_last_ntt_kernel<MODE, false, true>));
     PIRGPU_SET((ks_last_ntt_kernel<MODE, true, true>));
+    PIRGPU_SET((ks_last_ntt_kernel<MODE, false, false, 1>));
+    PIRGPU_SET((ks_last_ntt_kernel<MODE, false, true, 1>));
+    PIRGPU_SET((ks_last_ntt_kernel<MODE, true, false, 1>));
+    PIRGPU_SET((ks_last_ntt_kernel<MODE, true, true, 1>));
+    PIRGPU_SET((ks_last_ntt_kernel<MODE, true, false, 2>));
+    PIRGPU_SET((ks_last_ntt_kernel<MODE, true, true, 2>));
     PIRGPU_SET((upper_fused_kernel<MODE, false, true>));
   }
 #undef PIRGPU_SET
@@ -1431,29 +1741,72 @@ static hipError_t op_ks_mac_intt(hipStream_t st, int mode, const DevParams* P, u
 }
 
 // data residues of a level below the last, fused with the combine step (fp64 flavours)
+// xpow != nullptr: the tree's c0 polynomials are (and stay) in NTT form, xpow = NTT_j(x^(-shift_pow)) (ks_combine_c0_ntt)
 static hipError_t op_ks_mac_combine(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* dig,
                                     const KeyPtrs& key, const uint64_t* prod, const uint64_t* tree_in,
                                     uint32_t galois_elt, uint32_t nodes, uint32_t shift_pow, uint64_t* tree_out,
-                                    bool pack40, bool tin40, bool tout40) {
+                                    bool pack40, bool tin40, bool tout40, const uint64_t* xpow, const uint16_t* perm,
+                                    bool c0_split) {
   const dim3 grid = nodes >= kWideLevel && nodes % 8 == 0 ? dim3(nodes * k * 2) : dim3(nodes, k, 2);
   if (mode != kNttF64 && mode != kNttF64Wide) return hipErrorInvalidValue;
   if ((tin40 || tout40) && !pack40) return hipErrorInvalidValue;
   if (tout40 && shift_pow >= (uint32_t)NT) return hipErrorInvalidValue;   // the 5-byte hi store assumes shift < NT
-#define PIRGPU_MC(M, P40, TI, TO)                                                                                   \
-  hipLaunchKernelGGL((ks_mac_combine_kernel<M, P40, TI, TO>), grid, dim3(NT), kLdsBytes, st, P, dig, key, prod,     \
-                     tree_in, galois_elt, nodes, shift_pow, tree_out)
-#define PIRGPU_MC_MODE(M)                                   \
-  do {                                                      \
-    if (!pack40) PIRGPU_MC(M, false, false, false);         \
-    else if (tin40 && tout40) PIRGPU_MC(M, true, true, true);   \
-    else if (tin40) PIRGPU_MC(M, true, true, false);        \
-    else if (tout40) PIRGPU_MC(M, true, false, true);       \
-    else PIRGPU_MC(M, true, false, false);                  \
+  const double* X = reinterpret_cast<const double*>(xpow);
+  if (X && PIRGPU_PERM_TABLE != 0 && !perm) return hipErrorInvalidValue;
+  if (X && c0_split) {
+    // component 0 (NTT domain) and component 1 (inverse transform) as two launches
+    const bool wide = nodes >= kWideLevel && nodes % 8 == 0;
+    const dim3 g1 = wide ? dim3(nodes * k) : dim3(nodes, k, 1);
+#define PIRGPU_C0K(M, P40, TI, TO)                                                                                  \
+  do {                                                                                                              \
+    hipLaunchKernelGGL((ks_c0_ntt_kernel<M, P40, TI, TO>), g1, dim3(NT), kLdsBytes, st, P, dig, key, prod, tree_in, \
+                       galois_elt, nodes, tree_out, X, perm);                                                       \
+    hipLaunchKernelGGL((ks_mac_combine_kernel<M, P40, TI, TO, false>), g1, dim3(NT), kLdsBytes, st, P, dig, key,    \
+                       prod, tree_in, galois_elt, nodes, shift_pow, tree_out, X, perm, 1u);                         \
+  } while (0)
+#define PIRGPU_C0K_MODE(M)                                      \
+  do {                                                          \
+    if (!pack40) PIRGPU_C0K(M, false, false, false);            \
+    else if (tin40 && tout40) PIRGPU_C0K(M, true, true, true);  \
+    else if (tin40) PIRGPU_C0K(M, true, true, false);           \
+    else if (tout40) PIRGPU_C0K(M, true, false, true);          \
+    else PIRGPU_C0K(M, true, false, false);                     \
+  } while (0)
+    if (mode == kNttF64) PIRGPU_C0K_MODE(kNttF64);
+    else PIRGPU_C0K_MODE(kNttF64Wide);
+#undef PIRGPU_C0K_MODE
+#undef PIRGPU_C0K
+    return hipGetLastError();
+  }
+#define PIRGPU_MC(M, P40, TI, TO, C0)                                                                               \
+  hipLaunchKernelGGL((ks_mac_combine_kernel<M, P40, TI, TO, C0>), grid, dim3(NT), kLdsBytes, st, P, dig, key, prod, \
+                     tree_in, galois_elt, nodes, shift_pow, tree_out, X, perm, 0u)
+#define PIRGPU_MC_FMT(M, C0)                                    \
+  do {                                                          \
+    if (!pack40) PIRGPU_MC(M, false, false, false, C0);         \
+    else if (tin40 && tout40) PIRGPU_MC(M, true, true, true, C0);   \
+    else if (tin40) PIRGPU_MC(M, true, true, false, C0);        \
+    else if (tout40) PIRGPU_MC(M, true, false, true, C0);       \
+    else PIRGPU_MC(M, true, false, false, C0);                  \
+  } while (0)
+#define PIRGPU_MC_MODE(M)                 \
+  do {                                    \
+    if (X) PIRGPU_MC_FMT(M, true);        \
+    else PIRGPU_MC_FMT(M, false);         \
   } while (0)
   if (mode == kNttF64) PIRGPU_MC_MODE(kNttF64);
   else PIRGPU_MC_MODE(kNttF64Wide);
 #undef PIRGPU_MC_MODE
+#undef PIRGPU_MC_FMT
 #undef PIRGPU_MC
+  return hipGetLastError();
+}
+
+// c0 of `cts` tree ciphertexts (doubles) into NTT form, in place (fp64 flavours)
+static hipError_t op_tree_c0_fwd(hipStream_t st, int mode, const DevParams* P, uint32_t k, uint64_t* tree, uint32_t cts) {
+  if (mode == kNttF64) hipLaunchKernelGGL(tree_c0_fwd_kernel<kNttF64>, dim3(cts * k), dim3(NT), kLdsBytes, st, P, tree);
+  else if (mode == kNttF64Wide) hipLaunchKernelGGL(tree_c0_fwd_kernel<kNttF64Wide>, dim3(cts * k), dim3(NT), kLdsBytes, st, P, tree);
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 
@@ -1483,23 +1836,37 @@ static hipError_t op_ks_last_level(hipStream_t st, int mode, const DevParams* P,
 }
 
 // fp64 flavours: A_0 into the product buffer, then the NTT-domain last level
+// c0_tree: 0 = NTT(a_0) comes from the product buffer (computed here unless c0_done), 1 / 2 = the tree's c0 polynomials
+// are in NTT form already (doubles / 5-byte form)
 static hipError_t op_ks_last_ntt(hipStream_t st, int mode, const DevParams* P, uint32_t k, const uint64_t* tree,
                                  const uint64_t* dig, const KeyPtrs& key, uint64_t* prod, const uint64_t* xpow,
                                  uint32_t galois_elt, uint32_t galois_inv, uint32_t shift_pow, uint32_t n_items,
                                  uint32_t B, const MfmaPtrs& dst, uint32_t nodes, bool pack40, bool out_f64,
-                                 bool c0_done) {
+                                 bool c0_done, int c0_tree, const uint16_t* perm) {
   const dim3 g0(nodes * k);
   const dim3 grid = nodes >= kWideLevel && nodes % 8 == 0 ? dim3(nodes * k * 2) : dim3(nodes, k, 2);
   const double* X = reinterpret_cast<const double*>(xpow);
+  if (c0_tree == 2 && !pack40) return hipErrorInvalidValue;
+  if (PIRGPU_PERM_TABLE != 0 && !perm) return hipErrorInvalidValue;
+#define PIRGPU_LAST_NTT_K(M, P40, OF, CT)                                                                          \
+  hipLaunchKernelGGL((ks_last_ntt_kernel<M, P40, OF, CT>), grid, dim3(NT), kLdsBytes, st, P, dig, key, prod, X,    \
+                     galois_elt, galois_inv, shift_pow, n_items, B, dst, tree, perm)
 #define PIRGPU_LAST_NTT(M, P40)                                                                                    \
   do {                                                                                                             \
-    if (!c0_done) hipLaunchKernelGGL((tree_c0_ntt_kernel<M, P40>), g0, dim3(NT), kLdsBytes, st, P, tree, prod);    \
-    if (out_f64)                                                                                                   \
-      hipLaunchKernelGGL((ks_last_ntt_kernel<M, P40, true>), grid, dim3(NT), kLdsBytes, st, P, dig, key, prod, X,  \
-                         galois_elt, galois_inv, shift_pow, n_items, B, dst);                                      \
-    else                                                                                                           \
-      hipLaunchKernelGGL((ks_last_ntt_kernel<M, P40>), grid, dim3(NT), kLdsBytes, st, P, dig, key, prod, X,        \
-                         galois_elt, galois_inv, shift_pow, n_items, B, dst);                                      \
+    if (c0_tree == 0 && !c0_done)                                                                                  \
+      hipLaunchKernelGGL((tree_c0_ntt_kernel<M, P40>), g0, dim3(NT), kLdsBytes, st, P, tree, prod);                \
+    if (c0_tree == 2) {                                                                                            \
+      if constexpr (P40) {                                                                                         \
+        if (out_f64) PIRGPU_LAST_NTT_K(M, P40, true, 2);                                                           \
+        else PIRGPU_LAST_NTT_K(M, P40, false, 2);                                                                  \
+      }                                                                                                            \
+    } else if (c0_tree == 1) {                                                                                     \
+      if (out_f64) PIRGPU_LAST_NTT_K(M, P40, true, 1);                                                             \
+      else PIRGPU_LAST_NTT_K(M, P40, false, 1);                                                                    \
+    } else {                                                                                                       \
+      if (out_f64) PIRGPU_LAST_NTT_K(M, P40, true, 0);                                                             \
+      else PIRGPU_LAST_NTT_K(M, P40, false, 0);                                                                    \
+    }                                                                                                              \
   } while (0)
   if (mode == kNttF64) {
     if (pack40) PIRGPU_LAST_NTT(kNttF64, true);
@@ -1511,6 +1878,7 @@ static hipError_t op_ks_last_ntt(hipStream_t st, int mode, const DevParams* P, u
     return hipErrorInvalidValue;
   }
 #undef PIRGPU_LAST_NTT
+#undef PIRGPU_LAST_NTT_K
   return hipGetLastError();
 }
 
@@ -1579,7 +1947,7 @@ const NttOps* PIRGPU_OPS_NAME() {
   using namespace PIRGPU_DEG_NS;
   static const NttOps ops = {op_configure, op_ntt_batch,   op_ct_ntt_fwd_oop, op_ct_ntt_fwd_split, op_db_encode,
                              op_ks_digit,  op_ks_mac_intt, op_upper_fused,     op_ks_last_level,
-                             op_upper_ntt, op_ks_mac_combine, op_ks_last_ntt, op_ntt_inv_gather};
+                             op_upper_ntt, op_ks_mac_combine, op_ks_last_ntt, op_ntt_inv_gather, op_tree_c0_fwd};
   return &ops;
 }
 

@@ -42,6 +42,9 @@ typedef unsigned __int128 u128;
 #ifndef PIRGPU_SCAN_DIRECT
 #define PIRGPU_SCAN_DIRECT 0
 #endif
+#ifndef PIRGPU_SCAN_PAD
+#define PIRGPU_SCAN_PAD 1     // pad words per (row, x) run of the result staging: 1 = two 8-byte LDS reads per thread, 2 = one 16-byte read
+#endif
 
 // Byte offset of tile (slot j, row tile rt, column group kg, digit a) in the packed database.  Column chunks are
 // the outer dimension inside a slot, so the part of a slot's slab one workgroup row streams is contiguous
@@ -264,7 +267,7 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
   // kDirect (-DPIRGPU_SCAN_DIRECT=1): no staging and no workgroup barrier -- every lane stores its four values itself
   // (8 bytes each; the eight waves' stores to a (row, x) run of eight slots merge in L2) and the waves run decoupled.
   constexpr bool kDirect = PIRGPU_SCAN_DIRECT != 0;
-  __shared__ uint64_t stage[kDirect ? 1 : 2][kDirect ? 1 : 16][kDirect ? 1 : 16][NW + 1];
+  __shared__ __attribute__((aligned(16))) uint64_t stage[kDirect ? 1 : 2][kDirect ? 1 : 16][kDirect ? 1 : 16][NW + PIRGPU_SCAN_PAD];
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int g = l >> 4, i16 = l & 15;
   constexpr int LOGNW = NW == 8 ? 3 : 2;
@@ -430,7 +433,11 @@ scan_mfma_kernel(const DevParams* __restrict__ P, const uint8_t* __restrict__ db
         const uint32_t r = rt * 16 + r16;
         if (x < (int)nx && r < rows) {
           typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+#if PIRGPU_SCAN_PAD == 2
+          const u64x2 v = *reinterpret_cast<const u64x2*>(&stage[buf][r16][x][part * 2]);     // runs 80 bytes apart: one 16-byte read
+#else
           const u64x2 v = {stage[buf][r16][x][part * 2], stage[buf][r16][x][part * 2 + 1]};   // two 8-byte LDS reads
+#endif
           uint64_t* dst = obase + (size_t)(x >> 1) * out_qstride + ((size_t)r * 2 + (x & 1)) * out_rstride + j0 + part * 2;
           *reinterpret_cast<u64x2*>(dst) = v;
         }

@@ -159,6 +159,39 @@ def test_looped_transforms_match_the_oracle(monkeypatch, chain, items, off, d):
     db.close()
 
 
+@pytest.mark.parametrize("chain,items,knob,value", [
+    # round 6: the tree's c0 polynomials in NTT form from the first fused level on -- one kernel for both components of a
+    # level (1) or component 0 as a launch of its own (2); both measured slower than the coefficient-form tree and off by
+    # default (profiles/r06_ab_c0_ntt_*.txt), both must give the oracle's bits
+    ("n4096_36bit", 45000, "PIRGPU_C0_NTT", "1"), ("n4096_36bit", 45000, "PIRGPU_C0_NTT", "2"),
+    ("n8192_44bit", 95000, "PIRGPU_C0_NTT", "2"),
+    # packed key-switch intermediates wider than they need be (6 / 7 bytes for 36-bit moduli), the 44-bit chain in 7 bytes
+    # and in doubles, the 49-bit chain in doubles and with the tree packed as well
+    ("n4096_36bit", 45000, "PIRGPU_PACK_BYTES", "6"), ("n4096_36bit", 45000, "PIRGPU_PACK_BYTES", "7"),
+    ("n8192_44bit", 95000, "PIRGPU_PACK_BYTES", "7"), ("n8192_44bit", 95000, "PIRGPU_PACK_BYTES", "8"),
+    ("n16384_49bit", 49000, "PIRGPU_PACK_BYTES", "8"), ("n16384_49bit", 49000, "PIRGPU_TREE40_WIDE", "1"),
+    # the batch launches' scan fold in integer arithmetic again
+    ("n4096_36bit", 45000, "PIRGPU_SCAN_F64_FOLD_BATCH", "0")])
+def test_round6_knobs_match_the_oracle(monkeypatch, chain, items, knob, value):
+    """Every storage width of the packed intermediates and every form of the c0-in-NTT-form tree gives the oracle's reply,
+    for a full group of 8 queries (the fused wide levels and the NTT-domain last level are only reached by a group) and a
+    single query."""
+    N, moduli, _ = CHAINS[chain]
+    monkeypatch.setenv(knob, value)
+    s = PirSetup(items, 288, 2, N=N, plain_bits=24, moduli=moduli)
+    db, srv = _server(s)
+    rng = np.random.default_rng(23)
+    keys = {(N >> j) + 1: random_key(s.orc, rng) for j in range(N.bit_length() - 1)}
+    srv.set_galois_keys(keys)
+    queries = random_ct(s.orc, rng, 9)[:, None]
+    batch = srv.process_batch(queries, n_workers=9)          # one full group of 8 + a group of 1
+    for i in (0, 5, 8):
+        rc, exp = s.orc.process_query(s.db_ntt, s.params.dimensions, queries[i], keys)
+        assert rc == 0 and np.array_equal(batch[i], exp), i
+    assert np.array_equal(srv.process_query(queries[3]), batch[3])
+    db.close()
+
+
 def test_environment_knobs_need_the_gate():
     """PIRGPU_NTT_MODE (and every other PIRGPU_* knob of the library) is read only when
     PIRGPU_ALLOW_ENV=1 is set as well -- a server's arithmetic flavour does not depend on stray environment variables."""

@@ -21,12 +21,13 @@ SRC = os.path.join(ROOT, "pir_amd", "csrc", "ntt_kernels.hip")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
-def _compile(tmp_path_factory, logn):
+def _compile(tmp_path_factory, logn, pack_bytes=5):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available")
-    out = tmp_path_factory.mktemp("isa") / ("ntt%d.s" % logn)
+    out = tmp_path_factory.mktemp("isa") / ("ntt%d_p%d.s" % (logn, pack_bytes))
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-x", "hip", "-DPIRGPU_LOGN=%d" % logn,
-                    "--cuda-device-only", "-S", SRC, "-o", str(out)], check=True, capture_output=True, timeout=600)
+                    "-DPIRGPU_PACK_BYTES=%d" % pack_bytes, "--cuda-device-only", "-S", SRC, "-o", str(out)], check=True,
+                   capture_output=True, timeout=600)
     return out.read_text().split("\n")
 
 
@@ -183,3 +184,45 @@ def test_four_wave_scan_uses_the_unified_register_file_without_scratch(scan_isa,
         assert total <= 512, (L, KS, top4, total)
     total, accum_offset, scratch = _scan_descriptor(scan_isa, L, KS, 4, False)
     assert total <= 512 and (KS < 5 or total > 256), (L, KS, total, accum_offset)
+
+
+# ---- round 6: the packed intermediates at 6 / 7 bytes per residue (cfg 4: N = 8192, 43 / 44-bit moduli; cfg 5: N = 16384, 48 / 49
+# bits) -- the kernels that used to move doubles there now unpack 2 / 3 high bytes per residue and must still fit
+P13P6 = "_ZN6pirgpu7deg13p6"
+P14P7 = "_ZN6pirgpu7deg14p7"
+
+
+@pytest.fixture(scope="module")
+def isa13p6(tmp_path_factory):
+    return _compile(tmp_path_factory, 13, 6)
+
+
+@pytest.fixture(scope="module")
+def isa14p7(tmp_path_factory):
+    return _compile(tmp_path_factory, 14, 7)
+
+
+@pytest.mark.parametrize("kernel", ["18ks_mac_intt_kernelILi1ELb1E", "21ks_mac_combine_kernelILi1ELb1ELb0ELb0ELb0E",
+                                    "21ks_mac_combine_kernelILi1ELb1ELb1ELb1ELb0E", "18ks_last_ntt_kernelILi1ELb1ELb1ELi0E",
+                                    "15ks_digit_kernelILi1ELb1ELb0ELb0E", "15ks_digit_kernelILi1ELb1ELb1ELb0E"])
+def test_n8192_six_byte_kernels(isa13p6, kernel):
+    vgprs, scratch = _descriptor(isa13p6, P13P6 + kernel)
+    assert scratch == 0 and vgprs <= 128, (kernel, vgprs, scratch)
+    if "digit" not in kernel:
+        batches = _loop_load_batches(_function(isa13p6, P13P6 + kernel))
+        assert batches and max(batches) >= 30, (kernel, batches)
+
+
+# (the tree stays in doubles at N = 16384: the combine kernel with a packed tree on both sides spills 68 bytes there, ctx.hip)
+@pytest.mark.parametrize("kernel", ["18ks_mac_intt_kernelILi2ELb1E", "21ks_mac_combine_kernelILi2ELb1ELb0ELb0ELb0E",
+                                    "18ks_last_ntt_kernelILi2ELb1ELb0ELi0E", "15ks_digit_kernelILi2ELb1ELb0ELb0E"])
+def test_n16384_seven_byte_kernels(isa14p7, kernel):
+    vgprs, scratch = _descriptor(isa14p7, P14P7 + kernel)
+    assert vgprs <= 128 and scratch == 0, (kernel, vgprs, scratch)
+
+
+def test_c0_ntt_kernel_issues_its_product_loads_together(isa):
+    """ks_c0_ntt_kernel (option C0_NTT = 2): with the key word loaded inside the product expression the compiler waited for
+    every load on its own (33 dependent round trips per digit; the kernel took twice its twin's time, round 6)."""
+    batches = _loop_load_batches(_function(isa, P + "16ks_c0_ntt_kernelILi1ELb1ELb1ELb1E"))
+    assert batches and max(batches) >= 30, batches

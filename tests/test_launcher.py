@@ -116,6 +116,25 @@ def test_bench_output_stage_does_not_shadow_the_measurement_state():
     emit_line = next(n for n in ast.walk(main) if isinstance(n, ast.FunctionDef) and n.name == "emit_line")
     shadowed = targets(emit_line, skip_nested=False) & targets(main, skip_nested=True)
     assert shadowed <= {"t0", "_"}, shadowed      # t0: a timer both use locally; _: loop dummies -- never read across
+    # ... and every name of main() that the line reads exists BEFORE the watchdog can be armed: the watchdog prints the
+    # line from a timer thread in the middle of a later candidate (round 6: `batch_scan` was first assigned after the
+    # candidates -- a stalled candidate would have died with NameError instead of printing the headline it had)
+    first = {}
+    for node in main.body:
+        for x in ast.walk(node):
+            if isinstance(x, ast.FunctionDef) and x is not node:
+                continue
+            if isinstance(x, (ast.Assign, ast.AugAssign, ast.For)):
+                tgts = x.targets if isinstance(x, ast.Assign) else [x.target]
+                for t in tgts:
+                    for nm in ast.walk(t):
+                        if isinstance(nm, ast.Name):
+                            first.setdefault(nm.id, x.lineno)
+    arm = min(n.lineno for n in ast.walk(main) if isinstance(n, ast.Call) and getattr(n.func, "id", "") == "arm_watchdog")
+    reads = {x.id for x in ast.walk(emit_line) if isinstance(x, ast.Name) and isinstance(x.ctx, ast.Load)}
+    own = targets(emit_line, skip_nested=False)
+    late = sorted(n for n in reads if n in first and first[n] > arm and n not in own)
+    assert late == [], late
 
 
 def test_bench_traffic_staleness_and_timed_blocks(tmp_path, monkeypatch):

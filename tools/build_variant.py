@@ -20,12 +20,13 @@ from pir_amd import build as B  # noqa: E402
 UNITS = {"kernels": ("kernels.hip", None), "scan_mfma": ("scan_mfma.hip", None), "ctx": ("ctx.hip", None),
          "wire": ("wire.cpp", None), "wire_codec": ("wire_codec.cpp", None)}
 for n in B.NTT_LOGNS:
-    UNITS["ntt%d" % n] = (B.NTT_SOURCE, n)
+    for pb in B.NTT_PACK_BYTES:
+        UNITS["ntt%d" % n if pb == 5 else "ntt%dp%d" % (n, pb)] = (B.NTT_SOURCE, (n, pb))
 
 
 def obj_name(unit):
-    src, logn = UNITS[unit]
-    return "ntt_kernels_%d.o" % logn if logn else src.rsplit(".", 1)[0] + ".o"
+    src, deg = UNITS[unit]
+    return B.ntt_object(*deg) if deg else src.rsplit(".", 1)[0] + ".o"
 
 
 def main():
@@ -37,6 +38,8 @@ def main():
     a = ap.parse_args()
     B.build()  # the in-tree objects the variant borrows
     units = list(UNITS) if a.tu == "all" else [u for u in a.tu.split(",") if u]
+    if "ntt" in units:       # every degree and width
+        units = [u for u in units if u != "ntt"] + [u for u in UNITS if u.startswith("ntt")]
     out = os.path.join(ROOT, ".ab", a.name)
     os.makedirs(out, exist_ok=True)
     csrc = os.path.join(a.src, "pir_amd", "csrc") if a.src else B.CSRC
@@ -44,10 +47,11 @@ def main():
     jobs, objs = [], []
     for u in UNITS:
         if u in units:
-            src, logn = UNITS[u]
+            src, deg = UNITS[u]
             o = os.path.join(out, obj_name(u))
             cmd = [B.HIPCC] + flags + (["-x", "hip"] if src.endswith(".hip") else []) + \
-                  (["-DPIRGPU_LOGN=%d" % logn] if logn else []) + ["-c", os.path.join(csrc, src), "-o", o]
+                  (["-DPIRGPU_LOGN=%d" % deg[0], "-DPIRGPU_PACK_BYTES=%d" % deg[1]] if deg else []) + \
+                  ["-c", os.path.join(csrc, src), "-o", o]
             jobs.append(cmd)
             objs.append(o)
         else:

@@ -377,6 +377,15 @@ def kernel_sources_sha16():
     return h.hexdigest()[:16]
 
 
+def hip_runtime_in_use():
+    """Path of the libamdhip64 this process has mapped (torch's bundled copy or the system's: whichever was loaded first)."""
+    try:
+        libs = sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l})
+        return libs[0] if len(libs) == 1 else libs
+    except Exception:
+        return None
+
+
 def recorded_compute():
     """roofline_compute: the VALU-issue table of the transform kernels as RECORDED by the newest committed PMC passes
     (tools/pmc_kernels.sh + tools/valu_roofline.py).  `stale`: False when the kernels' sources are the ones that were
@@ -491,10 +500,35 @@ def main():
     if world != args.gpus and world > 1:
         args.gpus = world
 
-    import torch
-    if torch.cuda.device_count() <= local_rank:
-        raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible -- one process per GPU needs %d devices"
-                         % (rank, local_rank, torch.cuda.device_count(), world))
+    # Which HIP runtime serves the library.  This image's torch wheel bundles its own libamdhip64 / libhsa-runtime64 (ROCm
+    # 7.0); the system has ROCm 7.2.  Whichever is loaded FIRST serves the whole process (same soname), and torch.cuda
+    # cannot initialise on the system's copy ("No HIP GPUs are available").  Under torch's copy the wire path's group-wise
+    # reply downloads run as blit KERNELS (__amd_rocclr_copyBuffer: 256 workgroups x 512 threads sitting on every CU for
+    # the PCIe transfer), under the system runtime -- what a C++ server linking libpirgpu.so gets -- as SDMA copies
+    # (profiles/r06_wire_copy_engines.txt, profiles/r06_d2h_probe.txt).  Measured on one box, three alternating runs each
+    # (profiles/r06_ab_hip_runtime.txt): headline 5 390 against 5 389 queries/s, 64 clients' requests through the wire
+    # 5 329 against 5 310, one synchronous caller 4 655 against 4 628, a new client's first request 2.3 - 3.1 against
+    # 1.95 - 2.0 ms -- the engine that carries the downloads does not move the step.  The default therefore stays torch
+    # first (the bracket around the timed steps is torch.cuda.synchronize(), as the bench contract words it);
+    # PIRGPU_BENCH_TORCH_FIRST=0 runs a single-GPU bench WITHOUT torch in the process: the library loads the system
+    # runtime and the bracket is pirgpu_device_synchronize() (hipDeviceSynchronize of that runtime).
+    launcher_world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch_first = (os.environ.get("PIRGPU_BENCH_TORCH_FIRST", "1") == "1" or launcher_world > 1
+                   or bool(os.environ.get("PIRGPU_FORCE_DIST")))
+    if torch_first:
+        import torch
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible -- one process per GPU needs %d devices"
+                             % (rank, local_rank, torch.cuda.device_count(), world))
+        device_synchronize = torch.cuda.synchronize
+    else:
+        torch = None
+        from pir_amd import capi as _capi
+        _capi.load()                                  # pulls in the system's libamdhip64
+        sync_servers = []                             # the server whose context the bracket goes through (set below)
+
+        def device_synchronize():
+            sync_servers[-1].device_synchronize()     # pirgpu_device_synchronize: hipDeviceSynchronize of that runtime
     import pir_amd
     from pir_amd import distributed as D
 
@@ -552,14 +586,17 @@ def main():
     pipes = []                              # the pipelined rows step (multi-GPU): drained before every barrier
 
     def barrier_for(srv):
+        if not torch_first:
+            sync_servers.append(srv)
+
         def barrier():
             for pp_ in pipes:
                 pp_.flush()                 # multiply + reduce of the last submitted step, then wait
             srv.sync()                      # the library's own streams (not torch's current stream)
-            torch.cuda.synchronize()
+            device_synchronize()            # torch.cuda.synchronize(), or hipDeviceSynchronize() of the runtime in use
             if use_dist:
                 dist.barrier()
-                torch.cuda.synchronize()
+                device_synchronize()
         return barrier
 
     out_extra = {}
@@ -647,6 +684,7 @@ def main():
             # ranks of the RCCL process group the collectives of this run went through (null: no process group)
             "rccl_ranks": (dist.get_world_size() if dist.get_backend() == "nccl" else 0) if use_dist else None,
             **({"backend": "gloo (ranks share one GPU: test facility, not a multi-GPU measurement)"} if share_gpu else {}),
+            "hip_runtime": hip_runtime_in_use(),
             "steps": args.steps, "warmup": args.warmup,
             # blocks of K timed steps behind ms_per_step (median block; one block when K steps last >= 1 s)
             "timed_blocks": len(headline_blocks), "timed_block_seconds": headline_blocks,

@@ -75,7 +75,12 @@ typedef struct pirgpu_params {
   /* Slot sharding for multi-GPU (not in the reference; d = 2): this context holds the NTT slots
    * [slot_begin, slot_end) -- multiples of 16 out of the ring's k * N, device order -- of EVERY plaintext and serves the
    * pirgpu_slots_* step only; 0,0 = all slots.  (The base case of PIRDatabase::multiply, reference database.cpp:185-194,
-   * is a dyadic product in NTT form: independent per slot.) */
+   * is a dyadic product in NTT form: independent per slot.)
+   * Memory: AFTER pirgpu_db_finalize(ctx, 1) such a context holds (slot_end - slot_begin) / (k N) of the packed database.
+   * WHILE it is being loaded it holds the full u64 staging copy of every plaintext as well (every rank encodes and
+   * transforms the whole database, then packs its own slots out of it): the load-time peak per rank is the whole
+   * database at 8 bytes per residue + its share of the operand layout, so slot sharding spreads the scan's bytes, not yet a
+   * database larger than one GPU's memory (that needs the encode + pack in row blocks). */
   uint32_t slot_begin;
   uint32_t slot_end;
 } pirgpu_params;
@@ -187,6 +192,10 @@ int pirgpu_query_stage_async(pirgpu_ctx* ctx, const uint64_t* pinned_query, uint
 int pirgpu_query_run(pirgpu_ctx* ctx);
 int pirgpu_query_fetch(pirgpu_ctx* ctx, uint64_t* reply, uint64_t reply_capacity, uint64_t* reply_count);
 int pirgpu_sync(pirgpu_ctx* ctx);
+/* hipDeviceSynchronize() on the context's device, through the HIP runtime the library itself is linked against: every
+ * stream of the device, the library's own included.  (A measurement harness brackets its timed region with this when it
+ * has no other handle on the runtime -- bench.py at one GPU, which does not import torch; not in the reference.) */
+int pirgpu_device_synchronize(pirgpu_ctx* ctx);
 
 /* Batch mode -- the `for (const auto& query : request.query())` loop of
  * PIRServer::ProcessRequest (reference server.cpp:60-63) with several queries in flight:

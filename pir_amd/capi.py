@@ -128,6 +128,7 @@ SIGNATURES = {
     "pirgpu_query_run": (C.c_int, [C.c_void_p]),
     "pirgpu_query_fetch": (C.c_int, [C.c_void_p, u64p, C.c_uint64, u64p]),
     "pirgpu_sync": (C.c_int, [C.c_void_p]),
+    "pirgpu_device_synchronize": (C.c_int, [C.c_void_p]),
     "pirgpu_set_concurrency": (C.c_int, [C.c_void_p, C.c_uint32]),
     "pirgpu_batch_stage": (C.c_int, [C.c_void_p, u64p, C.c_uint32, C.c_uint32]),
     "pirgpu_batch_run": (C.c_int, [C.c_void_p]),

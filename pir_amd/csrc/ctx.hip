@@ -2023,6 +2023,14 @@ void* pirgpu_stream_handle(pirgpu_ctx* c) { return c ? (void*)c->stream : nullpt
 
 int pirgpu_join(pirgpu_ctx* c) { return pirgpu_join_stream(c, nullptr); }
 
+int pirgpu_device_synchronize(pirgpu_ctx* c) {
+  return guarded(c, [&]() -> int {
+    c->use_device();
+    HIP_TRY(hipDeviceSynchronize());
+    return PIRGPU_OK;
+  });
+}
+
 int pirgpu_join_stream(pirgpu_ctx* c, void* stream) {
   return guarded(c, [&]() -> int {
     hipStream_t target = stream ? (hipStream_t)stream : c->stream;

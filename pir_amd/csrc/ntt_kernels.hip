@@ -91,7 +91,10 @@ constexpr bool kPFLoop = kPF && (EPT == 32 || PIRGPU_PF_LOOP != 0);
 #else
 #define PIRGPU_PK_WAVES
 #endif
-#if PIRGPU_PF_LOOP
+#ifndef PIRGPU_DIG13_FOUR_WAVES
+#define PIRGPU_DIG13_FOUR_WAVES 0    // experiment: the looped digit kernel at N = 8192 held at 128 registers (two 512-thread workgroups per CU)
+#endif
+#if PIRGPU_PF_LOOP && !(PIRGPU_DIG13_FOUR_WAVES && PIRGPU_LOGN == 13)
 #define PIRGPU_FOUR_WAVES
 #else
 #define PIRGPU_FOUR_WAVES __attribute__((amdgpu_waves_per_eu(4)))

@@ -367,6 +367,10 @@ class PIRServer:
     def sync(self) -> None:
         self._check(self.lib.pirgpu_sync(self.db.handle))
 
+    def device_synchronize(self) -> None:
+        """hipDeviceSynchronize() through the library's own HIP runtime (every stream of the device)."""
+        self._check(self.lib.pirgpu_device_synchronize(self.db.handle))
+
     def fetch_reply(self) -> np.ndarray:
         n = self.db.reply_ct_count()
         out = np.empty((n, 2, self.k, self.N), dtype=np.uint64)

@@ -8,9 +8,11 @@ export PIRGPU_ALLOW_ENV=1
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 R=r06
 O=gpurun_out/final6
-rm -rf $O; mkdir -p $O
+mkdir -p $O
 COMMIT=${1:-unknown}
+PART=${2:-all}          # a: scan traffic, cfg 3 counters, bench lines; b: cfg 4 / 5 counters, per-rank budgets
 export PIRGPU_PROFILED_COMMIT=$COMMIT
+if [ $PART != b ]; then
 bash tools/pmc_scan_traffic.sh $O/${R}_pmc_scan_traffic.json $COMMIT 3 4 5 > $O/pmc_scan.log 2>&1
 cp $O/${R}_pmc_scan_traffic.json profiles/${R}_pmc_scan_traffic.json
 rm -rf gpurun_out/pmc_scan_cfg*_fetch gpurun_out/pmc_scan_cfg*_write
@@ -19,11 +21,15 @@ python3 tools/valu_roofline.py ${R}e $O/${R}_valu_roofline.json > $O/${R}_valu_t
 cp gpurun_out/pmc_${R}e.json $O/${R}_pmc_counters.json
 cp $O/${R}_valu_roofline.json profiles/${R}_valu_roofline.json
 rm -rf gpurun_out/pmc_${R}e_valu gpurun_out/pmc_${R}e_lds gpurun_out/pmc_${R}e_fetch gpurun_out/pmc_${R}e_write
+fi
+if [ $PART != a ]; then
 for c in 4 5; do
   bash tools/pmc_kernels.sh ${R}cfg$c --config $c --batch 8 --steps 1 --warmup 1 --latency-runs 2 --no-cpu-baseline > $O/pmc_cfg$c.log 2>&1
   python3 tools/valu_roofline.py ${R}cfg$c $O/${R}_valu_roofline_cfg$c.json > $O/${R}_valu_table_cfg$c.txt 2>&1
   rm -rf gpurun_out/pmc_${R}cfg${c}_valu gpurun_out/pmc_${R}cfg${c}_lds gpurun_out/pmc_${R}cfg${c}_fetch gpurun_out/pmc_${R}cfg${c}_write
 done
+fi
+if [ $PART != b ]; then
 python3 bench.py > $O/${R}_bench.json 2> $O/bench.err
 python3 bench.py --steps 20 --warmup 5 > $O/${R}_bench_driver_command.json 2> $O/bench_driver.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o ${R} -- python3 bench.py --steps 20 --warmup 5 > $O/${R}_bench_profiled.json 2> $O/bench_prof.err
@@ -31,9 +37,12 @@ cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/${R}_kernel_stats.csv
 python3 tools/trace_summary.py $(find $O/prof -name "*kernel_trace.csv" | head -1) 1000 > $O/${R}_trace_summary.txt
 rm -rf $O/prof
 for c in 2 4 5; do python3 bench.py --config $c --batch 16 --steps 10 --no-cpu-baseline > $O/${R}_bench_cfg${c}_reference.json 2> $O/cfg$c.err; done
+fi
+if [ $PART != a ]; then
 timeout 600 python tools/rank_budget.py --slots 3 1,2,4,8 > $O/budget_slots_cfg3.log 2>&1 && cp gpurun_out/rank_budget_slots_cfg3.json $O/${R}_rank_budget_slots_cfg3.json
 timeout 900 python tools/rank_budget.py --slots 4 8 > $O/budget_slots_cfg4.log 2>&1 && cp gpurun_out/rank_budget_slots_cfg4.json $O/${R}_rank_budget_slots_cfg4.json
 timeout 900 python tools/rank_budget.py --slots 5 8 > $O/budget_slots_cfg5.log 2>&1 && cp gpurun_out/rank_budget_slots_cfg5.json $O/${R}_rank_budget_slots_cfg5.json
+fi
 ls -la $O
 python3 - <<'PY'
 import json

@@ -345,7 +345,11 @@ class PIRServer:
         """Waits for the call and returns [(status, response bytes or None)] like ProcessRequests."""
         if not tok.pending():
             raise PirGpuError(9, "ProcessRequestsEnd: this call has already been ended")   # FailedPrecondition
-        self._check(tok.end())
+        rc = tok.end()
+        # (the call's return value is the first non-zero per-request status: a failing request is reported in its own slot
+        # below, like ProcessRequests does; only a failure of the call itself -- no request carries it -- is raised)
+        if rc and not any(tok.status[i] for i in range(tok.n)):
+            self._check(rc)
         out = []
         for i in range(tok.n):
             if tok.status[i] == 0:

@@ -99,6 +99,14 @@ constexpr bool kPFLoop = kPF && (EPT == 32 || PIRGPU_PF_LOOP != 0);
 #else
 #define PIRGPU_FOUR_WAVES __attribute__((amdgpu_waves_per_eu(4)))
 #endif
+// The plain form of upper_fused_kernel (twiddles from global memory, 34 KB of LDS at N = 4096) requests the NEXT child's source
+// words before this child's transform and reads sources and selectors through buffer resources: 1 = on (round 6: with it the
+// plain form beats the LDS-twiddle form at N = 4096 -- 5 552 against 5 495 queries/s, four alternating runs each,
+// profiles/r06_ab_upper_plain_prefetch.txt -- and is the default there; neutral at N = 8192), 2 = this child's first selector
+// polynomial as well (32 more registers: +0.5 % instead of +1.0 %), 0 = the round-5 kernel.
+#ifndef PIRGPU_UPPER_PLAIN_PF
+#define PIRGPU_UPPER_PLAIN_PF 1
+#endif
 // upper_fused_kernel with the twiddle table in LDS (exchange buffer + N doubles of LDS per workgroup, ~245 VGPRs).
 // N = 8192 spills there (four passes, more temporaries: 256 VGPRs + 76 bytes of scratch, cfg 4 363 -> 352 queries/s)
 // and N = 16384 runs the split upper level anyway.
@@ -1367,6 +1375,61 @@ upper_fused_kernel(const DevParams* __restrict__ P, const uint64_t* __restrict__
         }
       }
     }
+  } else if constexpr (MODE != kNttInt && PIRGPU_UPPER_PLAIN_PF != 0) {
+    // Plain form with the NEXT child's source words requested before this child's transform (16 buffer loads, 32
+    // registers across the transform): with one workgroup per CU (N = 8192: 204 registers, 512 threads) a child is three
+    // exposed memory round trips -- source, twiddles, selectors -- and this takes the first one out of the chain.
+    uint64_t in_raw[EPT];
+    auto load_in = [&](uint32_t ii) {
+      const __amdgpu_buffer_rsrc_t in = poly_rsrc(src + ((((size_t)(child0 + ii) * C + cc) * 2 + sp) * k + sj) * N);
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) in_raw[e] = poly_load_u64(in, tid, e);
+    };
+    if (ii0 < ii1) load_in(ii0);
+    for (uint32_t ii = ii0; ii < ii1; ++ii) {
+      T x[EPT];
+      if (fast_lift) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          const uint32_t v = (uint32_t)(in_raw[e] >> sh) & mask32;
+          const double d = (double)v;
+          x[e] = v >= thr32 ? d - td : d;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          uint64_t v = (in_raw[e] >> sh) & mask;
+          uint64_t rr = reduce64(v, mc);
+          if (v >= thr) rr = add_mod(rr, inc, mc.q);
+          x[e] = A::in(rr, m);
+        }
+      }
+      const __amdgpu_buffer_rsrc_t s0 = poly_rsrc(sv + (((size_t)(sv_first + ii) * 2 + 0) * k + jt) * N);
+      const __amdgpu_buffer_rsrc_t s1 = poly_rsrc(sv + (((size_t)(sv_first + ii) * 2 + 1) * k + jt) * N);
+      [[maybe_unused]] uint64_t s0r[EPT];
+      if constexpr (PIRGPU_UPPER_PLAIN_PF >= 2) {   // ... and this child's first selector polynomial (32 more registers)
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) s0r[e] = poly_load_u64(s0, tid, e);
+      }
+      if (ii + 1 < ii1) load_in(ii + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();  // previous iteration's transform may still be reading LDS
+      ntt_forward<MODE, LOGN, false, /*CANON=*/false>(x, smem_raw, P, jt, tid);
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const uint64_t w0 = PIRGPU_UPPER_PLAIN_PF >= 2 ? s0r[e] : poly_load_u64(s0, tid, e), w1 = poly_load_u64(s1, tid, e);
+        acc0[e] += f64_mulmod(x[e], SELF64 ? __longlong_as_double((long long)w0) : f64_from_u64(w0), m);
+        acc1[e] += f64_mulmod(x[e], SELF64 ? __longlong_as_double((long long)w1) : f64_from_u64(w1), m);
+      }
+      if (++since == 8) {
+        since = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          acc0[e] = f64_norm(acc0[e], m);
+          acc1[e] = f64_norm(acc1[e], m);
+        }
+      }
+    }
   } else
   for (uint32_t ii = ii0; ii < ii1; ++ii) {
     const uint64_t* in = src + ((((size_t)(child0 + ii) * C + cc) * 2 + sp) * k + sj) * N;
@@ -1923,7 +1986,8 @@ static hipError_t op_upper_fused(hipStream_t st, int mode, const DevParams* P, u
 #define PIRGPU_UF_ARGS P, src, svq, part, n_rows, n_dim, n_children_total, sv_first, C, chunk_len, n_chunks, src_qstride, part_qstride
   if (sel_f64 && mode == kNttInt) return hipErrorInvalidValue;
   if constexpr (kUpperLdsTw) {
-    static const bool lds_tw = !(pirgpu_env("PIRGPU_UPPER_LDS_TW") && atoi(pirgpu_env("PIRGPU_UPPER_LDS_TW")) == 0);
+    // (round 6: off by default -- the plain form with the source prefetch is 1 % faster; PIRGPU_UPPER_LDS_TW=1 selects it)
+    static const bool lds_tw = pirgpu_env("PIRGPU_UPPER_LDS_TW") && atoi(pirgpu_env("PIRGPU_UPPER_LDS_TW")) != 0;
     if (lds_tw && mode != kNttInt) {
       const size_t lds = kLdsBytes + (size_t)N * 8;
       if (mode == kNttF64 && sel_f64) hipLaunchKernelGGL((upper_fused_kernel<kNttF64, true, true>), grid, dim3(NT), lds, st, PIRGPU_UF_ARGS);

@@ -192,6 +192,22 @@ def test_round6_knobs_match_the_oracle(monkeypatch, chain, items, knob, value):
     db.close()
 
 
+def test_upper_level_lds_twiddle_form_still_matches_the_oracle():
+    """upper_fused_kernel's LDS-twiddle form (the default of rounds 2 - 5) is chosen once per process
+    (PIRGPU_UPPER_LDS_TW=1); since round 6 the plain form with the source prefetch is the default.  The multiply / query
+    parity tests (d = 2 and d = 3 against the oracle) are re-run in a child process with the old form selected."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PIRGPU_UPPER_LDS_TW="1", PIRGPU_ALLOW_ENV="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu", "-x",
+                        "-k", "multiply_and_query or multi_ciphertext_query"], env=env, capture_output=True, text=True,
+                       timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 def test_environment_knobs_need_the_gate():
     """PIRGPU_NTT_MODE (and every other PIRGPU_* knob of the library) is read only when
     PIRGPU_ALLOW_ENV=1 is set as well -- a server's arithmetic flavour does not depend on stray environment variables."""
